@@ -1,0 +1,189 @@
+/*
+ * nbx.h -- C ABI of libnbx: MI355X (gfx950) kernels for the embedded-SCF hot
+ * path of UCL-CCS/Nbed (Huzinaga / mu-shift Fock build, J/K contraction,
+ * projector products, symmetric eigensolve, SPADE / concentric-localisation
+ * SVDs, AO->active-MO four-index transform, spin-orbital scatter).
+ *
+ * The reference is pure Python and has no FFI of its own; what this library
+ * replaces are the calls the reference makes into PySCF's C libraries and
+ * into NumPy/SciPy LAPACK on that path.  Each entry point cites the reference
+ * call site(s) it stands in for (paths relative to the reference repository).
+ *
+ * Conventions (binding):
+ *   - extern "C", every function returns int: 0 = ok, < 0 = error
+ *     (NBX_E_*); nbx_last_error() returns a thread-local message.
+ *   - No exceptions cross the boundary.  Caller allocates every output.
+ *   - Matrices are row-major (C order) double precision.  "d_" pointers are
+ *     DEVICE pointers (hipMalloc / nbx_malloc / torch tensor data_ptr);
+ *     "h_" pointers are host pointers.
+ *   - Sizes are int64_t.  Work runs asynchronously on the context's HIP
+ *     stream; nbx_sync() or a d2h copy waits for it.
+ *   - A context is bound to one device and one stream and must not be used
+ *     from two threads at once; the library keeps no other global state.
+ *   - Multi-GPU: one process (context) per GPU.  Entry points that shard take
+ *     an index range [i0, i1) and compute that slab only; the exchange step
+ *     (all-gather over RCCL) is done by the host (torch.distributed).
+ */
+#ifndef NBX_H
+#define NBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBX_VERSION 1
+
+#define NBX_OK 0
+#define NBX_E_INVALID (-1)  /* bad argument (null pointer, negative size, shape mismatch) */
+#define NBX_E_HIP (-2)      /* a HIP runtime call failed (message has the HIP error string) */
+#define NBX_E_NOMEM (-3)    /* workspace too small / allocation failed */
+#define NBX_E_NOCONV (-4)   /* iterative kernel hit its sweep limit (results still written) */
+#define NBX_E_UNSUPPORTED (-5)
+
+typedef struct nbx_ctx nbx_ctx;
+
+/* ------------------------------------------------------------------ context */
+int nbx_version(void);
+const char* nbx_last_error(void);
+int nbx_device_count(int* count);
+/* stream: the hipStream_t to launch on (e.g. torch's current stream; NULL = the device's
+ * default stream).  private_stream != 0: ignore `stream` and create a private non-blocking
+ * stream owned by the context. */
+int nbx_ctx_create(int device, void* stream, int private_stream, nbx_ctx** ctx);
+int nbx_ctx_destroy(nbx_ctx* ctx);
+int nbx_ctx_set_stream(nbx_ctx* ctx, void* stream);
+int nbx_sync(nbx_ctx* ctx);
+int nbx_malloc(nbx_ctx* ctx, size_t bytes, void** d_ptr);
+int nbx_free(nbx_ctx* ctx, void* d_ptr);
+int nbx_memcpy_h2d(nbx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int nbx_memcpy_d2h(nbx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronises */
+int nbx_memcpy_d2d(nbx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+int nbx_memset(nbx_ctx* ctx, void* d_ptr, int value, size_t bytes);
+
+/* ------------------------------------------------------------------ synthetic inputs
+ * Counter-hash (pq|rs) of SURVEY.md section 8d, rows p in [p0,p1) of the dense
+ * C-order (N,N,N,N) tensor: d_eri[(p-p0),q,r,s] = val(canon(p,q,r,s)) / N.
+ * Stands in for mol.intor('int2e') (reached through PySCF get_veff / ao2mo.kernel,
+ * nbed/scf/huzinaga_scf.py:156, nbed/ham_builder.py:128). */
+int nbx_synth_eri(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, uint64_t seed, double* d_eri);
+
+/* ------------------------------------------------------------------ J/K contraction
+ * Replaces PySCF UHF.get_jk / get_veff (libcvhf) at nbed/scf/huzinaga_scf.py:156,
+ * nbed/scf/embedded_hcore_funcs.py:34, nbed/driver.py:344-345,847-849,
+ * nbed/localizers/virtual/concentric.py:104,109.
+ *   d_eri : slab rows p in [p0,p1) of the dense (N,N,N,N) chemist-order ERI
+ *   d_dm  : (ndm,N,N) density matrices (ndm = 1 or 2), symmetric
+ *   d_jk  : out, ((1+ndm), p1-p0, N):  [0] = J rows from sum_x dm[x],
+ *           [1+x] = K rows from dm[x]:  J_pq = sum_rs (pq|rs) D_rs,
+ *           K_pr = sum_qs (pq|rs) D_qs   (uses (pq|rs) = (pq|sr))
+ *   d_work: nbx_jk_dense_worksize() bytes                                  */
+size_t nbx_jk_dense_worksize(int64_t nao, int64_t np, int64_t ndm);
+int nbx_jk_dense(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri,
+                 const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes);
+
+/* ------------------------------------------------------------------ dense products (MFMA fp64)
+ * C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b], row-major, op = 'N' or 'T'.
+ * Replaces the OpenBLAS dgemm behind numpy matmul/einsum at
+ * nbed/scf/huzinaga_scf.py:78-86,132-134,144-146,166-169; nbed/driver.py:439,446;
+ * nbed/localizers/system.py:34-36; nbed/ham_builder.py:76-79;
+ * nbed/localizers/occupied/spade.py:98-99,132-134;
+ * nbed/localizers/virtual/concentric.py:146-153,175-176,205-207,228,235.      */
+int nbx_gemm(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t n, int64_t k,
+             double alpha, const double* d_a, int64_t lda, int64_t stride_a,
+             const double* d_b, int64_t ldb, int64_t stride_b, double beta,
+             double* d_c, int64_t ldc, int64_t stride_c, int64_t batch);
+
+/* ------------------------------------------------------------------ Fock assembly & reductions */
+/* F[x] = hcore[x or 0] + vemb[x] + J - K[x]  (x < 2); d_jk as written by nbx_jk_dense with
+ * p0=0,p1=N,ndm=2.  hcore_ndim = 2 -> (N,N) shared, 3 -> (2,N,N).  d_vemb may be NULL.
+ * nbed/scf/huzinaga_scf.py:157 (get_veff: vhf = J_a + J_b - K_x).                          */
+int nbx_fock_uhf(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
+                 const double* d_vemb, const double* d_jk, double* d_fock, double* d_vhf);
+/* Huzinaga operator, occupied part (nbed/scf/huzinaga_scf.py:78-80):
+ * given FDS[b] = F[b] @ (D_env[b] @ S):  Hz[b] = -kappa (FDS[b] + FDS[b]^T); if d_fock_io
+ * is not NULL also F[b] += Hz[b] (:160).                                                    */
+int nbx_huzinaga_sym(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_fds, double kappa,
+                     double* d_hz, double* d_fock_io);
+/* out[b] = sum_ij A[b,i,j] * B[b,j,i]   (einsum "ij,ji->"; huzinaga_scf.py:185,
+ * embedded_hcore_funcs.py:38-42, driver.py:957-962).  h_out: host, synchronises.          */
+int nbx_trace_prod(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_a, const double* d_b,
+                   double* h_out);
+/* Per-cycle scalars of the Huzinaga HF branch (huzinaga_scf.py:181-194):
+ *   h_out[x]   = tr[(hcore + vemb[x] + 0.5 vhf[x] + hz[x]) D[x]]      x = 0,1
+ *   h_out[2+x] = || D[x] - Dold[x] ||_F                                                     */
+int nbx_huz_cycle_scalars(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
+                          const double* d_vemb, const double* d_vhf, const double* d_hz,
+                          const double* d_dm, const double* d_dm_old, double* h_out);
+/* y = a*x + b*y over n doubles. */
+int nbx_axpby(nbx_ctx* ctx, int64_t n, double a, const double* d_x, double b, double* d_y);
+/* out = sum_k coef[k] * vecs[k] (k < nvec; vecs[k] = d_vecs + k*stride), DIIS extrapolation
+ * (pyscf.lib.diis.DIIS.extrapolate behind huzinaga_scf.py:164).                             */
+int nbx_lincomb(nbx_ctx* ctx, int64_t n, int64_t nvec, const double* h_coef, const double* d_vecs,
+                int64_t stride, double* d_out);
+/* h_out[k] = <x, vecs[k]>, k < nvec (DIIS B-matrix row). Synchronises. */
+int nbx_dots(nbx_ctx* ctx, int64_t n, int64_t nvec, const double* d_x, const double* d_vecs,
+             int64_t stride, double* h_out);
+/* B[b] = A[b]^T for (rows x cols) matrices. */
+int nbx_transpose(nbx_ctx* ctx, int64_t rows, int64_t cols, int64_t batch, const double* d_a,
+                  double* d_b);
+/* A[:, j] *= s[j]  (columns scaled; row-major (rows x cols)). */
+int nbx_scale_cols(nbx_ctx* ctx, int64_t rows, int64_t cols, int64_t batch, const double* d_s,
+                   double* d_a);
+
+/* ------------------------------------------------------------------ symmetric eigensolver
+ * Replaces np.linalg.eigh (LAPACK dsyevd) at nbed/scf/huzinaga_scf.py:145,168 and the
+ * eigensolve inside fractional_matrix_power at :128 / spade.py:99.
+ * d_a: (batch,N,N) symmetric, preserved.  d_w: (batch,N) ascending.  d_v: (batch,N,N),
+ * columns = eigenvectors.  Cyclic two-sided Jacobi (parallel ordering).
+ * d_work: nbx_eigh_worksize() bytes.  Returns NBX_E_NOCONV if max sweeps hit.             */
+size_t nbx_eigh_worksize(int64_t n, int64_t batch);
+int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
+             void* d_work, size_t work_bytes);
+/* Reads back the sweep counts of the last nbx_eigh on this workspace (synchronises):
+ * h_sweeps[b] > 0 = sweeps used; returns NBX_E_NOCONV if any matrix hit the sweep limit. */
+int nbx_eigh_status(nbx_ctx* ctx, int64_t n, int64_t batch, const void* d_work, int* h_sweeps);
+/* out = S^p for symmetric positive definite S (N,N): U diag(w^p) U^T.
+ * scipy.linalg.fractional_matrix_power(S, -0.5 / +0.5) at huzinaga_scf.py:128,
+ * spade.py:99; np.linalg.inv(S_AA) at concentric.py:147 (p = -1).                         */
+size_t nbx_sym_pow_worksize(int64_t n);
+int nbx_sym_pow(nbx_ctx* ctx, int64_t n, const double* d_s, double p, double* d_out,
+                void* d_work, size_t work_bytes);
+
+/* ------------------------------------------------------------------ SVD (right vectors)
+ * Replaces scipy.linalg.svd / np.linalg.svd (LAPACK dgesdd) at spade.py:101 and
+ * concentric.py:151,205: A (m x n) -> s (min(m,n)) descending, Vt (n x n) with rows the
+ * right singular vectors (full_matrices=True semantics).  One-sided Jacobi.              */
+size_t nbx_svd_worksize(int64_t m, int64_t n);
+int nbx_svd_right(nbx_ctx* ctx, int64_t m, int64_t n, const double* d_a, double* d_s, double* d_vt,
+                  void* d_work, size_t work_bytes);
+/* Sweep count of the last nbx_svd_right on this workspace (synchronises); NBX_E_NOCONV if the
+ * sweep limit was hit. */
+int nbx_svd_status(nbx_ctx* ctx, int64_t m, int64_t n, const void* d_work, int* h_sweeps);
+
+/* ------------------------------------------------------------------ four-index transform
+ * Replaces pyscf.ao2mo.kernel + ao2mo.restore(1, ...) at nbed/ham_builder.py:127-131:
+ *   out[i-i0,j,k,l] = sum_pqrs C1[p,i] C2[q,j] C3[r,k] C4[s,l] (pq|rs),  i in [i0,i1)
+ * d_eri dense (N,N,N,N); Cx are (N,nx) row-major.  Four quarter transforms (MFMA GEMMs).
+ * The outer MO index i is the multi-GPU shard axis.                                       */
+size_t nbx_ao2mo_worksize(int64_t nao, int64_t ni, int64_t n2, int64_t n3, int64_t n4);
+int nbx_ao2mo(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c1, int64_t n1,
+              int64_t i0, int64_t i1, const double* d_c2, int64_t n2, const double* d_c3,
+              int64_t n3, const double* d_c4, int64_t n4, double* d_out, void* d_work,
+              size_t work_bytes);
+/* out[a,c,d,b] = in[a,b,c,d]: chemist (ij|kl) -> the reference's physicist-ordered block
+ * eri.transpose(0,2,3,1) (ham_builder.py:133).                                            */
+int nbx_chem_to_phys(nbx_ctx* ctx, int64_t n1, int64_t n2, int64_t n3, int64_t n4,
+                     const double* d_in, double* d_out);
+/* Spin-orbital scatter + truncation (nbed/ham_builder.py:158-216) and the 0.5 factor of
+ * build() (:254):  h1 (2n,2n), h2 (2n,2n,2n,2n) from one_body (2,n,n), two_body (4,n,n,n,n);
+ * entries with |x| < tol are zeroed; h2 is multiplied by h2_scale afterwards.            */
+int nbx_spinorb_scatter(nbx_ctx* ctx, int64_t n, const double* d_one_body, const double* d_two_body,
+                        double tol, double h2_scale, double* d_h1, double* d_h2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBX_H */

@@ -1,0 +1,13 @@
+"""nbed_amd -- MI355X-native implementation of Nbed's embedded-SCF hot path.
+
+Host code is Python and keeps the reference's interface (``NbedDriver``,
+``HamiltonianBuilder``, the ``Localizer`` classes, ``huzinaga_scf``); all the
+arithmetic runs in hand-written gfx950 HIP kernels behind the C ABI of
+``include/nbx.h`` (``nbed_amd/libnbx.so``), reached through ctypes.
+Importing the package needs neither the library nor a GPU; computing does.
+"""
+
+from ._nbx import NbxError, NbxUnavailableError
+from .backend import HipBackend, get_backend, set_backend
+
+__all__ = ["HipBackend", "get_backend", "set_backend", "NbxError", "NbxUnavailableError"]

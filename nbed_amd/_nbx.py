@@ -1,0 +1,116 @@
+"""ctypes binding of libnbx (include/nbx.h) -- the thin FFI layer.
+
+Only plain pointers and sizes cross this boundary.  The product path fails
+loudly (``NbxUnavailableError``) when the shared library is missing; there is no
+CPU fallback anywhere in ``nbed_amd``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char, c_char_p, c_double, c_int, c_int64, c_size_t, c_uint64, c_void_p
+from pathlib import Path
+
+LIB_NAME = "libnbx.so"
+LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
+
+NBX_OK = 0
+NBX_E_INVALID = -1
+NBX_E_HIP = -2
+NBX_E_NOMEM = -3
+NBX_E_NOCONV = -4
+NBX_E_UNSUPPORTED = -5
+
+
+class NbxError(RuntimeError):
+    """A libnbx entry point returned an error code."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libnbx error {code}: {message}")
+        self.code = code
+
+
+class NbxUnavailableError(RuntimeError):
+    """libnbx.so is not built or no MI355X is visible: the HIP path cannot run."""
+
+
+# name -> (restype, argtypes); mirrors include/nbx.h one to one
+_P = c_void_p
+SIGNATURES = {
+    "nbx_version": (c_int, []),
+    "nbx_last_error": (c_char_p, []),
+    "nbx_device_count": (c_int, [POINTER(c_int)]),
+    "nbx_ctx_create": (c_int, [c_int, _P, c_int, POINTER(_P)]),
+    "nbx_ctx_destroy": (c_int, [_P]),
+    "nbx_ctx_set_stream": (c_int, [_P, _P]),
+    "nbx_sync": (c_int, [_P]),
+    "nbx_malloc": (c_int, [_P, c_size_t, POINTER(_P)]),
+    "nbx_free": (c_int, [_P, _P]),
+    "nbx_memcpy_h2d": (c_int, [_P, _P, _P, c_size_t]),
+    "nbx_memcpy_d2h": (c_int, [_P, _P, _P, c_size_t]),
+    "nbx_memcpy_d2d": (c_int, [_P, _P, _P, c_size_t]),
+    "nbx_memset": (c_int, [_P, _P, c_int, c_size_t]),
+    "nbx_synth_eri": (c_int, [_P, c_int64, c_int64, c_int64, c_uint64, _P]),
+    "nbx_jk_dense_worksize": (c_size_t, [c_int64, c_int64, c_int64]),
+    "nbx_jk_dense": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
+    "nbx_gemm": (c_int, [_P, c_char, c_char, c_int64, c_int64, c_int64, c_double, _P, c_int64, c_int64,
+                         _P, c_int64, c_int64, c_double, _P, c_int64, c_int64, c_int64]),
+    "nbx_fock_uhf": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P]),
+    "nbx_huzinaga_sym": (c_int, [_P, c_int64, c_int64, _P, c_double, _P, _P]),
+    "nbx_trace_prod": (c_int, [_P, c_int64, c_int64, _P, _P, POINTER(c_double)]),
+    "nbx_huz_cycle_scalars": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, _P, POINTER(c_double)]),
+    "nbx_axpby": (c_int, [_P, c_int64, c_double, _P, c_double, _P]),
+    "nbx_lincomb": (c_int, [_P, c_int64, c_int64, POINTER(c_double), _P, c_int64, _P]),
+    "nbx_dots": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, POINTER(c_double)]),
+    "nbx_transpose": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
+    "nbx_scale_cols": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
+    "nbx_eigh_worksize": (c_size_t, [c_int64, c_int64]),
+    "nbx_eigh": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, c_size_t]),
+    "nbx_eigh_status": (c_int, [_P, c_int64, c_int64, _P, POINTER(c_int)]),
+    "nbx_sym_pow_worksize": (c_size_t, [c_int64]),
+    "nbx_sym_pow": (c_int, [_P, c_int64, _P, c_double, _P, _P, c_size_t]),
+    "nbx_svd_worksize": (c_size_t, [c_int64, c_int64]),
+    "nbx_svd_right": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, c_size_t]),
+    "nbx_svd_status": (c_int, [_P, c_int64, c_int64, _P, POINTER(c_int)]),
+    "nbx_ao2mo_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64, c_int64]),
+    "nbx_ao2mo": (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P,
+                          c_int64, _P, _P, c_size_t]),
+    "nbx_chem_to_phys": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P]),
+    "nbx_spinorb_scatter": (c_int, [_P, c_int64, _P, _P, c_double, c_double, _P, _P]),
+}
+
+_lib = None
+
+
+def load_library(path: os.PathLike | None = None) -> ctypes.CDLL:
+    """dlopen libnbx.so and attach the prototypes of include/nbx.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path is not None else LIB_PATH
+    if not p.exists():
+        raise NbxUnavailableError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); nbed_amd has no CPU fallback."
+        )
+    try:
+        # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's): load torch first so
+        # that libnbx binds to the one HIP runtime already in the process.
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch-less FFI users get the system runtime
+        pass
+    lib = ctypes.CDLL(str(p), mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib: ctypes.CDLL, rc: int) -> None:
+    if rc != NBX_OK:
+        msg = lib.nbx_last_error()
+        raise NbxError(rc, msg.decode() if msg else "")

@@ -1,0 +1,298 @@
+"""Device backend: every numeric operation of the hot path as a libnbx call.
+
+``HipBackend`` owns one ``nbx_ctx`` (one GPU, launched on torch's current HIP
+stream).  torch is used only as plumbing: device memory (``torch.empty``),
+host<->device copies and, in multi-GPU runs, ``torch.distributed`` collectives;
+no arithmetic of the path is done with torch or numpy here.
+
+The methods form the interface the host-side mirror of the reference
+(``nbed_amd.scf``, ``nbed_amd.localizers``, ``nbed_amd.ham_builder``) is written
+against.  There is deliberately no CPU implementation in this package: without
+libnbx.so or without a GPU ``get_backend()`` raises ``NbxUnavailableError``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_double, c_int
+
+import numpy as np
+
+from . import _nbx
+from ._nbx import NbxError, NbxUnavailableError  # noqa: F401  (re-exported)
+
+_default_backend = None
+
+
+def get_backend(device: int | None = None):
+    """Process-wide default ``HipBackend`` (created on first use)."""
+    global _default_backend
+    if _default_backend is None:
+        _default_backend = HipBackend(device)
+    return _default_backend
+
+
+def set_backend(backend) -> None:
+    """Install ``backend`` as the default (tests inject their own checker backend)."""
+    global _default_backend
+    _default_backend = backend
+
+
+class HipBackend:
+    """libnbx on one MI355X."""
+
+    name = "hip"
+
+    def __init__(self, device: int | None = None):
+        import torch
+
+        self.torch = torch
+        self.lib = _nbx.load_library()
+        if not torch.cuda.is_available():
+            raise NbxUnavailableError("no HIP device visible: the nbed_amd compute path needs an MI355X")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        torch.cuda.set_device(self.device_index)
+        stream = torch.cuda.current_stream(self.device_index).cuda_stream
+        ctx = ctypes.c_void_p()
+        _nbx.check(self.lib, self.lib.nbx_ctx_create(self.device_index, ctypes.c_void_p(stream), 0, ctypes.byref(ctx)))
+        self.ctx = ctx
+        self._work: dict[str, object] = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.nbx_ctx_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def _call(self, name, *args):
+        _nbx.check(self.lib, getattr(self.lib, name)(self.ctx, *args))
+
+    def use_current_stream(self):
+        stream = self.torch.cuda.current_stream(self.device_index).cuda_stream
+        self._call("nbx_ctx_set_stream", ctypes.c_void_p(stream))
+
+    def synchronize(self):
+        self._call("nbx_sync")
+
+    def empty(self, *shape):
+        return self.torch.empty(*shape, dtype=self.torch.float64, device=self.device)
+
+    def zeros(self, *shape):
+        return self.torch.zeros(*shape, dtype=self.torch.float64, device=self.device)
+
+    def asarray(self, a):
+        """Host (numpy) or device array -> contiguous float64 device array."""
+        t = self.torch
+        if isinstance(a, t.Tensor):
+            return a.to(device=self.device, dtype=t.float64).contiguous()
+        return t.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    def to_host(self, a) -> np.ndarray:
+        if isinstance(a, self.torch.Tensor):
+            return a.detach().cpu().numpy()
+        return np.asarray(a)
+
+    def copy(self, a):
+        return a.clone()
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+    def _workspace(self, key: str, nbytes: int):
+        buf = self._work.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = None
+            self._work[key] = None
+            buf = self.torch.empty(max(int(nbytes), 256), dtype=self.torch.uint8, device=self.device)
+            self._work[key] = buf
+        return buf
+
+    def release_workspaces(self):
+        self._work.clear()
+
+    # ------------------------------------------------------------------ synthetic ERI
+    def synth_eri(self, nao: int, p0: int = 0, p1: int | None = None, seed: int = 20250829):
+        p1 = nao if p1 is None else p1
+        out = self.empty((p1 - p0, nao, nao, nao))
+        self._call("nbx_synth_eri", nao, p0, p1, seed, self._p(out))
+        return out
+
+    # ------------------------------------------------------------------ J/K
+    def jk(self, eri, dm, p0: int = 0, p1: int | None = None):
+        """(1+ndm, p1-p0, N): J rows from sum(dm), then K rows per dm (nbx_jk_dense)."""
+        nao = dm.shape[-1]
+        p1 = nao if p1 is None else p1
+        dm3 = dm.reshape(-1, nao, nao)
+        ndm = dm3.shape[0]
+        nbytes = self.lib.nbx_jk_dense_worksize(nao, p1 - p0, ndm)
+        work = self._workspace("jk", nbytes)
+        out = self.empty((1 + ndm, p1 - p0, nao))
+        self._call("nbx_jk_dense", nao, p0, p1, self._p(eri), self._p(dm3), ndm, self._p(out), self._p(work),
+                   work.numel())
+        return out
+
+    # ------------------------------------------------------------------ GEMM
+    def gemm(self, a, b, ta: str = "N", tb: str = "N", alpha: float = 1.0, beta: float = 0.0, out=None):
+        """op(a) @ op(b) for 2-D operands, or batched over a shared leading axis (3-D)."""
+        batched = a.dim() == 3 or b.dim() == 3
+        a3 = a if a.dim() == 3 else a.unsqueeze(0)
+        b3 = b if b.dim() == 3 else b.unsqueeze(0)
+        batch = max(a3.shape[0], b3.shape[0])
+        m, k = (a3.shape[2], a3.shape[1]) if ta == "T" else (a3.shape[1], a3.shape[2])
+        k2, n = (b3.shape[2], b3.shape[1]) if tb == "T" else (b3.shape[1], b3.shape[2])
+        if k != k2:
+            raise ValueError(f"gemm: inner dimensions differ ({k} vs {k2})")
+        if out is None:
+            out = self.empty((batch, m, n)) if batched else self.empty((m, n))
+        sa = a3.shape[1] * a3.shape[2] if a3.shape[0] > 1 else 0
+        sb = b3.shape[1] * b3.shape[2] if b3.shape[0] > 1 else 0
+        self._call("nbx_gemm", ta.encode(), tb.encode(), m, n, k, alpha, self._p(a3), a3.shape[2], sa,
+                   self._p(b3), b3.shape[2], sb, beta, self._p(out), n, m * n, batch)
+        return out
+
+    def gemm_raw(self, ta, tb, m, n, k, alpha, a, lda, sa, b, ldb, sb, beta, c, ldc, sc, batch):
+        self._call("nbx_gemm", ta.encode(), tb.encode(), m, n, k, alpha, self._p(a), lda, sa, self._p(b), ldb, sb,
+                   beta, self._p(c), ldc, sc, batch)
+
+    # ------------------------------------------------------------------ Fock pieces
+    def fock_uhf(self, hcore, vemb, jk, want_vhf: bool = True):
+        nao = jk.shape[-1]
+        fock = self.empty((2, nao, nao))
+        vhf = self.empty((2, nao, nao)) if want_vhf else None
+        self._call("nbx_fock_uhf", nao, self._p(hcore), hcore.dim(), self._p(vemb), self._p(jk), self._p(fock),
+                   self._p(vhf))
+        return fock, vhf
+
+    def huzinaga_sym(self, fds, kappa: float, fock_io=None):
+        nao = fds.shape[-1]
+        batch = 1 if fds.dim() == 2 else fds.shape[0]
+        hz = self.torch.empty_like(fds)
+        self._call("nbx_huzinaga_sym", nao, batch, self._p(fds), kappa, self._p(hz), self._p(fock_io))
+        return hz
+
+    def trace_prod(self, a, b) -> np.ndarray:
+        """einsum('...ij,...ji->...') on device; returns host floats."""
+        nao = a.shape[-1]
+        batch = 1 if a.dim() == 2 else a.shape[0]
+        out = (c_double * batch)()
+        self._call("nbx_trace_prod", nao, batch, self._p(a), self._p(b), out)
+        res = np.array(out[:], dtype=np.float64)
+        return res[0] if a.dim() == 2 else res
+
+    def huz_cycle_scalars(self, hcore, vemb, vhf, hz, dm, dm_old) -> np.ndarray:
+        nao = dm.shape[-1]
+        out = (c_double * 4)()
+        self._call("nbx_huz_cycle_scalars", nao, self._p(hcore), hcore.dim(), self._p(vemb), self._p(vhf),
+                   self._p(hz), self._p(dm), self._p(dm_old), out)
+        return np.array(out[:], dtype=np.float64)
+
+    def axpby(self, a: float, x, b: float, y):
+        self._call("nbx_axpby", x.numel(), a, self._p(x), b, self._p(y))
+        return y
+
+    def add(self, x, y):
+        """x + y (new array)."""
+        out = y.clone()
+        return self.axpby(1.0, x, 1.0, out)
+
+    def lincomb(self, coef, vecs, out=None):
+        nvec, n = vecs.shape[0], vecs[0].numel()
+        if out is None:
+            out = self.empty(vecs.shape[1:])
+        c = (c_double * nvec)(*[float(x) for x in coef])
+        self._call("nbx_lincomb", n, nvec, c, self._p(vecs), n, self._p(out))
+        return out
+
+    def dots(self, x, vecs) -> np.ndarray:
+        nvec, n = vecs.shape[0], x.numel()
+        out = (c_double * nvec)()
+        self._call("nbx_dots", n, nvec, self._p(x), self._p(vecs), vecs[0].numel(), out)
+        return np.array(out[:], dtype=np.float64)
+
+    def transpose(self, a):
+        """Swap the last two axes (materialised)."""
+        if a.dim() == 2:
+            rows, cols, batch = a.shape[0], a.shape[1], 1
+            out = self.empty((cols, rows))
+        else:
+            batch, rows, cols = a.shape
+            out = self.empty((batch, cols, rows))
+        self._call("nbx_transpose", rows, cols, batch, self._p(a), self._p(out))
+        return out
+
+    def scale_cols(self, a, s):
+        rows, cols = a.shape[-2], a.shape[-1]
+        batch = 1 if a.dim() == 2 else a.shape[0]
+        self._call("nbx_scale_cols", rows, cols, batch, self._p(s), self._p(a))
+        return a
+
+    # ------------------------------------------------------------------ eigh / svd
+    def eigh(self, a, check: bool = False):
+        n = a.shape[-1]
+        batch = 1 if a.dim() == 2 else a.shape[0]
+        nbytes = self.lib.nbx_eigh_worksize(n, batch)
+        work = self._workspace("eigh", nbytes)
+        w = self.empty(a.shape[:-1])
+        v = self.torch.empty_like(a)
+        self._call("nbx_eigh", n, batch, self._p(a), self._p(w), self._p(v), self._p(work), work.numel())
+        if check:
+            sweeps = (c_int * batch)()
+            self._call("nbx_eigh_status", n, batch, self._p(work), sweeps)
+            self.last_eigh_sweeps = list(sweeps)
+        return w, v
+
+    def sym_pow(self, s, p: float):
+        n = s.shape[-1]
+        nbytes = self.lib.nbx_sym_pow_worksize(n)
+        work = self._workspace("sym_pow", nbytes)
+        out = self.torch.empty_like(s)
+        self._call("nbx_sym_pow", n, self._p(s), p, self._p(out), self._p(work), work.numel())
+        return out
+
+    def svd_right(self, a, check: bool = True):
+        """Singular values (descending) and Vt (n x n) of the 2-D matrix ``a`` (m x n)."""
+        m, n = a.shape
+        nbytes = self.lib.nbx_svd_worksize(m, n)
+        work = self._workspace("svd", nbytes)
+        s = self.empty((min(m, n),))
+        vt = self.empty((n, n))
+        self._call("nbx_svd_right", m, n, self._p(a), self._p(s), self._p(vt), self._p(work), work.numel())
+        if check:
+            sweeps = (c_int * 1)()
+            self._call("nbx_svd_status", m, n, self._p(work), sweeps)
+            self.last_svd_sweeps = sweeps[0]
+        return s, vt
+
+    # ------------------------------------------------------------------ four-index transform
+    def ao2mo(self, eri, c1, c2, c3, c4, i0: int = 0, i1: int | None = None):
+        """(i1-i0, n2, n3, n4) chemist-order MO integrals (nbx_ao2mo)."""
+        nao = c1.shape[0]
+        n1, n2, n3, n4 = c1.shape[1], c2.shape[1], c3.shape[1], c4.shape[1]
+        i1 = n1 if i1 is None else i1
+        nbytes = self.lib.nbx_ao2mo_worksize(nao, i1 - i0, n2, n3, n4)
+        work = self._workspace("ao2mo", nbytes)
+        out = self.empty((i1 - i0, n2, n3, n4))
+        self._call("nbx_ao2mo", nao, self._p(eri), self._p(c1), n1, i0, i1, self._p(c2), n2, self._p(c3), n3,
+                   self._p(c4), n4, self._p(out), self._p(work), work.numel())
+        return out
+
+    def chem_to_phys(self, x):
+        n1, n2, n3, n4 = x.shape
+        out = self.empty((n1, n3, n4, n2))
+        self._call("nbx_chem_to_phys", n1, n2, n3, n4, self._p(x), self._p(out))
+        return out
+
+    def spinorb_scatter(self, one_body, two_body, tol: float, h2_scale: float):
+        n = one_body.shape[-1]
+        h1 = self.empty((2 * n, 2 * n))
+        h2 = self.empty((2 * n, 2 * n, 2 * n, 2 * n))
+        self._call("nbx_spinorb_scatter", n, self._p(one_body), self._p(two_body), tol, h2_scale, self._p(h1),
+                   self._p(h2))
+        return h1, h2

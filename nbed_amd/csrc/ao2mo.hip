@@ -1,0 +1,75 @@
+// libnbx: AO -> MO four-index transform (include/nbx.h "four-index transform").
+//
+//   (ij|kl) = sum_pqrs C1_pi C2_qj C3_rk C4_sl (pq|rs)          i in [i0, i1)
+//
+// Four sequential quarter transforms, each one (batched) fp64 MFMA GEMM (gemm.hip):
+//   Q1  X1[i,(qrs)]   = C1^T (ni x N)   . ERI  (N x N^3)                 2 ni N^4      flop
+//   Q2  X2[i][j,(rs)] = C2^T (n2 x N)   . X1[i] (N x N^2)    batch ni     2 ni n2 N^3
+//   Q3  X3[ij][k,s]   = C3^T (n3 x N)   . X2[ij] (N x N)     batch ni*n2  2 ni n2 n3 N^2
+//   Q4  out[(ijk),l]  = X3 (ni n2 n3 x N) . C4 (N x n4)                   2 ni n2 n3 n4 N
+// No permutational symmetry is used (SURVEY.md section 8d flop count).  The contiguous ERI
+// index s stays the fastest index of every intermediate, so all GEMM operand loads are
+// coalesced.  The outer MO index i is the multi-GPU shard axis: a rank transforms its own
+// i-slab against the full ERI and the slabs are all-gathered by the host.
+#include "nbx_common.h"
+
+namespace {
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Ao2moPlan {
+    size_t a_doubles, b_doubles;
+};
+
+Ao2moPlan plan(int64_t N, int64_t ni, int64_t n2, int64_t n3) {
+    Ao2moPlan p;
+    const size_t x1 = (size_t)ni * N * N * N;
+    const size_t x3 = (size_t)ni * n2 * n3 * N;
+    p.a_doubles = x1 > x3 ? x1 : x3;
+    p.b_doubles = (size_t)ni * n2 * N * N;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t nbx_ao2mo_worksize(int64_t nao, int64_t ni, int64_t n2, int64_t n3, int64_t n4) {
+    (void)n4;
+    if (nao <= 0 || ni <= 0 || n2 <= 0 || n3 <= 0) return 0;
+    const Ao2moPlan p = plan(nao, ni, n2, n3);
+    return align256(p.a_doubles * sizeof(double)) + align256(p.b_doubles * sizeof(double));
+}
+
+extern "C" int nbx_ao2mo(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c1, int64_t n1,
+                         int64_t i0, int64_t i1, const double* d_c2, int64_t n2, const double* d_c3, int64_t n3,
+                         const double* d_c4, int64_t n4, double* d_out, void* d_work, size_t work_bytes) {
+    NBX_CHECK_ARG(ctx && d_eri && d_c1 && d_c2 && d_c3 && d_c4 && d_out);
+    NBX_CHECK_ARG(nao > 0 && n1 > 0 && n2 > 0 && n3 > 0 && n4 > 0);
+    NBX_CHECK_ARG(i0 >= 0 && i1 >= i0 && i1 <= n1);
+    const int64_t ni = i1 - i0;
+    if (ni == 0) return NBX_OK;
+    const int64_t N = nao;
+    if (N * N * N >= (1ll << 31)) {
+        nbx_set_error("nbx_ao2mo: dense path needs N^3 < 2^31 (N=%lld)", (long long)N);
+        return NBX_E_UNSUPPORTED;
+    }
+    const size_t need = nbx_ao2mo_worksize(N, ni, n2, n3, n4);
+    if (d_work == nullptr || work_bytes < need) {
+        nbx_set_error("nbx_ao2mo: workspace %zu < %zu bytes", work_bytes, need);
+        return NBX_E_NOMEM;
+    }
+    const Ao2moPlan p = plan(N, ni, n2, n3);
+    double* bufA = static_cast<double*>(d_work);
+    double* bufB = reinterpret_cast<double*>(static_cast<char*>(d_work) + align256(p.a_doubles * sizeof(double)));
+    const int64_t N2 = N * N, N3 = N2 * N;
+    int rc;
+    // Q1
+    rc = nbx_gemm(ctx, 'T', 'N', ni, N3, N, 1.0, d_c1 + i0, n1, 0, d_eri, N3, 0, 0.0, bufA, N3, 0, 1);
+    if (rc != NBX_OK) return rc;
+    // Q2
+    rc = nbx_gemm(ctx, 'T', 'N', n2, N2, N, 1.0, d_c2, n2, 0, bufA, N2, N3, 0.0, bufB, N2, n2 * N2, ni);
+    if (rc != NBX_OK) return rc;
+    // Q3
+    rc = nbx_gemm(ctx, 'T', 'N', n3, N, N, 1.0, d_c3, n3, 0, bufB, N, N2, 0.0, bufA, N, n3 * N, ni * n2);
+    if (rc != NBX_OK) return rc;
+    // Q4
+    rc = nbx_gemm(ctx, 'N', 'N', ni * n2 * n3, n4, N, 1.0, bufA, N, 0, d_c4, n4, 0, 0.0, d_out, n4, 0, 1);
+    return rc;
+}

@@ -1,0 +1,148 @@
+// libnbx: context, memory and error plumbing (include/nbx.h, "context" section).
+#include "nbx_common.h"
+
+static thread_local char g_err[512] = "";
+
+void nbx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int nbx_version(void) { return NBX_VERSION; }
+
+const char* nbx_last_error(void) { return g_err; }
+
+int nbx_device_count(int* count) {
+    NBX_CHECK_ARG(count != nullptr);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        nbx_set_error("nbx_device_count: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return NBX_E_HIP;
+    }
+    *count = n;
+    return NBX_OK;
+}
+
+int nbx_ctx_create(int device, void* stream, int private_stream, nbx_ctx** out) {
+    NBX_CHECK_ARG(out != nullptr);
+    NBX_CHECK_ARG(device >= 0);
+    int n = 0;
+    NBX_HIP(hipGetDeviceCount(&n));
+    if (device >= n) {
+        nbx_set_error("nbx_ctx_create: device %d not present (%d visible)", device, n);
+        return NBX_E_INVALID;
+    }
+    NBX_HIP(hipSetDevice(device));
+    nbx_ctx* c = new nbx_ctx();
+    c->device = device;
+    c->own_stream = (private_stream != 0);
+    if (c->own_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            nbx_set_error("nbx_ctx_create: hipStreamCreate -> %s", hipGetErrorString(e));
+            return NBX_E_HIP;
+        }
+    } else {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+    }
+    c->d_scratch = nullptr;
+    c->h_pinned = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_scratch), NBX_SCRATCH_DOUBLES * sizeof(double)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), NBX_SCRATCH_DOUBLES * sizeof(double), 0) != hipSuccess) {
+        nbx_set_error("nbx_ctx_create: scratch allocation failed");
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return NBX_E_NOMEM;
+    }
+    *out = c;
+    return NBX_OK;
+}
+
+int nbx_ctx_destroy(nbx_ctx* ctx) {
+    if (ctx == nullptr) return NBX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return NBX_OK;
+}
+
+int nbx_ctx_set_stream(nbx_ctx* ctx, void* stream) {
+    NBX_CHECK_ARG(ctx != nullptr);
+    if (ctx->own_stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->own_stream = false;
+    }
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    return NBX_OK;
+}
+
+int nbx_sync(nbx_ctx* ctx) {
+    NBX_CHECK_ARG(ctx != nullptr);
+    NBX_HIP(hipStreamSynchronize(ctx->stream));
+    return NBX_OK;
+}
+
+int nbx_malloc(nbx_ctx* ctx, size_t bytes, void** d_ptr) {
+    NBX_CHECK_ARG(ctx != nullptr && d_ptr != nullptr);
+    NBX_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 8);
+    if (e != hipSuccess) {
+        nbx_set_error("nbx_malloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return NBX_E_NOMEM;
+    }
+    return NBX_OK;
+}
+
+int nbx_free(nbx_ctx* ctx, void* d_ptr) {
+    NBX_CHECK_ARG(ctx != nullptr);
+    if (d_ptr == nullptr) return NBX_OK;
+    NBX_HIP(hipFree(d_ptr));
+    return NBX_OK;
+}
+
+int nbx_memcpy_h2d(nbx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    NBX_CHECK_ARG(ctx != nullptr && (bytes == 0 || (d_dst != nullptr && h_src != nullptr)));
+    if (bytes == 0) return NBX_OK;
+    NBX_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // pageable source: make the call safe to return from
+    NBX_HIP(hipStreamSynchronize(ctx->stream));
+    return NBX_OK;
+}
+
+int nbx_memcpy_d2h(nbx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    NBX_CHECK_ARG(ctx != nullptr && (bytes == 0 || (h_dst != nullptr && d_src != nullptr)));
+    if (bytes == 0) return NBX_OK;
+    NBX_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    NBX_HIP(hipStreamSynchronize(ctx->stream));
+    return NBX_OK;
+}
+
+int nbx_memcpy_d2d(nbx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+    NBX_CHECK_ARG(ctx != nullptr && (bytes == 0 || (d_dst != nullptr && d_src != nullptr)));
+    if (bytes == 0) return NBX_OK;
+    NBX_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return NBX_OK;
+}
+
+int nbx_memset(nbx_ctx* ctx, void* d_ptr, int value, size_t bytes) {
+    NBX_CHECK_ARG(ctx != nullptr && (bytes == 0 || d_ptr != nullptr));
+    if (bytes == 0) return NBX_OK;
+    NBX_HIP(hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
+    return NBX_OK;
+}
+
+}  // extern "C"

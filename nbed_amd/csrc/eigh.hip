@@ -1,0 +1,269 @@
+// libnbx: batched symmetric eigensolver (include/nbx.h "symmetric eigensolver").
+//
+// Cyclic two-sided Jacobi with the round-robin ("chess tournament") parallel ordering,
+// one workgroup per matrix.  The rows/columns are kept PHYSICALLY permuted so that the
+// N/2 disjoint pivot pairs of a step are always the adjacent index pairs (2k, 2k+1):
+//   * every 2x2 block (I,K) of A is then two 16-byte loads, rotated independently of all
+//     other blocks as  J_I^T A_IK J_K  -- no reductions, no atomics;
+//   * the results are scattered to the next step's positions (ping-pong buffers), so one
+//     barrier separates the steps.
+// Eigenvectors: V <- V J with the same column permutation.  Rotation angles use
+// Rutishauser's formulas; a pivot is skipped once |a_pq| <= eps * sqrt(|a_pp a_qq|), which
+// preserves high relative accuracy on graded matrices (the mu-shifted Fock matrix has
+// eigenvalues of order 1e6 next to order 1).  Converged when a whole sweep rotates nothing.
+//
+// Matrices live in global memory (L2-resident: 4 * N^2 doubles of workspace per matrix);
+// the solver is latency-bound for the N <= ~400 of the dense-ERI regime.
+#include "nbx_common.h"
+
+namespace {
+
+constexpr int EIGH_THREADS = 1024;
+constexpr int EIGH_MAX_SWEEPS = 40;
+constexpr double EIGH_PAD_VALUE = 1.0e300;
+
+// next-step position of the row/column currently at position i (m = number of pairs)
+__device__ __forceinline__ int rr_next(int i, int m) {
+    if (m == 1) return i;
+    const int k = i >> 1;
+    if ((i & 1) == 0) {  // top row
+        if (k == 0) return 0;
+        if (k == m - 1) return 2 * m - 1;
+        return 2 * (k + 1);
+    }
+    // bottom row
+    if (k == 0) return 2;
+    return 2 * k - 1;
+}
+
+__global__ __launch_bounds__(EIGH_THREADS) void eigh_jacobi_kernel(const double* __restrict__ a_in, int N,
+                                                                   double* __restrict__ w_out,
+                                                                   double* __restrict__ v_out,
+                                                                   double* __restrict__ work,
+                                                                   int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int NP = (N + 1) & ~1;
+    const int m = NP / 2;
+    double* cs = smem;            // [3*m]: c, s, t per pair
+    double* dg = cs + 3 * m;      // [NP] diagonal (sorting)
+    int* rank = reinterpret_cast<int*>(dg + NP);  // [NP]
+    int& nrot = rank[NP];            // rotations in the current sweep
+    int& nrot_step = rank[NP + 1];   // rotations in the current step
+
+    const int b = blockIdx.x;
+    const int64_t np2 = (int64_t)NP * NP;
+    a_in += (int64_t)b * N * N;
+    w_out += (int64_t)b * N;
+    v_out += (int64_t)b * N * N;
+    double* A0 = work + (int64_t)b * 4 * np2;
+    double* A1 = A0 + np2;
+    double* V0 = A1 + np2;
+    double* V1 = V0 + np2;
+
+    const int tid = threadIdx.x;
+    for (int64_t i = tid; i < np2; i += EIGH_THREADS) {
+        const int r = (int)(i / NP), c = (int)(i - (int64_t)r * NP);
+        double v = 0.0;
+        if (r < N && c < N) v = a_in[(int64_t)r * N + c];
+        else if (r == c) v = EIGH_PAD_VALUE;
+        A0[i] = v;
+        V0[i] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+    const double eps = 2.220446049250313e-16;
+    const int steps = (m == 1) ? 1 : NP - 1;
+    double* Ac = A0;
+    double* An = A1;
+    double* Vc = V0;
+    double* Vn = V1;
+    int sweep = 0;
+    bool converged = false;
+    for (; sweep < EIGH_MAX_SWEEPS && !converged; ++sweep) {
+        if (tid == 0) nrot = 0;
+        for (int step = 0; step < steps; ++step) {
+            if (tid == 0) nrot_step = 0;
+            __syncthreads();
+            // ---- phase A: rotation parameters of the m adjacent pairs
+            if (tid < m) {
+                const int p = 2 * tid;
+                const double app = Ac[(int64_t)p * NP + p];
+                const double aqq = Ac[(int64_t)(p + 1) * NP + p + 1];
+                const double apq = Ac[(int64_t)p * NP + p + 1];
+                double c = 1.0, s = 0.0, t = 0.0;
+                const double aa = fabs(apq);
+                if (aa > eps * sqrt(fabs(app) * fabs(aqq)) && aa > 1.0e-290) {
+                    const double theta = (aqq - app) / (2.0 * apq);
+                    const double at = fabs(theta);
+                    t = 1.0 / (at + sqrt(at * at + 1.0));
+                    if (at > 1.0e150) t = 0.5 / at;
+                    if (theta < 0.0) t = -t;
+                    c = 1.0 / sqrt(t * t + 1.0);
+                    s = t * c;
+                    atomicAdd(&nrot_step, 1);
+                }
+                cs[3 * tid] = c;
+                cs[3 * tid + 1] = s;
+                cs[3 * tid + 2] = t;
+            }
+            __syncthreads();
+            const bool any = nrot_step > 0;
+            if (tid == 0 && any) nrot += nrot_step;
+            // ---- phase B: A' = P^T (J^T A J) P,  V' = V J P
+            for (int item = tid; item < m * m; item += EIGH_THREADS) {
+                const int I = item / m, K = item - I * m;
+                const double2 r0 = *reinterpret_cast<const double2*>(Ac + (int64_t)(2 * I) * NP + 2 * K);
+                const double2 r1 = *reinterpret_cast<const double2*>(Ac + (int64_t)(2 * I + 1) * NP + 2 * K);
+                double b00 = r0.x, b01 = r0.y, b10 = r1.x, b11 = r1.y;
+                if (any) {
+                    const double ci = cs[3 * I], si = cs[3 * I + 1];
+                    const double ck = cs[3 * K], sk = cs[3 * K + 1];
+                    if (I == K) {
+                        const double t = cs[3 * I + 2];
+                        b00 = r0.x - t * r0.y;
+                        b11 = r1.y + t * r0.y;
+                        if (t != 0.0) {
+                            b01 = 0.0;
+                            b10 = 0.0;
+                        }
+                    } else {
+                        // rows: J_I^T = [[c,-s],[s,c]]
+                        const double u00 = ci * r0.x - si * r1.x, u01 = ci * r0.y - si * r1.y;
+                        const double u10 = si * r0.x + ci * r1.x, u11 = si * r0.y + ci * r1.y;
+                        // cols: J_K = [[c,s],[-s,c]]
+                        b00 = u00 * ck - u01 * sk;
+                        b01 = u00 * sk + u01 * ck;
+                        b10 = u10 * ck - u11 * sk;
+                        b11 = u10 * sk + u11 * ck;
+                    }
+                }
+                const int ri0 = rr_next(2 * I, m), ri1 = rr_next(2 * I + 1, m);
+                const int ck0 = rr_next(2 * K, m), ck1 = rr_next(2 * K + 1, m);
+                An[(int64_t)ri0 * NP + ck0] = b00;
+                An[(int64_t)ri0 * NP + ck1] = b01;
+                An[(int64_t)ri1 * NP + ck0] = b10;
+                An[(int64_t)ri1 * NP + ck1] = b11;
+            }
+            for (int item = tid; item < NP * m; item += EIGH_THREADS) {
+                const int r = item / m, K = item - r * m;
+                const double2 v = *reinterpret_cast<const double2*>(Vc + (int64_t)r * NP + 2 * K);
+                double v0 = v.x, v1 = v.y;
+                if (any) {
+                    const double ck = cs[3 * K], sk = cs[3 * K + 1];
+                    v0 = ck * v.x - sk * v.y;
+                    v1 = sk * v.x + ck * v.y;
+                }
+                Vn[(int64_t)r * NP + rr_next(2 * K, m)] = v0;
+                Vn[(int64_t)r * NP + rr_next(2 * K + 1, m)] = v1;
+            }
+            __syncthreads();
+            double* tA = Ac; Ac = An; An = tA;
+            double* tV = Vc; Vc = Vn; Vn = tV;
+        }
+        __syncthreads();
+        converged = (nrot == 0);
+        __syncthreads();
+    }
+
+    // ---- sort ascending and write out (padded index carries EIGH_PAD_VALUE -> last)
+    for (int i = tid; i < NP; i += EIGH_THREADS) dg[i] = Ac[(int64_t)i * NP + i];
+    __syncthreads();
+    for (int i = tid; i < NP; i += EIGH_THREADS) {
+        const double di = dg[i];
+        int rk = 0;
+        for (int j = 0; j < NP; ++j) {
+            const double dj = dg[j];
+            rk += (dj < di || (dj == di && j < i)) ? 1 : 0;
+        }
+        rank[i] = rk;
+        if (rk < N) w_out[rk] = di;
+    }
+    __syncthreads();
+    for (int64_t item = tid; item < (int64_t)N * NP; item += EIGH_THREADS) {
+        const int r = (int)(item / NP), i = (int)(item - (int64_t)r * NP);
+        const int rk = rank[i];
+        if (rk < N) v_out[(int64_t)r * N + rk] = Vc[(int64_t)r * NP + i];
+    }
+    if (tid == 0) status[b] = converged ? sweep : -sweep;
+}
+
+__global__ void pow_kernel(int64_t n, double p, const double* __restrict__ w, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pow(w[i], p);
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" size_t nbx_eigh_worksize(int64_t n, int64_t batch) {
+    if (n <= 0 || batch <= 0) return 0;
+    const int64_t np = (n + 1) & ~1ll;
+    return align256((size_t)(4 * np * np * batch) * sizeof(double)) + align256((size_t)batch * sizeof(int));
+}
+
+extern "C" int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
+                        void* d_work, size_t work_bytes) {
+    NBX_CHECK_ARG(ctx && d_a && d_w && d_v && n > 0 && batch > 0 && batch <= 1024);
+    NBX_CHECK_ARG(n <= 4096);
+    const size_t need = nbx_eigh_worksize(n, batch);
+    if (d_work == nullptr || work_bytes < need) {
+        nbx_set_error("nbx_eigh: workspace %zu < %zu bytes", work_bytes, need);
+        return NBX_E_NOMEM;
+    }
+    NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
+    const int64_t np = (n + 1) & ~1ll;
+    double* work = static_cast<double*>(d_work);
+    int* status = reinterpret_cast<int*>(static_cast<char*>(d_work) +
+                                         align256((size_t)(4 * np * np * batch) * sizeof(double)));
+    const size_t lds = (size_t)(3 * (np / 2) + np) * sizeof(double) + (size_t)(np + 2) * sizeof(int);
+    hipLaunchKernelGGL(eigh_jacobi_kernel, dim3((unsigned)batch), dim3(EIGH_THREADS), lds, ctx->stream, d_a, (int)n,
+                       d_w, d_v, work, status);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+extern "C" int nbx_eigh_status(nbx_ctx* ctx, int64_t n, int64_t batch, const void* d_work, int* h_sweeps) {
+    NBX_CHECK_ARG(ctx && d_work && h_sweeps && n > 0 && batch > 0);
+    const int64_t np = (n + 1) & ~1ll;
+    const char* status = static_cast<const char*>(d_work) + align256((size_t)(4 * np * np * batch) * sizeof(double));
+    int rc = nbx_memcpy_d2h(ctx, h_sweeps, status, (size_t)batch * sizeof(int));
+    if (rc != NBX_OK) return rc;
+    for (int64_t b = 0; b < batch; ++b)
+        if (h_sweeps[b] <= 0) {
+            nbx_set_error("nbx_eigh: matrix %lld did not converge in %d sweeps", (long long)b, -h_sweeps[b]);
+            return NBX_E_NOCONV;
+        }
+    return NBX_OK;
+}
+
+extern "C" size_t nbx_sym_pow_worksize(int64_t n) {
+    if (n <= 0) return 0;
+    return nbx_eigh_worksize(n, 1) + align256((size_t)(2 * n * n + 2 * n) * sizeof(double));
+}
+
+extern "C" int nbx_sym_pow(nbx_ctx* ctx, int64_t n, const double* d_s, double p, double* d_out, void* d_work,
+                           size_t work_bytes) {
+    NBX_CHECK_ARG(ctx && d_s && d_out && n > 0);
+    const size_t need = nbx_sym_pow_worksize(n);
+    if (d_work == nullptr || work_bytes < need) {
+        nbx_set_error("nbx_sym_pow: workspace %zu < %zu bytes", work_bytes, need);
+        return NBX_E_NOMEM;
+    }
+    char* base = static_cast<char*>(d_work);
+    const size_t ew = nbx_eigh_worksize(n, 1);
+    double* u = reinterpret_cast<double*>(base + ew);  // eigenvectors
+    double* us = u + n * n;                             // U * diag(w^p)
+    double* w = us + n * n;
+    double* wp = w + n;
+    int rc = nbx_eigh(ctx, n, 1, d_s, w, u, base, ew);
+    if (rc != NBX_OK) return rc;
+    hipLaunchKernelGGL(pow_kernel, dim3((unsigned)nbx_cdiv(n, 256)), dim3(256), 0, ctx->stream, n, p, w, wp);
+    NBX_LAUNCH_CHECK();
+    rc = nbx_memcpy_d2d(ctx, us, u, (size_t)(n * n) * sizeof(double));
+    if (rc != NBX_OK) return rc;
+    rc = nbx_scale_cols(ctx, n, n, 1, wp, us);
+    if (rc != NBX_OK) return rc;
+    // out = (U diag(w^p)) U^T
+    return nbx_gemm(ctx, 'N', 'T', n, n, n, 1.0, us, n, 0, u, n, 0, 0.0, d_out, n, 0, 1);
+}

@@ -1,0 +1,403 @@
+// libnbx: Fock assembly, Huzinaga symmetrisation, trace/energy reductions, DIIS vector
+// algebra, transposes and the spin-orbital scatter (include/nbx.h).
+// All of these are O(N^2) (or O(n^4) for the scatter) and HBM/L2-bound: coalesced
+// accesses, transposed operands staged through a padded LDS tile, wavefront
+// reductions for the scalar outputs.
+#include "nbx_common.h"
+
+namespace {
+
+constexpr int TILE = 32;
+
+// ---------------------------------------------------------------- reductions
+// Stage 2 of every scalar reduction: out[o] = sum_b partial[b * nout + o] (fixed order).
+__global__ void final_reduce_kernel(const double* __restrict__ partial, int nblocks, int nout,
+                                    double* __restrict__ out) {
+    __shared__ double red[17];
+    for (int o = 0; o < nout; ++o) {
+        double t = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) t += partial[(int64_t)b * nout + o];
+        t = nbx_block_sum(t, red);
+        if (threadIdx.x == 0) out[o] = t;
+        __syncthreads();
+    }
+}
+
+// Load the TILE x TILE tile of M (N x N, row-major) whose top-left corner is (r0, c0)
+// into lds[r][c] (zero padded).  blockDim = (TILE, 8).
+__device__ __forceinline__ void load_tile(const double* __restrict__ M, int N, int r0, int c0,
+                                          double (*lds)[TILE + 1]) {
+    for (int r = threadIdx.y; r < TILE; r += blockDim.y) {
+        const int gr = r0 + r, gc = c0 + threadIdx.x;
+        lds[r][threadIdx.x] = (gr < N && gc < N) ? M[(int64_t)gr * N + gc] : 0.0;
+    }
+}
+
+// out[b] partial: sum_ij A[i,j] B[j,i] over one tile pair.
+__global__ void trace_prod_kernel(const double* __restrict__ A, const double* __restrict__ B, int N,
+                                  double* __restrict__ partial) {
+    __shared__ double bt[TILE][TILE + 1];
+    __shared__ double red[17];
+    const int b = blockIdx.z;
+    const int64_t n2 = (int64_t)N * N;
+    A += b * n2;
+    B += b * n2;
+    const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
+    load_tile(B, N, j0, i0, bt);  // bt[j][i] = B[j0+j][i0+i]
+    __syncthreads();
+    double acc = 0.0;
+    for (int r = threadIdx.y; r < TILE; r += blockDim.y) {
+        const int gi = i0 + r, gj = j0 + threadIdx.x;
+        if (gi < N && gj < N) acc = fma(A[(int64_t)gi * N + gj], bt[threadIdx.x][r], acc);
+    }
+    // flatten the 2-D block for the block reduction
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    double v = nbx_wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x * blockDim.y) / 64; ++w) t += red[w];
+        const int nblk = gridDim.x * gridDim.y;
+        partial[(int64_t)b * nblk + blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// F[x] = h + v[x] + J - K[x] ; vhf[x] = J - K[x]
+__global__ void fock_uhf_kernel(const double* __restrict__ h, int h3d, const double* __restrict__ vemb,
+                                const double* __restrict__ jk, double* __restrict__ fock,
+                                double* __restrict__ vhf, int64_t n2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    const double j = jk[i];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const double v = j - jk[(1 + x) * n2 + i];
+        double f = h[h3d ? x * n2 + i : i] + v;
+        if (vemb) f += vemb[x * n2 + i];
+        fock[x * n2 + i] = f;
+        if (vhf) vhf[x * n2 + i] = v;
+    }
+}
+
+// Hz = -kappa (FDS + FDS^T); optionally F += Hz
+__global__ void huzinaga_sym_kernel(const double* __restrict__ fds, int N, double kappa,
+                                    double* __restrict__ hz, double* __restrict__ fock) {
+    __shared__ double t[TILE][TILE + 1];
+    const int b = blockIdx.z;
+    const int64_t n2 = (int64_t)N * N;
+    fds += b * n2;
+    hz += b * n2;
+    if (fock) fock += b * n2;
+    const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
+    load_tile(fds, N, j0, i0, t);  // t[j][i] = FDS[j0+j][i0+i]
+    __syncthreads();
+    for (int r = threadIdx.y; r < TILE; r += blockDim.y) {
+        const int gi = i0 + r, gj = j0 + threadIdx.x;
+        if (gi < N && gj < N) {
+            const int64_t o = (int64_t)gi * N + gj;
+            const double v = -kappa * (fds[o] + t[threadIdx.x][r]);
+            hz[o] = v;
+            if (fock) fock[o] += v;
+        }
+    }
+}
+
+// partial[blk*4 + {0,1}] = sum (h + v + 0.5 vhf + hz)[x][i,j] * D[x][j,i];  [2,3] = sum (D-Dold)^2
+__global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const double* __restrict__ vemb,
+                                   const double* __restrict__ vhf, const double* __restrict__ hz,
+                                   const double* __restrict__ dm, const double* __restrict__ dm_old, int N,
+                                   double* __restrict__ partial) {
+    __shared__ double dt[TILE][TILE + 1];
+    __shared__ double red[4][4];
+    const int64_t n2 = (int64_t)N * N;
+    const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    double out[4];
+    for (int x = 0; x < 2; ++x) {
+        __syncthreads();
+        load_tile(dm + x * n2, N, j0, i0, dt);
+        __syncthreads();
+        double e = 0.0, d2 = 0.0;
+        for (int r = threadIdx.y; r < TILE; r += blockDim.y) {
+            const int gi = i0 + r, gj = j0 + threadIdx.x;
+            if (gi < N && gj < N) {
+                const int64_t o = (int64_t)gi * N + gj;
+                double ham = h[h3d ? x * n2 + o : o] + 0.5 * vhf[x * n2 + o] + hz[x * n2 + o];
+                if (vemb) ham += vemb[x * n2 + o];
+                e = fma(ham, dt[threadIdx.x][r], e);
+                const double dd = dm[x * n2 + o] - dm_old[x * n2 + o];
+                d2 = fma(dd, dd, d2);
+            }
+        }
+        out[x] = e;
+        out[2 + x] = d2;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double v = nbx_wave_sum(out[k]);
+        if ((tid & 63) == 0) red[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x * blockDim.y) / 64; ++w) t += red[w][tid];
+        partial[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + tid] = t;
+    }
+}
+
+__global__ void axpby_kernel(int64_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = (b == 0.0) ? a * x[i] : fma(a, x[i], b * y[i]);
+}
+
+constexpr int MAX_LINCOMB = 16;
+struct Coefs {
+    double c[MAX_LINCOMB];
+};
+
+__global__ void lincomb_kernel(int64_t n, int nvec, Coefs cf, const double* __restrict__ vecs, int64_t stride,
+                               double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double t = 0.0;
+        for (int k = 0; k < nvec; ++k) t = fma(cf.c[k], vecs[k * stride + i], t);
+        out[i] = t;
+    }
+}
+
+// partial[blk * nvec + k] = sum_i x[i] * vecs[k][i]
+__global__ void dots_kernel(int64_t n, int nvec, const double* __restrict__ x, const double* __restrict__ vecs,
+                            int64_t stride, double* __restrict__ partial) {
+    __shared__ double red[17];
+    for (int k = 0; k < nvec; ++k) {
+        double t = 0.0;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            t = fma(x[i], vecs[k * stride + i], t);
+        t = nbx_block_sum(t, red);
+        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * nvec + k] = t;
+        __syncthreads();
+    }
+}
+
+// B[b] (cols x rows) = A[b]^T (A: rows x cols)
+__global__ void transpose_kernel(const double* __restrict__ A, double* __restrict__ B, int64_t rows, int64_t cols) {
+    __shared__ double t[TILE][TILE + 1];
+    const int64_t b = blockIdx.z;
+    A += b * rows * cols;
+    B += b * rows * cols;
+    const int64_t r0 = (int64_t)blockIdx.y * TILE, c0 = (int64_t)blockIdx.x * TILE;
+    for (int r = threadIdx.y; r < TILE; r += blockDim.y) {
+        const int64_t gr = r0 + r, gc = c0 + threadIdx.x;
+        if (gr < rows && gc < cols) t[r][threadIdx.x] = A[gr * cols + gc];
+    }
+    __syncthreads();
+    for (int c = threadIdx.y; c < TILE; c += blockDim.y) {
+        const int64_t gc = c0 + c, gr = r0 + threadIdx.x;
+        if (gr < rows && gc < cols) B[gc * rows + gr] = t[threadIdx.x][c];
+    }
+}
+
+__global__ void scale_cols_kernel(int64_t rows, int64_t cols, const double* __restrict__ s, double* __restrict__ a) {
+    const int64_t b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    a[b * rows * cols + i] *= s[b * cols + (i % cols)];
+}
+
+// h2[P,Q,R,S] over the (2n)^4 output, coalesced stores (nbed/ham_builder.py:180-214)
+__global__ void spinorb_h2_kernel(int n, const double* __restrict__ tb, double tol, double scale,
+                                  double* __restrict__ h2, int64_t total) {
+    const int64_t nq = 2 * (int64_t)n;
+    const int64_t n4 = (int64_t)n * n * n * n;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t S = idx % nq;
+        int64_t t = idx / nq;
+        const int64_t R = t % nq;
+        t /= nq;
+        const int64_t Q = t % nq;
+        const int64_t P = t / nq;
+        const int sp = (int)(P & 1), sq = (int)(Q & 1), sr = (int)(R & 1), ss = (int)(S & 1);
+        int blk = -1;
+        if (sp == sq && sq == sr && sr == ss) blk = sp;          // aaaa -> 0, bbbb -> 1
+        else if (sp == 0 && sq == 1 && sr == 1 && ss == 0) blk = 2;  // [2p,2q+1,2r+1,2s] <- aabb block
+        else if (sp == 1 && sq == 0 && sr == 0 && ss == 1) blk = 3;  // [2p+1,2q,2r,2s+1] <- bbaa block
+        double v = 0.0;
+        if (blk >= 0) {
+            const int64_t p = P >> 1, q = Q >> 1, r = R >> 1, s = S >> 1;
+            v = tb[blk * n4 + ((p * n + q) * n + r) * n + s];
+            if (fabs(v) < tol) v = 0.0;
+            v *= scale;
+        }
+        h2[idx] = v;
+    }
+}
+
+__global__ void spinorb_h1_kernel(int n, const double* __restrict__ ob, double tol, double* __restrict__ h1) {
+    const int nq = 2 * n;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nq * nq) return;
+    const int P = idx / nq, Q = idx % nq;
+    double v = 0.0;
+    if ((P & 1) == (Q & 1)) {
+        v = ob[(int64_t)(P & 1) * n * n + (int64_t)(P >> 1) * n + (Q >> 1)];
+        if (fabs(v) < tol) v = 0.0;
+    }
+    h1[idx] = v;
+}
+
+inline unsigned grid1d(int64_t n, int block, int64_t cap = 65536) {
+    int64_t g = nbx_cdiv(n, block);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// second-stage reduce + copy to host (synchronises)
+int finish_reduction(nbx_ctx* ctx, int nblocks, int nout, double* h_out) {
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_scratch, nblocks, nout,
+                       ctx->d_scratch + NBX_SCRATCH_DOUBLES - 64);
+    NBX_LAUNCH_CHECK();
+    NBX_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch + NBX_SCRATCH_DOUBLES - 64, nout * sizeof(double),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    NBX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < nout; ++i) h_out[i] = ctx->h_pinned[i];
+    return NBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbx_fock_uhf(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim, const double* d_vemb,
+                 const double* d_jk, double* d_fock, double* d_vhf) {
+    NBX_CHECK_ARG(ctx && d_hcore && d_jk && d_fock && nao > 0);
+    NBX_CHECK_ARG(hcore_ndim == 2 || hcore_ndim == 3);
+    const int64_t n2 = nao * nao;
+    hipLaunchKernelGGL(fock_uhf_kernel, dim3((unsigned)nbx_cdiv(n2, 256)), dim3(256), 0, ctx->stream, d_hcore,
+                       hcore_ndim == 3 ? 1 : 0, d_vemb, d_jk, d_fock, d_vhf, n2);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+int nbx_huzinaga_sym(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_fds, double kappa, double* d_hz,
+                     double* d_fock_io) {
+    NBX_CHECK_ARG(ctx && d_fds && d_hz && nao > 0 && batch > 0 && batch < 65536);
+    const unsigned g = (unsigned)nbx_cdiv(nao, TILE);
+    hipLaunchKernelGGL(huzinaga_sym_kernel, dim3(g, g, (unsigned)batch), dim3(TILE, 8), 0, ctx->stream, d_fds,
+                       (int)nao, kappa, d_hz, d_fock_io);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+int nbx_trace_prod(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_a, const double* d_b,
+                   double* h_out) {
+    NBX_CHECK_ARG(ctx && d_a && d_b && h_out && nao > 0 && batch > 0);
+    const int64_t g = nbx_cdiv(nao, TILE);
+    NBX_CHECK_ARG(g * g <= NBX_SCRATCH_DOUBLES - 64 && batch <= 64);
+    // one batch entry at a time keeps the scratch small (batch is the spin axis: 1 or 2)
+    for (int64_t b = 0; b < batch; ++b) {
+        hipLaunchKernelGGL(trace_prod_kernel, dim3((unsigned)g, (unsigned)g, 1), dim3(TILE, 8), 0, ctx->stream,
+                           d_a + b * nao * nao, d_b + b * nao * nao, (int)nao, ctx->d_scratch);
+        NBX_LAUNCH_CHECK();
+        const int rc = finish_reduction(ctx, (int)(g * g), 1, h_out + b);
+        if (rc != NBX_OK) return rc;
+    }
+    return NBX_OK;
+}
+
+int nbx_huz_cycle_scalars(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
+                          const double* d_vemb, const double* d_vhf, const double* d_hz, const double* d_dm,
+                          const double* d_dm_old, double* h_out) {
+    NBX_CHECK_ARG(ctx && d_hcore && d_vhf && d_hz && d_dm && d_dm_old && h_out && nao > 0);
+    NBX_CHECK_ARG(hcore_ndim == 2 || hcore_ndim == 3);
+    const int64_t g = nbx_cdiv(nao, TILE);
+    NBX_CHECK_ARG(g * g * 4 <= NBX_SCRATCH_DOUBLES - 64);
+    hipLaunchKernelGGL(huz_scalars_kernel, dim3((unsigned)g, (unsigned)g), dim3(TILE, 8), 0, ctx->stream, d_hcore,
+                       hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch);
+    NBX_LAUNCH_CHECK();
+    const int rc = finish_reduction(ctx, (int)(g * g), 4, h_out);
+    if (rc != NBX_OK) return rc;
+    h_out[2] = sqrt(h_out[2]);
+    h_out[3] = sqrt(h_out[3]);
+    return NBX_OK;
+}
+
+int nbx_axpby(nbx_ctx* ctx, int64_t n, double a, const double* d_x, double b, double* d_y) {
+    NBX_CHECK_ARG(ctx && n >= 0);
+    if (n == 0) return NBX_OK;
+    NBX_CHECK_ARG(d_x && d_y);
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, n, a, d_x, b, d_y);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+int nbx_lincomb(nbx_ctx* ctx, int64_t n, int64_t nvec, const double* h_coef, const double* d_vecs,
+                int64_t stride, double* d_out) {
+    NBX_CHECK_ARG(ctx && n >= 0 && nvec > 0 && nvec <= MAX_LINCOMB && h_coef && d_vecs && d_out);
+    if (n == 0) return NBX_OK;
+    Coefs cf;
+    for (int k = 0; k < MAX_LINCOMB; ++k) cf.c[k] = k < nvec ? h_coef[k] : 0.0;
+    hipLaunchKernelGGL(lincomb_kernel, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, n, (int)nvec, cf, d_vecs,
+                       stride, d_out);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+int nbx_dots(nbx_ctx* ctx, int64_t n, int64_t nvec, const double* d_x, const double* d_vecs, int64_t stride,
+             double* h_out) {
+    NBX_CHECK_ARG(ctx && n > 0 && nvec > 0 && nvec <= MAX_LINCOMB && d_x && d_vecs && h_out);
+    const unsigned blocks = grid1d(n, 256, 128);
+    hipLaunchKernelGGL(dots_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, (int)nvec, d_x, d_vecs, stride,
+                       ctx->d_scratch);
+    NBX_LAUNCH_CHECK();
+    return finish_reduction(ctx, (int)blocks, (int)nvec, h_out);
+}
+
+int nbx_transpose(nbx_ctx* ctx, int64_t rows, int64_t cols, int64_t batch, const double* d_a, double* d_b) {
+    NBX_CHECK_ARG(ctx && rows >= 0 && cols >= 0 && batch >= 0);
+    if (rows == 0 || cols == 0 || batch == 0) return NBX_OK;
+    NBX_CHECK_ARG(d_a && d_b && d_a != d_b);
+    const int64_t gy = nbx_cdiv(rows, TILE), gx = nbx_cdiv(cols, TILE);
+    if (gy > 65535) {
+        nbx_set_error("nbx_transpose: more than 65535*32 rows per matrix is unsupported");
+        return NBX_E_UNSUPPORTED;
+    }
+    for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+        const int64_t nb = (batch - b0) < 65535 ? (batch - b0) : 65535;
+        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)nb), dim3(TILE, 8), 0,
+                           ctx->stream, d_a + b0 * rows * cols, d_b + b0 * rows * cols, rows, cols);
+        NBX_LAUNCH_CHECK();
+    }
+    return NBX_OK;
+}
+
+int nbx_scale_cols(nbx_ctx* ctx, int64_t rows, int64_t cols, int64_t batch, const double* d_s, double* d_a) {
+    NBX_CHECK_ARG(ctx && rows > 0 && cols > 0 && batch > 0 && batch < 65536 && d_s && d_a);
+    hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)nbx_cdiv(rows * cols, 256), (unsigned)batch), dim3(256), 0,
+                       ctx->stream, rows, cols, d_s, d_a);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+int nbx_chem_to_phys(nbx_ctx* ctx, int64_t n1, int64_t n2, int64_t n3, int64_t n4, const double* d_in,
+                     double* d_out) {
+    // out[a,c,d,b] = in[a,b,c,d]: per a, transpose the (n2) x (n3*n4) matrix
+    return nbx_transpose(ctx, n2, n3 * n4, n1, d_in, d_out);
+}
+
+int nbx_spinorb_scatter(nbx_ctx* ctx, int64_t n, const double* d_one_body, const double* d_two_body, double tol,
+                        double h2_scale, double* d_h1, double* d_h2) {
+    NBX_CHECK_ARG(ctx && n > 0 && n < 1024 && d_one_body && d_two_body && d_h1 && d_h2);
+    const int64_t nq = 2 * n;
+    hipLaunchKernelGGL(spinorb_h1_kernel, dim3((unsigned)nbx_cdiv(nq * nq, 256)), dim3(256), 0, ctx->stream, (int)n,
+                       d_one_body, tol, d_h1);
+    NBX_LAUNCH_CHECK();
+    const int64_t total = nq * nq * nq * nq;
+    hipLaunchKernelGGL(spinorb_h2_kernel, dim3(grid1d(total, 256, 8192)), dim3(256), 0, ctx->stream, (int)n,
+                       d_two_body, tol, h2_scale, d_h2, total);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+// libnbx: batched fp64 GEMM on the CDNA4 matrix cores (include/nbx.h "dense products").
+//
+//   C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]      row-major, op in {N, T}
+//
+// v_mfma_f64_16x16x4_f64 (one wave: 16x16 tile, K = 4):
+//   A operand: lane l holds A[i = l & 15][k = l >> 4]
+//   B operand: lane l holds B[k = l >> 4][j = l & 15]
+//   C/D      : 4 doubles per lane, reg r -> row (l >> 4) + 4 r, col l & 15
+// Workgroup = 4 waves (2 x 2); block tile BM x BN x 16 staged through LDS as
+// As[k][m] / Bs[k][n] with row stride (BM|BN) + 16 doubles so that the two
+// 16-lane groups a ds_read_b64 services together fall in different halves of the
+// 256-byte bank row (conflict-free fragment reads).  The next k-tile is fetched into
+// registers while the current one feeds the MFMAs.
+#include "nbx_common.h"
+
+namespace {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int GEMM_THREADS = 256;
+constexpr int BK = 16;
+constexpr int PAD = 16;
+
+// Stage one operand tile T[k][x] (k < BK, x < BX) where element (x, k) of op(.) lives at
+// base[x * sx + k * sk].  KCONTIG: memory is contiguous along k (sk == 1), else along x (sx == 1).
+template <int BX, bool KCONTIG>
+struct Stager {
+    static constexpr int PAIRS = BK * BX / 2;            // double2 items per tile
+    static constexpr int PER_THREAD = PAIRS / GEMM_THREADS;
+    static_assert(PAIRS % GEMM_THREADS == 0, "tile must divide evenly");
+    double2 reg[PER_THREAD];
+
+    __device__ __forceinline__ void load(const double* __restrict__ base, int64_t ld, int x0, int k0,
+                                         int xmax, int kmax, bool vec_ok) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int item = threadIdx.x + i * GEMM_THREADS;
+            int x, k;
+            if (KCONTIG) {  // pairs along k: BK/2 pairs per x
+                x = item / (BK / 2);
+                k = (item - x * (BK / 2)) * 2;
+            } else {  // pairs along x: BX/2 pairs per k
+                k = item / (BX / 2);
+                x = (item - k * (BX / 2)) * 2;
+            }
+            const int gx = x0 + x, gk = k0 + k;
+            double2 v = make_double2(0.0, 0.0);
+            if (KCONTIG) {
+                if (gx < xmax) {
+                    const double* p = base + (int64_t)gx * ld + gk;
+                    if (vec_ok && gk + 1 < kmax) {
+                        v = *reinterpret_cast<const double2*>(p);
+                    } else {
+                        if (gk < kmax) v.x = p[0];
+                        if (gk + 1 < kmax) v.y = p[1];
+                    }
+                }
+            } else {
+                if (gk < kmax) {
+                    const double* p = base + (int64_t)gk * ld + gx;
+                    if (vec_ok && gx + 1 < xmax) {
+                        v = *reinterpret_cast<const double2*>(p);
+                    } else {
+                        if (gx < xmax) v.x = p[0];
+                        if (gx + 1 < xmax) v.y = p[1];
+                    }
+                }
+            }
+            reg[i] = v;
+        }
+    }
+
+    __device__ __forceinline__ void store(double* __restrict__ tile /* [BK][BX+PAD] */) const {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int item = threadIdx.x + i * GEMM_THREADS;
+            if (KCONTIG) {
+                const int x = item / (BK / 2);
+                const int k = (item - x * (BK / 2)) * 2;
+                tile[k * (BX + PAD) + x] = reg[i].x;
+                tile[(k + 1) * (BX + PAD) + x] = reg[i].y;
+            } else {
+                const int k = item / (BX / 2);
+                const int x = (item - k * (BX / 2)) * 2;
+                *reinterpret_cast<double2*>(&tile[k * (BX + PAD) + x]) = reg[i];
+            }
+        }
+    }
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f64_kernel(
+    int M, int N, int K, double alpha, const double* __restrict__ A, int64_t lda, int64_t stride_a,
+    const double* __restrict__ B, int64_t ldb, int64_t stride_b, double beta, double* __restrict__ C,
+    int64_t ldc, int64_t stride_c, int vec_a, int vec_b) {
+    constexpr int WM = BM / 2, WN = BN / 2;  // 2 x 2 waves
+    constexpr int MT = WM / 16, NT = WN / 16;
+    __shared__ __attribute__((aligned(16))) double As[BK * (BM + PAD)];
+    __shared__ __attribute__((aligned(16))) double Bs[BK * (BN + PAD)];
+
+    const int batch = blockIdx.z;
+    A += (int64_t)batch * stride_a;
+    B += (int64_t)batch * stride_b;
+    C += (int64_t)batch * stride_c;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15;   // index inside the 16-wide fragment
+    const int fk = lane >> 4;   // k (A/B) or row group (C)
+
+    v4f64 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    Stager<BM, A_KC> sa;
+    Stager<BN, B_KC> sb;
+    const int nkt = (K + BK - 1) / BK;
+    sa.load(A, lda, m0, 0, M, K, vec_a);
+    sb.load(B, ldb, n0, 0, N, K, vec_b);
+    sa.store(As);
+    sb.store(Bs);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) {
+            sa.load(A, lda, m0, (kt + 1) * BK, M, K, vec_a);
+            sb.load(B, ldb, n0, (kt + 1) * BK, N, K, vec_b);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double af[MT], bf[NT];
+            const int krow = kk * 4 + fk;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = As[krow * (BM + PAD) + wr * WM + i * 16 + fr];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = Bs[krow * (BN + PAD) + wc * WN + j * 16 + fr];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            sa.store(As);
+            sb.store(Bs);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: lane holds rows fk + 4 r (r < 4), column fr of each 16 x 16 tile
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wc * WN + j * 16 + fr;
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr * WM + i * 16 + fk + 4 * r;
+                if (row < M) {
+                    double* c = C + (int64_t)row * ldc + col;
+                    const double v = alpha * acc[i][j][r];
+                    *c = (beta == 0.0) ? v : fma(beta, *c, v);
+                }
+            }
+        }
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int BM, int BN>
+void launch(nbx_ctx* ctx, bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, int64_t lda,
+            int64_t sa, const double* B, int64_t ldb, int64_t sb, double beta, double* C, int64_t ldc, int64_t sc,
+            int batch, int vec_a, int vec_b) {
+    dim3 grid((unsigned)nbx_cdiv(N, BN), (unsigned)nbx_cdiv(M, BM), (unsigned)batch);
+    dim3 block(GEMM_THREADS);
+#define NBX_GEMM_GO(AK, BKC)                                                                               \
+    hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, AK, BKC>), grid, block, 0, ctx->stream, M, N, K, alpha, A, \
+                       lda, sa, B, ldb, sb, beta, C, ldc, sc, vec_a, vec_b)
+    if (a_kc) {
+        if (b_kc) NBX_GEMM_GO(true, true);
+        else NBX_GEMM_GO(true, false);
+    } else {
+        if (b_kc) NBX_GEMM_GO(false, true);
+        else NBX_GEMM_GO(false, false);
+    }
+#undef NBX_GEMM_GO
+}
+
+}  // namespace
+
+extern "C" int nbx_gemm(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t n, int64_t k,
+                        double alpha, const double* d_a, int64_t lda, int64_t stride_a, const double* d_b,
+                        int64_t ldb, int64_t stride_b, double beta, double* d_c, int64_t ldc,
+                        int64_t stride_c, int64_t batch) {
+    NBX_CHECK_ARG(ctx != nullptr);
+    NBX_CHECK_ARG(trans_a == 'N' || trans_a == 'T' || trans_a == 'n' || trans_a == 't');
+    NBX_CHECK_ARG(trans_b == 'N' || trans_b == 'T' || trans_b == 'n' || trans_b == 't');
+    NBX_CHECK_ARG(m >= 0 && n >= 0 && k >= 0 && batch >= 0);
+    if (m == 0 || n == 0 || batch == 0) return NBX_OK;
+    NBX_CHECK_ARG(d_c != nullptr && ldc >= n);
+    NBX_CHECK_ARG(k == 0 || (d_a != nullptr && d_b != nullptr));
+    const bool ta = (trans_a == 'T' || trans_a == 't');
+    const bool tb = (trans_b == 'T' || trans_b == 't');
+    NBX_CHECK_ARG(k == 0 || lda >= (ta ? m : k));
+    NBX_CHECK_ARG(k == 0 || ldb >= (tb ? k : n));
+    NBX_CHECK_ARG(m < (1ll << 31) && n < (1ll << 31) && k < (1ll << 31));
+    // op(A)[m][k]: 'N' -> contiguous along k; 'T' -> contiguous along m.
+    const bool a_kc = !ta;
+    // op(B)[k][n]: 'N' -> contiguous along n; 'T' -> contiguous along k.
+    const bool b_kc = tb;
+    const int vec_a = (k > 0 && aligned16(d_a) && lda % 2 == 0 && stride_a % 2 == 0) ? 1 : 0;
+    const int vec_b = (k > 0 && aligned16(d_b) && ldb % 2 == 0 && stride_b % 2 == 0) ? 1 : 0;
+
+    // z-dimension of a grid is limited to 65535: loop over batch chunks
+    const int64_t zmax = 65535;
+    for (int64_t b0 = 0; b0 < batch; b0 += zmax) {
+        const int nb = (int)((batch - b0) < zmax ? (batch - b0) : zmax);
+        const double* A = d_a ? d_a + b0 * stride_a : nullptr;
+        const double* B = d_b ? d_b + b0 * stride_b : nullptr;
+        double* C = d_c + b0 * stride_c;
+        const int64_t tiles128 = nbx_cdiv(m, 128) * nbx_cdiv(n, 128) * nb;
+        if (tiles128 >= 512 && m > 64 && n > 64) {
+            launch<128, 128>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
+                             beta, C, ldc, stride_c, nb, vec_a, vec_b);
+        } else if (m <= 32 || n <= 32) {
+            launch<32, 32>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
+                           beta, C, ldc, stride_c, nb, vec_a, vec_b);
+        } else {
+            launch<64, 64>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
+                           beta, C, ldc, stride_c, nb, vec_a, vec_b);
+        }
+        NBX_LAUNCH_CHECK();
+    }
+    return NBX_OK;
+}

@@ -1,0 +1,324 @@
+// libnbx: dense J/K contraction (HBM-streaming), include/nbx.h "J/K contraction".
+//
+//   J_pq  = sum_rs (pq|rs) Dtot_rs          Dtot = sum_x D_x
+//   K^x_pb = sum_q sum_a (pq|ab) D^x_qa     (uses (pq|ab) = (pq|ba))
+//
+// Data layout in HBM: the ERI slab is the plain C-order (np,N,N,N) tensor, so the
+// (a,b) tile of a fixed (p,q) is N*N contiguous doubles.  One workgroup owns one p
+// and a chunk of q's; it streams each tile exactly once with 16-byte loads that are
+// contiguous across the workgroup (thread t always sees the same column pair b, so
+// the K accumulators live in registers and need no cross-lane reduction), three
+// FMAs per loaded double.  Algorithmic traffic: 8*N^4 bytes per J/K build
+// (SURVEY.md section 8d); 0.75 flop/byte => HBM-bound.
+//
+// Dtot (N*N doubles, read by every workgroup, served from L2) is loaded once per
+// group of QB tiles; the D rows the K update needs (QB rows per spin) sit in LDS.
+#include "nbx_common.h"
+
+namespace {
+
+constexpr int JK_THREADS = 256;
+constexpr int JK_QB = 4;
+
+template <bool VEC2>
+struct ColVec;
+template <>
+struct ColVec<true> {
+    using type = double2;
+    static constexpr int W = 2;
+};
+template <>
+struct ColVec<false> {
+    using type = double;
+    static constexpr int W = 1;
+};
+
+__device__ __forceinline__ double2 ld(const double2* p) { return *p; }
+__device__ __forceinline__ double ld(const double* p) { return *p; }
+__device__ __forceinline__ void fma_acc(double2& acc, double s, double2 v) {
+    acc.x = fma(s, v.x, acc.x);
+    acc.y = fma(s, v.y, acc.y);
+}
+__device__ __forceinline__ void fma_acc(double& acc, double s, double v) { acc = fma(s, v, acc); }
+__device__ __forceinline__ double dot_acc(double acc, double2 a, double2 b) {
+    return fma(a.y, b.y, fma(a.x, b.x, acc));
+}
+__device__ __forceinline__ double dot_acc(double acc, double a, double b) { return fma(a, b, acc); }
+__device__ __forceinline__ void zero(double2& v) { v.x = 0.0; v.y = 0.0; }
+__device__ __forceinline__ void zero(double& v) { v = 0.0; }
+
+// Stream QB tiles (q .. q+QB-1 of row p) and accumulate.
+//   tile0 : &eri[p_local][q][0][0]
+//   dsh   : LDS, dsh[(x*JK_QB + j)*N + a] = D^x[q+j][a]
+template <int QB, int NDM, int CS, bool VEC2>
+__device__ __forceinline__ void jk_group(const double* __restrict__ tile0, const double* __restrict__ dtot,
+                                         const double* dsh, int N, int row0, int rstep, int cx,
+                                         int cstep, int CX, double (&jacc)[JK_QB],
+                                         typename ColVec<VEC2>::type (&kacc)[NDM][CS]) {
+    using V = typename ColVec<VEC2>::type;
+    constexpr int W = ColVec<VEC2>::W;
+    const int64_t n2 = (int64_t)N * N;
+#pragma unroll
+    for (int seg = 0; seg < CS; ++seg) {
+        const int c = cx + seg * cstep;
+        if (c >= CX) break;
+        const int col = c * W;
+        int a = row0;
+        // two rows per trip: (QB+1)*2 independent 16-byte loads in flight per thread
+        for (; a + rstep < N; a += 2 * rstep) {
+            const int64_t o0 = (int64_t)a * N + col;
+            const int64_t o1 = o0 + (int64_t)rstep * N;
+            V t0[QB], t1[QB];
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                t0[j] = ld(reinterpret_cast<const V*>(tile0 + j * n2 + o0));
+                t1[j] = ld(reinterpret_cast<const V*>(tile0 + j * n2 + o1));
+            }
+            const V d0 = ld(reinterpret_cast<const V*>(dtot + o0));
+            const V d1 = ld(reinterpret_cast<const V*>(dtot + o1));
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                jacc[j] = dot_acc(jacc[j], t0[j], d0);
+                jacc[j] = dot_acc(jacc[j], t1[j], d1);
+#pragma unroll
+                for (int x = 0; x < NDM; ++x) {
+                    fma_acc(kacc[x][seg], dsh[(x * JK_QB + j) * N + a], t0[j]);
+                    fma_acc(kacc[x][seg], dsh[(x * JK_QB + j) * N + a + rstep], t1[j]);
+                }
+            }
+        }
+        if (a < N) {
+            const int64_t o0 = (int64_t)a * N + col;
+            V t0[QB];
+#pragma unroll
+            for (int j = 0; j < QB; ++j) t0[j] = ld(reinterpret_cast<const V*>(tile0 + j * n2 + o0));
+            const V d0 = ld(reinterpret_cast<const V*>(dtot + o0));
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                jacc[j] = dot_acc(jacc[j], t0[j], d0);
+#pragma unroll
+                for (int x = 0; x < NDM; ++x) fma_acc(kacc[x][seg], dsh[(x * JK_QB + j) * N + a], t0[j]);
+            }
+        }
+    }
+}
+
+template <int NDM, int CS, bool VEC2>
+__global__ __launch_bounds__(JK_THREADS) void jk_dense_kernel(
+    const double* __restrict__ eri, const double* __restrict__ dm, const double* __restrict__ dtot,
+    double* __restrict__ jout, double* __restrict__ kpart, int N, int np, int nqc, int qchunk) {
+    using V = typename ColVec<VEC2>::type;
+    constexpr int W = ColVec<VEC2>::W;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // smem: dsh[NDM*QB*N] | kred[R*NDM*N (CS==1) ] | red[17]
+    double* dsh = smem;
+    double* kred = dsh + NDM * JK_QB * N;
+
+    const int p_local = blockIdx.x / nqc;
+    const int qc = blockIdx.x - p_local * nqc;
+    const int q_begin = qc * qchunk;
+    const int q_end = min(N, q_begin + qchunk);
+
+    const int CX = (N + W - 1) / W;  // column groups per row
+    int R, rowg, cx, cstep;
+    bool active;
+    if (CS == 1) {
+        R = max(1, JK_THREADS / CX);
+        rowg = threadIdx.x / CX;
+        cx = threadIdx.x - rowg * CX;
+        active = rowg < R;
+        cstep = 0;
+    } else {
+        R = 1;
+        rowg = 0;
+        cx = threadIdx.x;
+        active = true;
+        cstep = JK_THREADS;
+    }
+    // `red` (block-reduction scratch) sits after kred; CS > 1 needs no kred at all
+    double* red = (CS == 1) ? kred + (size_t)R * NDM * N : kred;
+
+    V kacc[NDM][CS];
+#pragma unroll
+    for (int x = 0; x < NDM; ++x)
+#pragma unroll
+        for (int s = 0; s < CS; ++s) zero(kacc[x][s]);
+
+    const int64_t n2 = (int64_t)N * N;
+    const double* prow = eri + (int64_t)p_local * N * n2;
+
+    for (int q = q_begin; q < q_end; q += JK_QB) {
+        const int nq = min(JK_QB, q_end - q);
+        __syncthreads();  // previous group's dsh reads are done
+        for (int i = threadIdx.x; i < NDM * JK_QB * N; i += JK_THREADS) {
+            const int x = i / (JK_QB * N);
+            const int rem = i - x * JK_QB * N;
+            const int j = rem / N;
+            const int a = rem - j * N;
+            dsh[i] = (j < nq) ? dm[(int64_t)x * n2 + (int64_t)(q + j) * N + a] : 0.0;
+        }
+        __syncthreads();
+        double jacc[JK_QB] = {0.0, 0.0, 0.0, 0.0};
+        if (active) {
+            const double* tile0 = prow + (int64_t)q * n2;
+            if (nq == JK_QB) {
+                jk_group<JK_QB, NDM, CS, VEC2>(tile0, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc);
+            } else {
+                for (int j = 0; j < nq; ++j) {
+                    double j1[JK_QB] = {0.0, 0.0, 0.0, 0.0};
+                    jk_group<1, NDM, CS, VEC2>(tile0 + j * n2, dtot, dsh + j * N, N, rowg, R, cx, cstep,
+                                               CX, j1, kacc);
+                    jacc[j] = j1[0];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JK_QB; ++j) {
+            const double tot = nbx_block_sum(jacc[j], red);
+            if (threadIdx.x == 0 && j < nq) jout[(int64_t)p_local * N + q + j] = tot;
+        }
+    }
+
+    // K partials of this (p, q-chunk): reduce the R row groups through LDS, then store.
+    double* kout = kpart + ((int64_t)qc * NDM * np + p_local) * N;
+    if (CS == 1) {
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int x = 0; x < NDM; ++x) {
+                double* dst = kred + ((size_t)rowg * NDM + x) * N + cx * W;
+                *reinterpret_cast<V*>(dst) = kacc[x][0];
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NDM * N; i += JK_THREADS) {
+            const int x = i / N;
+            const int b = i - x * N;
+            double t = 0.0;
+            for (int g = 0; g < R; ++g) t += kred[((size_t)g * NDM + x) * N + b];
+            kout[(int64_t)x * np * N + b] = t;
+        }
+    } else {
+#pragma unroll
+        for (int x = 0; x < NDM; ++x)
+#pragma unroll
+            for (int s = 0; s < CS; ++s) {
+                const int c = cx + s * cstep;
+                if (c < CX) *reinterpret_cast<V*>(kout + (int64_t)x * np * N + c * W) = kacc[x][s];
+            }
+    }
+}
+
+// dtot = sum_x dm[x]
+__global__ void jk_dtot_kernel(const double* __restrict__ dm, double* __restrict__ dtot, int64_t n2, int ndm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    double t = dm[i];
+    for (int x = 1; x < ndm; ++x) t += dm[x * n2 + i];
+    dtot[i] = t;
+}
+
+// jk[1+x][p][b] = sum_c kpart[c][x][p][b]
+__global__ void jk_reduce_kernel(const double* __restrict__ kpart, double* __restrict__ kout, int64_t per_chunk,
+                                 int nqc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_chunk) return;
+    double t = 0.0;
+    for (int c = 0; c < nqc; ++c) t += kpart[c * per_chunk + i];
+    kout[i] = t;
+}
+
+struct JkPlan {
+    int nqc, qchunk, cs;
+    bool vec2;
+    size_t lds_bytes;
+};
+
+JkPlan jk_plan(int64_t N, int64_t np, int64_t ndm) {
+    JkPlan pl;
+    pl.vec2 = (N % 2 == 0);
+    const int64_t CX = pl.vec2 ? N / 2 : N;
+    pl.cs = CX <= JK_THREADS ? 1 : (CX <= 2 * JK_THREADS ? 2 : 4);
+    const int64_t groups = nbx_cdiv(N, JK_QB);
+    int64_t nqc = nbx_cdiv(2048, np > 0 ? np : 1);
+    if (nqc > groups) nqc = groups;
+    if (nqc < 1) nqc = 1;
+    const int64_t gpc = nbx_cdiv(groups, nqc);  // groups per chunk
+    pl.qchunk = (int)(gpc * JK_QB);
+    pl.nqc = (int)nbx_cdiv(N, pl.qchunk);
+    const int64_t R = pl.cs == 1 ? (JK_THREADS / CX > 0 ? JK_THREADS / CX : 1) : 0;
+    pl.lds_bytes = (size_t)(ndm * JK_QB * N + R * ndm * N + 17) * sizeof(double);
+    return pl;
+}
+
+}  // namespace
+
+extern "C" size_t nbx_jk_dense_worksize(int64_t nao, int64_t np, int64_t ndm) {
+    if (nao <= 0 || np < 0 || ndm <= 0) return 0;
+    const JkPlan pl = jk_plan(nao, np, ndm);
+    return (size_t)(nao * nao + (int64_t)pl.nqc * ndm * np * nao) * sizeof(double);
+}
+
+template <int NDM, int CS, bool VEC2>
+static void jk_launch(nbx_ctx* ctx, const JkPlan& pl, const double* eri, const double* dm, const double* dtot,
+                      double* jout, double* kpart, int N, int np) {
+    hipLaunchKernelGGL((jk_dense_kernel<NDM, CS, VEC2>), dim3((unsigned)(np * pl.nqc)), dim3(JK_THREADS),
+                       pl.lds_bytes, ctx->stream, eri, dm, dtot, jout, kpart, N, np, pl.nqc, pl.qchunk);
+}
+
+extern "C" int nbx_jk_dense(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri,
+                            const double* d_dm, int64_t ndm, double* d_jk, void* d_work,
+                            size_t work_bytes) {
+    NBX_CHECK_ARG(ctx != nullptr && d_eri != nullptr && d_dm != nullptr && d_jk != nullptr);
+    NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
+    NBX_CHECK_ARG(ndm == 1 || ndm == 2);
+    const int64_t np = p1 - p0;
+    if (np == 0) return NBX_OK;
+    if (nao > 2048 || (nao % 2 == 1 && nao > 1024)) {
+        nbx_set_error("nbx_jk_dense: N=%lld exceeds the dense-kernel limit (2048 even / 1024 odd)",
+                      (long long)nao);
+        return NBX_E_UNSUPPORTED;
+    }
+    const JkPlan pl = jk_plan(nao, np, ndm);
+    const size_t need = nbx_jk_dense_worksize(nao, np, ndm);
+    if (d_work == nullptr || work_bytes < need) {
+        nbx_set_error("nbx_jk_dense: workspace %zu < %zu bytes", work_bytes, need);
+        return NBX_E_NOMEM;
+    }
+    NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_eri) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
+    double* dtot = static_cast<double*>(d_work);
+    double* kpart = dtot + nao * nao;
+    const int64_t n2 = nao * nao;
+    hipLaunchKernelGGL(jk_dtot_kernel, dim3((unsigned)nbx_cdiv(n2, 256)), dim3(256), 0, ctx->stream, d_dm, dtot,
+                       n2, (int)ndm);
+    const int N = (int)nao;
+#define NBX_JK_CASE(NDM, CS, V2) jk_launch<NDM, CS, V2>(ctx, pl, d_eri, d_dm, dtot, d_jk, kpart, N, (int)np)
+    if (ndm == 2) {
+        if (pl.vec2) {
+            if (pl.cs == 1) NBX_JK_CASE(2, 1, true);
+            else if (pl.cs == 2) NBX_JK_CASE(2, 2, true);
+            else NBX_JK_CASE(2, 4, true);
+        } else {
+            if (pl.cs == 1) NBX_JK_CASE(2, 1, false);
+            else if (pl.cs == 2) NBX_JK_CASE(2, 2, false);
+            else NBX_JK_CASE(2, 4, false);
+        }
+    } else {
+        if (pl.vec2) {
+            if (pl.cs == 1) NBX_JK_CASE(1, 1, true);
+            else if (pl.cs == 2) NBX_JK_CASE(1, 2, true);
+            else NBX_JK_CASE(1, 4, true);
+        } else {
+            if (pl.cs == 1) NBX_JK_CASE(1, 1, false);
+            else if (pl.cs == 2) NBX_JK_CASE(1, 2, false);
+            else NBX_JK_CASE(1, 4, false);
+        }
+    }
+#undef NBX_JK_CASE
+    NBX_LAUNCH_CHECK();
+    const int64_t per_chunk = ndm * np * nao;
+    hipLaunchKernelGGL(jk_reduce_kernel, dim3((unsigned)nbx_cdiv(per_chunk, 256)), dim3(256), 0, ctx->stream,
+                       kpart, d_jk + np * nao, per_chunk, pl.nqc);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}

@@ -1,0 +1,70 @@
+// Internal helpers shared by the libnbx translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "nbx.h"
+
+struct nbx_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    double* d_scratch;      // small device scratch for reductions (NBX_SCRATCH_DOUBLES)
+    double* h_pinned;       // pinned host mirror of the scratch
+};
+
+constexpr int NBX_SCRATCH_DOUBLES = 4096;
+
+void nbx_set_error(const char* fmt, ...);
+
+#define NBX_CHECK_ARG(cond)                                                     \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            nbx_set_error("%s: invalid argument: %s", __func__, #cond);         \
+            return NBX_E_INVALID;                                               \
+        }                                                                       \
+    } while (0)
+
+#define NBX_HIP(call)                                                           \
+    do {                                                                        \
+        hipError_t e_ = (call);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            nbx_set_error("%s: %s -> %s", __func__, #call, hipGetErrorString(e_)); \
+            return NBX_E_HIP;                                                   \
+        }                                                                       \
+    } while (0)
+
+#define NBX_LAUNCH_CHECK() NBX_HIP(hipGetLastError())
+
+static inline int64_t nbx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ double nbx_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over a workgroup of up to 1024 threads; result valid in every thread.
+// `smem` needs 17 doubles.
+__device__ __forceinline__ double nbx_block_sum(double v, double* smem) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwave = (blockDim.x + 63) >> 6;
+    v = nbx_wave_sum(v);
+    __syncthreads();
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < nwave; ++w) t += smem[w];
+        smem[16] = t;
+    }
+    __syncthreads();
+    return smem[16];
+}

@@ -1,0 +1,288 @@
+"""GPU parity tests, kernel level: every libnbx entry point (through the C ABI via
+ctypes) against the CPU oracle / numpy on the same seeded inputs.
+
+Tolerances (fp64): element-wise ops and GEMMs 1e-12 relative to the operand scale;
+eigenvalues / singular values 1e-12 * ||A||; J/K 1e-12 (sums of N^2 products of O(1/N)).
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import hamiltonian, synth
+from oracle.pyscf_like import get_jk
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from nbed_amd.backend import HipBackend
+
+    return HipBackend()
+
+
+def rnd(stream, *shape):
+    return synth.val(stream, np.arange(int(np.prod(shape)))).reshape(shape)
+
+
+def symm(stream, n):
+    return synth.sym_matrix(stream, n)
+
+
+# ---------------------------------------------------------------- synthetic ERI
+@pytest.mark.parametrize("n", [1, 2, 7, 12, 13])
+def test_synth_eri_bit_exact(be, n):
+    got = be.to_host(be.synth_eri(n))
+    np.testing.assert_array_equal(got, synth.eri_dense(n))
+
+
+def test_synth_eri_slab(be):
+    n = 11
+    got = be.to_host(be.synth_eri(n, 3, 8))
+    np.testing.assert_array_equal(got, synth.eri_block(n, 3, 8))
+
+
+# ---------------------------------------------------------------- J/K
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 12, 24, 37, 64])
+@pytest.mark.parametrize("ndm", [1, 2])
+def test_jk_dense_vs_oracle(be, n, ndm):
+    eri_h = synth.eri_dense(n)
+    dm = np.stack([symm(20 + x, n) for x in range(ndm)])
+    vj, vk = get_jk(eri_h, dm)
+    out = be.to_host(be.jk(be.asarray(eri_h), be.asarray(dm)))
+    np.testing.assert_allclose(out[0], vj.sum(axis=0), rtol=0, atol=1e-12 * n)
+    for x in range(ndm):
+        np.testing.assert_allclose(out[1 + x], vk[x], rtol=0, atol=1e-12 * n)
+
+
+def test_jk_dense_slabs_equal_full(be):
+    n = 24
+    eri = be.synth_eri(n)
+    dm = be.asarray(np.stack([symm(31, n), symm(32, n)]))
+    full = be.to_host(be.jk(eri, dm))
+    for p0, p1 in [(0, 5), (5, 24), (7, 8)]:
+        slab = be.to_host(be.jk(eri[p0:p1].contiguous(), dm, p0, p1))
+        np.testing.assert_array_equal(slab, full[:, p0:p1])
+
+
+def test_jk_dense_full_size_properties(be):
+    """N = 148 (the bench shape): linearity and symmetry, no CPU reference needed."""
+    n = 148
+    eri = be.synth_eri(n)
+    d1 = np.stack([symm(41, n), symm(42, n)])
+    d2 = np.stack([symm(43, n), symm(44, n)])
+    j1 = be.to_host(be.jk(eri, be.asarray(d1)))
+    j2 = be.to_host(be.jk(eri, be.asarray(d2)))
+    j12 = be.to_host(be.jk(eri, be.asarray(d1 + 0.5 * d2)))
+    np.testing.assert_allclose(j12, j1 + 0.5 * j2, rtol=0, atol=1e-10)
+    for k in range(3):
+        np.testing.assert_allclose(j1[k], j1[k].T, rtol=0, atol=1e-10)
+    # a handful of elements against direct sums on the host
+    eri_rows = be.to_host(eri[5])  # (q, r, s) for p = 5
+    np.testing.assert_allclose(j1[0][5, 9], np.sum(eri_rows[9] * (d1[0] + d1[1])), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(j1[1][5, 17], np.einsum("qs,qs->", eri_rows[:, 17, :], d1[0]), rtol=0, atol=1e-10)
+
+
+# ---------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("ta", ["N", "T"])
+@pytest.mark.parametrize("tb", ["N", "T"])
+@pytest.mark.parametrize("mnk", [(1, 1, 1), (7, 5, 3), (16, 16, 4), (33, 65, 17), (148, 148, 148), (128, 300, 148),
+                                 (200, 40, 9)])
+def test_gemm(be, ta, tb, mnk):
+    m, n, k = mnk
+    a = rnd(50, *((k, m) if ta == "T" else (m, k)))
+    b = rnd(51, *((n, k) if tb == "T" else (k, n)))
+    ref = (a.T if ta == "T" else a) @ (b.T if tb == "T" else b)
+    got = be.to_host(be.gemm(be.asarray(a), be.asarray(b), ta, tb))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13 * max(k, 1))
+
+
+def test_gemm_identity_asymmetric(be):
+    # A = I with an asymmetric B catches a transposed C write (MFMA C/D lane map)
+    n = 48
+    b = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    got = be.to_host(be.gemm(be.asarray(np.eye(n)), be.asarray(b)))
+    np.testing.assert_array_equal(got, b)
+    got = be.to_host(be.gemm(be.asarray(b), be.asarray(np.eye(n))))
+    np.testing.assert_array_equal(got, b)
+
+
+def test_gemm_batched_alpha_beta(be):
+    a = rnd(52, 3, 20, 30)
+    b = rnd(53, 30, 25)  # shared across the batch
+    c0 = rnd(54, 3, 20, 25)
+    out = be.asarray(c0)
+    be.gemm(be.asarray(a), be.asarray(b), alpha=0.5, beta=-2.0, out=out)
+    np.testing.assert_allclose(be.to_host(out), 0.5 * (a @ b) - 2.0 * c0, rtol=0, atol=1e-12)
+
+
+def test_gemm_large_tile_path(be):
+    m, n, k = 256, 4096, 148  # 128x128 tile configuration
+    a, b = rnd(55, k, m), rnd(56, k, n)
+    got = be.to_host(be.gemm(be.asarray(a), be.asarray(b), "T", "N"))
+    np.testing.assert_allclose(got, a.T @ b, rtol=0, atol=1e-11)
+
+
+# ---------------------------------------------------------------- element-wise / reductions
+def test_fock_and_huzinaga_and_scalars(be):
+    n = 37
+    h = symm(60, n)
+    v = np.stack([symm(61, n), symm(62, n)]) * 0.1
+    jk = rnd(63, 3, n, n)
+    fock, vhf = be.fock_uhf(be.asarray(h), be.asarray(v), be.asarray(jk))
+    vhf_ref = jk[0] - jk[1:]
+    np.testing.assert_allclose(be.to_host(vhf), vhf_ref, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(be.to_host(fock), h + v + vhf_ref, rtol=0, atol=1e-14)
+    h3 = np.stack([h, h + 0.01])
+    fock3, _ = be.fock_uhf(be.asarray(h3), None, be.asarray(jk))
+    np.testing.assert_allclose(be.to_host(fock3), h3 + vhf_ref, rtol=0, atol=1e-14)
+
+    fds = rnd(64, 2, n, n)
+    f_io = be.asarray(h3)
+    hz = be.huzinaga_sym(be.asarray(fds), 1.0, f_io)
+    hz_ref = -(fds + fds.transpose(0, 2, 1))
+    np.testing.assert_allclose(be.to_host(hz), hz_ref, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(be.to_host(f_io), h3 + hz_ref, rtol=0, atol=1e-14)
+    hz2 = be.huzinaga_sym(be.asarray(fds[0]), 0.5)
+    np.testing.assert_allclose(be.to_host(hz2), -0.5 * (fds[0] + fds[0].T), rtol=0, atol=1e-15)
+
+    a, b = rnd(65, 2, n, n), rnd(66, 2, n, n)
+    np.testing.assert_allclose(be.trace_prod(be.asarray(a), be.asarray(b)), np.einsum("xij,xji->x", a, b),
+                               rtol=0, atol=1e-12)
+    np.testing.assert_allclose(be.trace_prod(be.asarray(a[0]), be.asarray(b[0])), np.einsum("ij,ji->", a[0], b[0]),
+                               rtol=0, atol=1e-12)
+
+    dm, dm_old = rnd(67, 2, n, n), rnd(68, 2, n, n)
+    sc = be.huz_cycle_scalars(be.asarray(h), be.asarray(v), be.asarray(vhf_ref), be.asarray(hz_ref),
+                              be.asarray(dm), be.asarray(dm_old))
+    ham = h + v + 0.5 * vhf_ref + hz_ref
+    np.testing.assert_allclose(sc[:2], np.einsum("xij,xji->x", ham, dm), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(sc[2:], np.linalg.norm(dm - dm_old, axis=(-2, -1)), rtol=0, atol=1e-12)
+
+
+def test_vector_algebra(be):
+    n = 1000
+    vecs = rnd(70, 5, n)
+    x = rnd(71, n)
+    np.testing.assert_allclose(be.dots(be.asarray(x), be.asarray(vecs)), vecs @ x, rtol=0, atol=1e-12)
+    coef = [0.3, -1.2, 2.0, 0.0, 1e-3]
+    np.testing.assert_allclose(be.to_host(be.lincomb(coef, be.asarray(vecs))), np.asarray(coef) @ vecs, rtol=0,
+                               atol=1e-14)
+    y = be.asarray(x)
+    be.axpby(2.0, be.asarray(vecs[0]), -0.5, y)
+    np.testing.assert_allclose(be.to_host(y), 2.0 * vecs[0] - 0.5 * x, rtol=0, atol=1e-15)
+
+
+def test_transpose_scale_and_chem_to_phys(be):
+    a = rnd(72, 3, 45, 70)
+    np.testing.assert_array_equal(be.to_host(be.transpose(be.asarray(a))), a.transpose(0, 2, 1))
+    s = rnd(73, 70)
+    got = be.to_host(be.scale_cols(be.asarray(a[0]), be.asarray(s)))
+    np.testing.assert_allclose(got, a[0] * s, rtol=0, atol=1e-16)
+    x = rnd(74, 3, 4, 5, 6)
+    np.testing.assert_array_equal(be.to_host(be.chem_to_phys(be.asarray(x))), x.transpose(0, 2, 3, 1))
+
+
+# ---------------------------------------------------------------- eigh
+def check_eigh(be, a, tol=1e-12):
+    w, v = be.eigh(be.asarray(a), check=True)
+    w, v = be.to_host(w), be.to_host(v)
+    scale = max(np.linalg.norm(a, axis=(-2, -1)).max(), 1e-300)
+    w_ref = np.linalg.eigvalsh(a)
+    np.testing.assert_allclose(w, w_ref, rtol=0, atol=tol * scale)
+    av = a @ v
+    np.testing.assert_allclose(av, v * w[..., None, :], rtol=0, atol=tol * scale)
+    eye = np.eye(a.shape[-1])
+    np.testing.assert_allclose(np.swapaxes(v, -1, -2) @ v, np.broadcast_to(eye, a.shape), rtol=0, atol=1e-12)
+    assert np.all(np.diff(w, axis=-1) >= 0)
+    assert all(s > 0 for s in be.last_eigh_sweeps)
+    return w, v
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 24, 37, 100, 148])
+def test_eigh_random(be, n):
+    check_eigh(be, symm(80, n))
+
+
+def test_eigh_batched_spin_pair(be):
+    check_eigh(be, np.stack([symm(81, 30), symm(82, 30)]))
+
+
+def test_eigh_degenerate_and_graded(be):
+    n = 20
+    u = rnd(83, n)
+    a = np.eye(n) + np.outer(u, u)  # (n-1)-fold degenerate eigenvalue 1
+    check_eigh(be, a)
+    # mu-shift-like grading: a 1e6 block next to O(1)
+    g = symm(84, n)
+    p = np.zeros((n, n))
+    p[:3, :3] = 1e6 * (np.eye(3) + 0.1 * symm(85, 3))
+    w, v = check_eigh(be, g + p)
+    # the O(1) eigenvalues must be accurate in ABSOLUTE terms, not relative to 1e6
+    w_ref = np.linalg.eigvalsh(g + p)
+    np.testing.assert_allclose(w[: n - 3], w_ref[: n - 3], rtol=0, atol=1e-9)
+    check_eigh(be, np.zeros((5, 5)))
+    check_eigh(be, np.diag(np.arange(6.0)))
+
+
+@pytest.mark.parametrize("p", [-0.5, 0.5, -1.0])
+def test_sym_pow(be, p):
+    n = 37
+    s = synth.overlap(n)
+    w, u = np.linalg.eigh(s)
+    ref = (u * w**p) @ u.T
+    got = be.to_host(be.sym_pow(be.asarray(s), p))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+
+
+# ---------------------------------------------------------------- SVD
+@pytest.mark.parametrize("shape", [(1, 1), (6, 5), (5, 8), (33, 33), (20, 64), (64, 20), (7, 3), (148, 33), (12, 41)])
+def test_svd_right(be, shape):
+    m, n = shape
+    a = rnd(90, m, n)
+    s, vt = be.svd_right(be.asarray(a))
+    s, vt = be.to_host(s), be.to_host(vt)
+    s_ref = np.linalg.svd(a, compute_uv=False)
+    np.testing.assert_allclose(s, s_ref, rtol=0, atol=1e-13 * s_ref[0] * max(m, n))
+    np.testing.assert_allclose(vt @ vt.T, np.eye(n), rtol=0, atol=1e-12)
+    g = a @ vt.T  # columns orthogonal, norms = singular values (then zeros)
+    norms = np.linalg.norm(g, axis=0)
+    np.testing.assert_allclose(norms[: len(s)], s, rtol=0, atol=1e-12 * s_ref[0])
+    np.testing.assert_allclose(norms[len(s):], 0, atol=1e-12 * s_ref[0])
+    gram = g.T @ g
+    np.testing.assert_allclose(gram - np.diag(np.diag(gram)), 0, atol=1e-12 * s_ref[0] ** 2)
+    assert be.last_svd_sweeps > 0
+
+
+def test_svd_rank_deficient_tiny_values(be):
+    # exactly rank-3 matrix: the remaining singular values must come out ~1e-16, not ~1e-8
+    m, n = 20, 12
+    a = rnd(91, m, 3) @ rnd(92, 3, n)
+    s, vt = be.svd_right(be.asarray(a))
+    s = be.to_host(s)
+    assert np.all(s[3:] < 1e-13 * s[0])
+    np.testing.assert_allclose(s[:3], np.linalg.svd(a, compute_uv=False)[:3], rtol=1e-12)
+
+
+# ---------------------------------------------------------------- four-index transform
+@pytest.mark.parametrize("n,dims", [(12, (5, 6, 7, 4)), (13, (3, 3, 3, 3)), (24, (20, 20, 20, 20))])
+def test_ao2mo_vs_oracle(be, n, dims):
+    eri_h = synth.eri_dense(n)
+    cs = [rnd(100 + i, n, d) for i, d in enumerate(dims)]
+    ref = hamiltonian.ao2mo_full(eri_h, *cs)
+    got = be.to_host(be.ao2mo(be.asarray(eri_h), *[be.asarray(c) for c in cs]))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+    # outer-index slabs (the multi-GPU shard axis) reproduce the full tensor bit for bit
+    lo = be.to_host(be.ao2mo(be.asarray(eri_h), *[be.asarray(c) for c in cs], i0=0, i1=2))
+    hi = be.to_host(be.ao2mo(be.asarray(eri_h), *[be.asarray(c) for c in cs], i0=2, i1=dims[0]))
+    np.testing.assert_array_equal(np.concatenate([lo, hi]), got)
+
+
+def test_spinorb_scatter_golden(be):
+    g = load_golden("spinorb_from_spatial")
+    h1, h2 = be.spinorb_scatter(be.asarray(g["one_body"]), be.asarray(g["two_body"]), 1e-8, 1.0)
+    np.testing.assert_array_equal(be.to_host(h1), g["h1"])
+    np.testing.assert_array_equal(be.to_host(h2), g["h2"])
+    h1, h2 = be.spinorb_scatter(be.asarray(g["one_body"]), be.asarray(g["two_body"]), 1e-8, 0.5)
+    np.testing.assert_array_equal(be.to_host(h2), 0.5 * g["h2"])
