@@ -1,0 +1,301 @@
+#!/usr/bin/env python
+"""bench.py -- embedded-SCF cycles/s (+ active-ERI transform GFLOP/s) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one cycle of the product's own ``nbed_amd.scf.huzinaga_scf`` (fused GPU path;
+SURVEY.md section 3.2), i.e. one Huzinaga-projected UHF SCF cycle of the hot path:
+J/K build from the dense (pq|rs) in HBM, Fock assembly, Huzinaga projector products, DIIS
+extrapolation, Loewdin orthogonalisation, symmetric eigensolve for both spins, density and
+the per-cycle energy/convergence scalars.  The stopping rule is disabled (conv_tol < 0), so the
+timed call runs exactly K cycles (plus the call's O(N^3) set-up and the final result download).
+
+Workload (default): synthetic tensors shaped like BASELINE.json configs[2] (octane/6-31G*,
+the largest single-GPU configuration): N_AO = 148, (33,33) occupied, 20 environment MOs
+projected out -> (13,13) active electrons, n = 128 embedded MOs for the transform.
+The N_AO = 2000 headline config does not fit one GPU (a dense (pq|rs) is 128 TB).
+
+After the timed SCF cycles the same run times the AO->active-MO four-index transform
+(3 unique spin blocks of HamiltonianBuilder, nbed/ham_builder.py:119-124) and reports it
+under "transform".  rank 0 prints ONE JSON line.
+
+Multi-GPU (strong scaling, fixed problem): the first AO index of (pq|rs) is sharded over
+the ranks (each rank generates only its slab); every cycle all-gathers the J/K row slabs
+(RCCL); the transform shards the outer MO index and all-gathers the (ij|kl) slabs.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (datasheet; v_mfma_f64_16x16x4_f64)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nao", type=int, default=148)
+    ap.add_argument("--nocc", type=int, default=33)
+    ap.add_argument("--nenv", type=int, default=20)
+    ap.add_argument("--nact", type=int, default=128, help="embedded MOs kept for the transform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-transform", action="store_true")
+    ap.add_argument("--cpu-cycles", type=int, default=8)
+    return ap.parse_args()
+
+
+def transform_flops(N, n):
+    """One spin block, sequential quarter transforms, no symmetry."""
+    return 2.0 * n * N**4 + 2.0 * n**2 * N**3 + 2.0 * n**3 * N**2 + 2.0 * n**4 * N
+
+
+def cpu_baseline_cycle(pr, eri_h, ncycles):
+    """The CPU oracle's cycle on the host cores: C/OpenMP one-pass J/K + numpy/LAPACK rest."""
+    import tempfile
+
+    from oracle import cref
+    from oracle.huzinaga import huzinaga_scf
+    from oracle.pyscf_like import ToyMol, ToyUHF
+
+    try:
+        lib = cref.load(cref.build(tempfile.mkdtemp(prefix="jkref_")))
+    except Exception:
+        lib = cref.load()
+
+    class CUHF(ToyUHF):
+        def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0):
+            jk = cref.jk(self._eri, np.asarray(dm), lib=lib)
+            return jk[0] - jk[1:]
+
+    mf = CUHF(ToyMol(pr["nao"], pr["nelec"]), pr["S"], pr["hcore"], eri_h)
+    mf.max_cycle = ncycles
+    mf.conv_tol = 0.0  # never "converged": exactly ncycles cycles
+    t0 = time.perf_counter()
+    huzinaga_scf(mf, pr["V_emb"], pr["D_env"], use_DIIS=True)
+    dt = time.perf_counter() - t0
+    return ncycles / dt
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    from nbed_amd import _nbx
+    from nbed_amd.backend import HipBackend
+    from nbed_amd.dist import Shards
+    from nbed_amd.scf import GpuUHF, Mole
+    from nbed_amd import synth
+
+    be = HipBackend(local_rank if world > 1 else 0)
+    N, n_act = args.nao, args.nact
+    pr = synth.problem(be, N, (args.nocc, args.nocc), args.nenv)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---------------- inputs resident in HBM before any timed region
+    shards = Shards(N, world, rank)
+    eri = be.synth_eri(N, shards.lo, shards.hi)
+    mf = GpuUHF(Mole(N, pr["nelec"]), pr["S"], pr["hcore"], eri, backend=be, shards=shards)
+    from nbed_amd.scf import huzinaga_scf
+
+    mf.conv_tol = -1.0  # the stopping rule can never fire: exactly max_cycle cycles run
+    barrier()
+    # warm-up cycles (untimed); their density seeds the timed run
+    mf.max_cycle = max(args.warmup, 1)
+    _, _, dm_warm, _, _ = huzinaga_scf(mf, pr["V_emb"], pr["D_env"], use_DIIS=True)
+    barrier()
+    be.profile(True)
+    be.profile_reset()
+    mf.max_cycle = args.steps
+    hist = []
+    t0 = time.perf_counter()
+    huzinaga_scf(mf, pr["V_emb"], pr["D_env"], dm_initial_guess=dm_warm, use_DIIS=True, history=hist)
+    barrier()
+    dt = time.perf_counter() - t0
+    be.profile(False)
+    assert len(hist) == args.steps
+    jk_ms, jk_cnt = be.profile_read(_nbx.PROF_JK_DENSE)
+    eigh_ms, eigh_cnt = be.profile_read(_nbx.PROF_EIGH)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=be.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    e_last = [float(x) for x in hist[-1][0]]
+    dm_change_last = float(hist[-1][1])
+
+    # ---------------- four-index transform (3 unique spin blocks), outer index sharded
+    transform = None
+    if not args.no_transform:
+        c_full = pr["C"]
+        ca = be.asarray(c_full[:, :n_act])
+        cb = be.asarray(np.ascontiguousarray(c_full[:, ::-1][:, :n_act]))
+        if world > 1:
+            full_eri = be.synth_eri(N)  # the transform needs every p: replicate (generated, not sent)
+        else:
+            full_eri = eri
+        ish = Shards(n_act, world, rank)
+        blocks = [(ca, ca, ca, ca), (cb, cb, cb, cb), (ca, ca, cb, cb)]
+
+        def run_transform():
+            outs = []
+            for cs in blocks:
+                slab = be.ao2mo(full_eri, *cs, i0=ish.lo, i1=ish.hi)
+                outs.append(ish.all_gather(be, slab, axis=0))
+            return outs
+
+        run_transform()
+        barrier()
+        be.profile(True)
+        be.profile_reset()
+        reps = 2
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            outs = run_transform()
+        barrier()
+        dtt = (time.perf_counter() - t1) / reps
+        be.profile(False)
+        q1_ms, q1_cnt = be.profile_read(_nbx.PROF_AO2MO_Q1)
+        all_ms, all_cnt = be.profile_read(_nbx.PROF_AO2MO)
+        if world > 1:
+            tmax = torch.tensor([dtt], dtype=torch.float64, device=be.device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dtt = float(tmax.item())
+        flops = 3 * transform_flops(N, n_act)
+        q1_flops = 2.0 * ish.size * N**4
+        transform = {
+            "metric": "active_eri_transform_gflops",
+            "value": flops / dtt / 1e9,
+            "unit": "GFLOP/s",
+            "ms_per_build": dtt * 1e3,
+            "spin_blocks": 3,
+            "nao": N,
+            "n_act": n_act,
+            "flop_count": "2nN^4+2n^2N^3+2n^3N^2+2n^4N per block, no symmetry",
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "gemm_f64_kernel<128,128> (quarter-1: (n x N).(N x N^3))",
+                "achieved": q1_flops / (q1_ms / max(q1_cnt, 1) * 1e-3) / 1e12 if q1_cnt else None,
+                "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": (q1_flops / (q1_ms / max(q1_cnt, 1) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS) if q1_cnt else None,
+                "traffic": None,
+            },
+            "device_ms_per_block_all_quarters": all_ms / max(all_cnt, 1),
+        }
+        del outs
+
+    # ---------------- CPU baseline (rank 0, N=1 only): the oracle on the host cores
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        eri_h = be.to_host(eri)  # bit-identical to oracle.synth.eri_dense(N), far faster to obtain
+        cps = cpu_baseline_cycle(pr, eri_h, args.cpu_cycles)
+        cpu = {
+            "value": cps,
+            "unit": "cycles/s",
+            "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": f"{args.cpu_cycles} Huzinaga UHF cycles at N_AO={N}: oracle loop with C/OpenMP one-pass dense J/K "
+                      "(oracle/c/jk_ref.c, -march=native) + numpy/LAPACK eigh, same inputs",
+        }
+        if transform is not None:
+            from oracle import hamiltonian
+
+            ca_h = be.to_host(ca)
+            tcpu0 = time.perf_counter()
+            hamiltonian.ao2mo_full(eri_h, ca_h[:, :32], ca_h, ca_h, ca_h)  # 1/4 of one block's quarter-1 work
+            tcpu = time.perf_counter() - tcpu0
+            fl = 2.0 * 32 * N**4 + 2.0 * 32 * n_act * N**3 + 2.0 * 32 * n_act**2 * N**2 + 2.0 * 32 * n_act**3 * N
+            transform["cpu_baseline"] = {
+                "value": fl / tcpu / 1e9, "unit": "GFLOP/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": "one (32 x n x n x n) outer-index slab of one spin block, numpy tensordot (OpenBLAS dgemm)",
+            }
+        del eri_h
+
+    if rank == 0:
+        cycles_per_s = args.steps / dt
+        jk_avg_ms = jk_ms / max(jk_cnt, 1)
+        alg_bytes = 8.0 * shards.size * N**3  # dense slab read once per launch (8 N^4 at 1 GPU)
+        achieved = alg_bytes / (jk_avg_ms * 1e-3) / 1e9 if jk_cnt else None
+        traffic = None
+        tfile = REPO / "profiles" / "jk_traffic.json"
+        if tfile.exists() and world == 1 and N == 148:
+            try:
+                traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "embedded_scf_cycles_per_sec",
+            "value": cycles_per_s,
+            "unit": "cycles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"synthetic octane/6-31G*-shaped embedded UHF (BASELINE configs[2]): N_AO={N}, "
+                            f"n_occ=({args.nocc},{args.nocc}), n_env={args.nenv}, n_act_mo={n_act}; dense (pq|rs) in HBM",
+                "nao": N,
+                "eri_bytes": 8 * N**4,
+                "parallelism": f"p-row shards x{world} + RCCL all-gather" if world > 1 else "single GPU",
+                "diis": True,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "jk_dense_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": jk_avg_ms,
+                "launches": jk_cnt,
+            },
+            "cpu_baseline": cpu,
+            "breakdown_ms_per_cycle": {"jk_dense_kernel": jk_avg_ms, "eigh_jacobi_kernel": eigh_ms / max(eigh_cnt, 1)},
+            "check": {"energy_last_cycle": e_last, "dm_change_last_cycle": dm_change_last},
+            "transform": transform,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

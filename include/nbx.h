@@ -63,6 +63,20 @@ int nbx_memcpy_d2h(nbx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); 
 int nbx_memcpy_d2d(nbx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 int nbx_memset(nbx_ctx* ctx, void* d_ptr, int value, size_t bytes);
 
+/* ------------------------------------------------------------------ in-library kernel timing
+ * While enabled, the listed launches are bracketed by HIP events recorded on the context's
+ * stream; nbx_profile_read() waits for them and returns the accumulated milliseconds and
+ * launch count of a slot.  bench.py uses this for the roofline numbers.                    */
+#define NBX_PROF_JK_DENSE 0    /* jk_dense_kernel (the streaming kernel of nbx_jk_dense)     */
+#define NBX_PROF_AO2MO_Q1 1    /* first quarter-transform GEMM of nbx_ao2mo                  */
+#define NBX_PROF_AO2MO 2       /* all four quarter transforms of one nbx_ao2mo call          */
+#define NBX_PROF_EIGH 3        /* eigh_jacobi_kernel                                         */
+#define NBX_PROF_SVD 4         /* svd_jacobi_kernel                                          */
+#define NBX_PROF_GEMM 5        /* every gemm_f64_kernel launch                               */
+int nbx_profile_enable(nbx_ctx* ctx, int on);
+int nbx_profile_read(nbx_ctx* ctx, int slot, double* ms_sum, int64_t* count);
+int nbx_profile_reset(nbx_ctx* ctx);
+
 /* ------------------------------------------------------------------ synthetic inputs
  * Counter-hash (pq|rs) of SURVEY.md section 8d, rows p in [p0,p1) of the dense
  * C-order (N,N,N,N) tensor: d_eri[(p-p0),q,r,s] = val(canon(p,q,r,s)) / N.

@@ -22,6 +22,8 @@ NBX_E_NOMEM = -3
 NBX_E_NOCONV = -4
 NBX_E_UNSUPPORTED = -5
 
+PROF_JK_DENSE, PROF_AO2MO_Q1, PROF_AO2MO, PROF_EIGH, PROF_SVD, PROF_GEMM = range(6)
+
 
 class NbxError(RuntimeError):
     """A libnbx entry point returned an error code."""
@@ -51,6 +53,9 @@ SIGNATURES = {
     "nbx_memcpy_d2h": (c_int, [_P, _P, _P, c_size_t]),
     "nbx_memcpy_d2d": (c_int, [_P, _P, _P, c_size_t]),
     "nbx_memset": (c_int, [_P, _P, c_int, c_size_t]),
+    "nbx_profile_enable": (c_int, [_P, c_int]),
+    "nbx_profile_read": (c_int, [_P, c_int, POINTER(c_double), POINTER(c_int64)]),
+    "nbx_profile_reset": (c_int, [_P]),
     "nbx_synth_eri": (c_int, [_P, c_int64, c_int64, c_int64, c_uint64, _P]),
     "nbx_jk_dense_worksize": (c_size_t, [c_int64, c_int64, c_int64]),
     "nbx_jk_dense": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),

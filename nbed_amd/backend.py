@@ -117,6 +117,48 @@ class HipBackend:
     def release_workspaces(self):
         self._work.clear()
 
+    # ------------------------------------------------------------------ in-library HIP-event timing
+    def profile(self, on: bool = True):
+        self._call("nbx_profile_enable", 1 if on else 0)
+
+    def profile_reset(self):
+        self._call("nbx_profile_reset")
+
+    def profile_read(self, slot: int) -> tuple[float, int]:
+        """(milliseconds summed over launches, launch count) of a NBX_PROF_* slot."""
+        ms = c_double()
+        cnt = ctypes.c_int64()
+        self._call("nbx_profile_read", slot, ctypes.byref(ms), ctypes.byref(cnt))
+        return ms.value, cnt.value
+
+    # ------------------------------------------------------------------ collectives (plumbing)
+    def pad_axis(self, a, axis: int, length: int):
+        """Zero-pad ``a`` along ``axis`` up to ``length`` (equal-sized all-gather pieces)."""
+        if a.shape[axis] == length:
+            return a.contiguous()
+        shape = list(a.shape)
+        shape[axis] = length
+        out = self.zeros(shape)
+        out.narrow(axis, 0, a.shape[axis]).copy_(a)
+        return out
+
+    def all_gather_stack(self, a, group=None):
+        """RCCL all-gather of equal-shaped pieces -> (world, *a.shape)."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group)
+        out = self.empty((world,) + tuple(a.shape))
+        dist.all_gather_into_tensor(out, a.contiguous(), group=group)
+        return out
+
+    def unstack_concat(self, stacked, axis: int, n: int):
+        """(world, ..., chunk, ...) -> (..., world*chunk, ...)[:n] along ``axis``."""
+        world = stacked.shape[0]
+        moved = stacked.movedim(0, axis)  # (..., world, chunk, ...)
+        shape = list(moved.shape)
+        merged = moved.reshape(shape[:axis] + [world * shape[axis + 1]] + shape[axis + 2:])
+        return merged.narrow(axis, 0, n).contiguous()
+
     # ------------------------------------------------------------------ synthetic ERI
     def synth_eri(self, nao: int, p0: int = 0, p1: int | None = None, seed: int = 20250829):
         p1 = nao if p1 is None else p1

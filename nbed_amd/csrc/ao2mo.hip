@@ -60,8 +60,12 @@ extern "C" int nbx_ao2mo(nbx_ctx* ctx, int64_t nao, const double* d_eri, const d
     double* bufB = reinterpret_cast<double*>(static_cast<char*>(d_work) + align256(p.a_doubles * sizeof(double)));
     const int64_t N2 = N * N, N3 = N2 * N;
     int rc;
+    nbx_prof_scope prof_all(ctx, NBX_PROF_AO2MO);
     // Q1
-    rc = nbx_gemm(ctx, 'T', 'N', ni, N3, N, 1.0, d_c1 + i0, n1, 0, d_eri, N3, 0, 0.0, bufA, N3, 0, 1);
+    {
+        nbx_prof_scope prof_q1(ctx, NBX_PROF_AO2MO_Q1);
+        rc = nbx_gemm(ctx, 'T', 'N', ni, N3, N, 1.0, d_c1 + i0, n1, 0, d_eri, N3, 0, 0.0, bufA, N3, 0, 1);
+    }
     if (rc != NBX_OK) return rc;
     // Q2
     rc = nbx_gemm(ctx, 'T', 'N', n2, N2, N, 1.0, d_c2, n2, 0, bufA, N2, N3, 0.0, bufB, N2, n2 * N2, ni);

@@ -71,6 +71,7 @@ int nbx_ctx_destroy(nbx_ctx* ctx) {
     if (ctx == nullptr) return NBX_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)nbx_profile_reset(ctx);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -142,6 +143,48 @@ int nbx_memset(nbx_ctx* ctx, void* d_ptr, int value, size_t bytes) {
     NBX_CHECK_ARG(ctx != nullptr && (bytes == 0 || d_ptr != nullptr));
     if (bytes == 0) return NBX_OK;
     NBX_HIP(hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
+    return NBX_OK;
+}
+
+int nbx_profile_enable(nbx_ctx* ctx, int on) {
+    NBX_CHECK_ARG(ctx != nullptr);
+    ctx->profiling = (on != 0);
+    return NBX_OK;
+}
+
+static int prof_drain(nbx_ctx* ctx, int slot) {
+    nbx_prof_slot& ps = ctx->prof[slot];
+    for (size_t i = 0; i < ps.start.size(); ++i) {
+        float ms = 0.f;
+        NBX_HIP(hipEventSynchronize(ps.stop[i]));
+        NBX_HIP(hipEventElapsedTime(&ms, ps.start[i], ps.stop[i]));
+        ps.ms_sum += ms;
+        ps.count += 1;
+        (void)hipEventDestroy(ps.start[i]);
+        (void)hipEventDestroy(ps.stop[i]);
+    }
+    ps.start.clear();
+    ps.stop.clear();
+    return NBX_OK;
+}
+
+int nbx_profile_read(nbx_ctx* ctx, int slot, double* ms_sum, int64_t* count) {
+    NBX_CHECK_ARG(ctx != nullptr && slot >= 0 && slot < NBX_PROF_SLOTS && ms_sum && count);
+    const int rc = prof_drain(ctx, slot);
+    if (rc != NBX_OK) return rc;
+    *ms_sum = ctx->prof[slot].ms_sum;
+    *count = ctx->prof[slot].count;
+    return NBX_OK;
+}
+
+int nbx_profile_reset(nbx_ctx* ctx) {
+    NBX_CHECK_ARG(ctx != nullptr);
+    for (int s = 0; s < NBX_PROF_SLOTS; ++s) {
+        const int rc = prof_drain(ctx, s);
+        if (rc != NBX_OK) return rc;
+        ctx->prof[s].ms_sum = 0.0;
+        ctx->prof[s].count = 0;
+    }
     return NBX_OK;
 }
 

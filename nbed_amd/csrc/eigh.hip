@@ -217,8 +217,11 @@ extern "C" int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_
     int* status = reinterpret_cast<int*>(static_cast<char*>(d_work) +
                                          align256((size_t)(4 * np * np * batch) * sizeof(double)));
     const size_t lds = (size_t)(3 * (np / 2) + np) * sizeof(double) + (size_t)(np + 2) * sizeof(int);
-    hipLaunchKernelGGL(eigh_jacobi_kernel, dim3((unsigned)batch), dim3(EIGH_THREADS), lds, ctx->stream, d_a, (int)n,
-                       d_w, d_v, work, status);
+    {
+        nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
+        hipLaunchKernelGGL(eigh_jacobi_kernel, dim3((unsigned)batch), dim3(EIGH_THREADS), lds, ctx->stream, d_a,
+                           (int)n, d_w, d_v, work, status);
+    }
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

@@ -292,6 +292,8 @@ extern "C" int nbx_jk_dense(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
     hipLaunchKernelGGL(jk_dtot_kernel, dim3((unsigned)nbx_cdiv(n2, 256)), dim3(256), 0, ctx->stream, d_dm, dtot,
                        n2, (int)ndm);
     const int N = (int)nao;
+    {
+    nbx_prof_scope prof(ctx, NBX_PROF_JK_DENSE);
 #define NBX_JK_CASE(NDM, CS, V2) jk_launch<NDM, CS, V2>(ctx, pl, d_eri, d_dm, dtot, d_jk, kpart, N, (int)np)
     if (ndm == 2) {
         if (pl.vec2) {
@@ -315,6 +317,7 @@ extern "C" int nbx_jk_dense(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
         }
     }
 #undef NBX_JK_CASE
+    }
     NBX_LAUNCH_CHECK();
     const int64_t per_chunk = ndm * np * nao;
     hipLaunchKernelGGL(jk_reduce_kernel, dim3((unsigned)nbx_cdiv(per_chunk, 256)), dim3(256), 0, ctx->stream,

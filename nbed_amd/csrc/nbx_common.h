@@ -7,8 +7,18 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "nbx.h"
+
+constexpr int NBX_PROF_SLOTS = 8;      // see include/nbx.h NBX_PROF_*
+constexpr int NBX_PROF_MAX_EVENTS = 4096;
+
+struct nbx_prof_slot {
+    std::vector<hipEvent_t> start, stop;  // recorded pairs not yet read
+    double ms_sum = 0.0;
+    int64_t count = 0;
+};
 
 struct nbx_ctx {
     int device;
@@ -16,6 +26,28 @@ struct nbx_ctx {
     bool own_stream;
     double* d_scratch;      // small device scratch for reductions (NBX_SCRATCH_DOUBLES)
     double* h_pinned;       // pinned host mirror of the scratch
+    bool profiling = false;
+    nbx_prof_slot prof[NBX_PROF_SLOTS];
+};
+
+// HIP-event bracket around a launch, active only while profiling is enabled.
+struct nbx_prof_scope {
+    nbx_ctx* ctx;
+    int slot;
+    hipEvent_t stop = nullptr;
+    nbx_prof_scope(nbx_ctx* c, int s) : ctx(c), slot(s) {
+        if (!ctx->profiling || (int)ctx->prof[slot].start.size() >= NBX_PROF_MAX_EVENTS) return;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess) return;
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+        (void)hipEventRecord(a, ctx->stream);
+        ctx->prof[slot].start.push_back(a);
+        ctx->prof[slot].stop.push_back(b);
+        stop = b;
+    }
+    ~nbx_prof_scope() {
+        if (stop) (void)hipEventRecord(stop, ctx->stream);
+    }
 };
 
 constexpr int NBX_SCRATCH_DOUBLES = 4096;

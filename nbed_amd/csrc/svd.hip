@@ -197,8 +197,11 @@ extern "C" int nbx_svd_right(nbx_ctx* ctx, int64_t m, int64_t n, const double* d
     int* status = reinterpret_cast<int*>(static_cast<char*>(d_work) +
                                          align256((size_t)(2 * np * m + 2 * np * np) * sizeof(double)));
     const size_t lds = (size_t)np * sizeof(double) + (size_t)(np + 2) * sizeof(int) + 17 * sizeof(double);
-    hipLaunchKernelGGL(svd_jacobi_kernel, dim3(1), dim3(SVD_THREADS), lds, ctx->stream, d_a, (int)m, (int)n, d_s,
-                       d_vt, static_cast<double*>(d_work), status);
+    {
+        nbx_prof_scope prof(ctx, NBX_PROF_SVD);
+        hipLaunchKernelGGL(svd_jacobi_kernel, dim3(1), dim3(SVD_THREADS), lds, ctx->stream, d_a, (int)m, (int)n, d_s,
+                           d_vt, static_cast<double*>(d_work), status);
+    }
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

@@ -1,0 +1,106 @@
+"""DIIS extrapolation with device-resident vectors.
+
+``DIIS`` mirrors ``pyscf.lib.diis.DIIS`` as the reference uses it
+(nbed/scf/huzinaga_scf.py:130,164: ``adiis.update(fock)`` with no explicit error vector):
+space 6, min_space 1, error = x - x_prev_returned, first call only stores x.  The vectors
+and their dot products live on the GPU (``nbx_dots`` / ``nbx_lincomb``); only the
+(<= 7 x 7) Pulay system is solved on the host, with PySCF's rule of dropping modes whose
+|eigenvalue| < 1e-14 when the system is singular.
+
+``CDIIS`` is PySCF's SCF default (``scf.diis.CDIIS``: error S D F - F D S, space 8), used
+by the mu-shift path's ``kernel()`` (nbed/driver.py:533).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+
+
+def diis_coefficients(h: np.ndarray) -> np.ndarray:
+    """Solve H c = (1, 0, ...) as pyscf.lib.diis.DIIS.extrapolate does."""
+    g = np.zeros(h.shape[0])
+    g[0] = 1
+    w, v = scipy.linalg.eigh(h)
+    if np.any(abs(w) < 1e-14):
+        idx = abs(w) > 1e-14
+        return np.dot(v[:, idx] * (1.0 / w[idx]), np.dot(v[:, idx].T.conj(), g))
+    return np.linalg.solve(h, g)
+
+
+class DIIS:
+    def __init__(self, backend, space: int = 6, min_space: int = 1):
+        self.be = backend
+        self.space = space
+        self.min_space = min_space
+        self._head = 0
+        self._nd = 0
+        self._xprev = None
+        self._xs = None  # (space, n) device
+        self._es = None
+        self._H = np.zeros((space + 1, space + 1))
+        self._H[0, 1:] = self._H[1:, 0] = 1
+
+    def get_num_vec(self) -> int:
+        return self._nd
+
+    def update(self, x):
+        be = self.be
+        flat = x.reshape(-1)
+        if self._xprev is None:
+            # no error vector yet: remember x as the "previous returned" vector
+            self._xprev = be.copy(flat)
+            return x
+        if self._xs is None:
+            self._xs = be.empty((self.space, flat.numel()))
+            self._es = be.empty((self.space, flat.numel()))
+        if self._head >= self.space:
+            self._head = 0
+        slot = self._head
+        be.axpby(1.0, flat, 0.0, self._xs[slot])
+        be.axpby(1.0, flat, 0.0, self._es[slot])
+        be.axpby(-1.0, self._xprev, 1.0, self._es[slot])  # e = x - x_prev
+        self._head += 1
+        self._nd = min(self._nd + 1, self.space)
+        nd = self._nd
+        if nd < self.min_space:
+            return x
+        row = be.dots(self._es[slot], self._es[:nd])
+        for i in range(nd):
+            self._H[self._head, i + 1] = row[i]
+            self._H[i + 1, self._head] = row[i]
+        c = diis_coefficients(self._H[: nd + 1, : nd + 1])
+        xnew = be.lincomb(c[1:], self._xs[:nd])
+        self._xprev = xnew
+        return xnew.reshape(x.shape)
+
+
+class CDIIS:
+    def __init__(self, backend, s_d, space: int = 8):
+        self.be = backend
+        self.s_d = s_d
+        self.space = space
+        self._fs = []
+        self._es = []
+
+    def update(self, dm_d, fock_d):
+        be = self.be
+        sdf = be.gemm(be.gemm(self.s_d, dm_d), fock_d)  # S D F  (batched over spin)
+        err = be.transpose(sdf)
+        be.axpby(-1.0, sdf, 1.0, err)  # (SDF)^T - SDF = FDS - SDF
+        self._fs.append(be.copy(fock_d).reshape(-1))
+        self._es.append(err.reshape(-1))
+        if len(self._fs) > self.space:
+            self._fs.pop(0)
+            self._es.pop(0)
+        nd = len(self._fs)
+        h = np.zeros((nd + 1, nd + 1))
+        h[0, 1:] = h[1:, 0] = 1
+        estack = be.torch.stack(self._es) if hasattr(be, "torch") else np.stack(self._es)
+        for i in range(nd):
+            row = be.dots(self._es[i], estack[: i + 1])
+            for j in range(i + 1):
+                h[i + 1, j + 1] = h[j + 1, i + 1] = row[j]
+        c = diis_coefficients(h)
+        fstack = be.torch.stack(self._fs) if hasattr(be, "torch") else np.stack(self._fs)
+        return be.lincomb(c[1:], fstack).reshape(fock_d.shape)

@@ -1,0 +1,243 @@
+"""Huzinaga-projected SCF on the GPU.
+
+Drop-in for nbed/scf/huzinaga_scf.py: same function names, arguments, return values and
+quirks:
+
+* Loewdin orthogonalisation with X = S^-1/2 computed once (:128);
+* plain DIIS on F starting at loop index 2 (:162-164) with pyscf.lib.diis semantics;
+* the energy uses ``vhf`` of the PREVIOUS density with the NEW density (:181-185);
+* ``E_prev`` starts at 0 and convergence takes the max over the spin components (:191);
+* the returned Huzinaga operator is the last cycle's, built from the pre-DIIS Fock (:159).
+
+Two execution paths, same arithmetic:
+
+* fused: ``scf_method`` is a ``GpuUHF`` whose ``get_veff``/``get_hcore`` are not monkey
+  patched -> J/K, Fock assembly, projector products, eigensolve, density and the per-cycle
+  scalars all stay in HBM; 4 doubles come back per cycle for the convergence test;
+* generic: any object implementing the reference's SCF protocol (numpy ``get_veff`` ...):
+  its ``get_veff``/``get_occ`` are called as the reference calls them, everything else
+  (projector GEMMs, eigensolve, density, traces) still runs on the GPU.
+"""
+
+from __future__ import annotations
+
+import logging
+from typing import Optional
+
+import numpy as np
+
+from ..backend import get_backend
+from .diis import DIIS
+from .gpu_scf import GpuUHF
+from .pyscf_compat import is_hf, is_ks
+
+logger = logging.getLogger(__name__)
+
+
+def _as3(be, a):
+    """Device array with a leading batch (spin) axis."""
+    d = be.asarray(np.asarray(a))
+    return d if d.dim() == 3 else d.reshape(1, *d.shape)
+
+
+def get_huzinaga_operator(fock, dm_occ_S, dm_virt_S, backend=None):
+    """Huzinaga operator -(kappa)[(F DS) + (F DS)^T] (+ virtual term), numpy in/out.
+
+    nbed/scf/huzinaga_scf.py:65-90; kappa = 1/2 for 2-D input, 1 for 3-D (:80,88).
+    """
+    be = backend if backend is not None else get_backend()
+    fock = np.asarray(fock)
+    out = _huzinaga_device(be, _as3(be, fock), _as3(be, dm_occ_S),
+                           None if dm_virt_S is None or not np.any(dm_virt_S) else _as3(be, dm_virt_S),
+                           0.5 if fock.ndim == 2 else 1.0)
+    out = be.to_host(out)
+    return out[0] if fock.ndim == 2 else out
+
+
+def _huzinaga_device(be, fock3, ds_occ3, ds_virt3, kappa, fock_io=None):
+    """Hz on device; if ``fock_io`` is given it is updated in place (F += Hz)."""
+    fds = be.gemm(fock3, ds_occ3)
+    hz = be.huzinaga_sym(fds, kappa, fock_io)
+    if ds_virt3 is not None:
+        # -(kappa)[FDvS + (FDvS)^T - 2 (DvS)^T (F DvS)]   (huzinaga_scf.py:82-88)
+        fdv = be.gemm(fock3, ds_virt3)
+        hzv = be.huzinaga_sym(fdv, kappa, None)
+        corr = be.gemm(ds_virt3, fdv, "T", "N")
+        be.axpby(2.0 * kappa, corr, 1.0, hzv)
+        be.axpby(1.0, hzv, 1.0, hz)
+        if fock_io is not None:
+            be.axpby(1.0, hzv, 1.0, fock_io)
+    return hz
+
+
+def calculate_hf_energy(scf_method, embedding_potential, density_matrix, vhf, huzinaga_op_occ, backend=None):
+    """tr[(hcore + V_emb + vhf/2 + Hz) D] per spin (nbed/scf/huzinaga_scf.py:14-33)."""
+    be = backend if backend is not None else get_backend()
+    ham = np.asarray(scf_method.get_hcore()) + embedding_potential + 0.5 * np.asarray(vhf) + huzinaga_op_occ
+    return be.trace_prod(be.asarray(ham), be.asarray(np.asarray(density_matrix)))
+
+
+def calculate_ks_energy(scf_method, embedding_potential, density_matrix, huzinaga_op_occ, backend=None):
+    """E_coul + E_xc + tr[D (hcore + Hz + V_emb)] (nbed/scf/huzinaga_scf.py:36-62).
+
+    The XC part comes from the SCF object's own ``get_veff`` (``.ecoul``/``.exc``), exactly as
+    in the reference; this package has no XC quadrature (out of scope).
+    """
+    be = backend if backend is not None else get_backend()
+    vhf_updated = scf_method.get_veff(dm=density_matrix)
+    energy = vhf_updated.ecoul + vhf_updated.exc
+    ham = np.asarray(scf_method.get_hcore()) + huzinaga_op_occ + embedding_potential
+    energy += be.trace_prod(be.asarray(np.asarray(density_matrix)), be.asarray(ham))
+    return energy
+
+
+def _is_fused(scf_method) -> bool:
+    """GpuUHF with the class's own get_veff/get_hcore/get_occ (no instance monkey patches)."""
+    if not isinstance(scf_method, GpuUHF):
+        return False
+    d = vars(scf_method)
+    return not any(k in d for k in ("get_veff", "get_hcore", "get_occ", "make_rdm1"))
+
+
+def huzinaga_scf(
+    scf_method,
+    embedding_potential: np.ndarray,
+    dm_environment_occupied: np.ndarray,
+    dm_environment_virtual: np.ndarray | None = None,
+    dm_conv_tol: float = 1e-6,
+    dm_initial_guess: Optional[np.ndarray] = None,
+    use_DIIS: Optional[bool] = True,
+    backend=None,
+    history: list | None = None,
+):
+    """Manual SCF with the Huzinaga projector; see the module docstring.
+
+    Returns (mo_coeff, mo_energy, density_matrix, huzinaga_op, conv_flag) as numpy arrays
+    (nbed/scf/huzinaga_scf.py:206).  ``history`` (optional) collects (energy, dm_diff) per cycle.
+    """
+    if not (is_ks(scf_method) or is_hf(scf_method)):
+        raise TypeError("Cannot run Huzinaga SCF with type %s" % type(scf_method))
+    be = backend if backend is not None else (getattr(scf_method, "be", None) or get_backend())
+    fused = _is_fused(scf_method)
+    ks = is_ks(scf_method)
+
+    embedding_potential = np.asarray(embedding_potential)
+    restricted = np.asarray(dm_environment_occupied).ndim == 2
+    kappa = 0.5 if restricted else 1.0
+    nb = 1 if restricted else 2
+
+    s_h = np.asarray(scf_method.get_ovlp())
+    s_d = scf_method._s_d if fused else be.asarray(s_h)
+    x_d = scf_method.x_device() if fused else be.sym_pow(s_d, -0.5)
+    adiis = DIIS(be) if use_DIIS else None
+
+    ds_occ = be.gemm(_as3(be, dm_environment_occupied), s_d)
+    ds_virt = None
+    if dm_environment_virtual is not None:
+        ds_virt = be.gemm(_as3(be, dm_environment_virtual), s_d)
+
+    hcore_h = np.asarray(scf_method.get_hcore())
+    hcore_d = be.asarray(hcore_h)
+    vemb_d = be.asarray(embedding_potential)
+    # h + V_emb broadcast to the batch shape (:139,157)
+    hv = be.zeros((nb,) + s_h.shape)
+    for x in range(nb):
+        be.axpby(1.0, hcore_d if hcore_d.dim() == 2 else hcore_d[x], 1.0, hv[x])
+        be.axpby(1.0, vemb_d if vemb_d.dim() == 2 else vemb_d[x], 1.0, hv[x])
+
+    def diagonalise(fock3):
+        fo = be.gemm(be.gemm(x_d, fock3), x_d)
+        e_d, c_ortho = be.eigh(fo)
+        return e_d, be.gemm(x_d, c_ortho)
+
+    def occupations(e_d, c_d):
+        e_h = be.to_host(e_d)
+        if fused:
+            return e_h, scf_method.get_occ(e_h)
+        c_h = be.to_host(c_d)
+        if restricted:
+            return e_h, scf_method.get_occ(e_h[0], c_h[0])[None]
+        return e_h, scf_method.get_occ(e_h, c_h)
+
+    def density(c_d, occ_h):
+        scaled = be.scale_cols(be.copy(c_d), be.asarray(np.asarray(occ_h, dtype=np.float64)))
+        return be.gemm(scaled, c_d, "N", "T")
+
+    def unbatch(a_h):
+        return a_h[0] if restricted else a_h
+
+    # ---- initial guess from the projected core Hamiltonian (:139-148)
+    if dm_initial_guess is None:
+        fock = be.copy(hv)
+        _huzinaga_device(be, fock, ds_occ, ds_virt, kappa, fock_io=fock)
+        e_d, c_d = diagonalise(fock)
+        _, occ_h = occupations(e_d, c_d)
+        dm_d = density(c_d, occ_h)
+    else:
+        dm_d = _as3(be, dm_initial_guess)
+
+    conv_flag = False
+    scf_energy_prev = 0
+    mo_energy_h = None
+    hz = None
+    c_d = None
+    for i in range(scf_method.max_cycle):
+        # ---- Fock build (:156-160)
+        if fused:
+            jk = scf_method.jk_device(dm_d)
+            fock, vhf = be.fock_uhf(hv, None, jk)
+        else:
+            vhf_h = scf_method.get_veff(dm=unbatch(be.to_host(dm_d)))
+            vhf = _as3(be, np.asarray(vhf_h))
+            fock = be.copy(hv)
+            be.axpby(1.0, vhf, 1.0, fock)
+        hz = _huzinaga_device(be, fock, ds_occ, ds_virt, kappa, fock_io=fock)
+
+        if use_DIIS and (i > 1):
+            fock = adiis.update(fock)
+
+        e_d, c_d = diagonalise(fock)
+        mo_energy_h, occ_h = occupations(e_d, c_d)
+        dm_old = dm_d
+        dm_d = density(c_d, occ_h)
+
+        # ---- energy and convergence scalars (:176-194)
+        if ks:
+            scf_energy = calculate_ks_energy(
+                scf_method, embedding_potential, unbatch(be.to_host(dm_d)), unbatch(be.to_host(hz)), backend=be
+            )
+            diff = be.copy(dm_d)
+            be.axpby(-1.0, dm_old, 1.0, diff)
+            norm_dm_diff = float(np.max(np.sqrt(be.trace_prod(diff, be.transpose(diff)))))
+        elif nb == 2:
+            sc = be.huz_cycle_scalars(hv, None, vhf, hz, dm_d, dm_old)
+            scf_energy = sc[:2].copy()
+            norm_dm_diff = float(np.max(sc[2:]))
+        else:
+            ham = be.copy(hv)
+            be.axpby(0.5, vhf, 1.0, ham)
+            be.axpby(1.0, hz, 1.0, ham)
+            scf_energy = float(be.trace_prod(ham, dm_d)[0])
+            diff = be.copy(dm_d)
+            be.axpby(-1.0, dm_old, 1.0, diff)
+            norm_dm_diff = float(np.sqrt(be.trace_prod(diff, be.transpose(diff))[0]))
+
+        run_diff = np.max(np.abs(scf_energy - scf_energy_prev))
+        if history is not None:
+            history.append((np.array(scf_energy, copy=True), norm_dm_diff))
+        if (run_diff < scf_method.conv_tol) and (norm_dm_diff < dm_conv_tol):
+            conv_flag = True
+            logger.debug("Huzinaga SCF converged in cycle %s", i)
+            break
+        scf_energy_prev = scf_energy
+
+    if conv_flag is False:
+        logger.warning("Huzinaga SCF has NOT converged.")
+
+    return (
+        unbatch(be.to_host(c_d)),
+        unbatch(mo_energy_h),
+        unbatch(be.to_host(dm_d)),
+        unbatch(be.to_host(hz)),
+        conv_flag,
+    )

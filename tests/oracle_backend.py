@@ -1,0 +1,205 @@
+"""A CHECKER backend for CPU-only tests: same interface as nbed_amd.backend.HipBackend, with
+every operation done by numpy/LAPACK (the oracle's arithmetic).
+
+It lives under tests/ on purpose: the product (nbed_amd) has no CPU implementation and never
+imports this.  Tests inject it (``backend=OracleBackend()``) to exercise the HOST logic of the
+product -- loop control, DIIS schedule, convergence rule, localiser bookkeeping, sharding and
+the gloo all-gather path -- on machines without a GPU, and as the reference side of the
+GPU parity tests.  Arrays are torch CPU float64 tensors so the host code is unchanged.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import hamiltonian
+from oracle.pyscf_like import get_jk
+from oracle import synth
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self):
+        self.torch = torch
+        self.device = torch.device("cpu")
+        self.calls: dict[str, int] = {}
+
+    def _count(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+
+    # ---- plumbing
+    def synchronize(self):
+        pass
+
+    def use_current_stream(self):
+        pass
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float64)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float64)
+
+    def asarray(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(torch.float64).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+
+    def to_host(self, a):
+        return a.detach().numpy().copy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+    def copy(self, a):
+        return a.clone()
+
+    def release_workspaces(self):
+        pass
+
+    @staticmethod
+    def _np(a):
+        return a.detach().numpy()
+
+    # ---- collectives
+    def pad_axis(self, a, axis, length):
+        if a.shape[axis] == length:
+            return a.contiguous()
+        shape = list(a.shape)
+        shape[axis] = length
+        out = self.zeros(shape)
+        out.narrow(axis, 0, a.shape[axis]).copy_(a)
+        return out
+
+    def all_gather_stack(self, a, group=None):
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group)
+        pieces = [torch.empty_like(a) for _ in range(world)]
+        dist.all_gather(pieces, a.contiguous(), group=group)
+        return torch.stack(pieces)
+
+    def unstack_concat(self, stacked, axis, n):
+        world = stacked.shape[0]
+        moved = stacked.movedim(0, axis)
+        shape = list(moved.shape)
+        merged = moved.reshape(shape[:axis] + [world * shape[axis + 1]] + shape[axis + 2:])
+        return merged.narrow(axis, 0, n).contiguous()
+
+    # ---- kernels
+    def synth_eri(self, nao, p0=0, p1=None, seed=synth.SEED):
+        p1 = nao if p1 is None else p1
+        return self.asarray(synth.eri_block(nao, p0, p1, seed))
+
+    def jk(self, eri, dm, p0=0, p1=None):
+        self._count("jk")
+        nao = dm.shape[-1]
+        p1 = nao if p1 is None else p1
+        e = self._np(eri)
+        d = self._np(dm).reshape(-1, nao, nao)
+        # slab rows only: J[p,q] = sum_rs e[p,q,r,s] Dtot[r,s]; K[p,r] = sum_qs e[p,q,r,s] D[q,s]
+        dtot = d.sum(axis=0)
+        out = np.empty((1 + d.shape[0], p1 - p0, nao))
+        out[0] = np.einsum("pqrs,rs->pq", e, dtot)
+        for x in range(d.shape[0]):
+            out[1 + x] = np.einsum("pqrs,qs->pr", e, d[x])
+        return self.asarray(out)
+
+    def gemm(self, a, b, ta="N", tb="N", alpha=1.0, beta=0.0, out=None):
+        self._count("gemm")
+        an, bn = self._np(a), self._np(b)
+        if ta == "T":
+            an = np.swapaxes(an, -1, -2)
+        if tb == "T":
+            bn = np.swapaxes(bn, -1, -2)
+        res = alpha * (an @ bn)
+        if out is not None:
+            out.copy_(torch.from_numpy(res + beta * self._np(out)))
+            return out
+        return self.asarray(res)
+
+    def fock_uhf(self, hcore, vemb, jk, want_vhf=True):
+        j = self._np(jk)
+        vhf = j[0] - j[1:]
+        f = self._np(hcore) + vhf
+        if vemb is not None:
+            f = f + self._np(vemb)
+        return self.asarray(f), self.asarray(vhf)
+
+    def huzinaga_sym(self, fds, kappa, fock_io=None):
+        f = self._np(fds)
+        hz = -kappa * (f + np.swapaxes(f, -1, -2))
+        if fock_io is not None:
+            fock_io += torch.from_numpy(hz)
+        return self.asarray(hz)
+
+    def trace_prod(self, a, b):
+        res = np.einsum("...ij,...ji->...", self._np(a), self._np(b))
+        return float(res) if res.ndim == 0 else res
+
+    def huz_cycle_scalars(self, hcore, vemb, vhf, hz, dm, dm_old):
+        ham = self._np(hcore) + 0.5 * self._np(vhf) + self._np(hz)
+        if vemb is not None:
+            ham = ham + self._np(vemb)
+        e = np.einsum("xij,xji->x", ham, self._np(dm))
+        d = np.linalg.norm(self._np(dm) - self._np(dm_old), axis=(-2, -1))
+        return np.concatenate([e, d])
+
+    def axpby(self, a, x, b, y):
+        yn = self._np(y)
+        if b == 0.0:
+            yn[...] = a * self._np(x).reshape(yn.shape)
+        else:
+            yn[...] = a * self._np(x).reshape(yn.shape) + b * yn
+        return y
+
+    def add(self, x, y):
+        return x + y
+
+    def lincomb(self, coef, vecs, out=None):
+        res = np.tensordot(np.asarray(coef, dtype=np.float64), self._np(vecs), axes=(0, 0))
+        if out is not None:
+            out.copy_(torch.from_numpy(res))
+            return out
+        return self.asarray(res)
+
+    def dots(self, x, vecs):
+        v = self._np(vecs)
+        return v.reshape(v.shape[0], -1) @ self._np(x).reshape(-1)
+
+    def transpose(self, a):
+        return self.asarray(np.swapaxes(self._np(a), -1, -2))
+
+    def scale_cols(self, a, s):
+        an = self._np(a)
+        an *= self._np(s)[..., None, :]
+        return a
+
+    def eigh(self, a, check=False):
+        self._count("eigh")
+        w, v = np.linalg.eigh(self._np(a))
+        self.last_eigh_sweeps = [1]
+        return self.asarray(w), self.asarray(v)
+
+    def sym_pow(self, s, p):
+        w, u = np.linalg.eigh(self._np(s))
+        return self.asarray((u * w**p) @ u.T)
+
+    def svd_right(self, a, check=True):
+        self._count("svd")
+        _, s, vt = np.linalg.svd(self._np(a))
+        self.last_svd_sweeps = 1
+        return self.asarray(s), self.asarray(vt)
+
+    def ao2mo(self, eri, c1, c2, c3, c4, i0=0, i1=None):
+        self._count("ao2mo")
+        c1n = self._np(c1)
+        i1 = c1n.shape[1] if i1 is None else i1
+        return self.asarray(hamiltonian.ao2mo_full(self._np(eri), c1n[:, i0:i1], self._np(c2), self._np(c3),
+                                                   self._np(c4)))
+
+    def chem_to_phys(self, x):
+        return self.asarray(self._np(x).transpose(0, 2, 3, 1))
+
+    def spinorb_scatter(self, one_body, two_body, tol, h2_scale):
+        h1, h2 = hamiltonian.spinorb_from_spatial(self._np(one_body), self._np(two_body), tol)
+        return self.asarray(h1), self.asarray(h2 * h2_scale)

@@ -1,0 +1,38 @@
+"""The host-level suites (tests/test_host_scf.py, tests/test_host_localizers_ham.py) re-run with
+the real HIP backend: the same product code, now with libnbx doing the arithmetic, against the
+same golden vectors of the reference.  The functions are imported, so pytest collects them here
+with this module's ``be`` fixture (a HipBackend) and the ``gpu`` mark."""
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from test_host_localizers_ham import (  # noqa: E402,F401
+    test_builder_errors_and_reduce_virtuals,
+    test_concentric_localize_virtual_on_scf_object,
+    test_concentric_matches_reference,
+    test_spade_matches_reference,
+    test_spade_open_shell_raises_like_reference,
+    test_spade_restricted_matches_reference,
+    test_spinorb_and_build_match_reference,
+)
+from test_host_scf import (  # noqa: E402,F401
+    test_energy_elec_matches_reference,
+    test_gpu_uhf_protocol_matches_oracle_scf,
+    test_huzinaga_operator_matches_reference,
+    test_huzinaga_scf_restricted_generic_path,
+    test_monkey_patched_get_veff_uses_generic_path,
+)
+
+
+class _CountingHip:
+    """HipBackend plus the call counter some shared tests read."""
+
+
+@pytest.fixture(scope="module")
+def be():
+    from nbed_amd.backend import HipBackend
+
+    b = HipBackend()
+    b.calls = {}
+    return b

@@ -1,0 +1,186 @@
+"""Host logic of the localizers and the Hamiltonian builder on CPU (checker backend injected),
+against the golden vectors written by the reference's own classes."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import synth
+from oracle_backend import OracleBackend
+
+from nbed_amd.exceptions import HamiltonianBuilderError
+from nbed_amd.ham_builder import HamiltonianBuilder, reduce_virtuals
+from nbed_amd.localizers import (ConcentricLocalizer, LocalizedSystem, OccupiedLocalizer, PMLocalizer, PAOLocalizer,
+                                 SPADELocalizer, VirtualLocalizer)
+from nbed_amd.localizers.occupied.base import check_values
+from nbed_amd.scf import GpuRHF, GpuUHF, Mole
+
+
+@pytest.fixture()
+def be():
+    return OracleBackend()
+
+
+def make_scf(be, g, cls=GpuUHF, nelec=None, with_eri=False):
+    n = int(g["nao"])
+    slices = [[0, 1, 0, int(g["n_act_aos"])], [1, 2, int(g["n_act_aos"]), n]]
+    occ = np.asarray(g["mo_occ"])
+    if nelec is None:
+        nelec = (int(occ[0].sum()), int(occ[1].sum())) if occ.ndim == 2 else (int(occ.sum()) // 2,) * 2
+    mf = cls(Mole(n, nelec, ao_slices=slices), g["S"], synth.hcore(n), synth.eri_dense(n) if with_eri else None,
+             backend=be)
+    mf.mo_coeff, mf.mo_occ = g["mo_coeff"], g["mo_occ"]
+    return mf
+
+
+@pytest.mark.parametrize("tag", ["n16_closed", "n16_overwrite", "n20_wide"])
+def test_spade_matches_reference(be, tag):
+    g = load_golden(f"spade_{tag}")
+    ow = tuple(None if o < 0 else int(o) for o in g["overwrite"])
+    loc = SPADELocalizer(make_scf(be, g), 1, n_mo_overwrite=ow, backend=be)
+    ls = loc.localize()
+    np.testing.assert_array_equal(ls.active_mo_inds, g["active_mo_inds"])
+    np.testing.assert_array_equal(ls.enviro_mo_inds, g["enviro_mo_inds"])
+    np.testing.assert_allclose(loc.enviro_selection_condition[0], g["sigma_a"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(loc.enviro_selection_condition[1], g["sigma_b"], rtol=0, atol=1e-12)
+    for k in ("dm_active", "dm_enviro", "dm_loc_occ"):
+        np.testing.assert_allclose(getattr(ls, k), g[k], rtol=0, atol=1e-10)
+    for k in ("c_active", "c_enviro", "c_loc_occ"):
+        assert getattr(ls, k).shape == g[k].shape
+    check_values(ls, loc._global_scf)
+
+
+def test_spade_restricted_matches_reference(be):
+    g = load_golden("spade_n14_restricted")
+    loc = SPADELocalizer(make_scf(be, g, GpuRHF), 1, backend=be)
+    ls = loc.localize()
+    np.testing.assert_array_equal(ls.active_mo_inds, g["active_mo_inds"])
+    np.testing.assert_allclose(ls.dm_active, g["dm_active"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(ls.dm_enviro, g["dm_enviro"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(loc.enviro_selection_condition[0], g["sigma_a"], rtol=0, atol=1e-12)
+    check_values(ls, loc._global_scf)
+
+
+def test_spade_open_shell_raises_like_reference(be):
+    g = load_golden("spade_n16_open_raises")
+    assert str(g["raised"]).startswith("ValueError")
+    n, nocc = int(g["nao"]), tuple(int(x) for x in g["nocc"])
+    pr = synth.problem(n, nocc, 0)
+    _, c = synth.lowdin_orthonormal(pr["S"], pr["hcore"])
+    occ = np.zeros((2, n))
+    occ[0, : nocc[0]] = 1
+    occ[1, : nocc[1]] = 1
+    fake = {"nao": n, "n_act_aos": int(g["n_act_aos"]), "S": pr["S"], "mo_coeff": np.stack([c, c]), "mo_occ": occ}
+    with pytest.raises(ValueError):
+        SPADELocalizer(make_scf(be, fake), 1, backend=be).localize()
+
+
+def test_plugin_surface():
+    with pytest.raises(TypeError):
+        OccupiedLocalizer(None, 1)  # abstract: _localize_spin missing (test_localizers.py:53-58)
+    with pytest.raises(TypeError):
+        VirtualLocalizer(1)
+    with pytest.raises(NotImplementedError):
+        PMLocalizer(None, 1)
+    with pytest.raises(NotImplementedError):
+        PAOLocalizer()
+
+    class Halves(OccupiedLocalizer):
+        """A user plugin: first half of the occupied orbitals is 'active'."""
+
+        def _localize_spin(self, c_matrix, occupancy, n_mo_overwrite=None):
+            nocc = int(np.count_nonzero(occupancy))
+            c = c_matrix[:, :nocc]
+            k = nocc // 2
+            return LocalizedSystem(np.arange(k), np.arange(k, nocc), c[:, :k], c[:, k:], c, backend=self._be)
+
+    g = load_golden("spade_n16_closed")
+    be = OracleBackend()
+    ls = Halves(make_scf(be, g), 1, backend=be).localize()
+    assert ls.c_active.shape == (2, 16, 2) and ls.dm_enviro.shape == (2, 16, 16)
+
+
+@pytest.mark.parametrize("max_shells", [4, 1])
+def test_concentric_matches_reference(be, max_shells):
+    g = load_golden(f"concentric_n18_shells{max_shells}")
+    na = int(g["n_act_proj_aos"])
+    cl = ConcentricLocalizer(None, 1, max_shells=int(g["max_shells"]), backend=be)
+    cl.projected_overlap, cl.overlap_two_basis, cl.n_act_proj_aos = g["S"][:na, :na], g["S"][:na, :], na
+    c, shells, svals = cl._localize_virtual_spin(g["occ"], g["mo_coeff"], g["fock"])
+    np.testing.assert_array_equal(shells, g["shells"])
+    assert len(svals) == int(g["n_sigma"])
+    for i, s in enumerate(svals):
+        np.testing.assert_allclose(s, g[f"sigma_{i}"], rtol=0, atol=1e-11)
+    edges = [int(np.count_nonzero(g["occ"]))] + list(shells)
+    for a, b in zip(edges[:-1], edges[1:]):
+        np.testing.assert_allclose(c[:, a:b] @ c[:, a:b].T, g["out_coeff"][:, a:b] @ g["out_coeff"][:, a:b].T,
+                                   rtol=0, atol=1e-9)
+
+
+def test_concentric_localize_virtual_on_scf_object(be):
+    """The public entry: reads S / aoslice / get_fock from the SCF object, updates mo_coeff."""
+    n, n_act_aos, nocc, n_mo = 18, 7, 4, 15
+    pr = synth.problem(n, (nocc, nocc), 0)
+    _, c = synth.lowdin_orthonormal(pr["S"], pr["hcore"])
+    mf = GpuUHF(Mole(n, (nocc, nocc), ao_slices=[[0, 1, 0, n_act_aos], [1, 2, n_act_aos, n]]), pr["S"], pr["hcore"],
+                synth.eri_dense(n), backend=be)
+    occ = np.zeros(n_mo)
+    occ[:nocc] = 1
+    mf.mo_coeff, mf.mo_occ = np.stack([c[:, :n_mo], c[:, :n_mo]]), np.stack([occ, occ])
+    fock = mf.get_fock()
+    cl = ConcentricLocalizer(mf, 1, max_shells=4, backend=be)
+    out = cl.localize_virtual()
+    assert out is mf and mf.mo_coeff.shape == (2, n, n_mo)
+    assert cl.shells[0] == cl.shells[1] and cl.shells[0][-1] == n_mo
+    # the localised set spans the same space as the input orbitals
+    for x in range(2):
+        np.testing.assert_allclose(mf.mo_coeff[x] @ mf.mo_coeff[x].T, c[:, :n_mo] @ c[:, :n_mo].T, rtol=0, atol=1e-9)
+    assert fock.shape == (2, n, n)
+
+
+def test_spinorb_and_build_match_reference(be):
+    g = load_golden("spinorb_from_spatial")
+    hb = HamiltonianBuilder.__new__(HamiltonianBuilder)
+    hb.be = be
+    h1, h2 = hb._spinorb_from_spatial(g["one_body"], g["two_body"])
+    np.testing.assert_array_equal(h1, g["h1"])
+    np.testing.assert_array_equal(h2, g["h2"])
+
+    g = load_golden("ham_build_n10")
+    n = int(g["nao"])
+    mf = GpuUHF(Mole(n, (3, 3)), synth.overlap(n), synth.hcore(n), synth.eri_dense(n), backend=be)
+    mf.mo_coeff = g["mo_coeff"]
+    mf.mo_occ = np.array([[1, 1, 1, 0, 0, 0, 0]] * 2, dtype=float)
+    h3 = g["hcore3"]
+    mf.get_hcore = lambda *a: h3
+    builder = HamiltonianBuilder(mf, constant_e_shift=float(g["const"]), backend=be)
+    const, h1, h2 = builder.build()
+    assert const == float(g["const"])
+    np.testing.assert_allclose(builder._one_body_integrals, g["one_body"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(builder._two_body_integrals, g["two_body"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(h1, g["h1"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(h2, g["h2"], rtol=0, atol=1e-11)
+
+
+def test_builder_errors_and_reduce_virtuals(be):
+    n = 10
+    mf = GpuUHF(Mole(n, (3, 3)), synth.overlap(n), synth.hcore(n), synth.eri_dense(n), backend=be)
+    c = synth.general_matrix(9, n, 7)
+    mf.mo_coeff = [c[:, :6], c[:, :5]]  # different alpha / beta counts
+    mf.mo_occ = np.array([[1, 1, 1, 0, 0, 0]] * 2, dtype=float)
+    with pytest.raises(HamiltonianBuilderError):
+        HamiltonianBuilder(mf, backend=be)._two_body_device()
+    mf.mo_coeff = np.stack([c, c])
+    mf.mo_occ = np.array([[1, 1, 1, 0, 0, 0, 0]] * 2, dtype=float)
+    red = reduce_virtuals(mf, 1)
+    assert red.mo_coeff.shape == (2, n, 6) and red.mo_occ.shape == (2, 6)
+    assert reduce_virtuals(mf, 0).mo_coeff.shape == (2, n, 7)
+    with pytest.raises(ValueError) as exc:
+        reduce_virtuals(mf, 7)
+    assert "more than exist" in str(exc)
+    # restricted object: 2-D arrays, the four blocks are copies of one transform
+    rf = GpuRHF(Mole(n, (3, 3)), synth.overlap(n), synth.hcore(n), synth.eri_dense(n), backend=be)
+    rf.mo_coeff, rf.mo_occ = c, np.array([2, 2, 2, 0, 0, 0, 0.0])
+    const, h1, h2 = HamiltonianBuilder(rf, backend=be).build()
+    assert h1.shape == (14, 14) and h2.shape == (14,) * 4
+    np.testing.assert_allclose(h1[0::2, 0::2], h1[1::2, 1::2])

@@ -1,0 +1,129 @@
+"""Host logic of nbed_amd.scf on CPU: the product's loop control (DIIS schedule, stopping
+rule, occupation handling, batching) driven through the checker backend of
+tests/oracle_backend.py, against the golden vectors written by the reference's huzinaga_scf.
+The arithmetic under test on the GPU is covered by tests/test_gpu_*.py."""
+
+import numpy as np
+import pytest
+
+from conftest import canon_sign, load_golden
+from oracle import synth
+from oracle.pyscf_like import ToyMol, ToyRHF, ToyUHF
+from oracle_backend import OracleBackend
+
+from nbed_amd.scf import GpuUHF, Mole, energy_elec, get_huzinaga_operator, huzinaga_scf
+from nbed_amd.scf.pyscf_compat import RHF, UHF
+
+
+class ForeignUHF(UHF, ToyUHF):
+    """A numpy SCF object NOT from this package: exercises the generic (protocol) path."""
+
+
+class ForeignRHF(RHF, ToyRHF):
+    pass
+
+
+@pytest.fixture()
+def be():
+    return OracleBackend()
+
+
+def test_huzinaga_operator_matches_reference(be):
+    g = load_golden("huzinaga_operator")
+    np.testing.assert_allclose(get_huzinaga_operator(g["fock"], g["dm_occ_S"], g["dm_virt_S"], backend=be),
+                               g["out_3d"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(get_huzinaga_operator(g["fock"], g["dm_occ_S"], np.zeros_like(g["dm_occ_S"]), backend=be),
+                               g["out_3d_novirt"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(get_huzinaga_operator(g["fock"][0], g["dm_occ_S"][0], g["dm_virt_S"][0], backend=be),
+                               g["out_2d"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["uhf_n12_nodiis", "uhf_n12_diis", "uhf_n24_diis_open", "uhf_n24_nodiis_open"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_huzinaga_scf_paths_match_reference(be, tag, fused):
+    g = load_golden(f"huzinaga_scf_{tag}")
+    n = int(g["nao"])
+    eri = synth.eri_dense(n)
+    if fused:
+        mf = GpuUHF(Mole(n, tuple(g["nelec"])), g["S"], g["hcore"], eri, backend=be)
+    else:
+        mf = ForeignUHF(ToyMol(n, tuple(g["nelec"])), g["S"], g["hcore"], eri)
+    mf.max_cycle, mf.conv_tol = int(g["max_cycle"]), float(g["conv_tol"])
+    hist = []
+    c, e, d, hz, conv = huzinaga_scf(mf, g["V_emb"], g["D_env"], use_DIIS=bool(g["use_DIIS"]), backend=be,
+                                     history=hist)
+    assert conv == bool(g["conv"])
+    np.testing.assert_allclose(e, g["mo_energy"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(d, g["dm"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(hz, g["huz_op"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(canon_sign(c), g["mo_coeff_canon"], rtol=0, atol=1e-7)
+    assert c.shape == (2, n, n) and e.shape == (2, n)
+    if fused:
+        assert be.calls["jk"] == len(hist)  # exactly one J/K build per cycle
+
+
+def test_huzinaga_scf_restricted_generic_path(be):
+    g = load_golden("huzinaga_scf_rhf_n12_diis")
+    n = int(g["nao"])
+    mf = ForeignRHF(ToyMol(n, tuple(g["nelec"])), g["S"], g["hcore"], synth.eri_dense(n))
+    mf.max_cycle, mf.conv_tol = int(g["max_cycle"]), float(g["conv_tol"])
+    c, e, d, hz, conv = huzinaga_scf(mf, g["V_emb"], g["D_env"], backend=be)
+    assert conv == bool(g["conv"])
+    assert c.shape == (n, n) and e.shape == (n,) and d.shape == (n, n) and hz.shape == (n, n)
+    np.testing.assert_allclose(e, g["mo_energy"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(d, g["dm"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(hz, g["huz_op"], rtol=0, atol=1e-9)
+
+
+def test_huzinaga_scf_rejects_unknown_objects(be):
+    with pytest.raises(TypeError):
+        huzinaga_scf(object(), np.zeros((2, 3, 3)), np.zeros((2, 3, 3)), backend=be)
+
+
+def test_monkey_patched_get_veff_uses_generic_path(be):
+    """The driver patches instances (driver.py:522-529): a patched GpuUHF must not be fused."""
+    g = load_golden("huzinaga_scf_uhf_n12_nodiis")
+    n = int(g["nao"])
+    mf = GpuUHF(Mole(n, tuple(g["nelec"])), g["S"], g["hcore"], synth.eri_dense(n), backend=be)
+    mf.max_cycle, mf.conv_tol = int(g["max_cycle"]), float(g["conv_tol"])
+    calls = []
+    orig = mf.get_veff
+    mf.get_veff = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    c, e, d, hz, conv = huzinaga_scf(mf, g["V_emb"], g["D_env"], use_DIIS=False, backend=be)
+    assert len(calls) == int(g["max_cycle"])
+    np.testing.assert_allclose(d, g["dm"], rtol=0, atol=1e-9)
+
+
+def test_energy_elec_matches_reference(be):
+    g = load_golden("energy_elec")
+    n = int(g["nao"])
+    mf = GpuUHF(Mole(n, (5, 4)), g["S"], g["hcore3"][0], synth.eri_dense(n), backend=be)
+    e_elec, e_coul = energy_elec(mf, g["dm"], g["hcore3"], None)
+    np.testing.assert_allclose(e_elec, g["e_elec"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(e_coul, g["e_coul"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(mf.scf_summary["e1"], g["e1"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(mf.scf_summary["e2"], g["e2"], rtol=0, atol=1e-11)
+
+
+def test_gpu_uhf_protocol_matches_oracle_scf(be):
+    """get_veff / get_jk / make_rdm1 / eig / kernel of GpuUHF vs the oracle's ToyUHF."""
+    n = 12
+    pr = synth.problem(n, (4, 3), 0)
+    eri = synth.eri_dense(n)
+    mf = GpuUHF(Mole(n, (4, 3), e_nuc=0.5), pr["S"], pr["hcore"], eri, backend=be)
+    ref = ToyUHF(ToyMol(n, (4, 3), e_nuc=0.5), pr["S"], pr["hcore"], eri)
+    mf.conv_tol = ref.conv_tol = 1e-10
+    dm = ref.get_init_guess()
+    np.testing.assert_allclose(mf.get_init_guess(), dm, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(mf.get_veff(dm=dm), ref.get_veff(dm=dm), rtol=0, atol=1e-12)
+    vj, vk = mf.get_jk(dm=dm)
+    rj, rk = ref.get_jk(dm=dm)
+    np.testing.assert_allclose(vj, rj, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(vk, rk, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(mf.get_j(dm=dm), rj, rtol=0, atol=1e-12)
+    e1, e2 = mf.kernel(), ref.kernel()
+    assert mf.converged and ref.converged
+    np.testing.assert_allclose(e1, e2, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(mf.mo_energy, ref.mo_energy, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(mf.make_rdm1(), ref.make_rdm1(), rtol=0, atol=1e-7)
+    assert mf.copy().get_hcore is not None and mf() is mf
