@@ -59,6 +59,14 @@ def parse_args():
     return ap.parse_args()
 
 
+def host_cores() -> int:
+    """Cores this process may run on (the GPU box gives a share of the host, not all of it)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def transform_flops(N, n):
     """One spin block, sequential quarter transforms, no symmetry."""
     return 2.0 * n * N**4 + 2.0 * n**2 * N**3 + 2.0 * n**3 * N**2 + 2.0 * n**4 * N
@@ -68,6 +76,7 @@ def cpu_baseline_cycle(pr, eri_h, ncycles):
     """The CPU oracle's cycle on the host cores: C/OpenMP one-pass J/K + numpy/LAPACK rest."""
     import tempfile
 
+    os.environ["OMP_NUM_THREADS"] = str(host_cores())  # libgomp reads it when the C oracle is loaded
     from oracle import cref
     from oracle.huzinaga import huzinaga_scf
     from oracle.pyscf_like import ToyMol, ToyUHF
@@ -222,7 +231,7 @@ def main():
         cpu = {
             "value": cps,
             "unit": "cycles/s",
-            "cores": os.cpu_count(),
+            "cores": host_cores(),
             "kind": "port",
             "sample": f"{args.cpu_cycles} Huzinaga UHF cycles at N_AO={N}: oracle loop with C/OpenMP one-pass dense J/K "
                       "(oracle/c/jk_ref.c, -march=native) + numpy/LAPACK eigh, same inputs",
@@ -236,7 +245,7 @@ def main():
             tcpu = time.perf_counter() - tcpu0
             fl = 2.0 * 32 * N**4 + 2.0 * 32 * n_act * N**3 + 2.0 * 32 * n_act**2 * N**2 + 2.0 * 32 * n_act**3 * N
             transform["cpu_baseline"] = {
-                "value": fl / tcpu / 1e9, "unit": "GFLOP/s", "cores": os.cpu_count(), "kind": "port",
+                "value": fl / tcpu / 1e9, "unit": "GFLOP/s", "cores": host_cores(), "kind": "port",
                 "sample": "one (32 x n x n x n) outer-index slab of one spin block, numpy tensordot (OpenBLAS dgemm)",
             }
         del eri_h

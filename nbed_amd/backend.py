@@ -276,14 +276,16 @@ class HipBackend:
         return a
 
     # ------------------------------------------------------------------ eigh / svd
-    def eigh(self, a, check: bool = False):
+    def eigh(self, a, check: bool = False, v0=None):
+        """Eigenpairs of symmetric ``a`` (lower triangle, ascending); ``v0``: warm-start vectors."""
         n = a.shape[-1]
         batch = 1 if a.dim() == 2 else a.shape[0]
         nbytes = self.lib.nbx_eigh_worksize(n, batch)
         work = self._workspace("eigh", nbytes)
         w = self.empty(a.shape[:-1])
         v = self.torch.empty_like(a)
-        self._call("nbx_eigh", n, batch, self._p(a), self._p(w), self._p(v), self._p(work), work.numel())
+        self._call("nbx_eigh_warm", n, batch, self._p(a), self._p(v0), self._p(w), self._p(v), self._p(work),
+                   work.numel())
         if check:
             sweeps = (c_int * batch)()
             self._call("nbx_eigh_status", n, batch, self._p(work), sweeps)

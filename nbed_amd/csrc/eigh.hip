@@ -109,52 +109,90 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_jacobi_kernel(const double*
             __syncthreads();
             const bool any = nrot_step > 0;
             if (tid == 0 && any) nrot += nrot_step;
-            // ---- phase B: A' = P^T (J^T A J) P,  V' = V J P
-            for (int item = tid; item < m * m; item += EIGH_THREADS) {
-                const int I = item / m, K = item - I * m;
-                const double2 r0 = *reinterpret_cast<const double2*>(Ac + (int64_t)(2 * I) * NP + 2 * K);
-                const double2 r1 = *reinterpret_cast<const double2*>(Ac + (int64_t)(2 * I + 1) * NP + 2 * K);
-                double b00 = r0.x, b01 = r0.y, b10 = r1.x, b11 = r1.y;
-                if (any) {
-                    const double ci = cs[3 * I], si = cs[3 * I + 1];
-                    const double ck = cs[3 * K], sk = cs[3 * K + 1];
-                    if (I == K) {
-                        const double t = cs[3 * I + 2];
-                        b00 = r0.x - t * r0.y;
-                        b11 = r1.y + t * r0.y;
-                        if (t != 0.0) {
-                            b01 = 0.0;
-                            b10 = 0.0;
+            // ---- phase B: A' = P^T (J^T A J) P,  V' = V J P.  Items are processed four at a
+            // time with all loads issued before the first store: stores and loads share the
+            // in-order vmcnt counter, so interleaving them would serialise on store latency.
+            {
+                const double* __restrict__ src = Ac;
+                double* __restrict__ dst = An;
+                constexpr int U = 4;
+                for (int base = tid; base < m * m; base += U * EIGH_THREADS) {
+                    double2 r0[U], r1[U];
+                    int II[U], KK[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int item = base + u * EIGH_THREADS;
+                        II[u] = -1;
+                        if (item < m * m) {
+                            II[u] = item / m;
+                            KK[u] = item - II[u] * m;
+                            r0[u] = *reinterpret_cast<const double2*>(src + (int64_t)(2 * II[u]) * NP + 2 * KK[u]);
+                            r1[u] = *reinterpret_cast<const double2*>(src + (int64_t)(2 * II[u] + 1) * NP + 2 * KK[u]);
                         }
-                    } else {
-                        // rows: J_I^T = [[c,-s],[s,c]]
-                        const double u00 = ci * r0.x - si * r1.x, u01 = ci * r0.y - si * r1.y;
-                        const double u10 = si * r0.x + ci * r1.x, u11 = si * r0.y + ci * r1.y;
-                        // cols: J_K = [[c,s],[-s,c]]
-                        b00 = u00 * ck - u01 * sk;
-                        b01 = u00 * sk + u01 * ck;
-                        b10 = u10 * ck - u11 * sk;
-                        b11 = u10 * sk + u11 * ck;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (II[u] < 0) continue;
+                        const int I = II[u], K = KK[u];
+                        double b00 = r0[u].x, b01 = r0[u].y, b10 = r1[u].x, b11 = r1[u].y;
+                        if (any) {
+                            const double ci = cs[3 * I], si = cs[3 * I + 1];
+                            const double ck = cs[3 * K], sk = cs[3 * K + 1];
+                            if (I == K) {
+                                const double t = cs[3 * I + 2];
+                                b00 = r0[u].x - t * r0[u].y;
+                                b11 = r1[u].y + t * r0[u].y;
+                                if (t != 0.0) {
+                                    b01 = 0.0;
+                                    b10 = 0.0;
+                                }
+                            } else {
+                                // rows: J_I^T = [[c,-s],[s,c]]; cols: J_K = [[c,s],[-s,c]]
+                                const double u00 = ci * r0[u].x - si * r1[u].x, u01 = ci * r0[u].y - si * r1[u].y;
+                                const double u10 = si * r0[u].x + ci * r1[u].x, u11 = si * r0[u].y + ci * r1[u].y;
+                                b00 = u00 * ck - u01 * sk;
+                                b01 = u00 * sk + u01 * ck;
+                                b10 = u10 * ck - u11 * sk;
+                                b11 = u10 * sk + u11 * ck;
+                            }
+                        }
+                        const int ri0 = rr_next(2 * I, m), ri1 = rr_next(2 * I + 1, m);
+                        const int ck0 = rr_next(2 * K, m), ck1 = rr_next(2 * K + 1, m);
+                        dst[(int64_t)ri0 * NP + ck0] = b00;
+                        dst[(int64_t)ri0 * NP + ck1] = b01;
+                        dst[(int64_t)ri1 * NP + ck0] = b10;
+                        dst[(int64_t)ri1 * NP + ck1] = b11;
                     }
                 }
-                const int ri0 = rr_next(2 * I, m), ri1 = rr_next(2 * I + 1, m);
-                const int ck0 = rr_next(2 * K, m), ck1 = rr_next(2 * K + 1, m);
-                An[(int64_t)ri0 * NP + ck0] = b00;
-                An[(int64_t)ri0 * NP + ck1] = b01;
-                An[(int64_t)ri1 * NP + ck0] = b10;
-                An[(int64_t)ri1 * NP + ck1] = b11;
-            }
-            for (int item = tid; item < NP * m; item += EIGH_THREADS) {
-                const int r = item / m, K = item - r * m;
-                const double2 v = *reinterpret_cast<const double2*>(Vc + (int64_t)r * NP + 2 * K);
-                double v0 = v.x, v1 = v.y;
-                if (any) {
-                    const double ck = cs[3 * K], sk = cs[3 * K + 1];
-                    v0 = ck * v.x - sk * v.y;
-                    v1 = sk * v.x + ck * v.y;
+                const double* __restrict__ vsrc = Vc;
+                double* __restrict__ vdst = Vn;
+                for (int base = tid; base < NP * m; base += U * EIGH_THREADS) {
+                    double2 v[U];
+                    int RR[U], KK[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int item = base + u * EIGH_THREADS;
+                        RR[u] = -1;
+                        if (item < NP * m) {
+                            RR[u] = item / m;
+                            KK[u] = item - RR[u] * m;
+                            v[u] = *reinterpret_cast<const double2*>(vsrc + (int64_t)RR[u] * NP + 2 * KK[u]);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (RR[u] < 0) continue;
+                        const int K = KK[u];
+                        double v0 = v[u].x, v1 = v[u].y;
+                        if (any) {
+                            const double ck = cs[3 * K], sk = cs[3 * K + 1];
+                            v0 = ck * v[u].x - sk * v[u].y;
+                            v1 = sk * v[u].x + ck * v[u].y;
+                        }
+                        vdst[(int64_t)RR[u] * NP + rr_next(2 * K, m)] = v0;
+                        vdst[(int64_t)RR[u] * NP + rr_next(2 * K + 1, m)] = v1;
+                    }
                 }
-                Vn[(int64_t)r * NP + rr_next(2 * K, m)] = v0;
-                Vn[(int64_t)r * NP + rr_next(2 * K + 1, m)] = v1;
             }
             __syncthreads();
             double* tA = Ac; Ac = An; An = tA;
@@ -196,22 +234,20 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
-extern "C" size_t nbx_eigh_worksize(int64_t n, int64_t batch) {
-    if (n <= 0 || batch <= 0) return 0;
+static size_t eigh_global_worksize(int64_t n, int64_t batch) {
     const int64_t np = (n + 1) & ~1ll;
     return align256((size_t)(4 * np * np * batch) * sizeof(double)) + align256((size_t)batch * sizeof(int));
 }
 
-extern "C" int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
-                        void* d_work, size_t work_bytes) {
-    NBX_CHECK_ARG(ctx && d_a && d_w && d_v && n > 0 && batch > 0 && batch <= 1024);
-    NBX_CHECK_ARG(n <= 4096);
-    const size_t need = nbx_eigh_worksize(n, batch);
-    if (d_work == nullptr || work_bytes < need) {
-        nbx_set_error("nbx_eigh: workspace %zu < %zu bytes", work_bytes, need);
-        return NBX_E_NOMEM;
-    }
-    NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
+extern "C" size_t nbx_eigh_worksize(int64_t n, int64_t batch) {
+    if (n <= 0 || batch <= 0) return 0;
+    if (nbx_eigh_lds_supported(n)) return nbx_eigh_lds_worksize(n, batch);
+    // warm starts on the global-memory path need V0^T A V0 and a GEMM temporary
+    return eigh_global_worksize(n, batch) + 2 * align256((size_t)(n * n * batch) * sizeof(double));
+}
+
+static int eigh_global(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
+                       void* d_work) {
     const int64_t np = (n + 1) & ~1ll;
     double* work = static_cast<double*>(d_work);
     int* status = reinterpret_cast<int*>(static_cast<char*>(d_work) +
@@ -226,10 +262,41 @@ extern "C" int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_
     return NBX_OK;
 }
 
+extern "C" int nbx_eigh_warm(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0,
+                             double* d_w, double* d_v, void* d_work, size_t work_bytes) {
+    NBX_CHECK_ARG(ctx && d_a && d_w && d_v && n > 0 && batch > 0 && batch <= 1024);
+    NBX_CHECK_ARG(n <= 4096);
+    const size_t need = nbx_eigh_worksize(n, batch);
+    if (d_work == nullptr || work_bytes < need) {
+        nbx_set_error("nbx_eigh: workspace %zu < %zu bytes", work_bytes, need);
+        return NBX_E_NOMEM;
+    }
+    NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
+    if (nbx_eigh_lds_supported(n)) return nbx_eigh_lds(ctx, n, batch, d_a, d_v0, d_w, d_v, d_work, work_bytes);
+    if (d_v0 == nullptr) return eigh_global(ctx, n, batch, d_a, d_w, d_v, d_work);
+    // global-memory path, warm start: solve V0^T A V0 = U w U^T, then V = V0 U
+    char* extra = static_cast<char*>(d_work) + eigh_global_worksize(n, batch);
+    double* a0 = reinterpret_cast<double*>(extra);
+    double* tmp = reinterpret_cast<double*>(extra + align256((size_t)(n * n * batch) * sizeof(double)));
+    int rc = nbx_gemm(ctx, 'T', 'N', n, n, n, 1.0, d_v0, n, n * n, d_a, n, n * n, 0.0, tmp, n, n * n, batch);
+    if (rc != NBX_OK) return rc;
+    rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, tmp, n, n * n, d_v0, n, n * n, 0.0, a0, n, n * n, batch);
+    if (rc != NBX_OK) return rc;
+    rc = eigh_global(ctx, n, batch, a0, d_w, tmp, d_work);
+    if (rc != NBX_OK) return rc;
+    return nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, d_v0, n, n * n, tmp, n, n * n, 0.0, d_v, n, n * n, batch);
+}
+
+extern "C" int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
+                        void* d_work, size_t work_bytes) {
+    return nbx_eigh_warm(ctx, n, batch, d_a, nullptr, d_w, d_v, d_work, work_bytes);
+}
+
 extern "C" int nbx_eigh_status(nbx_ctx* ctx, int64_t n, int64_t batch, const void* d_work, int* h_sweeps) {
     NBX_CHECK_ARG(ctx && d_work && h_sweeps && n > 0 && batch > 0);
     const int64_t np = (n + 1) & ~1ll;
     const char* status = static_cast<const char*>(d_work) + align256((size_t)(4 * np * np * batch) * sizeof(double));
+    if (nbx_eigh_lds_supported(n)) status = reinterpret_cast<const char*>(nbx_eigh_lds_status_ptr(n, batch, d_work));
     int rc = nbx_memcpy_d2h(ctx, h_sweeps, status, (size_t)batch * sizeof(int));
     if (rc != NBX_OK) return rc;
     for (int64_t b = 0; b < batch; ++b)

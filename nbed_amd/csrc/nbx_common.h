@@ -20,6 +20,14 @@ struct nbx_prof_slot {
     int64_t count = 0;
 };
 
+// Round-robin Jacobi schedule tables of one (even) matrix order, device resident (eigh_lds.hip)
+struct nbx_sched {
+    int np;
+    void* d_blocks;  // ushort4 [steps][m(m-1)/2]: packed-LDS indices of each 2x2 block
+    void* d_pairs;   // ushort4 [steps][m]: packed indices of (pp, qq, pq)
+    void* d_pq;      // ushort2 [steps][m]: the pair (p, q)
+};
+
 struct nbx_ctx {
     int device;
     hipStream_t stream;
@@ -28,7 +36,15 @@ struct nbx_ctx {
     double* h_pinned;       // pinned host mirror of the scratch
     bool profiling = false;
     nbx_prof_slot prof[NBX_PROF_SLOTS];
+    std::vector<nbx_sched> sched;
 };
+
+// eigh_lds.hip
+bool nbx_eigh_lds_supported(int64_t n);
+size_t nbx_eigh_lds_worksize(int64_t n, int64_t batch);
+int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0, double* d_w,
+                 double* d_v, void* d_work, size_t work_bytes);
+const int* nbx_eigh_lds_status_ptr(int64_t n, int64_t batch, const void* d_work);
 
 // HIP-event bracket around a launch, active only while profiling is enabled.
 struct nbx_prof_scope {

@@ -145,9 +145,14 @@ def huzinaga_scf(
         be.axpby(1.0, hcore_d if hcore_d.dim() == 2 else hcore_d[x], 1.0, hv[x])
         be.axpby(1.0, vemb_d if vemb_d.dim() == 2 else vemb_d[x], 1.0, hv[x])
 
+    warm = {"v": None}
+
     def diagonalise(fock3):
+        # Loewdin step (:166-169).  The previous cycle's orthonormal eigenvectors seed the
+        # Jacobi solver: X F X is nearly diagonal in that basis once the SCF is under way.
         fo = be.gemm(be.gemm(x_d, fock3), x_d)
-        e_d, c_ortho = be.eigh(fo)
+        e_d, c_ortho = be.eigh(fo, v0=warm["v"])
+        warm["v"] = c_ortho
         return e_d, be.gemm(x_d, c_ortho)
 
     def occupations(e_d, c_d):

@@ -174,7 +174,7 @@ class OracleBackend:
         an *= self._np(s)[..., None, :]
         return a
 
-    def eigh(self, a, check=False):
+    def eigh(self, a, check=False, v0=None):
         self._count("eigh")
         w, v = np.linalg.eigh(self._np(a))
         self.last_eigh_sweeps = [1]

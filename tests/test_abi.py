@@ -35,7 +35,7 @@ def test_every_entry_point_cites_the_reference():
     for fn in ("nbx_jk_dense", "nbx_gemm", "nbx_eigh", "nbx_svd_right", "nbx_ao2mo", "nbx_spinorb_scatter",
                "nbx_huzinaga_sym", "nbx_trace_prod", "nbx_sym_pow"):
         idx = HEADER.index(f" {fn}(")
-        assert "nbed/" in HEADER[max(0, idx - 1800):idx], fn
+        assert "nbed/" in HEADER[max(0, idx - 2600):idx], fn
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -226,6 +226,28 @@ def test_eigh_degenerate_and_graded(be):
     check_eigh(be, np.diag(np.arange(6.0)))
 
 
+def test_eigh_warm_start(be):
+    """Seeding with the eigenvectors of a nearby matrix gives the same decomposition in
+    fewer sweeps (what huzinaga_scf does from one SCF cycle to the next)."""
+    n = 148
+    a = np.stack([symm(86, n), symm(87, n)])
+    w0, v0 = be.eigh(be.asarray(a), check=True)
+    cold = list(be.last_eigh_sweeps)
+    a2 = a + 1e-3 * np.stack([symm(88, n), symm(89, n)])
+    w, v = be.eigh(be.asarray(a2), check=True, v0=v0)
+    warm = list(be.last_eigh_sweeps)
+    w, v = be.to_host(w), be.to_host(v)
+    np.testing.assert_allclose(w, np.linalg.eigvalsh(a2), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(a2 @ v, v * w[:, None, :], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(np.swapaxes(v, -1, -2) @ v, np.broadcast_to(np.eye(n), a.shape), rtol=0, atol=1e-12)
+    assert max(warm) < min(cold), (warm, cold)
+
+
+@pytest.mark.parametrize("n", [196, 197, 230])
+def test_eigh_lds_boundary_and_global_path(be, n):
+    check_eigh(be, symm(90, n))
+
+
 @pytest.mark.parametrize("p", [-0.5, 0.5, -1.0])
 def test_sym_pow(be, p):
     n = 37
