@@ -9,5 +9,10 @@ Importing the package needs neither the library nor a GPU; computing does.
 
 from ._nbx import NbxError, NbxUnavailableError
 from .backend import HipBackend, get_backend, set_backend
+from .config import NbedConfig
+from .driver import NbedDriver
+from .embed import nbed
+from .ham_builder import HamiltonianBuilder
 
-__all__ = ["HipBackend", "get_backend", "set_backend", "NbxError", "NbxUnavailableError"]
+__all__ = ["nbed", "NbedConfig", "NbedDriver", "HamiltonianBuilder", "HipBackend", "get_backend", "set_backend",
+           "NbxError", "NbxUnavailableError"]

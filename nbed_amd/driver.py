@@ -1,0 +1,424 @@
+"""NbedDriver: orchestration of the projection-based embedding, GPU hot path underneath.
+
+Drop-in for nbed/driver.py's ``NbedDriver``: ``NbedDriver(config)``, ``.embed()``,
+``.post_embed()``, the attributes ``embed`` sets (``e_nuc, localized_system, e_act, e_env,
+two_e_cross, embedding_potential, mu, huzinaga, embedded_scf, classical_energy``) and the
+result-dict keys (``scf, v_emb, mo_energies_emb_pre_del, mo_energies_emb_post_del, correction,
+beta_correction, cl, e_rhf, classical_energy, hf_emb, second_quantised``).
+
+What runs where
+---------------
+* The embedded-SCF hot path -- projector S D_env S, mu-shifted or Huzinaga SCF (J/K, projector
+  products, eigensolves), environment deletion scores, concentric localisation, correction
+  traces, the active-space Hamiltonian -- runs on the GPU through ``nbed_amd``'s own classes.
+* What the reference delegates to PySCF OUTSIDE that path -- building the molecule and its AO
+  integrals, the global B3LYP Kohn-Sham calculation that produces the densities and the
+  embedding potential, CCSD / FCI / DFT-in-DFT reference energies -- comes from a *provider*
+  object.  ``PySCFProvider`` (default) uses a local PySCF installation for exactly those
+  pieces; tests use a synthetic provider.  Without PySCF the default provider raises
+  ``NbedDriverError`` naming what is missing: there is no silent fallback.
+
+Reference quirks kept on purpose: the environment-selection score of
+the Huzinaga path is ``colsum(C) * colsum(P C)`` (driver.py:746-756, an einsum that is NOT
+diag(C^T P C)); the mu path deletes the LAST n_env orbitals by index (:758-766); n_env is the
+size of the union of the alpha and beta environment index sets (:671-675); the ``savefile``
+branch binds a boolean (:918) and is not reproduced.
+"""
+
+from __future__ import annotations
+
+import logging
+from functools import cached_property
+from typing import Optional
+
+import numpy as np
+
+from .backend import get_backend
+from .config import NbedConfig, OccupiedLocalizerTypes, ProjectorTypes, VirtualLocalizerTypes
+from .exceptions import NbedDriverError
+from .ham_builder import HamiltonianBuilder
+from .localizers import ConcentricLocalizer, LocalizedSystem, SPADELocalizer
+from .localizers.occupied.unsupported import BOYSLocalizer, IBOLocalizer, PMLocalizer
+from .scf import energy_elec
+from .scf.huzinaga_scf import huzinaga_scf
+
+logger = logging.getLogger(__name__)
+
+
+class PySCFProvider:
+    """The out-of-path pieces from a local PySCF: molecule/integrals and the global UKS."""
+
+    def __init__(self):
+        try:
+            import pyscf  # noqa: F401
+        except ImportError as err:
+            raise NbedDriverError(
+                "NbedDriver needs a provider for the molecule integrals and the global Kohn-Sham "
+                "calculation (outside the GPU hot path). The default provider uses PySCF, which is not "
+                "installed; pass provider=... (see INTEGRATION.md)."
+            ) from err
+
+    def build_mol(self, config: NbedConfig):
+        from pyscf import gto
+
+        return gto.Mole(atom=config.geometry[2:], basis=config.basis, charge=config.charge, unit=config.unit,
+                        spin=config.spin).build()
+
+    def global_ks(self, config: NbedConfig, run_qmmm: bool = False):
+        from pyscf import dft, qmmm
+
+        ks = dft.UKS(self.build_mol(config))
+        ks.conv_tol = config.convergence
+        ks.xc = config.xc_functional
+        ks.max_memory = config.max_ram_memory
+        ks.max_cycle = config.max_dft_cycles
+        ks.verbose = 1
+        if run_qmmm:
+            ks = qmmm.mm_charge(ks, config.mm_coords, config.mm_charges, config.mm_radii)
+        ks.kernel()
+        return ks
+
+    def local_hf(self, config: NbedConfig, embedded_mol, backend=None):
+        """GPU-backed UHF object over the embedded molecule's AO integrals."""
+        from pyscf import scf as pyscf_scf
+
+        from .scf import GpuUHF
+
+        s = embedded_mol.intor("int1e_ovlp")
+        h = pyscf_scf.hf.get_hcore(embedded_mol)
+        eri = embedded_mol.intor("int2e", aosym="s1")
+        return GpuUHF(embedded_mol, s, h, eri, backend=backend)
+
+
+class NbedDriver:
+    """Run projection-based embedding and produce the embedded active-space Hamiltonian."""
+
+    def __init__(self, config: NbedConfig, provider=None, backend=None):
+        self.config = config
+        self._provider = provider
+        self._be = backend
+        self.localized_system: LocalizedSystem
+        self.two_e_cross = None
+        self.mu: dict = None
+        self.huzinaga: dict = None
+        self.active_geometry = f"{config.n_active_atoms}\n\n" + "\n".join(
+            config.geometry.splitlines()[2 : 2 + config.n_active_atoms]
+        )
+        self._restricted_scf = False  # the reference is always unrestricted (driver.py:69-78)
+        self.run_qmmm = None not in [config.mm_charges, config.mm_coords, config.mm_radii]
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def be(self):
+        if self._be is None:
+            self._be = get_backend()
+        return self._be
+
+    @property
+    def provider(self):
+        if self._provider is None:
+            self._provider = PySCFProvider()
+        return self._provider
+
+    def _build_mol(self):
+        return self.provider.build_mol(self.config)
+
+    @cached_property
+    def _global_ks(self):
+        """Converged global (cheap) Kohn-Sham object: source of densities and potentials."""
+        ks = self.provider.global_ks(self.config, self.run_qmmm) if self.run_qmmm else self.provider.global_ks(self.config)
+        if getattr(ks, "converged", True) is not True:
+            logger.warning("(cheap) global DFT calculation has NOT converged!")
+        return ks
+
+    def _unsupported(self, what: str):
+        raise NotImplementedError(
+            f"{what} is outside the MI355X hot path (SURVEY.md section 2, component 4); run it with PySCF on the "
+            "embedded SCF object returned in result['scf']."
+        )
+
+    @cached_property
+    def _global_hf(self):
+        if hasattr(self.provider, "global_hf"):
+            return self.provider.global_hf(self.config)
+        self._unsupported("The global Hartree-Fock reference calculation")
+
+    @cached_property
+    def _global_ccsd(self):
+        self._unsupported("The global CCSD reference calculation")
+
+    @cached_property
+    def _global_fci(self):
+        self._unsupported("The global FCI reference calculation")
+
+    # ------------------------------------------------------------------ localisation
+    def _localize(self) -> LocalizedSystem:
+        match self.config.localization:
+            case OccupiedLocalizerTypes.SPADE:
+                localizer = SPADELocalizer(self._global_ks, self.config.n_active_atoms,
+                                           max_shells=self.config.max_shells, n_mo_overwrite=self.n_mo_overwrite,
+                                           backend=self.be)
+            case OccupiedLocalizerTypes.BOYS:
+                localizer = BOYSLocalizer(self._global_ks, self.config.n_active_atoms)
+            case OccupiedLocalizerTypes.IBO:
+                localizer = IBOLocalizer(self._global_ks, self.config.n_active_atoms)
+            case OccupiedLocalizerTypes.PM:
+                localizer = PMLocalizer(self._global_ks, self.config.n_active_atoms)
+        self.localizer = localizer
+        return localizer.localize()
+
+    # ------------------------------------------------------------------ embedded SCF objects
+    def _init_embedded_mol(self):
+        """Molecule whose electron count is overwritten with the active one (driver.py:262-287)."""
+        mol = self._build_mol()
+        inds = np.asarray(self.localized_system.active_mo_inds)
+        if inds.ndim == 1:
+            n = len(inds)
+            mol.nelectron, mol.nelec, mol.spin = 2 * n, (n, n), 0
+        else:
+            na, nb = len(inds[0]), len(inds[1])
+            mol.nelectron, mol.nelec, mol.spin = na + nb, (na, nb), na - nb
+        self._electron = mol.nelectron
+        return mol
+
+    def _init_local_hf(self):
+        local_hf = self.provider.local_hf(self.config, self._init_embedded_mol(), backend=self.be)
+        local_hf.max_memory = self.config.max_ram_memory
+        local_hf.conv_tol = self.config.convergence
+        local_hf.max_cycle = self.config.max_hf_cycles
+        local_hf.verbose = 1
+        return local_hf
+
+    def _init_local_ks(self, xc_functional: str):
+        self._unsupported("An embedded Kohn-Sham object (DFT-in-DFT)")
+
+    # ------------------------------------------------------------------ subsystem DFT (inputs)
+    def _subsystem_dft(self, global_ks, localized_system):
+        """Energies of the active / environment densities and their two-electron cross term
+        (driver.py:315-431).  The Kohn-Sham potential itself comes from ``global_ks``."""
+        be = self.be
+
+        def ks_components(dm):
+            two_e = global_ks.get_veff(dm=dm)
+            j_mat = global_ks.get_j(dm=dm)
+            dm_tot = dm[0] + dm[1] if dm.ndim == 3 else dm
+            e = float(be.trace_prod(be.asarray(np.asarray(global_ks.get_hcore())), be.asarray(dm_tot)))
+            return e + two_e.ecoul + two_e.exc, two_e, np.asarray(j_mat)
+
+        dm_act, dm_env = localized_system.dm_active, localized_system.dm_enviro
+        e_act, two_e_act, j_act = ks_components(dm_act)
+        e_env, two_e_env, j_env = ks_components(dm_env)
+
+        total_dm = dm_act + dm_env
+        if dm_act.ndim == 3:
+            total_dm = total_dm[0] + total_dm[1]
+        e_xc_total = global_ks.get_veff(dm=total_dm).exc
+
+        def dot(a, b):  # einsum("ij,ij")
+            return float(be.dots(be.asarray(a).reshape(-1), be.asarray(b).reshape(1, -1))[0])
+
+        if dm_act.ndim == 2:
+            j_cross = 0.5 * (dot(dm_act, j_env) + dot(dm_env, j_act))
+        else:
+            j_cross = 0.5 * sum(
+                dot(dm_act[x], j_env[y]) + dot(dm_env[x], j_act[y]) for x in range(2) for y in range(2)
+            )
+        k_cross = 0.0  # the projection makes the kinetic cross term vanish (driver.py:415)
+        xc_cross = e_xc_total - two_e_act.exc - two_e_env.exc
+        return e_act, e_env, j_cross + k_cross + xc_cross
+
+    @cached_property
+    def _env_projector(self) -> np.ndarray:
+        """P = S D_env S per spin (driver.py:433-449)."""
+        be = self.be
+        s = be.asarray(np.asarray(self._global_ks.get_ovlp()))
+        d = be.asarray(np.asarray(self.localized_system.dm_enviro))
+        return be.to_host(be.gemm(be.gemm(s, d), s))
+
+    # ------------------------------------------------------------------ projectors
+    def _mu_embed(self, localized_scf, embedding_potential):
+        """mu-shift projector: v_emb = mu P + V_emb added to hcore, then the SCF kernel
+        (driver.py:500-538)."""
+        v_emb = (self.config.mu_level_shift * self._env_projector) + embedding_potential
+        if v_emb.ndim == 3:
+            localized_scf.energy_elec = lambda *args: energy_elec(localized_scf, *args)
+        hcore_std = localized_scf.get_hcore
+        localized_scf.get_hcore = lambda *args: hcore_std(*args) + v_emb
+        localized_scf.kernel()
+        logger.info(f"Embedded scf energy MU_SHIFT: {localized_scf.e_tot}, converged: {localized_scf.converged}")
+        return localized_scf, v_emb
+
+    def _huzinaga_embed(self, active_scf, embedding_potential, localized_system, dmat_initial_guess=None):
+        """Huzinaga projector: own SCF loop, results written back to the SCF object
+        (driver.py:540-632)."""
+        if localized_system.c_loc_virt is not None:
+            c_virt = np.asarray(localized_system.c_loc_virt)
+            virtual_projector = c_virt @ np.swapaxes(c_virt, -1, -2)
+            dm_environment_virtual = np.identity(c_virt.shape[-2]) - localized_system.dm_loc_occ - virtual_projector
+        else:
+            dm_environment_virtual = None
+
+        c_emb, e_emb, dm_emb, huz_op, conv = huzinaga_scf(
+            active_scf, embedding_potential, localized_system.dm_enviro,
+            dm_environment_virtual=dm_environment_virtual, dm_conv_tol=1e-6, dm_initial_guess=dmat_initial_guess,
+        )
+        hcore_std = active_scf.get_hcore()
+        v_emb = huz_op + embedding_potential
+        active_scf.get_hcore = lambda *args: hcore_std + v_emb
+        if np.asarray(localized_system.c_active).ndim == 3:
+            active_scf.energy_elec = lambda *args: energy_elec(active_scf, *args)
+        active_scf.mo_occ = active_scf.get_occ(e_emb, c_emb)
+        if localized_system.c_loc_virt is not None:
+            occ_any = np.sum(active_scf.mo_occ, axis=0)
+            active_scf.mo_coeff = np.concatenate(
+                (c_emb[..., occ_any > 0], c_emb[..., occ_any == 0][: localized_system.c_loc_virt.shape[-1]]), axis=2
+            )
+            active_scf.mo_occ = active_scf.mo_occ[: active_scf.mo_coeff.shape[-1]]
+        else:
+            active_scf.mo_coeff = c_emb
+        active_scf.mo_energy = e_emb
+        active_scf.e_tot = active_scf.energy_tot(dm=dm_emb)
+        active_scf.converged = conv
+        logger.info(f"Embedded scf energy HUZINAGA: {active_scf.e_tot}")
+        return active_scf, v_emb
+
+    # ------------------------------------------------------------------ environment deletion
+    def _delete_environment(self, projector, scf, localized_system, env_projector):
+        c_env = np.asarray(localized_system.c_enviro)
+        if c_env.ndim == 2:
+            n_env = c_env.shape[-1]
+            scf.mo_coeff, scf.mo_energy, scf.mo_occ = self._delete_spin_environment(
+                projector, n_env, scf.mo_coeff, scf.mo_energy, scf.mo_occ, env_projector)
+        else:
+            n_env = len(set(localized_system.enviro_mo_inds[0]).union(localized_system.enviro_mo_inds[1]))
+            a = self._delete_spin_environment(projector, n_env, scf.mo_coeff[0], scf.mo_energy[0], scf.mo_occ[0],
+                                              env_projector[0])
+            b = self._delete_spin_environment(projector, n_env, scf.mo_coeff[1], scf.mo_energy[1], scf.mo_occ[1],
+                                              env_projector[1])
+            scf.mo_coeff = np.array([a[0], b[0]])
+            scf.mo_energy = np.array([a[1], b[1]])
+            scf.mo_occ = np.array([a[2], b[2]])
+        return scf
+
+    def _delete_spin_environment(self, projector, n_env_mo, mo_coeff, mo_energy, mo_occ, environment_projector):
+        """Drop the environment orbitals of one spin (driver.py:715-791)."""
+        mo_coeff = np.asarray(mo_coeff)
+        n_mo = mo_coeff.shape[-1]
+        match projector:
+            case ProjectorTypes.HUZ:
+                # einsum("ij, ki -> i", C^T, P C) = colsum(C)_i * colsum(P C)_i
+                be = self.be
+                c_d = be.asarray(mo_coeff)
+                pc = be.gemm(be.asarray(np.asarray(environment_projector)), c_d)
+                ones = be.asarray(np.ones((1, mo_coeff.shape[0])))
+                score = be.to_host(be.gemm(ones, c_d))[0] * be.to_host(be.gemm(ones, pc))[0]
+                frozen = list(score.argsort()[::-1][:n_env_mo])
+            case ProjectorTypes.MU:
+                frozen = list(range(n_mo - n_env_mo, n_mo))
+        keep = [i for i in range(n_mo) if i not in frozen]
+        logger.info(f"Orbital indices for embedded system: {keep}")
+        logger.info(f"Orbital indices removed from embedded system: {frozen}")
+        return mo_coeff[:, keep], np.asarray(mo_energy)[keep], np.asarray(mo_occ)[keep]
+
+    def _dft_in_dft(self, projection_method):
+        self._unsupported("DFT-in-DFT embedding")
+
+    def _run_emb_ccsd(self, emb_scf, frozen=None):
+        self._unsupported("Embedded CCSD")
+
+    def _run_emb_fci(self, emb_scf, frozen=None):
+        self._unsupported("Embedded FCI")
+
+    # ------------------------------------------------------------------ the embedding
+    def embed(self, init_huzinaga_rhf_with_mu: bool = False,
+              n_mo_overwrite: tuple[int | None, int | None] = (None, None)) -> None:
+        """Run the embedded SCF calculation(s) (driver.py:808-923)."""
+        cfg = self.config
+        if cfg.virtual_localization is VirtualLocalizerTypes.PROJECTED_AO:
+            raise NotImplementedError("PAO not yet fully implemented.")
+
+        self.e_nuc = self._global_ks.energy_nuc()
+        if n_mo_overwrite is not None and n_mo_overwrite != (None, None):
+            self.n_mo_overwrite = n_mo_overwrite
+        else:
+            self.n_mo_overwrite = cfg.n_mo_overwrite
+
+        self.localized_system = self._localize()
+        self.e_act, self.e_env, self.two_e_cross = self._subsystem_dft(self._global_ks, self.localized_system)
+
+        total_dm = self.localized_system.dm_active + self.localized_system.dm_enviro
+        g_act_and_env = self._global_ks.get_veff(dm=total_dm)
+        g_act = self._global_ks.get_veff(dm=self.localized_system.dm_active)
+        embedding_potential = np.asarray(g_act_and_env) - np.asarray(g_act)
+        self.embedding_potential = embedding_potential
+        logger.info(f"DFT potential average {np.mean(embedding_potential)}.")
+
+        if cfg.projector in [ProjectorTypes.MU, ProjectorTypes.BOTH] or init_huzinaga_rhf_with_mu:
+            local_hf = self._init_local_hf()
+            embedded_scf, v_emb = self._mu_embed(local_hf, embedding_potential)
+            self.mu = self.post_embed(embedded_scf, v_emb, ProjectorTypes.MU)
+
+        if cfg.projector in [ProjectorTypes.HUZ, ProjectorTypes.BOTH]:
+            local_hf = self._init_local_hf()
+            dmat_initial_guess: Optional[np.ndarray] = (
+                self.mu["scf"].make_rdm1() if init_huzinaga_rhf_with_mu else None
+            )
+            embedded_scf, v_emb = self._huzinaga_embed(local_hf, embedding_potential, self.localized_system,
+                                                       dmat_initial_guess)
+            self.huzinaga = self.post_embed(embedded_scf, v_emb, ProjectorTypes.HUZ)
+
+        match cfg.projector:
+            case ProjectorTypes.MU:
+                self.embedded_scf = self.mu["scf"]
+                self.classical_energy = self.mu["classical_energy"]
+            case ProjectorTypes.HUZ:
+                self.embedded_scf = self.huzinaga["scf"]
+                self.classical_energy = self.huzinaga["classical_energy"]
+            case ProjectorTypes.BOTH:
+                logger.warning("Outputting both mu and huzinaga embedding results as tuple.")
+                self.embedded_scf = (self.mu["scf"], self.huzinaga["scf"])
+                self.classical_energy = (self.mu["classical_energy"], self.huzinaga["classical_energy"])
+        logger.info("Embedding complete.")
+
+    def post_embed(self, embedded_scf, v_emb, projector: ProjectorTypes) -> dict:
+        """Projector-dependent components of the embedding (driver.py:925-1041)."""
+        cfg = self.config
+        be = self.be
+        result = {"scf": embedded_scf.copy(), "v_emb": v_emb}
+        result["mo_energies_emb_pre_del"] = result["scf"].mo_energy
+        result["scf"] = self._delete_environment(projector, result["scf"], self.localized_system, self._env_projector)
+        result["mo_energies_emb_post_del"] = result["scf"].mo_energy
+
+        def dot(a, b):  # einsum("ij,ij")
+            return float(be.dots(be.asarray(np.asarray(a)).reshape(-1), be.asarray(np.asarray(b)).reshape(1, -1))[0])
+
+        dm_active = self.localized_system.dm_active
+        if dm_active.ndim == 2:
+            result["correction"] = dot(result["v_emb"], dm_active)
+            result["beta_correction"] = 0
+        else:
+            result["correction"] = dot(result["v_emb"][0], dm_active[0])
+            result["beta_correction"] = dot(result["v_emb"][1], dm_active[1])
+
+        match cfg.virtual_localization:
+            case VirtualLocalizerTypes.CONCENTRIC:
+                result["cl"] = ConcentricLocalizer(result["scf"], cfg.n_active_atoms, max_shells=cfg.max_shells,
+                                                   backend=be)
+                result["scf"] = result["cl"].localize_virtual()
+            case VirtualLocalizerTypes.DISABLE:
+                logger.debug("Not performing virtual localization.")
+
+        corr = result["correction"] + result["beta_correction"]
+        result["e_rhf"] = result["scf"].e_tot + self.e_env + self.two_e_cross - corr
+        result["classical_energy"] = self.e_env + self.two_e_cross + self.e_nuc - corr
+
+        if cfg.run_ccsd_emb is True:
+            self._run_emb_ccsd(result["scf"])
+        if cfg.run_fci_emb is True:
+            self._run_emb_fci(result["scf"])
+        result["hf_emb"] = result["scf"].e_tot - self.e_nuc
+        if cfg.run_dft_in_dft is True:
+            self._dft_in_dft(projector)
+
+        result["second_quantised"] = HamiltonianBuilder(result["scf"], result["classical_energy"], backend=be).build()
+        return result

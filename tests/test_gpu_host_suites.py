@@ -16,6 +16,12 @@ from test_host_localizers_ham import (  # noqa: E402,F401
     test_spade_restricted_matches_reference,
     test_spinorb_and_build_match_reference,
 )
+from test_host_driver import (  # noqa: E402,F401
+    test_delete_environment_and_projector_match_reference,
+    test_embed_matches_oracle_flow,
+    test_post_embed_matches_reference_golden,
+    test_projectors_agree,
+)
 from test_host_scf import (  # noqa: E402,F401
     test_energy_elec_matches_reference,
     test_gpu_uhf_protocol_matches_oracle_scf,
@@ -23,10 +29,6 @@ from test_host_scf import (  # noqa: E402,F401
     test_huzinaga_scf_restricted_generic_path,
     test_monkey_patched_get_veff_uses_generic_path,
 )
-
-
-class _CountingHip:
-    """HipBackend plus the call counter some shared tests read."""
 
 
 @pytest.fixture(scope="module")

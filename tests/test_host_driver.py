@@ -1,0 +1,167 @@
+"""NbedDriver end to end on CPU (checker backend + synthetic provider): the product's
+orchestration against the oracle's restatement of the same driver arithmetic, and against the
+golden vectors of the reference's post_embed / _delete_spin_environment / _env_projector."""
+
+import numpy as np
+import pytest
+
+from conftest import canon_sign, load_golden
+from oracle import embed as o_embed
+from oracle import localize as o_loc
+from oracle import synth
+from oracle.pyscf_like import ToyMol, ToyUHF
+from oracle_backend import OracleBackend
+from synthetic_provider import SyntheticProvider
+
+from nbed_amd import NbedConfig, NbedDriver, nbed
+from nbed_amd.config import ProjectorTypes
+from nbed_amd.exceptions import NbedDriverError
+from nbed_amd.localizers import LocalizedSystem
+from nbed_amd.scf import GpuUHF, Mole
+
+GEOM = "3\n\nO   0.0000  0.000  0.115\nH   0.0000  0.754  -0.459\nH   0.0000  -0.754  -0.459"
+
+
+def config(**kw):
+    base = dict(geometry=GEOM, n_active_atoms=1, basis="synthetic", xc_functional="none", convergence=1e-9,
+                max_hf_cycles=80)
+    base.update(kw)
+    return NbedConfig(**base)
+
+
+@pytest.fixture()
+def be():
+    return OracleBackend()
+
+
+def reference_flow(provider, cfg, projector):
+    """The same flow written with the oracle's functions (numpy)."""
+    ks = provider.global_ks(cfg)
+    ls, _ = o_loc.spade_localize(ks.mo_coeff, ks.mo_occ, provider.S, provider.n_act_aos)
+    v_pot = np.asarray(ks.get_veff(dm=ls.dm_active + ls.dm_enviro)) - np.asarray(ks.get_veff(dm=ls.dm_active))
+    nelec = (len(ls.active_mo_inds[0]), len(ls.active_mo_inds[1]))
+    mf = ToyUHF(ToyMol(provider.nao, nelec, e_nuc=provider.e_nuc), provider.S, provider.h, provider.eri)
+    mf.conv_tol, mf.max_cycle = cfg.convergence, cfg.max_hf_cycles
+    if projector == "mu":
+        scf, v_emb = o_embed.mu_embed(mf, provider.S, ls.dm_enviro, v_pot, cfg.mu_level_shift)
+    else:
+        scf, v_emb = o_embed.huzinaga_embed(mf, v_pot, ls.dm_enviro)
+    return ls, v_pot, scf, v_emb
+
+
+@pytest.mark.parametrize("projector", ["huzinaga", "mu"])
+def test_embed_matches_oracle_flow(be, projector):
+    prov = SyntheticProvider(14, (5, 5), 5)
+    cfg = config(projector=projector, virtual_localization="disable")
+    drv = nbed(cfg, provider=prov, backend=be)
+    res = drv.huzinaga if projector == "huzinaga" else drv.mu
+    ls, v_pot, scf, v_emb = reference_flow(prov, cfg, projector)
+
+    np.testing.assert_array_equal(drv.localized_system.active_mo_inds, ls.active_mo_inds)
+    np.testing.assert_allclose(drv.localized_system.dm_enviro, ls.dm_enviro, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(drv.embedding_potential, v_pot, rtol=0, atol=1e-10)
+    assert bool(res["scf"].converged) and bool(scf.converged)
+    # mu = 1e6 amplifies rounding: the shifted operator has eigenvalues of 1e6, both sides lose ~1e-10
+    tol = 1e-8 if projector == "huzinaga" else 1e-6
+    np.testing.assert_allclose(res["scf"].e_tot, scf.e_tot, rtol=0, atol=tol)
+    np.testing.assert_allclose(res["v_emb"], v_emb, rtol=1e-12, atol=tol)
+
+    n_env = ls.c_enviro.shape[-1]
+    assert res["scf"].mo_coeff.shape == (2, prov.nao, prov.nao - n_env)
+    o_res = o_embed.post_embed(scf, v_emb, projector, ls.dm_active, ls.enviro_mo_inds,
+                               o_embed.env_projector(prov.S, ls.dm_enviro), drv.e_env, drv.two_e_cross, drv.e_nuc,
+                               eri=prov.eri)
+    for key in ("correction", "beta_correction", "e_rhf", "classical_energy", "hf_emb"):
+        np.testing.assert_allclose(res[key], o_res[key], rtol=0, atol=max(tol, 1e-8), err_msg=key)
+    np.testing.assert_allclose(res["mo_energies_emb_post_del"], o_res["mo_energies_emb_post_del"], rtol=0, atol=1e-5)
+    const, h1, h2 = res["second_quantised"]
+    nq = 2 * (prov.nao - n_env)
+    assert h1.shape == (nq, nq) and h2.shape == (nq,) * 4
+    assert const == res["classical_energy"] == drv.classical_energy
+    assert drv.embedded_scf is res["scf"]
+    if projector == "huzinaga":  # gauge-free comparison of the Hamiltonian: |coefficients|
+        np.testing.assert_allclose(np.abs(h1), np.abs(o_res["second_quantised"][1]), rtol=0, atol=1e-6)
+
+
+def test_projectors_agree(be):
+    """mu-shift and Huzinaga embedding give the same embedded energy (tests/test_driver.py:142-152)."""
+    prov = SyntheticProvider(14, (5, 5), 5)
+    drv = nbed(config(projector="both", virtual_localization="cl"), provider=prov, backend=be)
+    assert drv.mu["scf"].converged and drv.huzinaga["scf"].converged
+    assert abs(drv.mu["e_rhf"] - drv.huzinaga["e_rhf"]) < 1e-5
+    assert isinstance(drv.embedded_scf, tuple) and isinstance(drv.classical_energy, tuple)
+    for res in (drv.mu, drv.huzinaga):
+        assert set(res) >= {"scf", "v_emb", "mo_energies_emb_pre_del", "mo_energies_emb_post_del", "correction",
+                            "beta_correction", "cl", "e_rhf", "classical_energy", "hf_emb", "second_quantised"}
+        assert res["cl"].shells[0][-1] == res["scf"].mo_coeff.shape[-1]
+
+
+def test_post_embed_matches_reference_golden(be):
+    """Same inputs as tests/golden/post_embed_huzinaga_n12.npz (written by the reference's
+    _huzinaga_embed + post_embed)."""
+    g = load_golden("post_embed_huzinaga_n12")
+    n = int(g["nao"])
+    drv = NbedDriver(config(projector="huzinaga", virtual_localization="disable", convergence=float(g["conv_tol"]),
+                            max_hf_cycles=int(g["max_cycle"])), provider=object(), backend=be)
+
+    class KS:
+        def get_ovlp(self):
+            return g["S"]
+
+    drv.__dict__["_global_ks"] = KS()
+    drv.localized_system = LocalizedSystem(np.array([np.arange(3), np.arange(3)]),
+                                           np.array([np.arange(3, 5), np.arange(3, 5)]),
+                                           g["c_active"], g["c_enviro"], g["c_loc_occ"], backend=be)
+    drv.e_env, drv.two_e_cross, drv.e_nuc = float(g["e_env"]), float(g["two_e_cross"]), float(g["e_nuc"])
+    mf = GpuUHF(Mole(n, tuple(g["nelec"]), e_nuc=float(g["e_nuc"])), g["S"], g["hcore"], synth.eri_dense(n), backend=be)
+    mf.max_cycle, mf.conv_tol = int(g["max_cycle"]), float(g["conv_tol"])
+    scf, v_emb = drv._huzinaga_embed(mf, g["V_emb"], drv.localized_system, None)
+    res = drv.post_embed(scf, v_emb, ProjectorTypes.HUZ)
+    np.testing.assert_allclose(v_emb, g["v_emb"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(scf.e_tot, g["e_tot"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res["mo_energies_emb_pre_del"], g["mo_energies_pre"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res["mo_energies_emb_post_del"], g["mo_energies_post"], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(res["scf"].mo_occ, g["mo_occ_post"])
+    np.testing.assert_allclose(canon_sign(res["scf"].mo_coeff), g["mo_coeff_post_canon"], rtol=0, atol=1e-6)
+    for k in ("correction", "beta_correction", "e_rhf", "classical_energy", "hf_emb"):
+        np.testing.assert_allclose(res[k], g[k], rtol=0, atol=1e-9)
+    const, h1, h2 = res["second_quantised"]
+    np.testing.assert_allclose(const, g["const"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.abs(h1), g["h1_abs"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(np.abs(h2), g["h2_abs"], rtol=0, atol=1e-7)
+
+
+def test_delete_environment_and_projector_match_reference(be):
+    g = load_golden("delete_environment")
+    drv = NbedDriver(config(), provider=object(), backend=be)
+    for key, ptype in [("huz", ProjectorTypes.HUZ), ("mu", ProjectorTypes.MU)]:
+        for x in range(2):
+            c, e, o = drv._delete_spin_environment(ptype, int(g["n_env"]), g["mo_coeff"][x], g["mo_energy"][x],
+                                                   g["mo_occ"][x], g["projector"][x])
+            np.testing.assert_array_equal(c, g[f"{key}_coeff_{x}"])
+            np.testing.assert_array_equal(e, g[f"{key}_energy_{x}"])
+            np.testing.assert_array_equal(o, g[f"{key}_occ_{x}"])
+    g = load_golden("env_projector")
+
+    class KS:
+        def get_ovlp(self):
+            return g["S"]
+
+    drv.__dict__["_global_ks"] = KS()
+    drv.localized_system = type("LS", (), {"dm_enviro": g["dm_enviro"]})()
+    np.testing.assert_allclose(drv._env_projector, g["projector"], rtol=0, atol=1e-12)
+
+
+def test_driver_errors(be):
+    with pytest.raises(NotImplementedError, match="PAO"):
+        NbedDriver(config(virtual_localization="pao"), provider=SyntheticProvider(14, (5, 5), 5), backend=be).embed()
+    with pytest.raises(NotImplementedError):
+        nbed(config(localization="pm"), provider=SyntheticProvider(14, (5, 5), 5), backend=be)
+    with pytest.raises(NotImplementedError):
+        nbed(config(run_ccsd_emb=True, virtual_localization="disable"), provider=SyntheticProvider(14, (5, 5), 5),
+             backend=be)
+    try:
+        import pyscf  # noqa: F401
+    except ImportError:
+        with pytest.raises(NbedDriverError, match="PySCF"):
+            NbedDriver(config(), backend=be).embed()
