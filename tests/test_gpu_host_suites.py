@@ -22,6 +22,10 @@ from test_host_driver import (  # noqa: E402,F401
     test_post_embed_matches_reference_golden,
     test_projectors_agree,
 )
+from test_water_kat import (  # noqa: E402,F401
+    test_hf_in_hf_embedding_of_water_is_exact,
+    test_product_scf_reproduces_reference_uhf_literals,
+)
 from test_host_scf import (  # noqa: E402,F401
     test_energy_elec_matches_reference,
     test_gpu_uhf_protocol_matches_oracle_scf,
