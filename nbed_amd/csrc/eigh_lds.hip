@@ -3,14 +3,22 @@
 //
 // Why this shape.  A single workgroup streaming a global-memory matrix is limited by one
 // CU's ~64 B/clk L2 port (measured: 11 us per Jacobi step at N = 148, 15 ms per solve).  Here
-//   * the symmetric matrix lives PACKED (upper triangle, N(N+1)/2 doubles = 88 KB at N=148)
-//     in the CU's 160 KB LDS and is rotated in place: every 2x2 block (pair I x pair K,
-//     I < K) of the round-robin step is owned by one thread, diagonal blocks by the thread
+//   * the symmetric matrix lives in the CU's 160 KB LDS (N(N+1)/2 doubles = 88 KB at N = 148)
+//     and is rotated in place by the round-robin parallel Jacobi ordering: every 2x2 block
+//     (pair I x pair K, I < K) of a step is owned by one thread, diagonal blocks by the thread
 //     that computed the rotation -- no element has two writers, two barriers per step;
-//   * the index pairs of the round-robin ordering depend only on N, so all LDS addresses of
-//     all steps come from a table built once per N (cached in the context, read through L2
-//     and prefetched one step ahead) instead of being recomputed with integer arithmetic --
-//     the kernel is fp64-FMA-bound on one CU (16 flop per block);
+//   * storage is by CIRCULANT DIAGONALS of the tournament ring.  Index 0 is fixed, the other
+//     R = N-1 indices sit on a ring that turns by one position per step, so the element that a
+//     thread's block needs at step t is the one whose two ring positions were (P-t, Q-t) at
+//     t = 0: the ring distance d = (Q-P) mod R never changes.  Storing element (a, b) at
+//     [min(d, R-d)][a or b] makes the address of every operand of every step
+//         base(d) + ((off - t) mod R)
+//     -- one decrement per element per step, no index tables, no global loads in the loop --
+//     and consecutive lanes (consecutive K) touch consecutive diagonals, i.e. an odd stride of
+//     R doubles: conflict-free LDS banks on one branch, 2-way on the mirrored one (a packed
+//     row-major triangle gave ~3.5-way conflicts on random addresses);
+//   * rotation count / max |tan| are reduced with ballot and shuffles (same-address LDS
+//     atomics serialise per lane and cost ~2500 cycles per step);
 //   * eigenvector accumulation is DEFERRED: the kernel only records (c, s) per pair and step;
 //     a second kernel then applies the whole rotation sequence to the rows of V, one
 //     wavefront per row (rows are independent), spread over all CUs.  A warm start simply
@@ -29,10 +37,51 @@ constexpr int JL_MAX_SWEEPS = 24;
 constexpr int JL_MAX_NP = 196;
 constexpr double JL_PAD_VALUE = 1.0e300;
 
-__host__ __device__ inline int pk(int i, int j, int NP) {  // packed upper index, i <= j
-    return i * NP - i * (i - 1) / 2 + (j - i);
+// ---- tournament ring geometry (NP even, m = NP/2 pairs, R = NP-1 ring positions) ----------
+// t = 0: pair k = (top_k, bot_k) = (2k, 2k+1); top_0 = index 0 never moves; ring position r holds
+//   top_{r+1} for r <= m-2 and bot_{2m-2-r} for r >= m-1; every step turns the ring by +1.
+__host__ __device__ inline int ring_pos_top(int k) { return k - 1; }               // k >= 1
+__host__ __device__ inline int ring_pos_bot(int k, int m) { return 2 * m - 2 - k; }
+__host__ __device__ inline int ring_index0(int r, int m) {  // original index at ring position r, t = 0
+    return r <= m - 2 ? 2 * (r + 1) : 2 * (2 * m - 2 - r) + 1;
 }
-__host__ __device__ inline int pks(int i, int j, int NP) { return i <= j ? pk(i, j, NP) : pk(j, i, NP); }
+__host__ __device__ inline int ring_pos_of(int i, int m) {  // inverse of ring_index0, i >= 1
+    return (i & 1) ? 2 * m - 2 - (i >> 1) : (i >> 1) - 1;
+}
+
+// Address of the element at ring positions (P, Q) as base + offset, offset in [0, R).
+// P or Q == -1 denotes the fixed index 0.  Layout: diagonal d (0..m-1) at d*R + a, then the
+// row of index 0 at m*R + b, then element (0,0) at m*R + R.
+struct ElemRef {
+    int base, off;
+};
+__host__ __device__ inline ElemRef elem_ref(int P, int Q, int m) {
+    const int R = 2 * m - 1;
+    ElemRef e;
+    if (P < 0 && Q < 0) {
+        e.base = m * R + R;
+        e.off = -1;  // not on the ring: never updated
+    } else if (P < 0 || Q < 0) {
+        e.base = m * R;
+        e.off = P < 0 ? Q : P;
+    } else {
+        int d = Q - P;
+        if (d < 0) d += R;
+        if (d <= m - 1) {
+            e.base = d * R;
+            e.off = P;
+        } else {
+            e.base = (R - d) * R;
+            e.off = Q;
+        }
+    }
+    return e;
+}
+// static address of element (i, j) of the original matrix (t = 0 positions)
+__host__ __device__ inline int elem_addr(int i, int j, int m) {
+    const ElemRef e = elem_ref(i == 0 ? -1 : ring_pos_of(i, m), j == 0 ? -1 : ring_pos_of(j, m), m);
+    return e.off < 0 ? e.base : e.base + e.off;
+}
 
 __device__ __forceinline__ double fast_rcp(double x) {
     double y = __builtin_amdgcn_rcp(x);
@@ -48,26 +97,32 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 }
 
 // Workgroup barrier that waits for this wave's LDS traffic only: the per-step global stores
-// (rotation log) and the schedule prefetch stay in flight across it.  __syncthreads() would
-// add s_waitcnt vmcnt(0) and put a global-memory round trip on every Jacobi step.
+// (rotation log) stay in flight across it.  __syncthreads() would add s_waitcnt vmcnt(0) and
+// put a global-memory round trip on every Jacobi step.
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// one ring turn: offset <- (offset - 1) mod R   (offset == -1 marks the fixed element (0,0))
+__device__ __forceinline__ int turn(int off, int R) {
+    const int o = off - 1;
+    return off <= 0 ? (off < 0 ? -1 : R - 1) : o;
+}
+
 __global__ __launch_bounds__(JL_THREADS) void eigh_lds_kernel(
-    const double* __restrict__ a_in, int N, int NP, int steps, const ushort4* __restrict__ sched_blocks,
-    const ushort4* __restrict__ sched_pairs, double2* __restrict__ rot, int* __restrict__ any_flags,
-    int* __restrict__ nsteps_out, double* __restrict__ w_out, int* __restrict__ rank_out,
-    int* __restrict__ status, int64_t rot_stride, int64_t flag_stride) {
+    const double* __restrict__ a_in, int N, int NP, int steps, double2* __restrict__ rot,
+    int* __restrict__ any_flags, int* __restrict__ nsteps_out, double* __restrict__ w_out,
+    int* __restrict__ rank_out, int* __restrict__ status, int64_t rot_stride, int64_t flag_stride) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = NP / 2;
+    const int R = NP - 1;
     const int npk = NP * (NP + 1) / 2;
     const int nblk = m * (m - 1) / 2;
     double* A = smem;
     double2* cs = reinterpret_cast<double2*>(A + ((npk + 1) & ~1));
     double* dg = reinterpret_cast<double*>(cs + m);
     int* rank = reinterpret_cast<int*>(dg + NP);
-    int* misc = rank + NP;  // [0] rotations in sweep, [1],[2] per-step counters (parity), [3] max |t| bits
+    int* misc = rank + NP;  // [0] rotations in sweep, [2..3] per-wave max |t| bits, [4..7] per-step counts [parity][wave]
 
     const int b = blockIdx.x;
     a_in += (int64_t)b * N * N;
@@ -84,104 +139,125 @@ __global__ __launch_bounds__(JL_THREADS) void eigh_lds_kernel(
         double v = 0.0;
         if (j < N) v = a_in[(int64_t)j * N + i];
         else if (i == j) v = JL_PAD_VALUE;
-        A[pk(i, j, NP)] = v;
+        A[elem_addr(i, j, m)] = v;
     }
-    if (tid < 4) misc[tid] = 0;
+    if (tid < 8) misc[tid] = 0;
 
-    // this thread's blocks (fixed for the whole solve): b_r = tid + r * 1024 -> positions (I, K)
+    // this thread's blocks (fixed for the whole solve): b_r = tid + r * 1024 -> pair slots (I, K)
     int bI[JL_MAXR], bK[JL_MAXR];
+    int base[JL_MAXR][4], off[JL_MAXR][4];
 #pragma unroll
     for (int r = 0; r < JL_MAXR; ++r) {
         const int bb = tid + r * JL_THREADS;
         bI[r] = -1;
         bK[r] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            base[r][e] = 0;
+            off[r][e] = 0;
+        }
         if (bb < nblk) {
             // invert bb = I*m - I(I+1)/2 + (K - I - 1)
             int I = (int)((2.0 * m - 1.0 - sqrt((2.0 * m - 1.0) * (2.0 * m - 1.0) - 8.0 * bb)) * 0.5);
             while (I > 0 && I * m - I * (I + 1) / 2 > bb) --I;
             while ((I + 1) * m - (I + 1) * (I + 2) / 2 <= bb) ++I;
+            const int K = bb - (I * m - I * (I + 1) / 2) + I + 1;
             bI[r] = I;
-            bK[r] = bb - (I * m - I * (I + 1) / 2) + I + 1;
+            bK[r] = K;
+            const int pI[2] = {I == 0 ? -1 : ring_pos_top(I), ring_pos_bot(I, m)};
+            const int pK[2] = {ring_pos_top(K), ring_pos_bot(K, m)};  // K >= 1
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const ElemRef er = elem_ref(pI[e >> 1], pK[e & 1], m);
+                base[r][e] = er.base;
+                off[r][e] = er.off;
+            }
         }
+    }
+    // pair owned in phase A (tid < m): a_pp, a_qq, a_pq
+    int pbase[3] = {0, 0, 0}, poff[3] = {0, 0, 0};
+    if (tid < m) {
+        const int P = tid == 0 ? -1 : ring_pos_top(tid), Q = ring_pos_bot(tid, m);
+        const ElemRef e0 = elem_ref(P, P, m), e1 = elem_ref(Q, Q, m), e2 = elem_ref(P, Q, m);
+        pbase[0] = e0.base; poff[0] = e0.off;
+        pbase[1] = e1.base; poff[1] = e1.off;
+        pbase[2] = e2.base; poff[2] = e2.off;
     }
     __syncthreads();
 
     const double eps = 2.220446049250313e-16;
     int sweep = 0;
     bool converged = false;
-    // schedule entries are fetched one step ahead (registers), off the critical path
-    ushort4 addr_next[JL_MAXR];
-    ushort4 pair_next = make_ushort4(0, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < JL_MAXR; ++r) {
-        addr_next[r] = make_ushort4(0, 0, 0, 0);
-        if (bI[r] >= 0) addr_next[r] = sched_blocks[tid + r * JL_THREADS];
-    }
-    if (tid < m) pair_next = sched_pairs[tid];
+    float tmax_wave = 0.f;  // largest |tan| this wave rotated by in the current sweep
     for (; sweep < JL_MAX_SWEEPS && !converged; ++sweep) {
         for (int step = 0; step < steps; ++step) {
             const int gstep = sweep * steps + step;
-            const int par = gstep & 1;  // global parity: the two per-step counters alternate across sweeps too
-            ushort4 addr[JL_MAXR];
-#pragma unroll
-            for (int r = 0; r < JL_MAXR; ++r) addr[r] = addr_next[r];
-            const ushort4 pi = pair_next;
-            {
-                const int nstep = (step + 1 == steps) ? 0 : step + 1;
-#pragma unroll
-                for (int r = 0; r < JL_MAXR; ++r)
-                    if (bI[r] >= 0) addr_next[r] = sched_blocks[(int64_t)nstep * nblk + tid + r * JL_THREADS];
-                if (tid < m) pair_next = sched_pairs[nstep * m + tid];
-            }
+            const int par = gstep & 1;  // the per-step count slots alternate (also across sweeps)
 
-            // ---- phase A: rotation parameters + diagonal blocks
-            if (tid == 0) misc[1 + (par ^ 1)] = 0;
-            if (tid < m) {
-                const double app = A[pi.x], aqq = A[pi.y], apq = A[pi.z];
+            // ---- phase A: rotation parameters + diagonal blocks (waves 0 and 1: m <= 98 pairs)
+            if (tid < 128) {
                 double c = 1.0, s = 0.0;
-                const double aa = fabs(apq);
-                // rotate iff |a_pq| > eps sqrt(|a_pp a_qq|), compared in squares (no sqrt)
-                if (aa * aa > eps * eps * fabs(app) * fabs(aqq) && aa > 1.0e-150) {
-                    const double theta = 0.5 * (aqq - app) * fast_rcp(apq);
-                    const double at = fabs(theta);
-                    double t;
-                    if (at > 1.0e150) {
-                        t = 0.5 * fast_rcp(at);
-                    } else {
-                        const double z = fma(at, at, 1.0);
-                        t = fast_rcp(at + z * fast_rsqrt(z));  // 1 / (|theta| + sqrt(theta^2 + 1))
+                float tabs = 0.f;
+                bool rotated = false;
+                if (tid < m) {
+                    const int ipp = pbase[0] + (poff[0] < 0 ? 0 : poff[0]);
+                    const int iqq = pbase[1] + poff[1];
+                    const int ipq = pbase[2] + poff[2];
+                    const double app = A[ipp], aqq = A[iqq], apq = A[ipq];
+                    const double aa = fabs(apq);
+                    // rotate iff |a_pq| > eps sqrt(|a_pp a_qq|), compared in squares (no sqrt)
+                    if (aa * aa > eps * eps * fabs(app) * fabs(aqq) && aa > 1.0e-150) {
+                        const double theta = 0.5 * (aqq - app) * fast_rcp(apq);
+                        const double at = fabs(theta);
+                        double t;
+                        if (at > 1.0e150) {
+                            t = 0.5 * fast_rcp(at);
+                        } else {
+                            const double z = fma(at, at, 1.0);
+                            t = fast_rcp(at + z * fast_rsqrt(z));  // 1 / (|theta| + sqrt(theta^2 + 1))
+                        }
+                        if (theta < 0.0) t = -t;
+                        c = fast_rsqrt(fma(t, t, 1.0));
+                        s = t * c;
+                        A[ipp] = app - t * apq;
+                        A[iqq] = aqq + t * apq;
+                        A[ipq] = 0.0;
+                        rotated = true;
+                        tabs = (float)fabs(t);
                     }
-                    if (theta < 0.0) t = -t;
-                    c = fast_rsqrt(fma(t, t, 1.0));
-                    s = t * c;
-                    A[pi.x] = app - t * apq;
-                    A[pi.y] = aqq + t * apq;
-                    A[pi.z] = 0.0;
-                    atomicAdd(&misc[1 + par], 1);
-                    atomicMax(reinterpret_cast<unsigned*>(&misc[3]), __float_as_uint((float)fabs(t)));
+                    cs[tid] = make_double2(c, s);
+                    rot[(int64_t)gstep * m + tid] = make_double2(c, s);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) poff[e] = turn(poff[e], R);
                 }
-                cs[tid] = make_double2(c, s);
-                rot[(int64_t)gstep * m + tid] = make_double2(c, s);
+                const int cnt = __popcll(__ballot(rotated));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) tabs = fmaxf(tabs, __shfl_xor(tabs, o, 64));
+                tmax_wave = fmaxf(tmax_wave, tabs);
+                if ((tid & 63) == 0) misc[4 + 2 * par + (tid >> 6)] = cnt;
             }
             lds_barrier();
-            const int nr = misc[1 + par];
+            const int nr = misc[4 + 2 * par] + misc[4 + 2 * par + 1];
             // ---- phase B: off-diagonal 2x2 blocks  E <- J_I^T E J_K  in place
-            if (nr > 0) {
 #pragma unroll
-                for (int r = 0; r < JL_MAXR; ++r) {
-                    if (bI[r] < 0) continue;
-                    const double2 ri = cs[bI[r]], rk = cs[bK[r]];
-                    if (ri.y == 0.0 && rk.y == 0.0) continue;
-                    const double e11 = A[addr[r].x], e12 = A[addr[r].y], e21 = A[addr[r].z], e22 = A[addr[r].w];
-                    // rows: J_I^T = [[c,-s],[s,c]]
-                    const double u11 = ri.x * e11 - ri.y * e21, u12 = ri.x * e12 - ri.y * e22;
-                    const double u21 = ri.y * e11 + ri.x * e21, u22 = ri.y * e12 + ri.x * e22;
-                    // cols: J_K = [[c,s],[-s,c]]
-                    A[addr[r].x] = u11 * rk.x - u12 * rk.y;
-                    A[addr[r].y] = u11 * rk.y + u12 * rk.x;
-                    A[addr[r].z] = u21 * rk.x - u22 * rk.y;
-                    A[addr[r].w] = u21 * rk.y + u22 * rk.x;
-                }
+            for (int r = 0; r < JL_MAXR; ++r) {
+                if (bI[r] < 0) continue;
+                const int i11 = base[r][0] + off[r][0], i12 = base[r][1] + off[r][1];
+                const int i21 = base[r][2] + off[r][2], i22 = base[r][3] + off[r][3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) off[r][e] = turn(off[r][e], R);
+                if (nr == 0) continue;
+                const double2 ri = cs[bI[r]], rk = cs[bK[r]];
+                if (ri.y == 0.0 && rk.y == 0.0) continue;
+                const double e11 = A[i11], e12 = A[i12], e21 = A[i21], e22 = A[i22];
+                // rows: J_I^T = [[c,-s],[s,c]]
+                const double u11 = ri.x * e11 - ri.y * e21, u12 = ri.x * e12 - ri.y * e22;
+                const double u21 = ri.y * e11 + ri.x * e21, u22 = ri.y * e12 + ri.x * e22;
+                // cols: J_K = [[c,s],[-s,c]]
+                A[i11] = u11 * rk.x - u12 * rk.y;
+                A[i12] = u11 * rk.y + u12 * rk.x;
+                A[i21] = u21 * rk.x - u22 * rk.y;
+                A[i22] = u21 * rk.y + u22 * rk.x;
             }
             if (tid == 0) {
                 any_flags[gstep] = nr;
@@ -189,19 +265,19 @@ __global__ __launch_bounds__(JL_THREADS) void eigh_lds_kernel(
             }
             lds_barrier();
         }
-        const float tmax = __uint_as_float((unsigned)misc[3]);
-        converged = (misc[0] == 0) || (tmax < 1.0e-8f);
+        if (tid == 0 || tid == 64) misc[2 + (tid >> 6)] = (int)__float_as_uint(tmax_wave);
         lds_barrier();
-        if (tid == 0) {
-            misc[0] = 0;
-            misc[3] = 0;
-        }
+        const float tmax = fmaxf(__uint_as_float((unsigned)misc[2]), __uint_as_float((unsigned)misc[3]));
+        converged = (misc[0] == 0) || (tmax < 1.0e-8f);
+        tmax_wave = 0.f;
+        lds_barrier();
+        if (tid == 0) misc[0] = 0;
         lds_barrier();
     }
     __syncthreads();
 
     // eigenvalues = diagonal; rank them ascending (the padded index sorts last)
-    for (int i = tid; i < NP; i += JL_THREADS) dg[i] = A[pk(i, i, NP)];
+    for (int i = tid; i < NP; i += JL_THREADS) dg[i] = A[elem_addr(i, i, m)];
     __syncthreads();
     for (int i = tid; i < NP; i += JL_THREADS) {
         const double di = dg[i];
@@ -223,7 +299,6 @@ __global__ __launch_bounds__(JL_THREADS) void eigh_lds_kernel(
 constexpr int AV_GROUP = 4;  // steps fetched per software-pipeline stage
 
 __global__ __launch_bounds__(64) void eigh_apply_rot_kernel(const double* __restrict__ v0, int N, int NP, int steps,
-                                                            const ushort2* __restrict__ sched_pq,
                                                             const double2* __restrict__ rot,
                                                             const int* __restrict__ any_flags,
                                                             const int* __restrict__ nsteps_in,
@@ -232,7 +307,7 @@ __global__ __launch_bounds__(64) void eigh_apply_rot_kernel(const double* __rest
                                                             int64_t flag_stride) {
     extern __shared__ __attribute__((aligned(16))) double row[];
     const int b = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
-    const int m = NP / 2;
+    const int m = NP / 2, R = NP - 1;
     rot += (int64_t)b * rot_stride;
     any_flags += (int64_t)b * flag_stride;
     rank_in += (int64_t)b * NP;
@@ -245,8 +320,16 @@ __global__ __launch_bounds__(64) void eigh_apply_rot_kernel(const double* __rest
     __syncthreads();
     const int nsteps = nsteps_in[b];
     const int k0 = lane, k1 = lane + 64;  // m <= 98: two rounds cover every pair
+    // ring positions of this lane's two pair slots (top, bot); -1 = the fixed index 0
+    const int pt0 = k0 == 0 ? -1 : ring_pos_top(k0), pb0 = ring_pos_bot(k0, m);
+    const int pt1 = ring_pos_top(k1), pb1 = ring_pos_bot(k1, m);
+    auto index_at = [&](int pos, int t) {  // original index at ring position `pos` after t turns
+        if (pos < 0) return 0;
+        int q = pos - t;
+        if (q < 0) q += R;
+        return ring_index0(q, m);
+    };
 
-    ushort2 pq[AV_GROUP][2];
     double2 cs[AV_GROUP][2];
     int flag[AV_GROUP];
     auto fetch = [&](int g0) {
@@ -256,28 +339,18 @@ __global__ __launch_bounds__(64) void eigh_apply_rot_kernel(const double* __rest
             flag[u] = 0;
             if (gs < nsteps) flag[u] = any_flags[gs];
             if (flag[u] > 0) {
-                const int st = gs % steps;
-                if (k0 < m) {
-                    pq[u][0] = sched_pq[st * m + k0];
-                    cs[u][0] = rot[(int64_t)gs * m + k0];
-                }
-                if (k1 < m) {
-                    pq[u][1] = sched_pq[st * m + k1];
-                    cs[u][1] = rot[(int64_t)gs * m + k1];
-                }
+                if (k0 < m) cs[u][0] = rot[(int64_t)gs * m + k0];
+                if (k1 < m) cs[u][1] = rot[(int64_t)gs * m + k1];
             }
         }
     };
     fetch(0);
     for (int g0 = 0; g0 < nsteps; g0 += AV_GROUP) {
-        ushort2 cpq[AV_GROUP][2];
         double2 ccs[AV_GROUP][2];
         int cflag[AV_GROUP];
 #pragma unroll
         for (int u = 0; u < AV_GROUP; ++u) {
             cflag[u] = flag[u];
-            cpq[u][0] = pq[u][0];
-            cpq[u][1] = pq[u][1];
             ccs[u][0] = cs[u][0];
             ccs[u][1] = cs[u][1];
         }
@@ -285,15 +358,18 @@ __global__ __launch_bounds__(64) void eigh_apply_rot_kernel(const double* __rest
 #pragma unroll
         for (int u = 0; u < AV_GROUP; ++u) {
             if (cflag[u] <= 0) continue;  // wave-uniform
+            const int t = (g0 + u) % steps;
             if (k0 < m && ccs[u][0].y != 0.0) {
-                const double x = row[cpq[u][0].x], y = row[cpq[u][0].y];
-                row[cpq[u][0].x] = ccs[u][0].x * x - ccs[u][0].y * y;
-                row[cpq[u][0].y] = ccs[u][0].y * x + ccs[u][0].x * y;
+                const int p = index_at(pt0, t), q = index_at(pb0, t);
+                const double x = row[p], y = row[q];
+                row[p] = ccs[u][0].x * x - ccs[u][0].y * y;
+                row[q] = ccs[u][0].y * x + ccs[u][0].x * y;
             }
             if (k1 < m && ccs[u][1].y != 0.0) {
-                const double x = row[cpq[u][1].x], y = row[cpq[u][1].y];
-                row[cpq[u][1].x] = ccs[u][1].x * x - ccs[u][1].y * y;
-                row[cpq[u][1].y] = ccs[u][1].y * x + ccs[u][1].x * y;
+                const int p = index_at(pt1, t), q = index_at(pb1, t);
+                const double x = row[p], y = row[q];
+                row[p] = ccs[u][1].x * x - ccs[u][1].y * y;
+                row[q] = ccs[u][1].y * x + ccs[u][1].x * y;
             }
             // single-wave workgroup: LDS instructions of one wave execute in order, so only
             // the compiler must be kept from reordering across steps (no s_waitcnt vmcnt(0),
@@ -333,55 +409,6 @@ LdsLayout layout(int64_t n, int64_t batch) {
     return L;
 }
 
-// Round-robin schedule tables for a given NP, built on the host once and cached in the context.
-nbx_sched* get_sched(nbx_ctx* ctx, int NP) {
-    for (auto& s : ctx->sched)
-        if (s.np == NP) return &s;
-    const int m = NP / 2, nblk = m * (m - 1) / 2, steps = (m == 1) ? 1 : NP - 1;
-    std::vector<ushort4> blocks((size_t)steps * std::max(nblk, 1));
-    std::vector<ushort4> pairs((size_t)steps * m);
-    std::vector<ushort2> pqs((size_t)steps * m);
-    std::vector<int> top(m), bot(m), nt(m), nb(m);
-    for (int k = 0; k < m; ++k) {
-        top[k] = 2 * k;
-        bot[k] = 2 * k + 1;
-    }
-    for (int s = 0; s < steps; ++s) {
-        for (int k = 0; k < m; ++k) {
-            const int p = top[k], q = bot[k];
-            pairs[(size_t)s * m + k] = make_ushort4((unsigned short)pk(p, p, NP), (unsigned short)pk(q, q, NP),
-                                                    (unsigned short)pks(p, q, NP), 0);
-            pqs[(size_t)s * m + k] = make_ushort2((unsigned short)p, (unsigned short)q);
-        }
-        int bidx = 0;
-        for (int I = 0; I < m; ++I)
-            for (int K = I + 1; K < m; ++K, ++bidx)
-                blocks[(size_t)s * nblk + bidx] =
-                    make_ushort4((unsigned short)pks(top[I], top[K], NP), (unsigned short)pks(top[I], bot[K], NP),
-                                 (unsigned short)pks(bot[I], top[K], NP), (unsigned short)pks(bot[I], bot[K], NP));
-        if (m >= 2) {
-            nt[0] = top[0];
-            nt[1] = bot[0];
-            for (int k = 2; k < m; ++k) nt[k] = top[k - 1];
-            for (int k = 0; k < m - 1; ++k) nb[k] = bot[k + 1];
-            nb[m - 1] = top[m - 1];
-            top.swap(nt);
-            bot.swap(nb);
-        }
-    }
-    nbx_sched sc;
-    sc.np = NP;
-    sc.d_blocks = sc.d_pairs = sc.d_pq = nullptr;
-    if (hipMalloc(&sc.d_blocks, std::max(blocks.size(), (size_t)1) * sizeof(ushort4)) != hipSuccess) return nullptr;
-    if (hipMalloc(&sc.d_pairs, pairs.size() * sizeof(ushort4)) != hipSuccess) return nullptr;
-    if (hipMalloc(&sc.d_pq, pqs.size() * sizeof(ushort2)) != hipSuccess) return nullptr;
-    (void)hipMemcpy(sc.d_blocks, blocks.data(), blocks.size() * sizeof(ushort4), hipMemcpyHostToDevice);
-    (void)hipMemcpy(sc.d_pairs, pairs.data(), pairs.size() * sizeof(ushort4), hipMemcpyHostToDevice);
-    (void)hipMemcpy(sc.d_pq, pqs.data(), pqs.size() * sizeof(ushort2), hipMemcpyHostToDevice);
-    ctx->sched.push_back(sc);
-    return &ctx->sched.back();
-}
-
 }  // namespace
 
 bool nbx_eigh_lds_supported(int64_t n) { return ((n + 1) & ~1ll) <= JL_MAX_NP; }
@@ -398,11 +425,6 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
     }
     const int N = (int)n, NP = (int)((n + 1) & ~1ll), m = NP / 2;
     const int steps = (m == 1) ? 1 : NP - 1;
-    nbx_sched* sc = get_sched(ctx, NP);
-    if (sc == nullptr) {
-        nbx_set_error("nbx_eigh: could not build the rotation schedule for N=%d", N);
-        return NBX_E_NOMEM;
-    }
     char* base = static_cast<char*>(d_work);
     double2* rot = reinterpret_cast<double2*>(base + L.rot_off);
     int* flags = reinterpret_cast<int*>(base + L.flag_off);
@@ -421,7 +443,7 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
     }
     const int npk = NP * (NP + 1) / 2;
     const size_t lds = (size_t)((npk + 1) & ~1) * sizeof(double) + (size_t)m * sizeof(double2) +
-                       (size_t)NP * sizeof(double) + (size_t)(NP + 4) * sizeof(int);
+                       (size_t)NP * sizeof(double) + (size_t)(NP + 8) * sizeof(int);
     if (lds > 160 * 1024) {
         nbx_set_error("nbx_eigh: N=%d does not fit the LDS solver", N);
         return NBX_E_UNSUPPORTED;
@@ -435,13 +457,11 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
     {
         nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
         hipLaunchKernelGGL(eigh_lds_kernel, dim3((unsigned)batch), dim3(JL_THREADS), lds, ctx->stream, a_use, N, NP,
-                           steps, static_cast<const ushort4*>(sc->d_blocks), static_cast<const ushort4*>(sc->d_pairs),
-                           rot, flags, nsteps, d_w, rank, status, L.rot_stride, L.flag_stride);
+                           steps, rot, flags, nsteps, d_w, rank, status, L.rot_stride, L.flag_stride);
         NBX_LAUNCH_CHECK();
         hipLaunchKernelGGL(eigh_apply_rot_kernel, dim3((unsigned)N, (unsigned)batch), dim3(64),
-                           (size_t)NP * sizeof(double), ctx->stream, d_v0, N, NP, steps,
-                           static_cast<const ushort2*>(sc->d_pq), rot, flags, nsteps, rank, d_v, L.rot_stride,
-                           L.flag_stride);
+                           (size_t)NP * sizeof(double), ctx->stream, d_v0, N, NP, steps, rot, flags, nsteps, rank, d_v,
+                           L.rot_stride, L.flag_stride);
         NBX_LAUNCH_CHECK();
     }
     return NBX_OK;
