@@ -108,8 +108,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # NBED_FORCE_DIST=1 exercises the RCCL code path (init, all-gathers, barrier) with one rank
+    distributed = world > 1 or os.environ.get("NBED_FORCE_DIST") == "1"
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -121,18 +126,18 @@ def main():
     from nbed_amd.scf import GpuUHF, Mole
     from nbed_amd import synth
 
-    be = HipBackend(local_rank if world > 1 else 0)
+    be = HipBackend(local_rank if distributed else 0)
     N, n_act = args.nao, args.nact
     pr = synth.problem(be, N, (args.nocc, args.nocc), args.nenv)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
     # ---------------- inputs resident in HBM before any timed region
-    shards = Shards(N, world, rank)
+    shards = Shards(N, world, rank, force_collective=distributed)
     eri = be.synth_eri(N, shards.lo, shards.hi)
     mf = GpuUHF(Mole(N, pr["nelec"]), pr["S"], pr["hcore"], eri, backend=be, shards=shards)
     from nbed_amd.scf import huzinaga_scf
@@ -172,7 +177,7 @@ def main():
             full_eri = be.synth_eri(N)  # the transform needs every p: replicate (generated, not sent)
         else:
             full_eri = eri
-        ish = Shards(n_act, world, rank)
+        ish = Shards(n_act, world, rank, force_collective=distributed)
         blocks = [(ca, ca, ca, ca), (cb, cb, cb, cb), (ca, ca, cb, cb)]
 
         def run_transform():
@@ -301,7 +306,7 @@ def main():
             "transform": transform,
         }
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

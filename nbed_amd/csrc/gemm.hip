@@ -6,7 +6,9 @@
 //   A operand: lane l holds A[i = l & 15][k = l >> 4]
 //   B operand: lane l holds B[k = l >> 4][j = l & 15]
 //   C/D      : 4 doubles per lane, reg r -> row (l >> 4) + 4 r, col l & 15
-// Workgroup = 4 waves (2 x 2); block tile BM x BN x 16 staged through LDS as
+// Workgroup = WR x WC waves (2 x 4 for the 128 x 128 tile: 64 accumulator + ~70 other registers
+// per lane, so two workgroups = 4 waves/SIMD fit a CU -- one wave/SIMD cannot saturate the fp64
+// matrix pipe, see profiles/r01/mfma_f64_peak.txt); block tile BM x BN x 16 staged through LDS as
 // As[k][m] / Bs[k][n] with row stride (BM|BN) + 16 doubles so that the two
 // 16-lane groups a ds_read_b64 services together fall in different halves of the
 // 256-byte bank row (conflict-free fragment reads).  The next k-tile is fetched into
@@ -17,13 +19,12 @@ namespace {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-constexpr int GEMM_THREADS = 256;
 constexpr int BK = 16;
 constexpr int PAD = 16;
 
 // Stage one operand tile T[k][x] (k < BK, x < BX) where element (x, k) of op(.) lives at
 // base[x * sx + k * sk].  KCONTIG: memory is contiguous along k (sk == 1), else along x (sx == 1).
-template <int BX, bool KCONTIG>
+template <int BX, bool KCONTIG, int GEMM_THREADS>
 struct Stager {
     static constexpr int PAIRS = BK * BX / 2;            // double2 items per tile
     static constexpr int PER_THREAD = PAIRS / GEMM_THREADS;
@@ -88,12 +89,13 @@ struct Stager {
     }
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f64_kernel(
+template <int BM, int BN, int WR, int WC, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
     int M, int N, int K, double alpha, const double* __restrict__ A, int64_t lda, int64_t stride_a,
     const double* __restrict__ B, int64_t ldb, int64_t stride_b, double beta, double* __restrict__ C,
     int64_t ldc, int64_t stride_c, int vec_a, int vec_b) {
-    constexpr int WM = BM / 2, WN = BN / 2;  // 2 x 2 waves
+    constexpr int GEMM_THREADS = 64 * WR * WC;
+    constexpr int WM = BM / WR, WN = BN / WC;  // WR x WC waves
     constexpr int MT = WM / 16, NT = WN / 16;
     __shared__ __attribute__((aligned(16))) double As[BK * (BM + PAD)];
     __shared__ __attribute__((aligned(16))) double Bs[BK * (BN + PAD)];
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f64_kernel(
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
     const int fr = lane & 15;   // index inside the 16-wide fragment
     const int fk = lane >> 4;   // k (A/B) or row group (C)
 
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f64_kernel(
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
-    Stager<BM, A_KC> sa;
-    Stager<BN, B_KC> sb;
+    Stager<BM, A_KC, GEMM_THREADS> sa;
+    Stager<BN, B_KC, GEMM_THREADS> sb;
     const int nkt = (K + BK - 1) / BK;
     sa.load(A, lda, m0, 0, M, K, vec_a);
     sb.load(B, ldb, n0, 0, N, K, vec_b);
@@ -176,14 +178,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f64_kernel(
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int BM, int BN>
+template <int BM, int BN, int WR, int WC>
 void launch(nbx_ctx* ctx, bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, int64_t lda,
             int64_t sa, const double* B, int64_t ldb, int64_t sb, double beta, double* C, int64_t ldc, int64_t sc,
             int batch, int vec_a, int vec_b) {
     dim3 grid((unsigned)nbx_cdiv(N, BN), (unsigned)nbx_cdiv(M, BM), (unsigned)batch);
-    dim3 block(GEMM_THREADS);
-#define NBX_GEMM_GO(AK, BKC)                                                                               \
-    hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, AK, BKC>), grid, block, 0, ctx->stream, M, N, K, alpha, A, \
+    dim3 block(64 * WR * WC);
+#define NBX_GEMM_GO(AK, BKC)                                                                                       \
+    hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, WR, WC, AK, BKC>), grid, block, 0, ctx->stream, M, N, K, alpha, A, \
                        lda, sa, B, ldb, sb, beta, C, ldc, sc, vec_a, vec_b)
     if (a_kc) {
         if (b_kc) NBX_GEMM_GO(true, true);
@@ -229,13 +231,13 @@ extern "C" int nbx_gemm(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int
         double* C = d_c + b0 * stride_c;
         const int64_t tiles128 = nbx_cdiv(m, 128) * nbx_cdiv(n, 128) * nb;
         if (tiles128 >= 512 && m > 64 && n > 64) {
-            launch<128, 128>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
+            launch<128, 128, 2, 4>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
                              beta, C, ldc, stride_c, nb, vec_a, vec_b);
         } else if (m <= 32 || n <= 32) {
-            launch<32, 32>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
+            launch<32, 32, 2, 2>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
                            beta, C, ldc, stride_c, nb, vec_a, vec_b);
         } else {
-            launch<64, 64>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
+            launch<64, 64, 2, 2>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
                            beta, C, ldc, stride_c, nb, vec_a, vec_b);
         }
         NBX_LAUNCH_CHECK();

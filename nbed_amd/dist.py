@@ -20,7 +20,8 @@ import math
 class Shards:
     """Contiguous partition of ``range(n)`` over the ranks of a process group."""
 
-    def __init__(self, n: int, world: int = 1, rank: int = 0, group=None):
+    def __init__(self, n: int, world: int = 1, rank: int = 0, group=None, force_collective: bool = False):
+        self.force_collective = force_collective  # run the all-gather even with one rank (testing)
         self.n = int(n)
         self.world = int(world)
         self.rank = int(rank)
@@ -52,7 +53,7 @@ class Shards:
     def all_gather(self, be, slab, axis: int = 0):
         """Concatenate every rank's ``slab`` (its ``lo:hi`` piece along ``axis``) into the
         full-length array.  ``slab`` may be shorter than ``chunk`` on the last ranks."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return slab
         padded = be.pad_axis(slab, axis, self.chunk)
         gathered = be.all_gather_stack(padded, self.group)  # (world, ...)
