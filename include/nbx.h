@@ -98,6 +98,12 @@ size_t nbx_jk_dense_worksize(int64_t nao, int64_t np, int64_t ndm);
 int nbx_jk_dense(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri,
                  const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes);
 
+/* Same contraction with the synthetic (pq|rs) of nbx_synth_eri GENERATED in registers instead of
+ * read from HBM (the N_AO = 2000 configuration: a dense tensor would be 128 TB).  Workspace as
+ * nbx_jk_dense_worksize().  ALU-bound (one 64-bit counter hash per integral).               */
+int nbx_jk_synth(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, uint64_t seed, const double* d_dm,
+                 int64_t ndm, double* d_jk, void* d_work, size_t work_bytes);
+
 /* ------------------------------------------------------------------ dense products (MFMA fp64)
  * C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b], row-major, op = 'N' or 'T'.
  * Replaces the OpenBLAS dgemm behind numpy matmul/einsum at
@@ -192,6 +198,14 @@ int nbx_ao2mo(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c1
               int64_t i0, int64_t i1, const double* d_c2, int64_t n2, const double* d_c3,
               int64_t n3, const double* d_c4, int64_t n4, double* d_out, void* d_work,
               size_t work_bytes);
+/* Streamed transform of the synthetic (pq|rs) of nbx_synth_eri, never stored (N_AO = 2000):
+ *   out[i,j,k,l] = sum_{r in [r0,r1)} sum_pqs C1[p,i] C2[q,j] C3[r,k] C4[s,l] (pq|rs)
+ * Same four quarter transforms / flop count as nbx_ao2mo.  [r0,r1) is the multi-GPU shard axis:
+ * the partial tensors of the ranks are SUMMED (all-reduce) by the host.                       */
+size_t nbx_ao2mo_synth_worksize(int64_t nao, int64_t n1, int64_t n2, int64_t n3, int64_t n4);
+int nbx_ao2mo_synth(nbx_ctx* ctx, int64_t nao, uint64_t seed, int64_t r0, int64_t r1, const double* d_c1,
+                    int64_t n1, const double* d_c2, int64_t n2, const double* d_c3, int64_t n3,
+                    const double* d_c4, int64_t n4, double* d_out, void* d_work, size_t work_bytes);
 /* out[a,c,d,b] = in[a,b,c,d]: chemist (ij|kl) -> the reference's physicist-ordered block
  * eri.transpose(0,2,3,1) (ham_builder.py:133).                                            */
 int nbx_chem_to_phys(nbx_ctx* ctx, int64_t n1, int64_t n2, int64_t n3, int64_t n4,

@@ -59,6 +59,7 @@ SIGNATURES = {
     "nbx_synth_eri": (c_int, [_P, c_int64, c_int64, c_int64, c_uint64, _P]),
     "nbx_jk_dense_worksize": (c_size_t, [c_int64, c_int64, c_int64]),
     "nbx_jk_dense": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
+    "nbx_jk_synth": (c_int, [_P, c_int64, c_int64, c_int64, c_uint64, _P, c_int64, _P, _P, c_size_t]),
     "nbx_gemm": (c_int, [_P, c_char, c_char, c_int64, c_int64, c_int64, c_double, _P, c_int64, c_int64,
                          _P, c_int64, c_int64, c_double, _P, c_int64, c_int64, c_int64]),
     "nbx_fock_uhf": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P]),
@@ -82,6 +83,9 @@ SIGNATURES = {
     "nbx_ao2mo_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64, c_int64]),
     "nbx_ao2mo": (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P,
                           c_int64, _P, _P, c_size_t]),
+    "nbx_ao2mo_synth_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64, c_int64]),
+    "nbx_ao2mo_synth": (c_int, [_P, c_int64, c_uint64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P,
+                                c_int64, _P, _P, c_size_t]),
     "nbx_chem_to_phys": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P]),
     "nbx_spinorb_scatter": (c_int, [_P, c_int64, _P, _P, c_double, c_double, _P, _P]),
 }

@@ -180,6 +180,17 @@ class HipBackend:
                    work.numel())
         return out
 
+    def jk_synth(self, nao: int, dm, p0: int = 0, p1: int | None = None, seed: int = 20250829):
+        """J/K against the synthetic (pq|rs) generated in registers (no ERI in memory)."""
+        p1 = nao if p1 is None else p1
+        dm3 = dm.reshape(-1, nao, nao)
+        ndm = dm3.shape[0]
+        nbytes = self.lib.nbx_jk_dense_worksize(nao, p1 - p0, ndm)
+        work = self._workspace("jk", nbytes)
+        out = self.empty((1 + ndm, p1 - p0, nao))
+        self._call("nbx_jk_synth", nao, p0, p1, seed, self._p(dm3), ndm, self._p(out), self._p(work), work.numel())
+        return out
+
     # ------------------------------------------------------------------ GEMM
     def gemm(self, a, b, ta: str = "N", tb: str = "N", alpha: float = 1.0, beta: float = 0.0, out=None):
         """op(a) @ op(b) for 2-D operands, or batched over a shared leading axis (3-D)."""
@@ -324,6 +335,17 @@ class HipBackend:
         work = self._workspace("ao2mo", nbytes)
         out = self.empty((i1 - i0, n2, n3, n4))
         self._call("nbx_ao2mo", nao, self._p(eri), self._p(c1), n1, i0, i1, self._p(c2), n2, self._p(c3), n3,
+                   self._p(c4), n4, self._p(out), self._p(work), work.numel())
+        return out
+
+    def ao2mo_synth(self, nao: int, c1, c2, c3, c4, r0: int = 0, r1: int | None = None, seed: int = 20250829):
+        """Streamed transform of the synthetic ERI (never stored); partial sum over r in [r0,r1)."""
+        n1, n2, n3, n4 = c1.shape[1], c2.shape[1], c3.shape[1], c4.shape[1]
+        r1 = nao if r1 is None else r1
+        nbytes = self.lib.nbx_ao2mo_synth_worksize(nao, n1, n2, n3, n4)
+        work = self._workspace("ao2mo_synth", nbytes)
+        out = self.empty((n1, n2, n3, n4))
+        self._call("nbx_ao2mo_synth", nao, seed, r0, r1, self._p(c1), n1, self._p(c2), n2, self._p(c3), n3,
                    self._p(c4), n4, self._p(out), self._p(work), work.numel())
         return out
 

@@ -1,0 +1,116 @@
+// libnbx: AO -> MO four-index transform of the SYNTHETIC (pq|rs) without ever storing it
+// (include/nbx.h "streamed transform"; the N_AO = 2000 configuration of BASELINE.json).
+//
+//   out[i,j,k,l] = sum_{r in [r0,r1)} sum_{pqs} C1_pi C2_qj C3_rk C4_sl (pq|rs)
+//
+// The tensor is produced slab by slab from the counter hash (synth.hip) and consumed at once:
+//   for r:                                                        flop (summed over r, s)
+//     for s-chunks:  M[s][p,q] = (pq|rs)              generate   (hash, ALU)
+//                    Y[s] = C1^T M[s]   (n1 x N)      GEMM       2 n1 N^4
+//                    Z[s] = Y[s] C2     (n1 x n2)     GEMM       2 n1 n2 N^3
+//     U[r] = C4^T Z   (n4 x n1 n2)                    GEMM       2 n1 n2 n4 N^2
+//   every RB r's:  acc += C3[rb]^T U[rb]  (n3 x n4 n1 n2)  GEMM  2 n1 n2 n3 n4 N
+//   out = acc^T   ((k,l),(i,j)) -> ((i,j),(k,l))
+// i.e. the same four quarter transforms and flop count as the dense path, with O(N^2 n^2 / N)
+// memory instead of O(N^4).  The r range is the multi-GPU shard axis here (partial sums are
+// all-reduced by the host): sharding the MO index i would make every rank regenerate the
+// whole tensor.  The generated slab still makes one round trip through HBM (8 N^2 bytes per
+// (r,s), written then read); fusing the generator into the GEMM operand staging is the next step.
+#include "nbx_common.h"
+#include "synth_device.h"
+
+namespace {
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// M[(s - s0)][p][q] = val(canon(p,q,r,s)) / N : one workgroup per (s, p) row
+__global__ __launch_bounds__(256) void synth_rs_kernel(double* __restrict__ M, int N, int r, int s0, uint64_t seed) {
+    const int sl = blockIdx.x / N;
+    const int p = blockIdx.x - sl * N;
+    const uint64_t rs = nbx_tri((uint64_t)r, (uint64_t)(s0 + sl));
+    const double scale = 1.0 / (double)N;
+    double* row = M + ((int64_t)sl * N + p) * N;
+    for (int q = threadIdx.x; q < N; q += blockDim.x)
+        row[q] = nbx_synth_val(0, nbx_tri(nbx_tri((uint64_t)p, (uint64_t)q), rs), seed) * scale;
+}
+
+struct SynthPlan {
+    int64_t sc, rb;
+    size_t m_off, y_off, z_off, u_off, acc_off, total;
+};
+
+SynthPlan plan(int64_t N, int64_t n1, int64_t n2, int64_t n3, int64_t n4) {
+    SynthPlan p;
+    int64_t sc = (int64_t)(2.0e9 / (8.0 * (double)N * (double)N));  // ~2 GB generated slab
+    if (sc < 1) sc = 1;
+    if (sc > N) sc = N;
+    p.sc = sc;
+    p.rb = 8;
+    size_t off = 0;
+    p.m_off = off; off += align256((size_t)(sc * N * N) * sizeof(double));
+    p.y_off = off; off += align256((size_t)(sc * n1 * N) * sizeof(double));
+    p.z_off = off; off += align256((size_t)(N * n1 * n2) * sizeof(double));
+    p.u_off = off; off += align256((size_t)(p.rb * n4 * n1 * n2) * sizeof(double));
+    p.acc_off = off; off += align256((size_t)(n3 * n4 * n1 * n2) * sizeof(double));
+    p.total = off;
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t nbx_ao2mo_synth_worksize(int64_t nao, int64_t n1, int64_t n2, int64_t n3, int64_t n4) {
+    if (nao <= 0 || n1 <= 0 || n2 <= 0 || n3 <= 0 || n4 <= 0) return 0;
+    return plan(nao, n1, n2, n3, n4).total;
+}
+
+extern "C" int nbx_ao2mo_synth(nbx_ctx* ctx, int64_t nao, uint64_t seed, int64_t r0, int64_t r1, const double* d_c1,
+                               int64_t n1, const double* d_c2, int64_t n2, const double* d_c3, int64_t n3,
+                               const double* d_c4, int64_t n4, double* d_out, void* d_work, size_t work_bytes) {
+    NBX_CHECK_ARG(ctx && d_c1 && d_c2 && d_c3 && d_c4 && d_out);
+    NBX_CHECK_ARG(nao > 0 && n1 > 0 && n2 > 0 && n3 > 0 && n4 > 0 && r0 >= 0 && r1 >= r0 && r1 <= nao);
+    const int64_t N = nao, n12 = n1 * n2;
+    NBX_CHECK_ARG(n4 * n12 < (1ll << 31) && N * N < (1ll << 31));
+    const SynthPlan pl = plan(N, n1, n2, n3, n4);
+    if (d_work == nullptr || work_bytes < pl.total) {
+        nbx_set_error("nbx_ao2mo_synth: workspace %zu < %zu bytes", work_bytes, pl.total);
+        return NBX_E_NOMEM;
+    }
+    char* base = static_cast<char*>(d_work);
+    double* M = reinterpret_cast<double*>(base + pl.m_off);
+    double* Y = reinterpret_cast<double*>(base + pl.y_off);
+    double* Z = reinterpret_cast<double*>(base + pl.z_off);
+    double* U = reinterpret_cast<double*>(base + pl.u_off);
+    double* acc = reinterpret_cast<double*>(base + pl.acc_off);
+    nbx_prof_scope prof_all(ctx, NBX_PROF_AO2MO);
+    int rc = nbx_memset(ctx, acc, 0, (size_t)(n3 * n4 * n12) * sizeof(double));
+    if (rc != NBX_OK) return rc;
+    int64_t rb0 = r0;  // first r of the U block being filled
+    for (int64_t r = r0; r < r1; ++r) {
+        for (int64_t s0 = 0; s0 < N; s0 += pl.sc) {
+            const int64_t ns = (N - s0) < pl.sc ? (N - s0) : pl.sc;
+            hipLaunchKernelGGL(synth_rs_kernel, dim3((unsigned)(ns * N)), dim3(256), 0, ctx->stream, M, (int)N, (int)r,
+                               (int)s0, seed);
+            NBX_LAUNCH_CHECK();
+            {
+                nbx_prof_scope prof_q1(ctx, NBX_PROF_AO2MO_Q1);
+                rc = nbx_gemm(ctx, 'T', 'N', n1, N, N, 1.0, d_c1, n1, 0, M, N, N * N, 0.0, Y, N, n1 * N, ns);
+            }
+            if (rc != NBX_OK) return rc;
+            rc = nbx_gemm(ctx, 'N', 'N', n1, n2, N, 1.0, Y, N, n1 * N, d_c2, n2, 0, 0.0, Z + s0 * n12, n2, n12, ns);
+            if (rc != NBX_OK) return rc;
+        }
+        // U[r - rb0] (n4 x n12) = C4^T (n4 x N) . Z (N x n12)
+        rc = nbx_gemm(ctx, 'T', 'N', n4, n12, N, 1.0, d_c4, n4, 0, Z, n12, 0, 0.0, U + (r - rb0) * n4 * n12, n12, 0, 1);
+        if (rc != NBX_OK) return rc;
+        if (r - rb0 + 1 == pl.rb || r + 1 == r1) {
+            const int64_t nr = r - rb0 + 1;
+            // acc (n3 x n4 n12) += C3[rb0:rb0+nr]^T (n3 x nr) . U (nr x n4 n12)
+            rc = nbx_gemm(ctx, 'T', 'N', n3, n4 * n12, nr, 1.0, d_c3 + rb0 * n3, n3, 0, U, n4 * n12, 0, 1.0, acc,
+                          n4 * n12, 0, 1);
+            if (rc != NBX_OK) return rc;
+            rb0 = r + 1;
+        }
+    }
+    // acc[(k,l)][(i,j)] -> out[(i,j)][(k,l)]
+    return nbx_transpose(ctx, n3 * n4, n12, 1, acc, d_out);
+}

@@ -239,11 +239,17 @@ static size_t eigh_global_worksize(int64_t n, int64_t batch) {
     return align256((size_t)(4 * np * np * batch) * sizeof(double)) + align256((size_t)batch * sizeof(int));
 }
 
+static size_t eigh_jacobi_global_total(int64_t n, int64_t batch) {
+    // global-memory Jacobi + (for warm starts) V0^T A V0 and a GEMM temporary
+    return eigh_global_worksize(n, batch) + 2 * align256((size_t)(n * n * batch) * sizeof(double));
+}
+
 extern "C" size_t nbx_eigh_worksize(int64_t n, int64_t batch) {
     if (n <= 0 || batch <= 0) return 0;
     if (nbx_eigh_lds_supported(n)) return nbx_eigh_lds_worksize(n, batch);
-    // warm starts on the global-memory path need V0^T A V0 and a GEMM temporary
-    return eigh_global_worksize(n, batch) + 2 * align256((size_t)(n * n * batch) * sizeof(double));
+    // tridiagonal pipeline, then (only if needed) the Jacobi polisher, then a copy of V
+    return nbx_eigh_tridiag_worksize(n, batch) + eigh_jacobi_global_total(n, batch) +
+           align256((size_t)(n * n * batch) * sizeof(double));
 }
 
 static int eigh_global(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
@@ -262,19 +268,9 @@ static int eigh_global(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a
     return NBX_OK;
 }
 
-extern "C" int nbx_eigh_warm(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0,
-                             double* d_w, double* d_v, void* d_work, size_t work_bytes) {
-    NBX_CHECK_ARG(ctx && d_a && d_w && d_v && n > 0 && batch > 0 && batch <= 1024);
-    NBX_CHECK_ARG(n <= 4096);
-    const size_t need = nbx_eigh_worksize(n, batch);
-    if (d_work == nullptr || work_bytes < need) {
-        nbx_set_error("nbx_eigh: workspace %zu < %zu bytes", work_bytes, need);
-        return NBX_E_NOMEM;
-    }
-    NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
-    if (nbx_eigh_lds_supported(n)) return nbx_eigh_lds(ctx, n, batch, d_a, d_v0, d_w, d_v, d_work, work_bytes);
-    if (d_v0 == nullptr) return eigh_global(ctx, n, batch, d_a, d_w, d_v, d_work);
-    // global-memory path, warm start: solve V0^T A V0 = U w U^T, then V = V0 U
+// Jacobi in global memory warm-started from orthonormal V0: solve V0^T A V0 = U w U^T, V = V0 U
+static int eigh_global_warm(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0,
+                            double* d_w, double* d_v, void* d_work) {
     char* extra = static_cast<char*>(d_work) + eigh_global_worksize(n, batch);
     double* a0 = reinterpret_cast<double*>(extra);
     double* tmp = reinterpret_cast<double*>(extra + align256((size_t)(n * n * batch) * sizeof(double)));
@@ -287,6 +283,39 @@ extern "C" int nbx_eigh_warm(nbx_ctx* ctx, int64_t n, int64_t batch, const doubl
     return nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, d_v0, n, n * n, tmp, n, n * n, 0.0, d_v, n, n * n, batch);
 }
 
+extern "C" int nbx_eigh_warm(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0,
+                             double* d_w, double* d_v, void* d_work, size_t work_bytes) {
+    NBX_CHECK_ARG(ctx && d_a && d_w && d_v && n > 0 && batch > 0 && batch <= 1024);
+    NBX_CHECK_ARG(n <= 2048);
+    const size_t need = nbx_eigh_worksize(n, batch);
+    if (d_work == nullptr || work_bytes < need) {
+        nbx_set_error("nbx_eigh: workspace %zu < %zu bytes", work_bytes, need);
+        return NBX_E_NOMEM;
+    }
+    NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
+    if (nbx_eigh_lds_supported(n)) return nbx_eigh_lds(ctx, n, batch, d_a, d_v0, d_w, d_v, d_work, work_bytes);
+
+    // N > 196: Householder + multisection + inverse iteration; Jacobi only as a polisher.
+    char* base = static_cast<char*>(d_work);
+    const size_t td = nbx_eigh_tridiag_worksize(n, batch);
+    char* jac = base + td;
+    double* vcopy = reinterpret_cast<double*>(jac + eigh_jacobi_global_total(n, batch));
+    std::vector<double> quality((size_t)batch, 0.0);
+    int rc = nbx_eigh_tridiag(ctx, n, batch, d_a, d_w, d_v, base, td, quality.data());
+    if (rc != NBX_OK) return rc;
+    double worst = 0.0;
+    for (double q : quality) worst = q > worst ? q : worst;
+    int* status = reinterpret_cast<int*>(jac + align256((size_t)(4 * ((n + 1) & ~1ll) * ((n + 1) & ~1ll) * batch) * sizeof(double)));
+    if (!(worst <= 1.0e-13)) {  // also catches NaN
+        rc = nbx_memcpy_d2d(ctx, vcopy, d_v, (size_t)(n * n * batch) * sizeof(double));
+        if (rc != NBX_OK) return rc;
+        return eigh_global_warm(ctx, n, batch, d_a, vcopy, d_w, d_v, jac);
+    }
+    // accepted as is: report "1 sweep" through the status words the Jacobi kernel would have written
+    std::vector<int> ones((size_t)batch, 1);
+    return nbx_memcpy_h2d(ctx, status, ones.data(), (size_t)batch * sizeof(int));
+}
+
 extern "C" int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
                         void* d_work, size_t work_bytes) {
     return nbx_eigh_warm(ctx, n, batch, d_a, nullptr, d_w, d_v, d_work, work_bytes);
@@ -295,7 +324,8 @@ extern "C" int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_
 extern "C" int nbx_eigh_status(nbx_ctx* ctx, int64_t n, int64_t batch, const void* d_work, int* h_sweeps) {
     NBX_CHECK_ARG(ctx && d_work && h_sweeps && n > 0 && batch > 0);
     const int64_t np = (n + 1) & ~1ll;
-    const char* status = static_cast<const char*>(d_work) + align256((size_t)(4 * np * np * batch) * sizeof(double));
+    const char* status = static_cast<const char*>(d_work) + nbx_eigh_tridiag_worksize(n, batch) +
+                         align256((size_t)(4 * np * np * batch) * sizeof(double));
     if (nbx_eigh_lds_supported(n)) status = reinterpret_cast<const char*>(nbx_eigh_lds_status_ptr(n, batch, d_work));
     int rc = nbx_memcpy_d2h(ctx, h_sweeps, status, (size_t)batch * sizeof(int));
     if (rc != NBX_OK) return rc;

@@ -14,6 +14,7 @@
 // Dtot (N*N doubles, read by every workgroup, served from L2) is loaded once per
 // group of QB tiles; the D rows the K update needs (QB rows per spin) sit in LDS.
 #include "nbx_common.h"
+#include "synth_device.h"
 
 namespace {
 
@@ -47,17 +48,43 @@ __device__ __forceinline__ double dot_acc(double acc, double a, double b) { retu
 __device__ __forceinline__ void zero(double2& v) { v.x = 0.0; v.y = 0.0; }
 __device__ __forceinline__ void zero(double& v) { v = 0.0; }
 
+// Where the (a, b) tile values of (pq|ab) come from: the dense slab in HBM, or the counter hash
+// of SURVEY.md section 8d evaluated in registers (N_AO = 2000: a dense tensor would be 128 TB).
+struct TileLoad {
+    const double* tile0;  // &eri[p_local][q][0][0]
+    int64_t n2;
+    __device__ __forceinline__ double2 get2(int j, int64_t o, int, int) const {
+        return *reinterpret_cast<const double2*>(tile0 + j * n2 + o);
+    }
+    __device__ __forceinline__ double get1(int j, int64_t o, int, int) const { return tile0[j * n2 + o]; }
+};
+struct TileGen {
+    uint64_t pq[JK_QB];  // tri(p, q + j)
+    uint64_t seed;
+    double scale;
+    __device__ __forceinline__ double val(int j, int a, int b) const {
+        return nbx_synth_val(0, nbx_tri(pq[j], nbx_tri((uint64_t)a, (uint64_t)b)), seed) * scale;
+    }
+    __device__ __forceinline__ double2 get2(int j, int64_t, int a, int b) const {
+        return make_double2(val(j, a, b), val(j, a, b + 1));
+    }
+    __device__ __forceinline__ double get1(int j, int64_t, int a, int b) const { return val(j, a, b); }
+};
+template <class SRC>
+__device__ __forceinline__ double2 src_get(const SRC& s, int j, int64_t o, int a, int b, double2*) { return s.get2(j, o, a, b); }
+template <class SRC>
+__device__ __forceinline__ double src_get(const SRC& s, int j, int64_t o, int a, int b, double*) { return s.get1(j, o, a, b); }
+
 // Stream QB tiles (q .. q+QB-1 of row p) and accumulate.
 //   tile0 : &eri[p_local][q][0][0]
 //   dsh   : LDS, dsh[(x*JK_QB + j)*N + a] = D^x[q+j][a]
-template <int QB, int NDM, int CS, bool VEC2>
-__device__ __forceinline__ void jk_group(const double* __restrict__ tile0, const double* __restrict__ dtot,
+template <int QB, int NDM, int CS, bool VEC2, class SRC>
+__device__ __forceinline__ void jk_group(const SRC& src, const double* __restrict__ dtot,
                                          const double* dsh, int N, int row0, int rstep, int cx,
                                          int cstep, int CX, double (&jacc)[JK_QB],
                                          typename ColVec<VEC2>::type (&kacc)[NDM][CS]) {
     using V = typename ColVec<VEC2>::type;
     constexpr int W = ColVec<VEC2>::W;
-    const int64_t n2 = (int64_t)N * N;
 #pragma unroll
     for (int seg = 0; seg < CS; ++seg) {
         const int c = cx + seg * cstep;
@@ -71,8 +98,8 @@ __device__ __forceinline__ void jk_group(const double* __restrict__ tile0, const
             V t0[QB], t1[QB];
 #pragma unroll
             for (int j = 0; j < QB; ++j) {
-                t0[j] = ld(reinterpret_cast<const V*>(tile0 + j * n2 + o0));
-                t1[j] = ld(reinterpret_cast<const V*>(tile0 + j * n2 + o1));
+                t0[j] = src_get(src, j, o0, a, col, (V*)nullptr);
+                t1[j] = src_get(src, j, o1, a + rstep, col, (V*)nullptr);
             }
             const V d0 = ld(reinterpret_cast<const V*>(dtot + o0));
             const V d1 = ld(reinterpret_cast<const V*>(dtot + o1));
@@ -91,7 +118,7 @@ __device__ __forceinline__ void jk_group(const double* __restrict__ tile0, const
             const int64_t o0 = (int64_t)a * N + col;
             V t0[QB];
 #pragma unroll
-            for (int j = 0; j < QB; ++j) t0[j] = ld(reinterpret_cast<const V*>(tile0 + j * n2 + o0));
+            for (int j = 0; j < QB; ++j) t0[j] = src_get(src, j, o0, a, col, (V*)nullptr);
             const V d0 = ld(reinterpret_cast<const V*>(dtot + o0));
 #pragma unroll
             for (int j = 0; j < QB; ++j) {
@@ -103,10 +130,11 @@ __device__ __forceinline__ void jk_group(const double* __restrict__ tile0, const
     }
 }
 
-template <int NDM, int CS, bool VEC2>
+template <int NDM, int CS, bool VEC2, bool GEN>
 __global__ __launch_bounds__(JK_THREADS) void jk_dense_kernel(
     const double* __restrict__ eri, const double* __restrict__ dm, const double* __restrict__ dtot,
-    double* __restrict__ jout, double* __restrict__ kpart, int N, int np, int nqc, int qchunk) {
+    double* __restrict__ jout, double* __restrict__ kpart, int N, int np, int nqc, int qchunk, int p0,
+    uint64_t seed) {
     using V = typename ColVec<VEC2>::type;
     constexpr int W = ColVec<VEC2>::W;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -145,7 +173,7 @@ __global__ __launch_bounds__(JK_THREADS) void jk_dense_kernel(
         for (int s = 0; s < CS; ++s) zero(kacc[x][s]);
 
     const int64_t n2 = (int64_t)N * N;
-    const double* prow = eri + (int64_t)p_local * N * n2;
+    const double* prow = GEN ? nullptr : eri + (int64_t)p_local * N * n2;
 
     for (int q = q_begin; q < q_end; q += JK_QB) {
         const int nq = min(JK_QB, q_end - q);
@@ -160,15 +188,37 @@ __global__ __launch_bounds__(JK_THREADS) void jk_dense_kernel(
         __syncthreads();
         double jacc[JK_QB] = {0.0, 0.0, 0.0, 0.0};
         if (active) {
-            const double* tile0 = prow + (int64_t)q * n2;
-            if (nq == JK_QB) {
-                jk_group<JK_QB, NDM, CS, VEC2>(tile0, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc);
+            if constexpr (GEN) {
+                TileGen src;
+                src.seed = seed;
+                src.scale = 1.0 / (double)N;
+                const uint64_t pg = (uint64_t)(p0 + p_local);
+                if (nq == JK_QB) {
+#pragma unroll
+                    for (int j = 0; j < JK_QB; ++j) src.pq[j] = nbx_tri(pg, (uint64_t)(q + j));
+                    jk_group<JK_QB, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc);
+                } else {
+                    for (int j = 0; j < nq; ++j) {
+                        double j1[JK_QB] = {0.0, 0.0, 0.0, 0.0};
+                        src.pq[0] = nbx_tri(pg, (uint64_t)(q + j));
+                        jk_group<1, NDM, CS, VEC2>(src, dtot, dsh + j * N, N, rowg, R, cx, cstep, CX, j1, kacc);
+                        jacc[j] = j1[0];
+                    }
+                }
             } else {
-                for (int j = 0; j < nq; ++j) {
-                    double j1[JK_QB] = {0.0, 0.0, 0.0, 0.0};
-                    jk_group<1, NDM, CS, VEC2>(tile0 + j * n2, dtot, dsh + j * N, N, rowg, R, cx, cstep,
-                                               CX, j1, kacc);
-                    jacc[j] = j1[0];
+                TileLoad src;
+                src.n2 = n2;
+                src.tile0 = prow + (int64_t)q * n2;
+                if (nq == JK_QB) {
+                    jk_group<JK_QB, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc);
+                } else {
+                    for (int j = 0; j < nq; ++j) {
+                        double j1[JK_QB] = {0.0, 0.0, 0.0, 0.0};
+                        TileLoad s1 = src;
+                        s1.tile0 = src.tile0 + j * n2;
+                        jk_group<1, NDM, CS, VEC2>(s1, dtot, dsh + j * N, N, rowg, R, cx, cstep, CX, j1, kacc);
+                        jacc[j] = j1[0];
+                    }
                 }
             }
         }
@@ -261,31 +311,33 @@ extern "C" size_t nbx_jk_dense_worksize(int64_t nao, int64_t np, int64_t ndm) {
 
 template <int NDM, int CS, bool VEC2>
 static void jk_launch(nbx_ctx* ctx, const JkPlan& pl, const double* eri, const double* dm, const double* dtot,
-                      double* jout, double* kpart, int N, int np) {
-    hipLaunchKernelGGL((jk_dense_kernel<NDM, CS, VEC2>), dim3((unsigned)(np * pl.nqc)), dim3(JK_THREADS),
-                       pl.lds_bytes, ctx->stream, eri, dm, dtot, jout, kpart, N, np, pl.nqc, pl.qchunk);
+                      double* jout, double* kpart, int N, int np, int p0, bool gen, uint64_t seed) {
+    if (gen)
+        hipLaunchKernelGGL((jk_dense_kernel<NDM, CS, VEC2, true>), dim3((unsigned)(np * pl.nqc)), dim3(JK_THREADS),
+                           pl.lds_bytes, ctx->stream, eri, dm, dtot, jout, kpart, N, np, pl.nqc, pl.qchunk, p0, seed);
+    else
+        hipLaunchKernelGGL((jk_dense_kernel<NDM, CS, VEC2, false>), dim3((unsigned)(np * pl.nqc)), dim3(JK_THREADS),
+                           pl.lds_bytes, ctx->stream, eri, dm, dtot, jout, kpart, N, np, pl.nqc, pl.qchunk, p0, seed);
 }
 
-extern "C" int nbx_jk_dense(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri,
-                            const double* d_dm, int64_t ndm, double* d_jk, void* d_work,
-                            size_t work_bytes) {
-    NBX_CHECK_ARG(ctx != nullptr && d_eri != nullptr && d_dm != nullptr && d_jk != nullptr);
+static int jk_impl(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri, bool gen, uint64_t seed,
+                   const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes) {
+    NBX_CHECK_ARG(ctx != nullptr && (gen || d_eri != nullptr) && d_dm != nullptr && d_jk != nullptr);
     NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
     NBX_CHECK_ARG(ndm == 1 || ndm == 2);
     const int64_t np = p1 - p0;
     if (np == 0) return NBX_OK;
     if (nao > 2048 || (nao % 2 == 1 && nao > 1024)) {
-        nbx_set_error("nbx_jk_dense: N=%lld exceeds the dense-kernel limit (2048 even / 1024 odd)",
-                      (long long)nao);
+        nbx_set_error("nbx_jk: N=%lld exceeds the kernel limit (2048 even / 1024 odd)", (long long)nao);
         return NBX_E_UNSUPPORTED;
     }
     const JkPlan pl = jk_plan(nao, np, ndm);
     const size_t need = nbx_jk_dense_worksize(nao, np, ndm);
     if (d_work == nullptr || work_bytes < need) {
-        nbx_set_error("nbx_jk_dense: workspace %zu < %zu bytes", work_bytes, need);
+        nbx_set_error("nbx_jk: workspace %zu < %zu bytes", work_bytes, need);
         return NBX_E_NOMEM;
     }
-    NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_eri) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
+    NBX_CHECK_ARG((gen || (reinterpret_cast<uintptr_t>(d_eri) & 15) == 0) && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
     double* dtot = static_cast<double*>(d_work);
     double* kpart = dtot + nao * nao;
     const int64_t n2 = nao * nao;
@@ -294,7 +346,8 @@ extern "C" int nbx_jk_dense(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
     const int N = (int)nao;
     {
     nbx_prof_scope prof(ctx, NBX_PROF_JK_DENSE);
-#define NBX_JK_CASE(NDM, CS, V2) jk_launch<NDM, CS, V2>(ctx, pl, d_eri, d_dm, dtot, d_jk, kpart, N, (int)np)
+#define NBX_JK_CASE(NDM, CS, V2) \
+    jk_launch<NDM, CS, V2>(ctx, pl, d_eri, d_dm, dtot, d_jk, kpart, N, (int)np, (int)p0, gen, seed)
     if (ndm == 2) {
         if (pl.vec2) {
             if (pl.cs == 1) NBX_JK_CASE(2, 1, true);
@@ -324,4 +377,15 @@ extern "C" int nbx_jk_dense(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
                        kpart, d_jk + np * nao, per_chunk, pl.nqc);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
+}
+
+extern "C" int nbx_jk_dense(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri,
+                            const double* d_dm, int64_t ndm, double* d_jk, void* d_work,
+                            size_t work_bytes) {
+    return jk_impl(ctx, nao, p0, p1, d_eri, false, 0, d_dm, ndm, d_jk, d_work, work_bytes);
+}
+
+extern "C" int nbx_jk_synth(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, uint64_t seed, const double* d_dm,
+                            int64_t ndm, double* d_jk, void* d_work, size_t work_bytes) {
+    return jk_impl(ctx, nao, p0, p1, nullptr, true, seed, d_dm, ndm, d_jk, d_work, work_bytes);
 }

@@ -46,6 +46,11 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
                  double* d_v, void* d_work, size_t work_bytes);
 const int* nbx_eigh_lds_status_ptr(int64_t n, int64_t batch, const void* d_work);
 
+// eigh_tridiag.hip
+size_t nbx_eigh_tridiag_worksize(int64_t n, int64_t batch);
+int nbx_eigh_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
+                     void* d_work, size_t work_bytes, double* h_quality);
+
 // HIP-event bracket around a launch, active only while profiling is enabled.
 struct nbx_prof_scope {
     nbx_ctx* ctx;

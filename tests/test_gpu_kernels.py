@@ -243,9 +243,23 @@ def test_eigh_warm_start(be):
     assert max(warm) < min(cold), (warm, cold)
 
 
-@pytest.mark.parametrize("n", [196, 197, 230])
-def test_eigh_lds_boundary_and_global_path(be, n):
+@pytest.mark.parametrize("n", [196, 197, 230, 431])
+def test_eigh_lds_boundary_and_tridiagonal_path(be, n):
     check_eigh(be, symm(90, n))
+
+
+def test_eigh_tridiagonal_path_hard_cases(be):
+    """N > 196 (Householder + multisection + inverse iteration, Jacobi polish when clustered)."""
+    n = 230
+    u = rnd(83, n)
+    check_eigh(be, np.eye(n) + np.outer(u, u))          # (n-1)-fold degenerate eigenvalue
+    g = symm(84, n)
+    p = np.zeros((n, n))
+    p[:5, :5] = 1e6 * (np.eye(5) + 0.1 * symm(85, 5))    # mu-shift-like grading
+    w, v = check_eigh(be, g + p)
+    np.testing.assert_allclose(w[: n - 5], np.linalg.eigvalsh(g + p)[: n - 5], rtol=0, atol=1e-8)
+    check_eigh(be, np.diag(np.arange(float(n))))          # already diagonal: every reflector is trivial
+    check_eigh(be, np.stack([symm(86, n), symm(87, n) + np.eye(n)]))  # batched
 
 
 @pytest.mark.parametrize("p", [-0.5, 0.5, -1.0])
@@ -299,6 +313,32 @@ def test_ao2mo_vs_oracle(be, n, dims):
     lo = be.to_host(be.ao2mo(be.asarray(eri_h), *[be.asarray(c) for c in cs], i0=0, i1=2))
     hi = be.to_host(be.ao2mo(be.asarray(eri_h), *[be.asarray(c) for c in cs], i0=2, i1=dims[0]))
     np.testing.assert_array_equal(np.concatenate([lo, hi]), got)
+
+
+# ---------------------------------------------------------------- streamed (generated) ERI path
+@pytest.mark.parametrize("n", [7, 12, 37, 64])
+@pytest.mark.parametrize("ndm", [1, 2])
+def test_jk_synth_equals_dense(be, n, ndm):
+    """J/K with the integrals generated in registers == J/K on the materialised tensor, bit for bit
+    in the values read (same hash), so only summation order could differ: it does not."""
+    dm = be.asarray(np.stack([symm(20 + x, n) for x in range(ndm)]))
+    dense = be.to_host(be.jk(be.synth_eri(n), dm))
+    streamed = be.to_host(be.jk_synth(n, dm))
+    np.testing.assert_array_equal(streamed, dense)
+    slab = be.to_host(be.jk_synth(n, dm, 2, n - 1))
+    np.testing.assert_array_equal(slab, dense[:, 2 : n - 1])
+
+
+@pytest.mark.parametrize("n,dims", [(12, (5, 6, 7, 4)), (24, (9, 9, 8, 8))])
+def test_ao2mo_synth_vs_oracle(be, n, dims):
+    cs = [rnd(100 + i, n, d) for i, d in enumerate(dims)]
+    ref = hamiltonian.ao2mo_full(synth.eri_dense(n), *cs)
+    dcs = [be.asarray(c) for c in cs]
+    got = be.to_host(be.ao2mo_synth(n, *dcs))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+    # r shards are partial sums (the multi-GPU axis of the streamed path)
+    part = be.to_host(be.ao2mo_synth(n, *dcs, r0=0, r1=5)) + be.to_host(be.ao2mo_synth(n, *dcs, r0=5, r1=n))
+    np.testing.assert_allclose(part, ref, rtol=0, atol=1e-12)
 
 
 def test_spinorb_scatter_golden(be):
