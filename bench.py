@@ -62,9 +62,17 @@ def parse_args():
 def host_cores() -> int:
     """Cores this process may run on (the GPU box gives a share of the host, not all of it)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:  # cgroup v2 CPU quota, if the box sets one
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    # a one-GPU box's CPU share is 16 cores; never start more worker threads than that
+    return max(1, min(n, int(os.environ.get("NBED_BENCH_CORES", "16"))))
 
 
 def transform_flops(N, n):

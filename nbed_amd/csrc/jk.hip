@@ -4,8 +4,9 @@
 //   K^x_pb = sum_q sum_a (pq|ab) D^x_qa     (uses (pq|ab) = (pq|ba))
 //
 // Data layout in HBM: the ERI slab is the plain C-order (np,N,N,N) tensor, so the
-// (a,b) tile of a fixed (p,q) is N*N contiguous doubles.  One workgroup owns one p
-// and a chunk of q's; it streams each tile exactly once with 16-byte loads that are
+// (a,b) tile of a fixed (p,q) is N*N contiguous doubles.  Persistent workgroups each own
+// an equal contiguous range of tiles; a tile is streamed exactly once with 16-byte
+// non-temporal loads that are
 // contiguous across the workgroup (thread t always sees the same column pair b, so
 // the K accumulators live in registers and need no cross-lane reduction), three
 // FMAs per loaded double.  Algorithmic traffic: 8*N^4 bytes per J/K build
@@ -54,7 +55,9 @@ struct TileLoad {
     const double* tile0;  // &eri[p_local][q][0][0]
     int64_t n2;
     __device__ __forceinline__ double2 get2(int j, int64_t o, int, int) const {
-        return *reinterpret_cast<const double2*>(tile0 + j * n2 + o);
+        typedef double nbx_d2 __attribute__((ext_vector_type(2)));
+        const nbx_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nbx_d2*>(tile0 + j * n2 + o));
+        return make_double2(t.x, t.y);
     }
     __device__ __forceinline__ double get1(int j, int64_t o, int, int) const { return tile0[j * n2 + o]; }
 };
@@ -130,22 +133,30 @@ __device__ __forceinline__ void jk_group(const SRC& src, const double* __restric
     }
 }
 
+// One persistent workgroup per occupancy slot of the chip.  The np*N tiles of the slab are numbered
+// t = p_local*N + q and split into equal contiguous ranges of L tiles, one range per workgroup, so
+// every slot streams the same number of bytes and they all finish together (a grid of (p, q-chunk)
+// workgroups loses up to 30 % to the partially filled last round: 1924 workgroups on 1024 slots).
+// A range walks q inside one p in groups of up to QB tiles; when p changes (and at the end of the
+// range) the K accumulators are written to the workgroup's next partial slot:
+//   kpart[(w*S + (p - p_first(w)))*NDM + x][b],  p_first(w) = (w*L) / N.
 template <int NDM, int CS, bool VEC2, bool GEN>
-__global__ __launch_bounds__(JK_THREADS) void jk_dense_kernel(
+__global__ __launch_bounds__(JK_THREADS) __attribute__((amdgpu_waves_per_eu(CS == 4 ? 2 : 4)))
+void jk_dense_kernel(
     const double* __restrict__ eri, const double* __restrict__ dm, const double* __restrict__ dtot,
-    double* __restrict__ jout, double* __restrict__ kpart, int N, int np, int nqc, int qchunk, int p0,
+    double* __restrict__ jout, double* __restrict__ kpart, int N, int64_t ntiles, int L, int S, int p0,
     uint64_t seed) {
     using V = typename ColVec<VEC2>::type;
     constexpr int W = ColVec<VEC2>::W;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    // smem: dsh[NDM*QB*N] | kred[R*NDM*N (CS==1) ] | red[17]
+    // smem: dsh[NDM*QB*N] | kred[R*NDM*N (CS==1)] | red[17]
     double* dsh = smem;
     double* kred = dsh + NDM * JK_QB * N;
 
-    const int p_local = blockIdx.x / nqc;
-    const int qc = blockIdx.x - p_local * nqc;
-    const int q_begin = qc * qchunk;
-    const int q_end = min(N, q_begin + qchunk);
+    int64_t t = (int64_t)blockIdx.x * L;
+    const int64_t t_end = min(ntiles, t + L);
+    if (t >= t_end) return;  // uniform for the whole workgroup
+    const int p_first = (int)(t / N);
 
     const int CX = (N + W - 1) / W;  // column groups per row
     int R, rowg, cx, cstep;
@@ -173,11 +184,52 @@ __global__ __launch_bounds__(JK_THREADS) void jk_dense_kernel(
         for (int s = 0; s < CS; ++s) zero(kacc[x][s]);
 
     const int64_t n2 = (int64_t)N * N;
-    const double* prow = GEN ? nullptr : eri + (int64_t)p_local * N * n2;
 
-    for (int q = q_begin; q < q_end; q += JK_QB) {
-        const int nq = min(JK_QB, q_end - q);
-        __syncthreads();  // previous group's dsh reads are done
+    // K partials of the p just finished: reduce the R row groups through LDS, store, clear.
+    auto flush = [&](int p_local) {
+        double* kout = kpart + ((int64_t)blockIdx.x * S + (p_local - p_first)) * NDM * N;
+        if (CS == 1) {
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int x = 0; x < NDM; ++x) {
+                    double* dst = kred + ((size_t)rowg * NDM + x) * N + cx * W;
+                    *reinterpret_cast<V*>(dst) = kacc[x][0];
+                }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < NDM * N; i += JK_THREADS) {
+                const int x = i / N;
+                const int b = i - x * N;
+                double tot = 0.0;
+                for (int g = 0; g < R; ++g) tot += kred[((size_t)g * NDM + x) * N + b];
+                kout[i] = tot;
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < NDM; ++x)
+#pragma unroll
+                for (int s = 0; s < CS; ++s) {
+                    const int c = cx + s * cstep;
+                    if (c < CX) *reinterpret_cast<V*>(kout + (int64_t)x * N + c * W) = kacc[x][s];
+                }
+        }
+#pragma unroll
+        for (int x = 0; x < NDM; ++x)
+#pragma unroll
+            for (int s = 0; s < CS; ++s) zero(kacc[x][s]);
+    };
+
+    int p_cur = p_first;
+    while (t < t_end) {
+        const int p_local = (int)(t / N);
+        const int q = (int)(t - (int64_t)p_local * N);
+        if (p_local != p_cur) {
+            flush(p_cur);
+            p_cur = p_local;
+        }
+        const int nq = (int)min((int64_t)min(JK_QB, N - q), t_end - t);
+        __syncthreads();  // previous group's dsh (and kred) reads are done
         for (int i = threadIdx.x; i < NDM * JK_QB * N; i += JK_THREADS) {
             const int x = i / (JK_QB * N);
             const int rem = i - x * JK_QB * N;
@@ -193,70 +245,34 @@ __global__ __launch_bounds__(JK_THREADS) void jk_dense_kernel(
                 src.seed = seed;
                 src.scale = 1.0 / (double)N;
                 const uint64_t pg = (uint64_t)(p0 + p_local);
-                if (nq == JK_QB) {
 #pragma unroll
-                    for (int j = 0; j < JK_QB; ++j) src.pq[j] = nbx_tri(pg, (uint64_t)(q + j));
-                    jk_group<JK_QB, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc);
-                } else {
-                    for (int j = 0; j < nq; ++j) {
-                        double j1[JK_QB] = {0.0, 0.0, 0.0, 0.0};
-                        src.pq[0] = nbx_tri(pg, (uint64_t)(q + j));
-                        jk_group<1, NDM, CS, VEC2>(src, dtot, dsh + j * N, N, rowg, R, cx, cstep, CX, j1, kacc);
-                        jacc[j] = j1[0];
-                    }
+                for (int j = 0; j < JK_QB; ++j) src.pq[j] = nbx_tri(pg, (uint64_t)min(q + j, N - 1));
+                switch (nq) {
+                    case 4: jk_group<4, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc); break;
+                    case 3: jk_group<3, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc); break;
+                    case 2: jk_group<2, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc); break;
+                    default: jk_group<1, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc); break;
                 }
             } else {
                 TileLoad src;
                 src.n2 = n2;
-                src.tile0 = prow + (int64_t)q * n2;
-                if (nq == JK_QB) {
-                    jk_group<JK_QB, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc);
-                } else {
-                    for (int j = 0; j < nq; ++j) {
-                        double j1[JK_QB] = {0.0, 0.0, 0.0, 0.0};
-                        TileLoad s1 = src;
-                        s1.tile0 = src.tile0 + j * n2;
-                        jk_group<1, NDM, CS, VEC2>(s1, dtot, dsh + j * N, N, rowg, R, cx, cstep, CX, j1, kacc);
-                        jacc[j] = j1[0];
-                    }
+                src.tile0 = eri + t * n2;
+                switch (nq) {
+                    case 4: jk_group<4, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc); break;
+                    case 3: jk_group<3, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc); break;
+                    case 2: jk_group<2, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc); break;
+                    default: jk_group<1, NDM, CS, VEC2>(src, dtot, dsh, N, rowg, R, cx, cstep, CX, jacc, kacc); break;
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < JK_QB; ++j) {
             const double tot = nbx_block_sum(jacc[j], red);
-            if (threadIdx.x == 0 && j < nq) jout[(int64_t)p_local * N + q + j] = tot;
+            if (threadIdx.x == 0 && j < nq) jout[t + j] = tot;
         }
+        t += nq;
     }
-
-    // K partials of this (p, q-chunk): reduce the R row groups through LDS, then store.
-    double* kout = kpart + ((int64_t)qc * NDM * np + p_local) * N;
-    if (CS == 1) {
-        __syncthreads();
-        if (active) {
-#pragma unroll
-            for (int x = 0; x < NDM; ++x) {
-                double* dst = kred + ((size_t)rowg * NDM + x) * N + cx * W;
-                *reinterpret_cast<V*>(dst) = kacc[x][0];
-            }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < NDM * N; i += JK_THREADS) {
-            const int x = i / N;
-            const int b = i - x * N;
-            double t = 0.0;
-            for (int g = 0; g < R; ++g) t += kred[((size_t)g * NDM + x) * N + b];
-            kout[(int64_t)x * np * N + b] = t;
-        }
-    } else {
-#pragma unroll
-        for (int x = 0; x < NDM; ++x)
-#pragma unroll
-            for (int s = 0; s < CS; ++s) {
-                const int c = cx + s * cstep;
-                if (c < CX) *reinterpret_cast<V*>(kout + (int64_t)x * np * N + c * W) = kacc[x][s];
-            }
-    }
+    flush(p_cur);
 }
 
 // dtot = sum_x dm[x]
@@ -268,36 +284,52 @@ __global__ void jk_dtot_kernel(const double* __restrict__ dm, double* __restrict
     dtot[i] = t;
 }
 
-// jk[1+x][p][b] = sum_c kpart[c][x][p][b]
-__global__ void jk_reduce_kernel(const double* __restrict__ kpart, double* __restrict__ kout, int64_t per_chunk,
-                                 int nqc) {
+// jk[1+x][p][b] = sum over the workgroups w whose tile range meets row p of their partial for p
+// (fixed order => bitwise reproducible)
+__global__ void jk_reduce_kernel(const double* __restrict__ kpart, double* __restrict__ kout, int N, int np,
+                                 int ndm, int L, int S) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per_chunk) return;
+    if (i >= (int64_t)ndm * np * N) return;
+    const int b = (int)(i % N);
+    const int p = (int)((i / N) % np);
+    const int x = (int)(i / ((int64_t)N * np));
+    const int64_t w_lo = ((int64_t)p * N) / L, w_hi = ((int64_t)(p + 1) * N - 1) / L;
     double t = 0.0;
-    for (int c = 0; c < nqc; ++c) t += kpart[c * per_chunk + i];
+    for (int64_t w = w_lo; w <= w_hi; ++w) {
+        const int slot = p - (int)((w * L) / N);
+        t += kpart[((w * S + slot) * ndm + x) * N + b];
+    }
     kout[i] = t;
 }
 
+// Launch geometry.  Fixed by (N, np, ndm) alone -- not by the device it runs on -- so results are
+// bitwise identical everywhere: the slot count is that of the MI355X (256 CUs; 4 workgroups of
+// 4 waves per CU at the kernel's ~100 VGPRs, fewer when the D rows in LDS are large).
 struct JkPlan {
-    int nqc, qchunk, cs;
+    int cs, wgs, L, S;
     bool vec2;
     size_t lds_bytes;
 };
+
+constexpr int JK_CUS = 256;
+constexpr size_t JK_LDS_PER_CU = 160 * 1024;
 
 JkPlan jk_plan(int64_t N, int64_t np, int64_t ndm) {
     JkPlan pl;
     pl.vec2 = (N % 2 == 0);
     const int64_t CX = pl.vec2 ? N / 2 : N;
     pl.cs = CX <= JK_THREADS ? 1 : (CX <= 2 * JK_THREADS ? 2 : 4);
-    const int64_t groups = nbx_cdiv(N, JK_QB);
-    int64_t nqc = nbx_cdiv(2048, np > 0 ? np : 1);
-    if (nqc > groups) nqc = groups;
-    if (nqc < 1) nqc = 1;
-    const int64_t gpc = nbx_cdiv(groups, nqc);  // groups per chunk
-    pl.qchunk = (int)(gpc * JK_QB);
-    pl.nqc = (int)nbx_cdiv(N, pl.qchunk);
     const int64_t R = pl.cs == 1 ? (JK_THREADS / CX > 0 ? JK_THREADS / CX : 1) : 0;
     pl.lds_bytes = (size_t)(ndm * JK_QB * N + R * ndm * N + 17) * sizeof(double);
+    int64_t per_cu = pl.cs == 4 ? 2 : 4;  // matches amdgpu_waves_per_eu of the kernel
+    const int64_t by_lds = (int64_t)(JK_LDS_PER_CU / (pl.lds_bytes + 256));
+    if (per_cu > by_lds) per_cu = by_lds > 0 ? by_lds : 1;
+    const int64_t slots = JK_CUS * per_cu;
+    const int64_t ntiles = np * N;
+    const int64_t L = nbx_cdiv(ntiles, slots) > 0 ? nbx_cdiv(ntiles, slots) : 1;
+    pl.L = (int)L;
+    pl.wgs = (int)nbx_cdiv(ntiles, L);
+    pl.S = (int)((L + N - 2) / N + 1);
     return pl;
 }
 
@@ -306,18 +338,20 @@ JkPlan jk_plan(int64_t N, int64_t np, int64_t ndm) {
 extern "C" size_t nbx_jk_dense_worksize(int64_t nao, int64_t np, int64_t ndm) {
     if (nao <= 0 || np < 0 || ndm <= 0) return 0;
     const JkPlan pl = jk_plan(nao, np, ndm);
-    return (size_t)(nao * nao + (int64_t)pl.nqc * ndm * np * nao) * sizeof(double);
+    return (size_t)(nao * nao + (int64_t)pl.wgs * pl.S * ndm * nao) * sizeof(double);
 }
 
 template <int NDM, int CS, bool VEC2>
 static void jk_launch(nbx_ctx* ctx, const JkPlan& pl, const double* eri, const double* dm, const double* dtot,
                       double* jout, double* kpart, int N, int np, int p0, bool gen, uint64_t seed) {
     if (gen)
-        hipLaunchKernelGGL((jk_dense_kernel<NDM, CS, VEC2, true>), dim3((unsigned)(np * pl.nqc)), dim3(JK_THREADS),
-                           pl.lds_bytes, ctx->stream, eri, dm, dtot, jout, kpart, N, np, pl.nqc, pl.qchunk, p0, seed);
+        hipLaunchKernelGGL((jk_dense_kernel<NDM, CS, VEC2, true>), dim3((unsigned)pl.wgs), dim3(JK_THREADS),
+                           pl.lds_bytes, ctx->stream, eri, dm, dtot, jout, kpart, N, (int64_t)np * N, pl.L, pl.S, p0,
+                           seed);
     else
-        hipLaunchKernelGGL((jk_dense_kernel<NDM, CS, VEC2, false>), dim3((unsigned)(np * pl.nqc)), dim3(JK_THREADS),
-                           pl.lds_bytes, ctx->stream, eri, dm, dtot, jout, kpart, N, np, pl.nqc, pl.qchunk, p0, seed);
+        hipLaunchKernelGGL((jk_dense_kernel<NDM, CS, VEC2, false>), dim3((unsigned)pl.wgs), dim3(JK_THREADS),
+                           pl.lds_bytes, ctx->stream, eri, dm, dtot, jout, kpart, N, (int64_t)np * N, pl.L, pl.S, p0,
+                           seed);
 }
 
 static int jk_impl(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri, bool gen, uint64_t seed,
@@ -372,9 +406,8 @@ static int jk_impl(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const doub
 #undef NBX_JK_CASE
     }
     NBX_LAUNCH_CHECK();
-    const int64_t per_chunk = ndm * np * nao;
-    hipLaunchKernelGGL(jk_reduce_kernel, dim3((unsigned)nbx_cdiv(per_chunk, 256)), dim3(256), 0, ctx->stream,
-                       kpart, d_jk + np * nao, per_chunk, pl.nqc);
+    hipLaunchKernelGGL(jk_reduce_kernel, dim3((unsigned)nbx_cdiv(ndm * np * nao, 256)), dim3(256), 0, ctx->stream,
+                       kpart, d_jk + np * nao, N, (int)np, (int)ndm, pl.L, pl.S);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
