@@ -137,6 +137,23 @@ int nbx_trace_prod(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_a, 
 int nbx_huz_cycle_scalars(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
                           const double* d_vemb, const double* d_vhf, const double* d_hz,
                           const double* d_dm, const double* d_dm_old, double* h_out);
+/* Same scalars, left in device memory (d_out[4], square roots applied) with no synchronisation,
+ * so that the host can queue the next SCF cycle before it reads them.                         */
+int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
+                              const double* d_vemb, const double* d_vhf, const double* d_hz,
+                              const double* d_dm, const double* d_dm_old, double* d_out);
+/* One pyscf.lib.diis.DIIS.update step (behind huzinaga_scf.py:130,164) with nothing leaving
+ * the device.  State: d_xs, d_es = (space, n) trial / error vectors, d_h = the
+ * (space+1)x(space+1) Pulay matrix (row 0 / column 0 = 1, H[0][0] = 0; the caller initialises
+ * it once), d_xprev = the vector returned by the previous update.  The call stores x in slot
+ * `slot`, e = x - xprev beside it, fills row/column slot+1 of H with <e_slot|e_k> (k < nd, nd
+ * counts the vectors held including this one), solves H[:nd+1,:nd+1] c = (1,0,...) with
+ * PySCF's rule (modes with |eigenvalue| < 1e-14 are dropped when there are any, otherwise an
+ * LU solve), and overwrites d_xprev with sum_k c[k+1] xs[k]: the extrapolated vector.
+ * d_coef (>= space doubles) receives c[1:]; 1 <= nd <= space <= 16.                           */
+int nbx_diis_update(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_t nd,
+                    const double* d_x, double* d_xprev, double* d_xs, double* d_es, double* d_h,
+                    double* d_coef);
 /* y = a*x + b*y over n doubles. */
 int nbx_axpby(nbx_ctx* ctx, int64_t n, double a, const double* d_x, double b, double* d_y);
 /* out = sum_k coef[k] * vecs[k] (k < nvec; vecs[k] = d_vecs + k*stride), DIIS extrapolation

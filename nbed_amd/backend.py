@@ -38,6 +38,22 @@ def set_backend(backend) -> None:
     _default_backend = backend
 
 
+class _PendingScalars:
+    """A few doubles on their way from HBM to pinned host memory (stream-ordered copy + event)."""
+
+    def __init__(self, torch, d_vals):
+        self._host = torch.empty(d_vals.shape, dtype=d_vals.dtype, pin_memory=True)
+        self._host.copy_(d_vals, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self._keep = d_vals  # the source must outlive the copy
+
+    def get(self) -> np.ndarray:
+        self._event.synchronize()
+        self._keep = None
+        return self._host.numpy().copy()
+
+
 class HipBackend:
     """libnbx on one MI355X."""
 
@@ -245,6 +261,21 @@ class HipBackend:
         self._call("nbx_huz_cycle_scalars", nao, self._p(hcore), hcore.dim(), self._p(vemb), self._p(vhf),
                    self._p(hz), self._p(dm), self._p(dm_old), out)
         return np.array(out[:], dtype=np.float64)
+
+    def huz_cycle_scalars_async(self, hcore, vemb, vhf, hz, dm, dm_old):
+        """Same four scalars without stalling the stream: returns a handle whose ``get()`` waits
+        for (only) the copy of those 32 bytes, so later work can be queued before it is read."""
+        nao = dm.shape[-1]
+        d_out = self.empty(4)
+        self._call("nbx_huz_cycle_scalars_dev", nao, self._p(hcore), hcore.dim(), self._p(vemb), self._p(vhf),
+                   self._p(hz), self._p(dm), self._p(dm_old), self._p(d_out))
+        return _PendingScalars(self.torch, d_out)
+
+    def diis_update(self, space: int, slot: int, nd: int, x, xprev, xs, es, h, coef):
+        """Device-resident pyscf.lib.diis.DIIS.update step; ``xprev`` becomes the extrapolated vector."""
+        self._call("nbx_diis_update", x.numel(), space, slot, nd, self._p(x), self._p(xprev), self._p(xs),
+                   self._p(es), self._p(h), self._p(coef))
+        return xprev
 
     def axpby(self, a: float, x, b: float, y):
         self._call("nbx_axpby", x.numel(), a, self._p(x), b, self._p(y))

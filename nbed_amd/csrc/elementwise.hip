@@ -179,6 +179,191 @@ __global__ void dots_kernel(int64_t n, int nvec, const double* __restrict__ x, c
     }
 }
 
+// ------------------------------------------------------------------ device-resident DIIS
+constexpr int DIIS_MAX_SPACE = 16;
+constexpr int DIIS_M = DIIS_MAX_SPACE + 1;
+
+// xs[slot] = x, es[slot] = e = x - xprev, partial[blk*nd + k] = sum_i e[i] * es[k][i]
+__global__ void diis_push_kernel(int64_t n, int nd, int slot, const double* __restrict__ x,
+                                 const double* __restrict__ xprev, double* __restrict__ xs,
+                                 double* __restrict__ es, double* __restrict__ partial) {
+    __shared__ double red[17];
+    double acc[DIIS_MAX_SPACE];
+#pragma unroll
+    for (int k = 0; k < DIIS_MAX_SPACE; ++k) acc[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double xv = x[i];
+        const double e = xv - xprev[i];
+        xs[(int64_t)slot * n + i] = xv;
+        es[(int64_t)slot * n + i] = e;
+#pragma unroll
+        for (int k = 0; k < DIIS_MAX_SPACE; ++k)
+            if (k < nd) acc[k] = fma(e, (k == slot) ? e : es[(int64_t)k * n + i], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < DIIS_MAX_SPACE; ++k) {
+        if (k < nd) {  // uniform
+            const double t = nbx_block_sum(acc[k], red);
+            if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * nd + k] = t;
+            __syncthreads();
+        }
+    }
+}
+
+// One wavefront: finish the dot products, update H, solve the Pulay system as PySCF does.
+//   eigenvalues by cyclic Jacobi (lane k owns row k of A and of V in LDS);
+//   any |w| < 1e-14  ->  c = V_keep diag(1/w_keep) V_keep^T g      (g = e_0)
+//   otherwise        ->  c = LU solve with partial pivoting (numpy.linalg.solve)
+__global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict__ partial, int nblocks, int nd,
+                                                        int slot, double* __restrict__ H, int ldh,
+                                                        double* __restrict__ coef) {
+    __shared__ double A[DIIS_M][DIIS_M + 1], V[DIIS_M][DIIS_M + 1], A0[DIIS_M][DIIS_M + 1];
+    __shared__ double row[DIIS_MAX_SPACE], w[DIIS_M], c_out[DIIS_M];
+    __shared__ int lu_failed;
+    const int lane = threadIdx.x;
+    const int m = nd + 1;
+    for (int k = 0; k < nd; ++k) {
+        double t = 0.0;
+        for (int b = lane; b < nblocks; b += 64) t += partial[(int64_t)b * nd + k];
+        t = nbx_wave_sum(t);
+        if (lane == 0) row[k] = t;
+    }
+    __syncthreads();
+    if (lane < nd) {
+        H[(int64_t)(slot + 1) * ldh + lane + 1] = row[lane];
+        H[(int64_t)(lane + 1) * ldh + slot + 1] = row[lane];
+    }
+    for (int idx = lane; idx < m * m; idx += 64) {
+        const int r = idx / m, c = idx - r * m;
+        double v;
+        if (r == slot + 1 && c >= 1) v = row[c - 1];
+        else if (c == slot + 1 && r >= 1) v = row[r - 1];
+        else v = H[(int64_t)r * ldh + c];
+        A[r][c] = v;
+        A0[r][c] = v;
+        V[r][c] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    double fro = 0.0;
+    for (int idx = lane; idx < m * m; idx += 64) {
+        const double v = A[idx / m][idx % m];
+        fro = fma(v, v, fro);
+    }
+    fro = nbx_wave_sum(fro);
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0;
+        for (int idx = lane; idx < m * m; idx += 64) {
+            const int r = idx / m, c = idx - r * m;
+            if (r < c) off = fma(A[r][c], A[r][c], off);
+        }
+        off = nbx_wave_sum(off);
+        if (off <= 1e-40 * fro) break;
+        for (int p = 0; p < m - 1; ++p)
+            for (int q = p + 1; q < m; ++q) {
+                const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
+                __syncthreads();
+                if (fabs(apq) < 1e-290) continue;  // uniform: every lane read the same LDS words
+                const double tau = (aqq - app) / (2.0 * apq);
+                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                if (lane < m) {  // A <- A J, V <- V J
+                    const double akp = A[lane][p], akq = A[lane][q];
+                    A[lane][p] = c * akp - s * akq;
+                    A[lane][q] = s * akp + c * akq;
+                    const double vkp = V[lane][p], vkq = V[lane][q];
+                    V[lane][p] = c * vkp - s * vkq;
+                    V[lane][q] = s * vkp + c * vkq;
+                }
+                __syncthreads();
+                if (lane < m) {  // A <- J^T A
+                    const double apk = A[p][lane], aqk = A[q][lane];
+                    A[p][lane] = c * apk - s * aqk;
+                    A[q][lane] = s * apk + c * aqk;
+                }
+                __syncthreads();
+                if (lane == 0) {
+                    A[p][q] = 0.0;
+                    A[q][p] = 0.0;
+                }
+                __syncthreads();
+            }
+    }
+    if (lane < m) w[lane] = A[lane][lane];
+    if (lane == 0) lu_failed = 0;
+    __syncthreads();
+    bool singular = false;
+    for (int k = 0; k < m; ++k) singular = singular || (fabs(w[k]) < 1e-14);
+    if (!singular) {
+        if (lane == 0) {  // Gaussian elimination with partial pivoting on A0, rhs e_0
+            double rhs[DIIS_M];
+            for (int i = 0; i < m; ++i) rhs[i] = (i == 0) ? 1.0 : 0.0;
+            for (int k = 0; k < m && !lu_failed; ++k) {
+                int piv = k;
+                double best = fabs(A0[k][k]);
+                for (int i = k + 1; i < m; ++i)
+                    if (fabs(A0[i][k]) > best) {
+                        best = fabs(A0[i][k]);
+                        piv = i;
+                    }
+                if (best == 0.0) {
+                    lu_failed = 1;
+                    break;
+                }
+                if (piv != k) {
+                    for (int j = 0; j < m; ++j) {
+                        const double tmp = A0[k][j];
+                        A0[k][j] = A0[piv][j];
+                        A0[piv][j] = tmp;
+                    }
+                    const double tmp = rhs[k];
+                    rhs[k] = rhs[piv];
+                    rhs[piv] = tmp;
+                }
+                const double inv = 1.0 / A0[k][k];
+                for (int i = k + 1; i < m; ++i) {
+                    const double f = A0[i][k] * inv;
+                    if (f != 0.0) {
+                        for (int j = k + 1; j < m; ++j) A0[i][j] -= f * A0[k][j];
+                        rhs[i] -= f * rhs[k];
+                    }
+                }
+            }
+            if (!lu_failed) {
+                for (int i = m - 1; i >= 0; --i) {
+                    double t = rhs[i];
+                    for (int j = i + 1; j < m; ++j) t -= A0[i][j] * c_out[j];
+                    c_out[i] = t / A0[i][i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (singular || lu_failed) {
+        if (lane < m) {
+            double t = 0.0;
+            for (int k = 0; k < m; ++k)
+                if (!singular || fabs(w[k]) > 1e-14) t += V[lane][k] * (1.0 / w[k]) * V[0][k];
+            c_out[lane] = t;
+        }
+        __syncthreads();
+    }
+    if (lane >= 1 && lane < m) coef[lane - 1] = c_out[lane];
+}
+
+// out[i] = sum_k coef[k] * vecs[k][i] with the coefficients read from device memory
+__global__ void lincomb_dev_kernel(int64_t n, int nvec, const double* __restrict__ coef,
+                                   const double* __restrict__ vecs, int64_t stride, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double t = 0.0;
+        for (int k = 0; k < nvec; ++k) t = fma(coef[k], vecs[k * stride + i], t);
+        out[i] = t;
+    }
+}
+
+__global__ void sqrt_tail_kernel(double* __restrict__ v) {
+    if (threadIdx.x < 2) v[2 + threadIdx.x] = sqrt(v[2 + threadIdx.x]);
+}
+
 // B[b] (cols x rows) = A[b]^T (A: rows x cols)
 __global__ void transpose_kernel(const double* __restrict__ A, double* __restrict__ B, int64_t rows, int64_t cols) {
     __shared__ double t[TILE][TILE + 1];
@@ -320,6 +505,43 @@ int nbx_huz_cycle_scalars(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int 
     if (rc != NBX_OK) return rc;
     h_out[2] = sqrt(h_out[2]);
     h_out[3] = sqrt(h_out[3]);
+    return NBX_OK;
+}
+
+int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
+                              const double* d_vemb, const double* d_vhf, const double* d_hz, const double* d_dm,
+                              const double* d_dm_old, double* d_out) {
+    NBX_CHECK_ARG(ctx && d_hcore && d_vhf && d_hz && d_dm && d_dm_old && d_out && nao > 0);
+    NBX_CHECK_ARG(hcore_ndim == 2 || hcore_ndim == 3);
+    const int64_t g = nbx_cdiv(nao, TILE);
+    NBX_CHECK_ARG(g * g * 4 <= NBX_SCRATCH_DOUBLES - 64);
+    hipLaunchKernelGGL(huz_scalars_kernel, dim3((unsigned)g, (unsigned)g), dim3(TILE, 8), 0, ctx->stream, d_hcore,
+                       hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch);
+    NBX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_scratch, (int)(g * g), 4,
+                       d_out);
+    NBX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sqrt_tail_kernel, dim3(1), dim3(64), 0, ctx->stream, d_out);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+int nbx_diis_update(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_t nd, const double* d_x,
+                    double* d_xprev, double* d_xs, double* d_es, double* d_h, double* d_coef) {
+    NBX_CHECK_ARG(ctx && d_x && d_xprev && d_xs && d_es && d_h && d_coef && n > 0);
+    NBX_CHECK_ARG(space >= 1 && space <= DIIS_MAX_SPACE && slot >= 0 && slot < space && nd >= 1 && nd <= space &&
+                  slot < nd);
+    const unsigned blocks = grid1d(n, 256, 128);
+    NBX_CHECK_ARG((int64_t)blocks * nd <= NBX_SCRATCH_DOUBLES - 64);
+    hipLaunchKernelGGL(diis_push_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, (int)nd, (int)slot, d_x,
+                       d_xprev, d_xs, d_es, ctx->d_scratch);
+    NBX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(diis_solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scratch, (int)blocks, (int)nd,
+                       (int)slot, d_h, (int)(space + 1), d_coef);
+    NBX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lincomb_dev_kernel, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, n, (int)nd, d_coef, d_xs,
+                       n, d_xprev);
+    NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
 

@@ -2,10 +2,12 @@
 
 ``DIIS`` mirrors ``pyscf.lib.diis.DIIS`` as the reference uses it
 (nbed/scf/huzinaga_scf.py:130,164: ``adiis.update(fock)`` with no explicit error vector):
-space 6, min_space 1, error = x - x_prev_returned, first call only stores x.  The vectors
-and their dot products live on the GPU (``nbx_dots`` / ``nbx_lincomb``); only the
-(<= 7 x 7) Pulay system is solved on the host, with PySCF's rule of dropping modes whose
-|eigenvalue| < 1e-14 when the system is singular.
+space 6, min_space 1, error = x - x_prev_returned, first call only stores x.  On the HIP
+backend the whole step -- error vector, Pulay row, the (<= 7 x 7) solve with PySCF's rule of
+dropping modes whose |eigenvalue| < 1e-14 when there are any, and the extrapolation -- is one
+``nbx_diis_update`` call that leaves nothing for the host to wait on.  A backend without it
+(the tests' checker backend) gets the vectors' dot products (``dots``), solves the system on
+the host and calls ``lincomb``.
 
 ``CDIIS`` is PySCF's SCF default (``scf.diis.CDIIS``: error S D F - F D S, space 8), used
 by the mu-shift path's ``kernel()`` (nbed/driver.py:533).
@@ -40,6 +42,8 @@ class DIIS:
         self._es = None
         self._H = np.zeros((space + 1, space + 1))
         self._H[0, 1:] = self._H[1:, 0] = 1
+        self._Hd = None  # device copy of H (HIP backend)
+        self._coef = None
 
     def get_num_vec(self) -> int:
         return self._nd
@@ -57,6 +61,15 @@ class DIIS:
         if self._head >= self.space:
             self._head = 0
         slot = self._head
+        if hasattr(be, "diis_update") and self.min_space <= 1:
+            if self._Hd is None:
+                self._Hd = be.asarray(self._H)
+                self._coef = be.zeros(self.space)
+            self._head += 1
+            self._nd = min(self._nd + 1, self.space)
+            be.diis_update(self.space, slot, self._nd, flat, self._xprev, self._xs, self._es, self._Hd, self._coef)
+            # xprev now holds the extrapolated vector (valid until the next update overwrites it)
+            return self._xprev.reshape(x.shape)
         be.axpby(1.0, flat, 0.0, self._xs[slot])
         be.axpby(1.0, flat, 0.0, self._es[slot])
         be.axpby(-1.0, self._xprev, 1.0, self._es[slot])  # e = x - x_prev

@@ -12,8 +12,11 @@ quirks:
 Two execution paths, same arithmetic:
 
 * fused: ``scf_method`` is a ``GpuUHF`` whose ``get_veff``/``get_hcore`` are not monkey
-  patched -> J/K, Fock assembly, projector products, eigensolve, density and the per-cycle
-  scalars all stay in HBM; 4 doubles come back per cycle for the convergence test;
+  patched -> J/K, Fock assembly, projector products, DIIS, eigensolve, density and the
+  per-cycle scalars all stay in HBM and nothing in a cycle waits for the host.  The 4 doubles
+  of the convergence test are copied back asynchronously and read one cycle late: cycle i+1
+  is already queued when cycle i is judged, and is simply dropped if cycle i had converged
+  (results are those of cycle i, exactly as in the sequential loop);
 * generic: any object implementing the reference's SCF protocol (numpy ``get_veff`` ...):
   its ``get_veff``/``get_occ`` are called as the reference calls them, everything else
   (projector GEMMs, eigensolve, density, traces) still runs on the GPU.
@@ -109,11 +112,14 @@ def huzinaga_scf(
     use_DIIS: Optional[bool] = True,
     backend=None,
     history: list | None = None,
+    callback=None,
 ):
     """Manual SCF with the Huzinaga projector; see the module docstring.
 
     Returns (mo_coeff, mo_energy, density_matrix, huzinaga_op, conv_flag) as numpy arrays
-    (nbed/scf/huzinaga_scf.py:206).  ``history`` (optional) collects (energy, dm_diff) per cycle.
+    (nbed/scf/huzinaga_scf.py:206).  Not in the reference's signature: ``backend``; ``history``
+    collects (energy, dm_diff) per cycle; ``callback(i)`` is called on the host before cycle
+    ``i`` is queued (bench.py uses it to separate warm-up cycles from timed ones).
     """
     if not (is_ks(scf_method) or is_hf(scf_method)):
         raise TypeError("Cannot run Huzinaga SCF with type %s" % type(scf_method))
@@ -155,7 +161,20 @@ def huzinaga_scf(
         warm["v"] = c_ortho
         return e_d, be.gemm(x_d, c_ortho)
 
+    # fused path: the eigensolver returns ascending eigenvalues, so aufbau occupation
+    # (get_occ: the n_alpha / n_beta lowest, as the reference's UHF object does) is a fixed
+    # vector and the MO energies need not leave the device inside the loop
+    lookahead = fused and (not ks) and nb == 2 and hasattr(be, "huz_cycle_scalars_async")
+    occ_fixed = None
+    if lookahead:
+        occ_fixed = np.zeros((2, s_h.shape[0]))
+        occ_fixed[0, : scf_method.mol.nelec[0]] = 1
+        occ_fixed[1, : scf_method.mol.nelec[1]] = 1
+        occ_fixed_d = be.asarray(occ_fixed)
+
     def occupations(e_d, c_d):
+        if lookahead:
+            return e_d, occ_fixed_d
         e_h = be.to_host(e_d)
         if fused:
             return e_h, scf_method.get_occ(e_h)
@@ -165,7 +184,8 @@ def huzinaga_scf(
         return e_h, scf_method.get_occ(e_h, c_h)
 
     def density(c_d, occ_h):
-        scaled = be.scale_cols(be.copy(c_d), be.asarray(np.asarray(occ_h, dtype=np.float64)))
+        occ_d = occ_h if lookahead else be.asarray(np.asarray(occ_h, dtype=np.float64))
+        scaled = be.scale_cols(be.copy(c_d), occ_d)
         return be.gemm(scaled, c_d, "N", "T")
 
     def unbatch(a_h):
@@ -186,7 +206,30 @@ def huzinaga_scf(
     mo_energy_h = None
     hz = None
     c_d = None
+    pending = None
+    result = {"state": None}
+
+    def judge(state):
+        """Convergence test of a queued cycle (:186-194); records it as the current result."""
+        nonlocal conv_flag, scf_energy_prev
+        cycle, handle = state[0], state[1]
+        sc = handle.get()
+        scf_energy = sc[:2].copy()
+        norm_dm_diff = float(np.max(sc[2:]))
+        run_diff = np.max(np.abs(scf_energy - scf_energy_prev))
+        if history is not None:
+            history.append((np.array(scf_energy, copy=True), norm_dm_diff))
+        result["state"] = state
+        if (run_diff < scf_method.conv_tol) and (norm_dm_diff < dm_conv_tol):
+            conv_flag = True
+            logger.debug("Huzinaga SCF converged in cycle %s", cycle)
+            return True
+        scf_energy_prev = scf_energy
+        return False
+
     for i in range(scf_method.max_cycle):
+        if callback is not None:
+            callback(i)
         # ---- Fock build (:156-160)
         if fused:
             jk = scf_method.jk_device(dm_d)
@@ -214,6 +257,9 @@ def huzinaga_scf(
             diff = be.copy(dm_d)
             be.axpby(-1.0, dm_old, 1.0, diff)
             norm_dm_diff = float(np.max(np.sqrt(be.trace_prod(diff, be.transpose(diff)))))
+        elif lookahead:
+            scf_energy = norm_dm_diff = None
+            pending_now = be.huz_cycle_scalars_async(hv, None, vhf, hz, dm_d, dm_old)
         elif nb == 2:
             sc = be.huz_cycle_scalars(hv, None, vhf, hz, dm_d, dm_old)
             scf_energy = sc[:2].copy()
@@ -227,6 +273,14 @@ def huzinaga_scf(
             be.axpby(-1.0, dm_old, 1.0, diff)
             norm_dm_diff = float(np.sqrt(be.trace_prod(diff, be.transpose(diff))[0]))
 
+        if lookahead:
+            # judge the PREVIOUS cycle now that this one is queued behind it
+            state_now = (i, pending_now, c_d, mo_energy_h, dm_d, hz)
+            if pending is not None and judge(pending):
+                break
+            pending = state_now
+            continue
+
         run_diff = np.max(np.abs(scf_energy - scf_energy_prev))
         if history is not None:
             history.append((np.array(scf_energy, copy=True), norm_dm_diff))
@@ -235,6 +289,13 @@ def huzinaga_scf(
             logger.debug("Huzinaga SCF converged in cycle %s", i)
             break
         scf_energy_prev = scf_energy
+
+    if lookahead:
+        if not conv_flag and pending is not None:
+            judge(pending)  # the last cycle queued
+        if result["state"] is not None:
+            _, _, c_d, mo_energy_d, dm_d, hz = result["state"]
+            mo_energy_h = be.to_host(mo_energy_d)
 
     if conv_flag is False:
         logger.warning("Huzinaga SCF has NOT converged.")

@@ -159,6 +159,10 @@ def test_fock_and_huzinaga_and_scalars(be):
     ham = h + v + 0.5 * vhf_ref + hz_ref
     np.testing.assert_allclose(sc[:2], np.einsum("xij,xji->x", ham, dm), rtol=0, atol=1e-11)
     np.testing.assert_allclose(sc[2:], np.linalg.norm(dm - dm_old, axis=(-2, -1)), rtol=0, atol=1e-12)
+    # the no-synchronisation variant: same numbers through a stream-ordered copy
+    pend = be.huz_cycle_scalars_async(be.asarray(h), be.asarray(v), be.asarray(vhf_ref), be.asarray(hz_ref),
+                                      be.asarray(dm), be.asarray(dm_old))
+    np.testing.assert_array_equal(pend.get(), sc)
 
 
 def test_vector_algebra(be):
@@ -172,6 +176,30 @@ def test_vector_algebra(be):
     y = be.asarray(x)
     be.axpby(2.0, be.asarray(vecs[0]), -0.5, y)
     np.testing.assert_allclose(be.to_host(y), 2.0 * vecs[0] - 0.5 * x, rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("case", ["generic", "converging", "wraparound"])
+def test_diis_device_matches_pyscf_semantics(be, case):
+    """nbx_diis_update against the oracle's pyscf.lib.diis.DIIS restatement, update by update:
+    first call only stores x; slots wrap after `space`; near convergence the Pulay matrix has
+    |eigenvalues| < 1e-14 and PySCF's mode-dropping branch decides the coefficients."""
+    from nbed_amd.scf.diis import DIIS as DeviceDIIS
+    from oracle.pyscf_like import DIIS as OracleDIIS
+
+    n = 2 * 37 * 37
+    dev, ref = DeviceDIIS(be), OracleDIIS()
+    fixed = rnd(80, n)
+    nsteps = {"generic": 5, "converging": 9, "wraparound": 11}[case]
+    for it in range(nsteps):
+        if case == "converging":  # geometric approach to a fixed point: errors ~ 1e-1 ... 1e-9
+            x = fixed + rnd(81 + it, n) * 10.0 ** (-1 - it)
+        else:
+            x = fixed + rnd(81 + it, n) * 0.1
+        got = be.to_host(dev.update(be.asarray(x)))
+        want = ref.update(x)
+        scale = np.max(np.abs(want))
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-9 * scale, err_msg=f"update {it}")
+    assert dev.get_num_vec() == ref.get_num_vec()
 
 
 def test_transpose_scale_and_chem_to_phys(be):
