@@ -180,12 +180,16 @@ size_t nbx_eigh_worksize(int64_t n, int64_t batch);
 int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
              void* d_work, size_t work_bytes);
 /* Warm start: d_v0 (batch,N,N) holds approximate eigenvectors (orthonormal columns, e.g. the
- * previous SCF cycle's); the Jacobi sweeps then run on V0^T A V0, which is nearly diagonal, and
- * converge in 2-4 sweeps instead of 8-10.  d_v0 == NULL is nbx_eigh.  Same outputs/workspace. */
+ * previous SCF cycle's).  For N <= 196 the pair is first refined with GEMMs only (Ogita-Aishima
+ * iteration, <= 3 steps, quadratically convergent); a matrix the refinement does not bring to
+ * max|E| < 3e-8 -- or that has coupled near-degenerate eigenvalues -- falls through, on the
+ * device and with no host round trip, to Jacobi sweeps on V0^T A V0 (nearly diagonal: 1-4
+ * sweeps instead of 8-10).  d_v0 == NULL is nbx_eigh.  Same outputs/workspace.               */
 int nbx_eigh_warm(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0,
                   double* d_w, double* d_v, void* d_work, size_t work_bytes);
 /* Reads back the sweep counts of the last nbx_eigh on this workspace (synchronises):
- * h_sweeps[b] > 0 = sweeps used; returns NBX_E_NOCONV if any matrix hit the sweep limit. */
+ * h_sweeps[b] > 0 = sweeps used (1000 + k: accepted by the warm-start refinement after k
+ * iterations, no sweeps); returns NBX_E_NOCONV if any matrix hit the sweep limit.          */
 int nbx_eigh_status(nbx_ctx* ctx, int64_t n, int64_t batch, const void* d_work, int* h_sweeps);
 /* out = S^p for symmetric positive definite S (N,N): U diag(w^p) U^T.
  * scipy.linalg.fractional_matrix_power(S, -0.5 / +0.5) at huzinaga_scf.py:128,

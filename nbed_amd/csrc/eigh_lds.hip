@@ -112,8 +112,10 @@ __device__ __forceinline__ int turn(int off, int R) {
 __global__ __launch_bounds__(JL_THREADS) void eigh_lds_kernel(
     const double* __restrict__ a_in, int N, int NP, int steps, double2* __restrict__ rot,
     int* __restrict__ any_flags, int* __restrict__ nsteps_out, double* __restrict__ w_out,
-    int* __restrict__ rank_out, int* __restrict__ status, int64_t rot_stride, int64_t flag_stride) {
+    int* __restrict__ rank_out, int* __restrict__ status, int64_t rot_stride, int64_t flag_stride,
+    const int* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (gate != nullptr && gate[blockIdx.x] > 0) return;  // eigh_refine.hip already delivered this matrix
     const int m = NP / 2;
     const int R = NP - 1;
     const int npk = NP * (NP + 1) / 2;
@@ -304,7 +306,8 @@ __global__ __launch_bounds__(64) void eigh_apply_rot_kernel(const double* __rest
                                                             const int* __restrict__ nsteps_in,
                                                             const int* __restrict__ rank_in,
                                                             double* __restrict__ v_out, int64_t rot_stride,
-                                                            int64_t flag_stride) {
+                                                            int64_t flag_stride, const int* __restrict__ gate) {
+    if (gate != nullptr && gate[blockIdx.y] > 0) return;
     extern __shared__ __attribute__((aligned(16))) double row[];
     const int b = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
     const int m = NP / 2, R = NP - 1;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(64) void eigh_apply_rot_kernel(const double* __rest
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct LdsLayout {
-    size_t rot_off, flag_off, nsteps_off, rank_off, status_off, a0_off, tmp_off, total;
+    size_t rot_off, flag_off, nsteps_off, rank_off, status_off, a0_off, tmp_off, refine_off, total;
     int64_t rot_stride, flag_stride;
 };
 
@@ -405,6 +408,8 @@ LdsLayout layout(int64_t n, int64_t batch) {
     L.status_off = off; off += align256((size_t)batch * sizeof(int));
     L.a0_off = off; off += align256((size_t)(batch * n * n) * sizeof(double));
     L.tmp_off = off; off += align256((size_t)(batch * n * n) * sizeof(double));
+    L.refine_off = off;
+    if (nbx_eigh_refine_supported(n, batch)) off += nbx_eigh_refine_worksize(n, batch);
     L.total = off;
     return L;
 }
@@ -432,13 +437,29 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
     int* rank = reinterpret_cast<int*>(base + L.rank_off);
     int* status = reinterpret_cast<int*>(base + L.status_off);
     const double* a_use = d_a;
+    const int* gate = nullptr;
     if (d_v0 != nullptr) {
         double* a0 = reinterpret_cast<double*>(base + L.a0_off);
         double* tmp = reinterpret_cast<double*>(base + L.tmp_off);
-        int rc = nbx_gemm(ctx, 'T', 'N', n, n, n, 1.0, d_v0, n, n * n, d_a, n, n * n, 0.0, tmp, n, n * n, batch);
-        if (rc != NBX_OK) return rc;
-        rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, tmp, n, n * n, d_v0, n, n * n, 0.0, a0, n, n * n, batch);
-        if (rc != NBX_OK) return rc;
+        int rc;
+        if (nbx_eigh_refine_supported(n, batch)) {
+            // GEMM-only refinement of (V0, w) first; Jacobi below runs only for the matrices whose
+            // status word says the refinement did not get there (decided on the device)
+            nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
+            rc = nbx_eigh_refine(ctx, n, batch, d_a, d_v0, d_w, d_v, base + L.refine_off, status, &gate);
+            if (rc != NBX_OK) return rc;
+            rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, d_v0, n, n * n, d_a, n, n * n, 0.0, tmp, n, n * n,
+                                      batch, gate, 0, -1);
+            if (rc != NBX_OK) return rc;
+            rc = nbx_gemm_small_gated(ctx, 'N', 'N', n, n, n, 1.0, tmp, n, n * n, d_v0, n, n * n, 0.0, a0, n, n * n,
+                                      batch, gate, 0, -1);
+            if (rc != NBX_OK) return rc;
+        } else {
+            rc = nbx_gemm(ctx, 'T', 'N', n, n, n, 1.0, d_v0, n, n * n, d_a, n, n * n, 0.0, tmp, n, n * n, batch);
+            if (rc != NBX_OK) return rc;
+            rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, tmp, n, n * n, d_v0, n, n * n, 0.0, a0, n, n * n, batch);
+            if (rc != NBX_OK) return rc;
+        }
         a_use = a0;
     }
     const int npk = NP * (NP + 1) / 2;
@@ -457,11 +478,11 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
     {
         nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
         hipLaunchKernelGGL(eigh_lds_kernel, dim3((unsigned)batch), dim3(JL_THREADS), lds, ctx->stream, a_use, N, NP,
-                           steps, rot, flags, nsteps, d_w, rank, status, L.rot_stride, L.flag_stride);
+                           steps, rot, flags, nsteps, d_w, rank, status, L.rot_stride, L.flag_stride, gate);
         NBX_LAUNCH_CHECK();
         hipLaunchKernelGGL(eigh_apply_rot_kernel, dim3((unsigned)N, (unsigned)batch), dim3(64),
                            (size_t)NP * sizeof(double), ctx->stream, d_v0, N, NP, steps, rot, flags, nsteps, rank, d_v,
-                           L.rot_stride, L.flag_stride);
+                           L.rot_stride, L.flag_stride, gate);
         NBX_LAUNCH_CHECK();
     }
     return NBX_OK;

@@ -176,6 +176,94 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
     }
 }
 
+// Latency-bound small products (the N x N x N GEMMs of an SCF cycle at N ~ 150: 18 workgroups
+// of the 64 x 64 kernel, each crawling through K in 16-wide steps at one HBM/L2 latency per
+// step = 16 us).  Here one wavefront owns one 16 x 16 tile of C and feeds the MFMA operands
+// straight from global memory (the operands are a few hundred KB: L2 resident), no LDS and no
+// barriers, so every load of the whole K range can be in flight at once: ~10 x 10 x batch
+// single-wave workgroups spread over the chip, one memory latency end to end.
+//
+// The k-slot mapping and the order of accumulation are those of gemm_f64_kernel (MFMA j takes
+// k = 4j .. 4j+3, lane group fk supplies k = 4j + fk), so the two kernels give bitwise identical
+// results: which one a product is routed to (it depends on the slab height when the outer index
+// is sharded over GPUs) never changes a bit of the answer.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64) void gemm_small_kernel(int M, int N, int K, double alpha,
+                                                        const double* __restrict__ A, int64_t lda, int64_t stride_a,
+                                                        const double* __restrict__ B, int64_t ldb, int64_t stride_b,
+                                                        double beta, double* __restrict__ C, int64_t ldc,
+                                                        int64_t stride_c, const int* __restrict__ gate, int gate_a,
+                                                        int gate_b) {
+    const int batch = blockIdx.z;
+    if (gate != nullptr) {  // device-side "run only if": see nbx_gemm_small_gated
+        const int g = gate[batch];
+        if (g != gate_a && g != gate_b) return;
+    }
+    A += (int64_t)batch * stride_a;
+    B += (int64_t)batch * stride_b;
+    C += (int64_t)batch * stride_c;
+    const int lane = threadIdx.x;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int row_a = blockIdx.y * 16 + fr;  // A fragment: row fr, k-slot fk
+    const int col_b = blockIdx.x * 16 + fr;  // B fragment: k-slot fk, column fr
+    const bool a_ok = row_a < M, b_ok = col_b < N;
+    // element (x, k) of op(.) sits at base[x * sx + k * sk]
+    const int64_t a_sx = A_KC ? lda : 1, a_sk = A_KC ? 1 : lda;
+    const int64_t b_sx = B_KC ? ldb : 1, b_sk = B_KC ? 1 : ldb;
+    const double* ap = A + (int64_t)(a_ok ? row_a : 0) * a_sx;
+    const double* bp = B + (int64_t)(b_ok ? col_b : 0) * b_sx;
+
+    v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int kfull = K & ~15;
+    int k0 = 0;
+    // 64 k per trip: 32 independent loads are issued before the first MFMA needs one
+    for (; k0 + 64 <= kfull; k0 += 64) {
+        double a[16], b[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            a[j] = ap[(int64_t)(k0 + 4 * j + fk) * a_sk];
+            b[j] = bp[(int64_t)(k0 + 4 * j + fk) * b_sk];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ok ? a[j] : 0.0, b_ok ? b[j] : 0.0, acc, 0, 0, 0);
+    }
+    for (; k0 < kfull; k0 += 16) {
+        double a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = ap[(int64_t)(k0 + 4 * j + fk) * a_sk];
+            b[j] = bp[(int64_t)(k0 + 4 * j + fk) * b_sk];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ok ? a[j] : 0.0, b_ok ? b[j] : 0.0, acc, 0, 0, 0);
+    }
+    if (kfull < K) {
+        double a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kfull + 4 * j + fk;
+            const bool in = k < K;
+            a[j] = (in && a_ok) ? ap[(int64_t)k * a_sk] : 0.0;
+            b[j] = (in && b_ok) ? bp[(int64_t)k * b_sk] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], b[j], acc, 0, 0, 0);
+    }
+    if (b_ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = blockIdx.y * 16 + fk + 4 * r;
+            if (row < M) {
+                double* c = C + (int64_t)row * ldc + col_b;
+                const double v = alpha * acc[r];
+                *c = (beta == 0.0) ? v : fma(beta, *c, v);
+            }
+        }
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int BM, int BN, int WR, int WC>
@@ -198,6 +286,37 @@ void launch(nbx_ctx* ctx, bool a_kc, bool b_kc, int M, int N, int K, double alph
 }
 
 }  // namespace
+
+bool nbx_gemm_small_supported(int64_t m, int64_t n, int64_t k, int64_t batch) {
+    return batch <= 65535 && nbx_cdiv(m, 16) * nbx_cdiv(n, 16) * batch <= 512 && k <= 4096;
+}
+
+// Small-product kernel whose workgroups of batch entry b return at once unless gate[b] is gate_a
+// or gate_b when the kernel starts: lets a sequence of launches be queued whose tail depends on
+// a result computed on the device (eigh_refine.hip), with no host round trip.
+int nbx_gemm_small_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t n, int64_t k, double alpha,
+                         const double* d_a, int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb,
+                         int64_t stride_b, double beta, double* d_c, int64_t ldc, int64_t stride_c, int64_t batch,
+                         const int* d_gate, int gate_a, int gate_b) {
+    NBX_CHECK_ARG(ctx && d_a && d_b && d_c && m > 0 && n > 0 && k > 0 && batch > 0);
+    NBX_CHECK_ARG(nbx_gemm_small_supported(m, n, k, batch));
+    const bool a_kc = !(trans_a == 'T' || trans_a == 't');
+    const bool b_kc = (trans_b == 'T' || trans_b == 't');
+    dim3 grid((unsigned)nbx_cdiv(n, 16), (unsigned)nbx_cdiv(m, 16), (unsigned)batch);
+#define NBX_GEMM_SMALL(AK, BKC)                                                                               \
+    hipLaunchKernelGGL((gemm_small_kernel<AK, BKC>), grid, dim3(64), 0, ctx->stream, (int)m, (int)n, (int)k, \
+                       alpha, d_a, lda, stride_a, d_b, ldb, stride_b, beta, d_c, ldc, stride_c, d_gate, gate_a, gate_b)
+    if (a_kc) {
+        if (b_kc) NBX_GEMM_SMALL(true, true);
+        else NBX_GEMM_SMALL(true, false);
+    } else {
+        if (b_kc) NBX_GEMM_SMALL(false, true);
+        else NBX_GEMM_SMALL(false, false);
+    }
+#undef NBX_GEMM_SMALL
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
 
 extern "C" int nbx_gemm(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t n, int64_t k,
                         double alpha, const double* d_a, int64_t lda, int64_t stride_a, const double* d_b,
@@ -230,7 +349,21 @@ extern "C" int nbx_gemm(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int
         const double* B = d_b ? d_b + b0 * stride_b : nullptr;
         double* C = d_c + b0 * stride_c;
         const int64_t tiles128 = nbx_cdiv(m, 128) * nbx_cdiv(n, 128) * nb;
-        if (tiles128 >= 512 && m > 64 && n > 64) {
+        const int64_t tiles16 = nbx_cdiv(m, 16) * nbx_cdiv(n, 16) * nb;
+        if (tiles16 <= 512 && k <= 4096) {
+            dim3 grid((unsigned)nbx_cdiv(n, 16), (unsigned)nbx_cdiv(m, 16), (unsigned)nb);
+#define NBX_GEMM_SMALL(AK, BKC)                                                                               \
+    hipLaunchKernelGGL((gemm_small_kernel<AK, BKC>), grid, dim3(64), 0, ctx->stream, (int)m, (int)n, (int)k, \
+                       alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c, nullptr, 0, 0)
+            if (a_kc) {
+                if (b_kc) NBX_GEMM_SMALL(true, true);
+                else NBX_GEMM_SMALL(true, false);
+            } else {
+                if (b_kc) NBX_GEMM_SMALL(false, true);
+                else NBX_GEMM_SMALL(false, false);
+            }
+#undef NBX_GEMM_SMALL
+        } else if (tiles128 >= 512 && m > 64 && n > 64) {
             launch<128, 128, 2, 4>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
                              beta, C, ldc, stride_c, nb, vec_a, vec_b);
         } else if (m <= 32 || n <= 32) {

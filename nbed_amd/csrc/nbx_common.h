@@ -46,6 +46,21 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
                  double* d_v, void* d_work, size_t work_bytes);
 const int* nbx_eigh_lds_status_ptr(int64_t n, int64_t batch, const void* d_work);
 
+// gemm.hip
+bool nbx_gemm_small_supported(int64_t m, int64_t n, int64_t k, int64_t batch);
+int nbx_gemm_small_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t n, int64_t k, double alpha,
+                         const double* d_a, int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb,
+                         int64_t stride_b, double beta, double* d_c, int64_t ldc, int64_t stride_c, int64_t batch,
+                         const int* d_gate, int gate_a, int gate_b);
+
+// eigh_refine.hip
+bool nbx_eigh_refine_supported(int64_t n, int64_t batch);
+size_t nbx_eigh_refine_worksize(int64_t n, int64_t batch);
+// Queues the refinement of (A, V0); returns in *d_status_out the device int[batch] that is > 0
+// for every matrix whose eigenpairs were accepted and written to d_w / d_v.
+int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0, double* d_w,
+                    double* d_v, void* d_work, int* d_jacobi_status, const int** d_status_out);
+
 // eigh_tridiag.hip
 size_t nbx_eigh_tridiag_worksize(int64_t n, int64_t batch);
 int nbx_eigh_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,

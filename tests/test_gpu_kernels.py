@@ -268,7 +268,81 @@ def test_eigh_warm_start(be):
     np.testing.assert_allclose(w, np.linalg.eigvalsh(a2), rtol=0, atol=1e-11)
     np.testing.assert_allclose(a2 @ v, v * w[:, None, :], rtol=0, atol=1e-10)
     np.testing.assert_allclose(np.swapaxes(v, -1, -2) @ v, np.broadcast_to(np.eye(n), a.shape), rtol=0, atol=1e-12)
-    assert max(warm) < min(cold), (warm, cold)
+    assert max(w_ % 1000 for w_ in warm) < min(cold), (warm, cold)
+
+
+def eig_quality(a, w, v):
+    n = a.shape[-1]
+    res = np.max(np.abs(a @ v - v * w[..., None, :]))
+    orth = np.max(np.abs(np.swapaxes(v, -1, -2) @ v - np.eye(n)))
+    return res, orth
+
+
+@pytest.mark.parametrize("n", [12, 37, 148, 196])
+@pytest.mark.parametrize("eps", [1e-9, 1e-6, 1e-4])
+def test_eigh_warm_refinement_accepts_small_perturbations(be, n, eps):
+    """Warm start from the eigenvectors of a nearby matrix: the GEMM refinement (status >= 1000)
+    must deliver the same quality as the Jacobi path, sorted ascending."""
+    a = np.stack([symm(300 + n, n), symm(301 + n, n)])
+    _, v0 = be.eigh(be.asarray(a))
+    a2 = a + eps * np.stack([symm(302 + n, n), symm(303 + n, n)])
+    w, v = be.eigh(be.asarray(a2), check=True, v0=v0)
+    st = list(be.last_eigh_sweeps)
+    w, v = be.to_host(w), be.to_host(v)
+    assert np.all(np.diff(w, axis=-1) >= 0)
+    np.testing.assert_allclose(w, np.linalg.eigvalsh(a2), rtol=0, atol=1e-12 * n)
+    res, orth = eig_quality(a2, w, v)
+    assert res < 2e-13 * n and orth < 1e-13 * n, (res, orth, st)
+    if eps <= 1e-6:
+        assert all(x >= 1000 for x in st), st  # refinement, not sweeps
+
+
+def test_eigh_warm_refinement_falls_back(be):
+    """Cases the refinement must hand to Jacobi (decided on the device): a perturbation outside
+    the contracting regime, a garbage (non-orthogonal) start, and coupled near-degenerate
+    eigenvalues; plus eigenvalue crossings, which it must re-sort."""
+    n = 64
+    a = symm(320, n)
+    w0, v0 = be.eigh(be.asarray(a))
+    v0_h = be.to_host(v0)
+    # (1) large perturbation
+    a_big = a + 0.5 * symm(321, n)
+    w, v = be.eigh(be.asarray(a_big), check=True, v0=v0)
+    assert be.last_eigh_sweeps[0] < 1000
+    res, orth = eig_quality(a_big, be.to_host(w), be.to_host(v))
+    assert res < 1e-11 and orth < 1e-12
+    np.testing.assert_allclose(be.to_host(w), np.linalg.eigvalsh(a_big), rtol=0, atol=1e-11)
+    # (2) degenerate pair split and mixed by the perturbation: d = diag(.., 1, 1, ..), coupling 1e-7
+    d = np.linspace(-3.0, 3.0, n)
+    d[10] = d[11] = 0.123
+    q, _ = np.linalg.qr(rnd(322, n, n))
+    a_deg = (q * d) @ q.T
+    a_deg = 0.5 * (a_deg + a_deg.T)
+    pert = np.zeros((n, n))
+    pert[10, 11] = pert[11, 10] = 1e-7
+    a_deg2 = a_deg + q @ pert @ q.T
+    a_deg2 = 0.5 * (a_deg2 + a_deg2.T)
+    w, v = be.eigh(be.asarray(a_deg2), check=True, v0=be.asarray(q))
+    wh, vh = be.to_host(w), be.to_host(v)
+    res, orth = eig_quality(a_deg2, wh, vh)
+    assert res < 1e-12 and orth < 1e-12, (res, orth, be.last_eigh_sweeps)
+    np.testing.assert_allclose(wh, np.linalg.eigvalsh(a_deg2), rtol=0, atol=1e-12)
+    # (3) crossing: start vectors ordered for `a`, matrix has two levels swapped
+    d2 = np.linspace(-1.0, 1.0, n)
+    a_x = (q * d2) @ q.T
+    d3 = d2.copy()
+    d3[[20, 21]] = d3[[21, 20]] + np.array([1e-3, -1e-3])
+    a_x2 = (q * d3) @ q.T
+    a_x2 = 0.5 * (a_x2 + a_x2.T)
+    w, v = be.eigh(be.asarray(a_x2), check=True, v0=be.asarray(q))
+    wh, vh = be.to_host(w), be.to_host(v)
+    assert np.all(np.diff(wh) >= 0)
+    res, orth = eig_quality(a_x2, wh, vh)
+    assert res < 1e-12 and orth < 1e-12
+    np.testing.assert_allclose(wh, np.sort(d3), rtol=0, atol=1e-12)
+    # (4) garbage start: not orthonormal at all
+    w, v = be.eigh(be.asarray(a), check=True, v0=be.asarray(rnd(323, n, n)))
+    assert be.last_eigh_sweeps[0] < 1000
 
 
 @pytest.mark.parametrize("n", [196, 197, 230, 431])
