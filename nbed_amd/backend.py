@@ -226,6 +226,22 @@ class HipBackend:
                    self._p(b3), b3.shape[2], sb, beta, self._p(out), n, m * n, batch)
         return out
 
+    def density_occ(self, c, nocc):
+        """D[x] = C[x][:, :nocc[x]] C[x][:, :nocc[x]]^T for (batch, N, N) MO coefficients whose
+        columns are in aufbau order: the occupied block is addressed through lda, nothing is copied."""
+        batch, n = c.shape[0], c.shape[-1]
+        out = self.zeros((batch, n, n))
+        if len(set(int(x) for x in nocc)) == 1:
+            k = int(nocc[0])
+            if k > 0:
+                self.gemm_raw("N", "T", n, n, k, 1.0, c, n, n * n, c, n, n * n, 0.0, out, n, n * n, batch)
+            return out
+        for x in range(batch):
+            k = int(nocc[x])
+            if k > 0:
+                self.gemm_raw("N", "T", n, n, k, 1.0, c[x], n, 0, c[x], n, 0, 0.0, out[x], n, 0, 1)
+        return out
+
     def gemm_raw(self, ta, tb, m, n, k, alpha, a, lda, sa, b, ldb, sb, beta, c, ldc, sc, batch):
         self._call("nbx_gemm", ta.encode(), tb.encode(), m, n, k, alpha, self._p(a), lda, sa, self._p(b), ldb, sb,
                    beta, self._p(c), ldc, sc, batch)

@@ -28,18 +28,6 @@ constexpr double RF_TOL = 3.0e-8;       // accepted update has max|E| below this
 constexpr double RF_GIVE_UP = 0.25;     // not in the contracting regime
 constexpr double RF_CLUSTER_NOISE = 1.0e-14;
 
-__device__ __forceinline__ double block_max(double v, double* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double t = red[0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, red[w]);
-    __syncthreads();
-    return t;
-}
-
 // One workgroup per matrix.  G = X^T X, S = X^T A X  ->  Ep = I + E, lambda, status.
 __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const double* __restrict__ A,
                                                               const double* __restrict__ S,
@@ -58,26 +46,41 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
     Ep += b * n2;
     for (int i = threadIdx.x; i < N; i += RF_THREADS) lam[i] = S[(int64_t)i * N + i] / G[(int64_t)i * N + i];
     double off2 = 0.0, r2 = 0.0, a2 = 0.0;
-    for (int64_t idx = threadIdx.x; idx < n2; idx += RF_THREADS) {
-        const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
-        const double s = S[idx], g = G[idx];
-        const double r = (i == j) ? 1.0 - g : -g;
-        if (i != j) off2 = fma(s, s, off2);
-        r2 = fma(r, r, r2);
-        if (iter == 0) {
-            const double a = A[idx];
-            a2 = fma(a, a, a2);
+    // wavefront w walks rows w, w+16, ...; lanes walk the columns (coalesced, no divisions)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = wave; i < N; i += RF_THREADS / 64) {
+        for (int j = lane; j < N; j += 64) {
+            const int64_t idx = (int64_t)i * N + j;
+            const double s = S[idx], g = G[idx];
+            const double r = (i == j) ? 1.0 - g : -g;
+            if (i != j) off2 = fma(s, s, off2);
+            r2 = fma(r, r, r2);
+            if (iter == 0) {
+                const double a = A[idx];
+                a2 = fma(a, a, a2);
+            }
         }
     }
+    // three sums with one pair of barriers: wave partials side by side in LDS
+    off2 = nbx_wave_sum(off2);
+    r2 = nbx_wave_sum(r2);
+    a2 = nbx_wave_sum(a2);
     __syncthreads();
-    off2 = nbx_block_sum(off2, red);
+    if (lane == 0) {
+        red[wave] = off2;
+        red[16 + wave] = r2;
+        red[32 + wave] = a2;
+    }
     __syncthreads();
-    r2 = nbx_block_sum(r2, red);
+    off2 = r2 = a2 = 0.0;
+    for (int w = 0; w < RF_THREADS / 64; ++w) {
+        off2 += red[w];
+        r2 += red[16 + w];
+        a2 += red[32 + w];
+    }
     __syncthreads();
     double na;
     if (iter == 0) {
-        a2 = nbx_block_sum(a2, red);
-        __syncthreads();
         na = sqrt(a2);
         if (threadIdx.x == 0) norm_a[b] = na;
     } else {
@@ -85,28 +88,44 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
     }
     const double omega = 2.0 * (sqrt(off2) + na * sqrt(r2));
     double emax = 0.0, cmax = 0.0;
-    for (int64_t idx = threadIdx.x; idx < n2; idx += RF_THREADS) {
-        const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
-        const double s = S[idx], g = G[idx];
-        double e;
-        if (i == j) {
-            e = 0.5 * (1.0 - g);
-            emax = fmax(emax, fabs(e));
-            Ep[idx] = 1.0 + e;
-        } else {
-            const double d = lam[j] - lam[i];
-            if (fabs(d) > omega) {
-                e = (s - lam[j] * g) / d;  // R_ij = -G_ij
+    for (int i = wave; i < N; i += RF_THREADS / 64) {
+        const double li = lam[i];
+        for (int j = lane; j < N; j += 64) {
+            const int64_t idx = (int64_t)i * N + j;
+            const double s = S[idx], g = G[idx];
+            double e;
+            if (i == j) {
+                e = 0.5 * (1.0 - g);
+                emax = fmax(emax, fabs(e));
+                Ep[idx] = 1.0 + e;
             } else {
-                e = -0.5 * g;
-                cmax = fmax(cmax, fabs(s));
+                const double lj = lam[j];
+                const double d = lj - li;
+                if (fabs(d) > omega) {
+                    e = (s - lj * g) / d;  // R_ij = -G_ij
+                } else {
+                    e = -0.5 * g;
+                    cmax = fmax(cmax, fabs(s));
+                }
+                emax = fmax(emax, fabs(e));
+                Ep[idx] = e;
             }
-            emax = fmax(emax, fabs(e));
-            Ep[idx] = e;
         }
     }
-    emax = block_max(emax, red);
-    cmax = block_max(cmax, red);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        emax = fmax(emax, __shfl_xor(emax, o));
+        cmax = fmax(cmax, __shfl_xor(cmax, o));
+    }
+    if (lane == 0) {
+        red[wave] = emax;
+        red[16 + wave] = cmax;
+    }
+    __syncthreads();
+    for (int w = 0; w < RF_THREADS / 64; ++w) {
+        emax = fmax(emax, red[w]);
+        cmax = fmax(cmax, red[16 + w]);
+    }
     if (threadIdx.x == 0) {
         int st = 0;
         if (!(emax < RF_GIVE_UP)) st = -1;  // also NaN
@@ -185,7 +204,7 @@ RefineLayout rlayout(int64_t n, int64_t batch) {
 }  // namespace
 
 bool nbx_eigh_refine_supported(int64_t n, int64_t batch) {
-    return n >= 2 && nbx_gemm_small_supported(n, n, n, batch) && (size_t)(n + 64) * sizeof(double) <= 64 * 1024;
+    return n >= 2 && nbx_gemm_small_supported(n, n, n, batch) && (size_t)(n + 48) * sizeof(double) <= 64 * 1024;
 }
 
 size_t nbx_eigh_refine_worksize(int64_t n, int64_t batch) { return rlayout(n, batch).total; }
@@ -215,7 +234,7 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
         if (rc != NBX_OK) return rc;
         rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, src, n, n2, 0.0, g, n, n2, batch, gate, 0, 0);
         if (rc != NBX_OK) return rc;
-        hipLaunchKernelGGL(refine_e_kernel, dim3((unsigned)batch), dim3(RF_THREADS), (size_t)(n + 40) * sizeof(double),
+        hipLaunchKernelGGL(refine_e_kernel, dim3((unsigned)batch), dim3(RF_THREADS), (size_t)(n + 48) * sizeof(double),
                            ctx->stream, (int)n, d_a, s, g, ep, lam, status, norm, it);
         NBX_LAUNCH_CHECK();
         rc = nbx_gemm_small_gated(ctx, 'N', 'N', n, n, n, 1.0, src, n, n2, ep, n, n2, 0.0, dst, n, n2, batch, status, 0,

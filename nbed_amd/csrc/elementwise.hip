@@ -11,14 +11,15 @@ constexpr int TILE = 32;
 
 // ---------------------------------------------------------------- reductions
 // Stage 2 of every scalar reduction: out[o] = sum_b partial[b * nout + o] (fixed order).
+// Outputs o >= sqrt_from are stored as sqrt(sum) (Frobenius norms).
 __global__ void final_reduce_kernel(const double* __restrict__ partial, int nblocks, int nout,
-                                    double* __restrict__ out) {
+                                    double* __restrict__ out, int sqrt_from) {
     __shared__ double red[17];
     for (int o = 0; o < nout; ++o) {
         double t = 0.0;
         for (int b = threadIdx.x; b < nblocks; b += blockDim.x) t += partial[(int64_t)b * nout + o];
         t = nbx_block_sum(t, red);
-        if (threadIdx.x == 0) out[o] = t;
+        if (threadIdx.x == 0) out[o] = (o >= sqrt_from) ? sqrt(t) : t;
         __syncthreads();
     }
 }
@@ -211,14 +212,16 @@ __global__ void diis_push_kernel(int64_t n, int nd, int slot, const double* __re
 }
 
 // One wavefront: finish the dot products, update H, solve the Pulay system as PySCF does.
-//   eigenvalues by cyclic Jacobi (lane k owns row k of A and of V in LDS);
+//   eigenvalues by parallel-order Jacobi in LDS;
 //   any |w| < 1e-14  ->  c = V_keep diag(1/w_keep) V_keep^T g      (g = e_0)
 //   otherwise        ->  c = LU solve with partial pivoting (numpy.linalg.solve)
 __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict__ partial, int nblocks, int nd,
                                                         int slot, double* __restrict__ H, int ldh,
                                                         double* __restrict__ coef) {
-    __shared__ double A[DIIS_M][DIIS_M + 1], V[DIIS_M][DIIS_M + 1], A0[DIIS_M][DIIS_M + 1];
+    __shared__ double A[DIIS_M + 1][DIIS_M + 2], V[DIIS_M + 1][DIIS_M + 2], A0[DIIS_M][DIIS_M + 1];
     __shared__ double row[DIIS_MAX_SPACE], w[DIIS_M], c_out[DIIS_M];
+    __shared__ double rot_c[(DIIS_M + 1) / 2], rot_s[(DIIS_M + 1) / 2];
+    __shared__ int rot_p[(DIIS_M + 1) / 2], rot_q[(DIIS_M + 1) / 2];
     __shared__ int lu_failed;
     const int lane = threadIdx.x;
     const int m = nd + 1;
@@ -244,6 +247,17 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
         V[r][c] = (r == c) ? 1.0 : 0.0;
     }
     __syncthreads();
+    // Parallel-order (round-robin) Jacobi: M/2 disjoint rotations per step, M-1 steps per sweep;
+    // an odd m is padded with a decoupled zero row/column that never rotates.
+    const int M = (m + 1) & ~1, npair = M / 2;
+    if (M > m) {
+        for (int k = lane; k < M; k += 64) {
+            A[M - 1][k] = 0.0;
+            A[k][M - 1] = 0.0;
+            V[M - 1][k] = V[k][M - 1] = (k == M - 1) ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
     double fro = 0.0;
     for (int idx = lane; idx < m * m; idx += 64) {
         const double v = A[idx / m][idx % m];
@@ -257,36 +271,63 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
             if (r < c) off = fma(A[r][c], A[r][c], off);
         }
         off = nbx_wave_sum(off);
-        if (off <= 1e-40 * fro) break;
-        for (int p = 0; p < m - 1; ++p)
-            for (int q = p + 1; q < m; ++q) {
-                const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
-                __syncthreads();
-                if (fabs(apq) < 1e-290) continue;  // uniform: every lane read the same LDS words
-                const double tau = (aqq - app) / (2.0 * apq);
-                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-                if (lane < m) {  // A <- A J, V <- V J
-                    const double akp = A[lane][p], akq = A[lane][q];
-                    A[lane][p] = c * akp - s * akq;
-                    A[lane][q] = s * akp + c * akq;
-                    const double vkp = V[lane][p], vkq = V[lane][q];
-                    V[lane][p] = c * vkp - s * vkq;
-                    V[lane][q] = s * vkp + c * vkq;
-                }
-                __syncthreads();
-                if (lane < m) {  // A <- J^T A
-                    const double apk = A[p][lane], aqk = A[q][lane];
-                    A[p][lane] = c * apk - s * aqk;
-                    A[q][lane] = s * apk + c * aqk;
-                }
-                __syncthreads();
+        if (off <= 1e-34 * fro) break;
+        for (int step = 0; step < M - 1; ++step) {
+            if (lane < npair) {  // pair `lane` of this step
+                int p, q;
                 if (lane == 0) {
-                    A[p][q] = 0.0;
-                    A[q][p] = 0.0;
+                    p = M - 1;
+                    q = step;
+                } else {
+                    p = (step + lane) % (M - 1);
+                    q = (step - lane + (M - 1)) % (M - 1);
                 }
-                __syncthreads();
+                if (p > q) {
+                    const int tmp = p;
+                    p = q;
+                    q = tmp;
+                }
+                const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
+                double c = 1.0, sn = 0.0;
+                if (fabs(apq) > 1e-290) {
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + t * t);
+                    sn = t * c;
+                }
+                rot_c[lane] = c;
+                rot_s[lane] = sn;
+                rot_p[lane] = p;
+                rot_q[lane] = q;
             }
+            __syncthreads();
+            for (int idx = lane; idx < npair * M; idx += 64) {  // A <- A J, V <- V J
+                const int r = idx / M, k = idx - r * M;
+                const int p = rot_p[r], q = rot_q[r];
+                const double c = rot_c[r], sn = rot_s[r];
+                const double akp = A[k][p], akq = A[k][q];
+                A[k][p] = c * akp - sn * akq;
+                A[k][q] = sn * akp + c * akq;
+                const double vkp = V[k][p], vkq = V[k][q];
+                V[k][p] = c * vkp - sn * vkq;
+                V[k][q] = sn * vkp + c * vkq;
+            }
+            __syncthreads();
+            for (int idx = lane; idx < npair * M; idx += 64) {  // A <- J^T A
+                const int r = idx / M, k = idx - r * M;
+                const int p = rot_p[r], q = rot_q[r];
+                const double c = rot_c[r], sn = rot_s[r];
+                const double apk = A[p][k], aqk = A[q][k];
+                A[p][k] = c * apk - sn * aqk;
+                A[q][k] = sn * apk + c * aqk;
+            }
+            __syncthreads();
+            if (lane < npair && rot_s[lane] != 0.0) {
+                A[rot_p[lane]][rot_q[lane]] = 0.0;
+                A[rot_q[lane]][rot_p[lane]] = 0.0;
+            }
+            __syncthreads();
+        }
     }
     if (lane < m) w[lane] = A[lane][lane];
     if (lane == 0) lu_failed = 0;
@@ -358,10 +399,6 @@ __global__ void lincomb_dev_kernel(int64_t n, int nvec, const double* __restrict
         for (int k = 0; k < nvec; ++k) t = fma(coef[k], vecs[k * stride + i], t);
         out[i] = t;
     }
-}
-
-__global__ void sqrt_tail_kernel(double* __restrict__ v) {
-    if (threadIdx.x < 2) v[2 + threadIdx.x] = sqrt(v[2 + threadIdx.x]);
 }
 
 // B[b] (cols x rows) = A[b]^T (A: rows x cols)
@@ -441,7 +478,7 @@ inline unsigned grid1d(int64_t n, int block, int64_t cap = 65536) {
 // second-stage reduce + copy to host (synchronises)
 int finish_reduction(nbx_ctx* ctx, int nblocks, int nout, double* h_out) {
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_scratch, nblocks, nout,
-                       ctx->d_scratch + NBX_SCRATCH_DOUBLES - 64);
+                       ctx->d_scratch + NBX_SCRATCH_DOUBLES - 64, nout);
     NBX_LAUNCH_CHECK();
     NBX_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch + NBX_SCRATCH_DOUBLES - 64, nout * sizeof(double),
                            hipMemcpyDeviceToHost, ctx->stream));
@@ -519,9 +556,7 @@ int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
                        hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch);
     NBX_LAUNCH_CHECK();
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_scratch, (int)(g * g), 4,
-                       d_out);
-    NBX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sqrt_tail_kernel, dim3(1), dim3(64), 0, ctx->stream, d_out);
+                       d_out, 2);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

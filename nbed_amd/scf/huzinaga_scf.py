@@ -171,6 +171,7 @@ def huzinaga_scf(
         occ_fixed[0, : scf_method.mol.nelec[0]] = 1
         occ_fixed[1, : scf_method.mol.nelec[1]] = 1
         occ_fixed_d = be.asarray(occ_fixed)
+    lookahead = lookahead and hasattr(be, "density_occ")
 
     def occupations(e_d, c_d):
         if lookahead:
@@ -184,8 +185,9 @@ def huzinaga_scf(
         return e_h, scf_method.get_occ(e_h, c_h)
 
     def density(c_d, occ_h):
-        occ_d = occ_h if lookahead else be.asarray(np.asarray(occ_h, dtype=np.float64))
-        scaled = be.scale_cols(be.copy(c_d), occ_d)
+        if lookahead:  # occupied columns are the leading ones: D = C_occ C_occ^T, no copy/scale
+            return be.density_occ(c_d, scf_method.mol.nelec)
+        scaled = be.scale_cols(be.copy(c_d), be.asarray(np.asarray(occ_h, dtype=np.float64)))
         return be.gemm(scaled, c_d, "N", "T")
 
     def unbatch(a_h):

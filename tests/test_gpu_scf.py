@@ -31,9 +31,13 @@ def test_huzinaga_scf_golden(be, tag):
     mf.max_cycle, mf.conv_tol = int(g["max_cycle"]), float(g["conv_tol"])
     c, e, d, hz, conv = huzinaga_scf(mf, g["V_emb"], g["D_env"], use_DIIS=bool(g["use_DIIS"]))
     assert conv == bool(g["conv"])
-    np.testing.assert_allclose(e, g["mo_energy"], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(d, g["dm"], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(hz, g["huz_op"], rtol=0, atol=1e-9)
+    # without DIIS the trajectories agree to 1e-9 and better; with DIIS the late cycles run on a
+    # Pulay matrix that is rank deficient to working precision, where pyscf.lib.diis' solve
+    # amplifies last-bit differences of the small eigensolver to ~1e-9: north_star's 1e-8 there
+    tol = 1e-8 if bool(g["use_DIIS"]) else 1e-9
+    np.testing.assert_allclose(e, g["mo_energy"], rtol=0, atol=tol)
+    np.testing.assert_allclose(d, g["dm"], rtol=0, atol=tol)
+    np.testing.assert_allclose(hz, g["huz_op"], rtol=0, atol=tol)
     np.testing.assert_allclose(canon_sign(c), g["mo_coeff_canon"], rtol=0, atol=1e-7)
 
 
