@@ -187,20 +187,30 @@ int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* 
  * sweeps instead of 8-10).  d_v0 == NULL is nbx_eigh.  Same outputs/workspace.               */
 int nbx_eigh_warm(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0,
                   double* d_w, double* d_v, void* d_work, size_t work_bytes);
+/* Same with the number of refinement iterations queued before the Jacobi fallback chosen by the
+ * caller (0 = none ... 3 = default).  Results do not depend on it -- a matrix the queued
+ * iterations do not finish is solved by the sweeps -- only the number of launches does: an SCF
+ * driver that saw the last cycles accepted after one iteration queues one.                   */
+int nbx_eigh_warm_ex(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0,
+                     double* d_w, double* d_v, void* d_work, size_t work_bytes, int refine_iters);
+/* Byte offset inside the nbx_eigh workspace of the int[batch] status words nbx_eigh_status reads,
+ * for callers that fetch them with their own stream-ordered copy instead of synchronising.   */
+size_t nbx_eigh_status_offset(int64_t n, int64_t batch);
 /* Reads back the sweep counts of the last nbx_eigh on this workspace (synchronises):
  * h_sweeps[b] > 0 = sweeps used (1000 + k: accepted by the warm-start refinement after k
  * iterations, no sweeps); returns NBX_E_NOCONV if any matrix hit the sweep limit.          */
 int nbx_eigh_status(nbx_ctx* ctx, int64_t n, int64_t batch, const void* d_work, int* h_sweeps);
 /* out = S^p for symmetric positive definite S (N,N): U diag(w^p) U^T.
- * scipy.linalg.fractional_matrix_power(S, -0.5 / +0.5) at huzinaga_scf.py:128,
- * spade.py:99; np.linalg.inv(S_AA) at concentric.py:147 (p = -1).                         */
+ * scipy.linalg.fractional_matrix_power(S, -0.5 / +0.5) at nbed/scf/huzinaga_scf.py:128,
+ * nbed/localizers/occupied/spade.py:99; np.linalg.inv(S_AA) at
+ * nbed/localizers/virtual/concentric.py:147 (p = -1).                                      */
 size_t nbx_sym_pow_worksize(int64_t n);
 int nbx_sym_pow(nbx_ctx* ctx, int64_t n, const double* d_s, double p, double* d_out,
                 void* d_work, size_t work_bytes);
 
 /* ------------------------------------------------------------------ SVD (right vectors)
- * Replaces scipy.linalg.svd / np.linalg.svd (LAPACK dgesdd) at spade.py:101 and
- * concentric.py:151,205: A (m x n) -> s (min(m,n)) descending, Vt (n x n) with rows the
+ * Replaces scipy.linalg.svd / np.linalg.svd (LAPACK dgesdd) at
+ * nbed/localizers/occupied/spade.py:101 and nbed/localizers/virtual/concentric.py:151,205: A (m x n) -> s (min(m,n)) descending, Vt (n x n) with rows the
  * right singular vectors (full_matrices=True semantics).  One-sided Jacobi.              */
 size_t nbx_svd_worksize(int64_t m, int64_t n);
 int nbx_svd_right(nbx_ctx* ctx, int64_t m, int64_t n, const double* d_a, double* d_s, double* d_vt,

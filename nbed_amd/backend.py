@@ -41,17 +41,25 @@ def set_backend(backend) -> None:
 class _PendingScalars:
     """A few doubles on their way from HBM to pinned host memory (stream-ordered copy + event)."""
 
-    def __init__(self, torch, d_vals):
+    def __init__(self, torch, d_vals, d_extra=None):
         self._host = torch.empty(d_vals.shape, dtype=d_vals.dtype, pin_memory=True)
         self._host.copy_(d_vals, non_blocking=True)
+        self._host_extra = None
+        if d_extra is not None:
+            self._host_extra = torch.empty(d_extra.shape, dtype=d_extra.dtype, pin_memory=True)
+            self._host_extra.copy_(d_extra, non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
-        self._keep = d_vals  # the source must outlive the copy
+        self._keep = (d_vals, d_extra)  # the sources must outlive the copies
 
     def get(self) -> np.ndarray:
         self._event.synchronize()
         self._keep = None
         return self._host.numpy().copy()
+
+    def get_extra(self):
+        self._event.synchronize()
+        return None if self._host_extra is None else self._host_extra.numpy().copy()
 
 
 class HipBackend:
@@ -278,14 +286,15 @@ class HipBackend:
                    self._p(hz), self._p(dm), self._p(dm_old), out)
         return np.array(out[:], dtype=np.float64)
 
-    def huz_cycle_scalars_async(self, hcore, vemb, vhf, hz, dm, dm_old):
+    def huz_cycle_scalars_async(self, hcore, vemb, vhf, hz, dm, dm_old, extra=None):
         """Same four scalars without stalling the stream: returns a handle whose ``get()`` waits
-        for (only) the copy of those 32 bytes, so later work can be queued before it is read."""
+        for (only) the copy of those 32 bytes, so later work can be queued before it is read.
+        ``extra``: a small device tensor to bring back with them (``get_extra()``)."""
         nao = dm.shape[-1]
         d_out = self.empty(4)
         self._call("nbx_huz_cycle_scalars_dev", nao, self._p(hcore), hcore.dim(), self._p(vemb), self._p(vhf),
                    self._p(hz), self._p(dm), self._p(dm_old), self._p(d_out))
-        return _PendingScalars(self.torch, d_out)
+        return _PendingScalars(self.torch, d_out, extra)
 
     def diis_update(self, space: int, slot: int, nd: int, x, xprev, xs, es, h, coef):
         """Device-resident pyscf.lib.diis.DIIS.update step; ``xprev`` becomes the extrapolated vector."""
@@ -334,16 +343,21 @@ class HipBackend:
         return a
 
     # ------------------------------------------------------------------ eigh / svd
-    def eigh(self, a, check: bool = False, v0=None):
-        """Eigenpairs of symmetric ``a`` (lower triangle, ascending); ``v0``: warm-start vectors."""
+    def eigh(self, a, check: bool = False, v0=None, refine_iters: int = 3):
+        """Eigenpairs of symmetric ``a`` (lower triangle, ascending); ``v0``: warm-start vectors;
+        ``refine_iters``: refinement iterations queued ahead of the Jacobi fallback (a launch-count
+        knob, results do not depend on it)."""
         n = a.shape[-1]
         batch = 1 if a.dim() == 2 else a.shape[0]
         nbytes = self.lib.nbx_eigh_worksize(n, batch)
         work = self._workspace("eigh", nbytes)
         w = self.empty(a.shape[:-1])
         v = self.torch.empty_like(a)
-        self._call("nbx_eigh_warm", n, batch, self._p(a), self._p(v0), self._p(w), self._p(v), self._p(work),
-                   work.numel())
+        self._call("nbx_eigh_warm_ex", n, batch, self._p(a), self._p(v0), self._p(w), self._p(v), self._p(work),
+                   work.numel(), int(refine_iters))
+        off = self.lib.nbx_eigh_status_offset(n, batch)
+        # device view of the status words (1000 + k: refined in k iterations; else Jacobi sweeps)
+        self.last_eigh_status_d = work[off:off + 4 * batch].view(self.torch.int32)
         if check:
             sweeps = (c_int * batch)()
             self._call("nbx_eigh_status", n, batch, self._p(work), sweeps)

@@ -285,6 +285,19 @@ static int eigh_global_warm(nbx_ctx* ctx, int64_t n, int64_t batch, const double
 
 extern "C" int nbx_eigh_warm(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0,
                              double* d_w, double* d_v, void* d_work, size_t work_bytes) {
+    return nbx_eigh_warm_ex(ctx, n, batch, d_a, d_v0, d_w, d_v, d_work, work_bytes, NBX_EIGH_REFINE_ITERS);
+}
+
+extern "C" size_t nbx_eigh_status_offset(int64_t n, int64_t batch) {
+    if (n <= 0 || batch <= 0) return 0;
+    if (nbx_eigh_lds_supported(n)) return nbx_eigh_lds_status_offset(n, batch);
+    const int64_t np = (n + 1) & ~1ll;
+    return nbx_eigh_tridiag_worksize(n, batch) + align256((size_t)(4 * np * np * batch) * sizeof(double));
+}
+
+extern "C" int nbx_eigh_warm_ex(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0,
+                                double* d_w, double* d_v, void* d_work, size_t work_bytes, int refine_iters) {
+    NBX_CHECK_ARG(refine_iters >= 0);
     NBX_CHECK_ARG(ctx && d_a && d_w && d_v && n > 0 && batch > 0 && batch <= 1024);
     NBX_CHECK_ARG(n <= 2048);
     const size_t need = nbx_eigh_worksize(n, batch);
@@ -293,7 +306,8 @@ extern "C" int nbx_eigh_warm(nbx_ctx* ctx, int64_t n, int64_t batch, const doubl
         return NBX_E_NOMEM;
     }
     NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
-    if (nbx_eigh_lds_supported(n)) return nbx_eigh_lds(ctx, n, batch, d_a, d_v0, d_w, d_v, d_work, work_bytes);
+    if (nbx_eigh_lds_supported(n))
+        return nbx_eigh_lds(ctx, n, batch, d_a, d_v0, d_w, d_v, d_work, work_bytes, refine_iters);
 
     // N > 196: Householder + multisection + inverse iteration; Jacobi only as a polisher.
     char* base = static_cast<char*>(d_work);

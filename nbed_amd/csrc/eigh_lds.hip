@@ -422,7 +422,7 @@ size_t nbx_eigh_lds_worksize(int64_t n, int64_t batch) { return layout(n, batch)
 
 // d_v0 == nullptr: cold start.  Otherwise Jacobi runs on V0^T A V0 and accumulates onto V0.
 int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0, double* d_w,
-                 double* d_v, void* d_work, size_t work_bytes) {
+                 double* d_v, void* d_work, size_t work_bytes, int refine_iters) {
     const LdsLayout L = layout(n, batch);
     if (d_work == nullptr || work_bytes < L.total) {
         nbx_set_error("nbx_eigh: workspace %zu < %zu bytes", work_bytes, L.total);
@@ -442,11 +442,12 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
         double* a0 = reinterpret_cast<double*>(base + L.a0_off);
         double* tmp = reinterpret_cast<double*>(base + L.tmp_off);
         int rc;
-        if (nbx_eigh_refine_supported(n, batch)) {
+        if (nbx_eigh_refine_supported(n, batch) && refine_iters > 0) {
             // GEMM-only refinement of (V0, w) first; Jacobi below runs only for the matrices whose
             // status word says the refinement did not get there (decided on the device)
             nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
-            rc = nbx_eigh_refine(ctx, n, batch, d_a, d_v0, d_w, d_v, base + L.refine_off, status, &gate);
+            rc = nbx_eigh_refine(ctx, n, batch, d_a, d_v0, d_w, d_v, base + L.refine_off, status, &gate,
+                                 refine_iters < NBX_EIGH_REFINE_ITERS ? refine_iters : NBX_EIGH_REFINE_ITERS);
             if (rc != NBX_OK) return rc;
             rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, d_v0, n, n * n, d_a, n, n * n, 0.0, tmp, n, n * n,
                                       batch, gate, 0, -1);
@@ -487,6 +488,8 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
     }
     return NBX_OK;
 }
+
+size_t nbx_eigh_lds_status_offset(int64_t n, int64_t batch) { return layout(n, batch).status_off; }
 
 const int* nbx_eigh_lds_status_ptr(int64_t n, int64_t batch, const void* d_work) {
     return reinterpret_cast<const int*>(static_cast<const char*>(d_work) + layout(n, batch).status_off);

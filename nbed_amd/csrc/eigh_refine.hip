@@ -33,7 +33,8 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
                                                               const double* __restrict__ S,
                                                               const double* __restrict__ G, double* __restrict__ Ep,
                                                               double* __restrict__ lam_out, int* __restrict__ status,
-                                                              double* __restrict__ norm_a, int iter) {
+                                                              double* __restrict__ norm_a, int iter,
+                                                              int max_iter) {
     extern __shared__ double sm[];
     double* lam = sm;
     double* red = sm + N;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
         int st = 0;
         if (!(emax < RF_GIVE_UP)) st = -1;  // also NaN
         else if (emax < RF_TOL && cmax <= RF_CLUSTER_NOISE * na) st = iter + 1;
-        else if (iter == RF_MAX_ITER - 1) st = -1;
+        else if (iter == max_iter - 1) st = -1;
         status[b] = st;
 #ifdef NBX_REFINE_DEBUG
         printf("refine b=%d iter=%d emax=%.3e cmax=%.3e omega=%.3e na=%.3e off=%.3e r=%.3e st=%d\n", b, iter, emax, cmax, omega, na, sqrt(off2), sqrt(r2), st);
@@ -210,7 +211,8 @@ bool nbx_eigh_refine_supported(int64_t n, int64_t batch) {
 size_t nbx_eigh_refine_worksize(int64_t n, int64_t batch) { return rlayout(n, batch).total; }
 
 int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0, double* d_w,
-                    double* d_v, void* d_work, int* d_jacobi_status, const int** d_status_out) {
+                    double* d_v, void* d_work, int* d_jacobi_status, const int** d_status_out, int max_iter) {
+    NBX_CHECK_ARG(max_iter >= 1 && max_iter <= RF_MAX_ITER);
     const RefineLayout L = rlayout(n, batch);
     char* base = static_cast<char*>(d_work);
     double* xb[2] = {reinterpret_cast<double*>(base + L.xb0), reinterpret_cast<double*>(base + L.xb1)};
@@ -222,7 +224,7 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
     double* norm = reinterpret_cast<double*>(base + L.norm);
     int* status = reinterpret_cast<int*>(base + L.status);
     const int64_t n2 = n * n;
-    for (int it = 0; it < RF_MAX_ITER; ++it) {
+    for (int it = 0; it < max_iter; ++it) {
         // iteration `it` reads src and writes dst; the first one reads V0 in place and its
         // GEMMs are not gated (its E kernel initialises the status words)
         const double* src = (it == 0) ? d_v0 : xb[it & 1];
@@ -235,7 +237,7 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
         rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, src, n, n2, 0.0, g, n, n2, batch, gate, 0, 0);
         if (rc != NBX_OK) return rc;
         hipLaunchKernelGGL(refine_e_kernel, dim3((unsigned)batch), dim3(RF_THREADS), (size_t)(n + 48) * sizeof(double),
-                           ctx->stream, (int)n, d_a, s, g, ep, lam, status, norm, it);
+                           ctx->stream, (int)n, d_a, s, g, ep, lam, status, norm, it, max_iter);
         NBX_LAUNCH_CHECK();
         rc = nbx_gemm_small_gated(ctx, 'N', 'N', n, n, n, 1.0, src, n, n2, ep, n, n2, 0.0, dst, n, n2, batch, status, 0,
                                   it + 1);

@@ -43,8 +43,9 @@ struct nbx_ctx {
 bool nbx_eigh_lds_supported(int64_t n);
 size_t nbx_eigh_lds_worksize(int64_t n, int64_t batch);
 int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0, double* d_w,
-                 double* d_v, void* d_work, size_t work_bytes);
+                 double* d_v, void* d_work, size_t work_bytes, int refine_iters);
 const int* nbx_eigh_lds_status_ptr(int64_t n, int64_t batch, const void* d_work);
+size_t nbx_eigh_lds_status_offset(int64_t n, int64_t batch);
 
 // gemm.hip
 bool nbx_gemm_small_supported(int64_t m, int64_t n, int64_t k, int64_t batch);
@@ -59,7 +60,8 @@ size_t nbx_eigh_refine_worksize(int64_t n, int64_t batch);
 // Queues the refinement of (A, V0); returns in *d_status_out the device int[batch] that is > 0
 // for every matrix whose eigenpairs were accepted and written to d_w / d_v.
 int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0, double* d_w,
-                    double* d_v, void* d_work, int* d_jacobi_status, const int** d_status_out);
+                    double* d_v, void* d_work, int* d_jacobi_status, const int** d_status_out, int max_iter);
+constexpr int NBX_EIGH_REFINE_ITERS = 3;
 
 // eigh_tridiag.hip
 size_t nbx_eigh_tridiag_worksize(int64_t n, int64_t batch);

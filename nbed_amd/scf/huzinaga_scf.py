@@ -151,13 +151,16 @@ def huzinaga_scf(
         be.axpby(1.0, hcore_d if hcore_d.dim() == 2 else hcore_d[x], 1.0, hv[x])
         be.axpby(1.0, vemb_d if vemb_d.dim() == 2 else vemb_d[x], 1.0, hv[x])
 
-    warm = {"v": None}
+    warm = {"v": None, "iters": 3}
 
     def diagonalise(fock3):
         # Loewdin step (:166-169).  The previous cycle's orthonormal eigenvectors seed the
-        # Jacobi solver: X F X is nearly diagonal in that basis once the SCF is under way.
+        # solver: X F X is nearly diagonal in that basis once the SCF is under way.
         fo = be.gemm(be.gemm(x_d, fock3), x_d)
-        e_d, c_ortho = be.eigh(fo, v0=warm["v"])
+        if lookahead:
+            e_d, c_ortho = be.eigh(fo, v0=warm["v"], refine_iters=warm["iters"])
+        else:
+            e_d, c_ortho = be.eigh(fo, v0=warm["v"])
         warm["v"] = c_ortho
         return e_d, be.gemm(x_d, c_ortho)
 
@@ -216,6 +219,12 @@ def huzinaga_scf(
         nonlocal conv_flag, scf_energy_prev
         cycle, handle = state[0], state[1]
         sc = handle.get()
+        # launch-count policy for the eigensolver (results do not depend on it): once a cycle's
+        # matrices were all accepted after ONE refinement iteration, queue only one from now on
+        # (anything it does not finish falls through to Jacobi on the device); otherwise three
+        st = handle.get_extra()
+        if st is not None:
+            warm["iters"] = 1 if np.all(st == 1001) else 3
         scf_energy = sc[:2].copy()
         norm_dm_diff = float(np.max(sc[2:]))
         run_diff = np.max(np.abs(scf_energy - scf_energy_prev))
@@ -261,7 +270,8 @@ def huzinaga_scf(
             norm_dm_diff = float(np.max(np.sqrt(be.trace_prod(diff, be.transpose(diff)))))
         elif lookahead:
             scf_energy = norm_dm_diff = None
-            pending_now = be.huz_cycle_scalars_async(hv, None, vhf, hz, dm_d, dm_old)
+            pending_now = be.huz_cycle_scalars_async(hv, None, vhf, hz, dm_d, dm_old,
+                                                     extra=getattr(be, "last_eigh_status_d", None))
         elif nb == 2:
             sc = be.huz_cycle_scalars(hv, None, vhf, hz, dm_d, dm_old)
             scf_energy = sc[:2].copy()
