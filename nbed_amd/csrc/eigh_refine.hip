@@ -24,6 +24,7 @@ namespace {
 
 constexpr int RF_THREADS = 1024;
 constexpr int RF_MAX_ITER = 3;
+constexpr int RF_UNROLL = 8;
 constexpr double RF_TOL = 3.0e-8;       // accepted update has max|E| below this: error ~ tol^2
 constexpr double RF_GIVE_UP = 0.25;     // not in the contracting regime
 constexpr double RF_CLUSTER_NOISE = 1.0e-14;
@@ -47,18 +48,36 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
     Ep += b * n2;
     for (int i = threadIdx.x; i < N; i += RF_THREADS) lam[i] = S[(int64_t)i * N + i] / G[(int64_t)i * N + i];
     double off2 = 0.0, r2 = 0.0, a2 = 0.0;
-    // wavefront w walks rows w, w+16, ...; lanes walk the columns (coalesced, no divisions)
+    // flat element index e = tid + k * RF_THREADS, RF_UNROLL of them per trip so that their loads
+    // are all in flight together (the matrices sit in L2; one workgroup is latency bound otherwise)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = wave; i < N; i += RF_THREADS / 64) {
-        for (int j = lane; j < N; j += 64) {
-            const int64_t idx = (int64_t)i * N + j;
-            const double s = S[idx], g = G[idx];
-            const double r = (i == j) ? 1.0 - g : -g;
-            if (i != j) off2 = fma(s, s, off2);
-            r2 = fma(r, r, r2);
-            if (iter == 0) {
-                const double a = A[idx];
-                a2 = fma(a, a, a2);
+    const int total = N * N;
+    const float inv_n = 1.0f / (float)N;
+    auto row_of = [&](int e) {  // e / N for e < 2^24 without an integer division
+        int i = (int)((float)e * inv_n);
+        i -= (i * N > e) ? 1 : 0;
+        i += ((i + 1) * N <= e) ? 1 : 0;
+        return i;
+    };
+    for (int e0 = threadIdx.x; e0 < total; e0 += RF_THREADS * RF_UNROLL) {
+        double sv[RF_UNROLL], gv[RF_UNROLL], av[RF_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RF_UNROLL; ++u) {
+            const int e = e0 + u * RF_THREADS;
+            const bool in = e < total;
+            sv[u] = in ? S[e] : 0.0;
+            gv[u] = in ? G[e] : 0.0;
+            av[u] = (in && iter == 0) ? A[e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < RF_UNROLL; ++u) {
+            const int e = e0 + u * RF_THREADS;
+            if (e < total) {
+                const int i = row_of(e), j = e - i * N;
+                const double r = (i == j) ? 1.0 - gv[u] : -gv[u];
+                if (i != j) off2 = fma(sv[u], sv[u], off2);
+                r2 = fma(r, r, r2);
+                a2 = fma(av[u], av[u], a2);
             }
         }
     }
@@ -89,27 +108,38 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
     }
     const double omega = 2.0 * (sqrt(off2) + na * sqrt(r2));
     double emax = 0.0, cmax = 0.0;
-    for (int i = wave; i < N; i += RF_THREADS / 64) {
-        const double li = lam[i];
-        for (int j = lane; j < N; j += 64) {
-            const int64_t idx = (int64_t)i * N + j;
-            const double s = S[idx], g = G[idx];
-            double e;
-            if (i == j) {
-                e = 0.5 * (1.0 - g);
-                emax = fmax(emax, fabs(e));
-                Ep[idx] = 1.0 + e;
-            } else {
-                const double lj = lam[j];
-                const double d = lj - li;
-                if (fabs(d) > omega) {
-                    e = (s - lj * g) / d;  // R_ij = -G_ij
+    for (int e0 = threadIdx.x; e0 < total; e0 += RF_THREADS * RF_UNROLL) {
+        double sv[RF_UNROLL], gv[RF_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RF_UNROLL; ++u) {
+            const int e = e0 + u * RF_THREADS;
+            const bool in = e < total;
+            sv[u] = in ? S[e] : 0.0;
+            gv[u] = in ? G[e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < RF_UNROLL; ++u) {
+            const int e = e0 + u * RF_THREADS;
+            if (e < total) {
+                const int i = row_of(e), j = e - i * N;
+                const double sx = sv[u], g = gv[u];
+                double ev;
+                if (i == j) {
+                    ev = 0.5 * (1.0 - g);
+                    emax = fmax(emax, fabs(ev));
+                    Ep[e] = 1.0 + ev;
                 } else {
-                    e = -0.5 * g;
-                    cmax = fmax(cmax, fabs(s));
+                    const double lj = lam[j];
+                    const double d = lj - lam[i];
+                    if (fabs(d) > omega) {
+                        ev = (sx - lj * g) / d;  // R_ij = -G_ij
+                    } else {
+                        ev = -0.5 * g;
+                        cmax = fmax(cmax, fabs(sx));
+                    }
+                    emax = fmax(emax, fabs(ev));
+                    Ep[e] = ev;
                 }
-                emax = fmax(emax, fabs(e));
-                Ep[idx] = e;
             }
         }
     }
@@ -205,7 +235,7 @@ RefineLayout rlayout(int64_t n, int64_t batch) {
 }  // namespace
 
 bool nbx_eigh_refine_supported(int64_t n, int64_t batch) {
-    return n >= 2 && nbx_gemm_small_supported(n, n, n, batch) && (size_t)(n + 48) * sizeof(double) <= 64 * 1024;
+    return n >= 2 && n <= 4096 && nbx_gemm_small_supported(n, n, n, batch) && (size_t)(n + 48) * sizeof(double) <= 64 * 1024;
 }
 
 size_t nbx_eigh_refine_worksize(int64_t n, int64_t batch) { return rlayout(n, batch).total; }
