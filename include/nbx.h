@@ -73,6 +73,9 @@ int nbx_memset(nbx_ctx* ctx, void* d_ptr, int value, size_t bytes);
 #define NBX_PROF_EIGH 3        /* eigh_jacobi_kernel                                         */
 #define NBX_PROF_SVD 4         /* svd_jacobi_kernel                                          */
 #define NBX_PROF_GEMM 5        /* every gemm_f64_kernel launch                               */
+/* on = 0: off; on = 1: every slot; on = 2 | (mask << 2): only the slots whose bit is set in
+ * mask (an event pair costs a few microseconds of stream time, which matters inside an SCF
+ * cycle: bench.py brackets the J/K kernel only).                                             */
 int nbx_profile_enable(nbx_ctx* ctx, int on);
 int nbx_profile_read(nbx_ctx* ctx, int slot, double* ms_sum, int64_t* count);
 int nbx_profile_reset(nbx_ctx* ctx);
@@ -137,11 +140,14 @@ int nbx_trace_prod(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_a, 
 int nbx_huz_cycle_scalars(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
                           const double* d_vemb, const double* d_vhf, const double* d_hz,
                           const double* d_dm, const double* d_dm_old, double* h_out);
-/* Same scalars, left in device memory (d_out[4], square roots applied) with no synchronisation,
- * so that the host can queue the next SCF cycle before it reads them.                         */
+/* Same scalars, left in device memory (d_out[4 + tail_n], square roots applied) with no
+ * synchronisation, so that the host can queue the next SCF cycle before it reads them.
+ * d_tail (optional): tail_n <= 64 device ints appended as doubles, e.g. the eigensolver status
+ * words, so that they reach the host in the same copy.                                        */
 int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
                               const double* d_vemb, const double* d_vhf, const double* d_hz,
-                              const double* d_dm, const double* d_dm_old, double* d_out);
+                              const double* d_dm, const double* d_dm_old, double* d_out,
+                              const int* d_tail, int64_t tail_n);
 /* One pyscf.lib.diis.DIIS.update step (behind huzinaga_scf.py:130,164) with nothing leaving
  * the device.  State: d_xs, d_es = (space, n) trial / error vectors, d_h = the
  * (space+1)x(space+1) Pulay matrix (row 0 / column 0 = 1, H[0][0] = 0; the caller initialises

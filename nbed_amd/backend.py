@@ -41,25 +41,25 @@ def set_backend(backend) -> None:
 class _PendingScalars:
     """A few doubles on their way from HBM to pinned host memory (stream-ordered copy + event)."""
 
-    def __init__(self, torch, d_vals, d_extra=None):
+    def __init__(self, torch, d_vals, ntail=0):
         self._host = torch.empty(d_vals.shape, dtype=d_vals.dtype, pin_memory=True)
         self._host.copy_(d_vals, non_blocking=True)
-        self._host_extra = None
-        if d_extra is not None:
-            self._host_extra = torch.empty(d_extra.shape, dtype=d_extra.dtype, pin_memory=True)
-            self._host_extra.copy_(d_extra, non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
-        self._keep = (d_vals, d_extra)  # the sources must outlive the copies
+        self._keep = d_vals  # the source must outlive the copy
+        self._ntail = ntail
 
     def get(self) -> np.ndarray:
         self._event.synchronize()
         self._keep = None
-        return self._host.numpy().copy()
+        return self._host.numpy()[:4].copy()
 
     def get_extra(self):
+        """The appended status words (as ints), or None."""
         self._event.synchronize()
-        return None if self._host_extra is None else self._host_extra.numpy().copy()
+        if not self._ntail:
+            return None
+        return self._host.numpy()[4:4 + self._ntail].astype(np.int64)
 
 
 class HipBackend:
@@ -142,8 +142,15 @@ class HipBackend:
         self._work.clear()
 
     # ------------------------------------------------------------------ in-library HIP-event timing
-    def profile(self, on: bool = True):
-        self._call("nbx_profile_enable", 1 if on else 0)
+    def profile(self, on: bool = True, slots=None):
+        """Bracket launches with HIP events; ``slots``: only these NBX_PROF_* slots."""
+        if on and slots is not None:
+            mask = 0
+            for sl in slots:
+                mask |= 1 << int(sl)
+            self._call("nbx_profile_enable", 2 | (mask << 2))
+        else:
+            self._call("nbx_profile_enable", 1 if on else 0)
 
     def profile_reset(self):
         self._call("nbx_profile_reset")
@@ -238,7 +245,10 @@ class HipBackend:
         """D[x] = C[x][:, :nocc[x]] C[x][:, :nocc[x]]^T for (batch, N, N) MO coefficients whose
         columns are in aufbau order: the occupied block is addressed through lda, nothing is copied."""
         batch, n = c.shape[0], c.shape[-1]
-        out = self.zeros((batch, n, n))
+        if any(int(x) <= 0 for x in nocc):
+            out = self.zeros((batch, n, n))
+        else:
+            out = self.empty((batch, n, n))  # beta = 0: every element is written
         if len(set(int(x) for x in nocc)) == 1:
             k = int(nocc[0])
             if k > 0:
@@ -291,10 +301,11 @@ class HipBackend:
         for (only) the copy of those 32 bytes, so later work can be queued before it is read.
         ``extra``: a small device tensor to bring back with them (``get_extra()``)."""
         nao = dm.shape[-1]
-        d_out = self.empty(4)
+        ntail = 0 if extra is None else int(extra.numel())
+        d_out = self.empty(4 + ntail)
         self._call("nbx_huz_cycle_scalars_dev", nao, self._p(hcore), hcore.dim(), self._p(vemb), self._p(vhf),
-                   self._p(hz), self._p(dm), self._p(dm_old), self._p(d_out))
-        return _PendingScalars(self.torch, d_out, extra)
+                   self._p(hz), self._p(dm), self._p(dm_old), self._p(d_out), self._p(extra), ntail)
+        return _PendingScalars(self.torch, d_out, ntail)
 
     def diis_update(self, space: int, slot: int, nd: int, x, xprev, xs, es, h, coef):
         """Device-resident pyscf.lib.diis.DIIS.update step; ``xprev`` becomes the extrapolated vector."""

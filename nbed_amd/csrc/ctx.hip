@@ -154,6 +154,7 @@ int nbx_memset(nbx_ctx* ctx, void* d_ptr, int value, size_t bytes) {
 int nbx_profile_enable(nbx_ctx* ctx, int on) {
     NBX_CHECK_ARG(ctx != nullptr);
     ctx->profiling = (on != 0);
+    ctx->prof_mask = (on == 1 || on == 0) ? ~0u : ((unsigned)on >> 2);
     return NBX_OK;
 }
 

@@ -262,9 +262,9 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
         const int* gate = (it == 0) ? nullptr : status;
         int rc = nbx_gemm_small_gated(ctx, 'N', 'N', n, n, n, 1.0, d_a, n, n2, src, n, n2, 0.0, y, n, n2, batch, gate, 0, 0);
         if (rc != NBX_OK) return rc;
-        rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, y, n, n2, 0.0, s, n, n2, batch, gate, 0, 0);
-        if (rc != NBX_OK) return rc;
-        rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, src, n, n2, 0.0, g, n, n2, batch, gate, 0, 0);
+        // S = X^T Y and G = X^T X in one launch (they share op(A) = X^T)
+        rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, y, n, n2, 0.0, s, n, n2, batch, gate, 0, 0,
+                                  src, g);
         if (rc != NBX_OK) return rc;
         hipLaunchKernelGGL(refine_e_kernel, dim3((unsigned)batch), dim3(RF_THREADS), (size_t)(n + 48) * sizeof(double),
                            ctx->stream, (int)n, d_a, s, g, ep, lam, status, norm, it, max_iter);

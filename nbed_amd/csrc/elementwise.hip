@@ -11,10 +11,13 @@ constexpr int TILE = 32;
 
 // ---------------------------------------------------------------- reductions
 // Stage 2 of every scalar reduction: out[o] = sum_b partial[b * nout + o] (fixed order).
-// Outputs o >= sqrt_from are stored as sqrt(sum) (Frobenius norms).
+// Outputs o >= sqrt_from are stored as sqrt(sum) (Frobenius norms); `tail_n` ints from `tail` are
+// appended as doubles (status words that travel to the host in the same copy).
 __global__ void final_reduce_kernel(const double* __restrict__ partial, int nblocks, int nout,
-                                    double* __restrict__ out, int sqrt_from) {
+                                    double* __restrict__ out, int sqrt_from, const int* __restrict__ tail = nullptr,
+                                    int tail_n = 0) {
     __shared__ double red[17];
+    if ((int)threadIdx.x < tail_n) out[nout + threadIdx.x] = (double)tail[threadIdx.x];
     for (int o = 0; o < nout; ++o) {
         double t = 0.0;
         for (int b = threadIdx.x; b < nblocks; b += blockDim.x) t += partial[(int64_t)b * nout + o];
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
             if (r < c) off = fma(A[r][c], A[r][c], off);
         }
         off = nbx_wave_sum(off);
-        if (off <= 1e-34 * fro) break;
+        if (off <= 1e-31 * fro) break;  // eigenvalue error ~ off^2 / gap: far below 1e-16 |H|
         for (int step = 0; step < M - 1; ++step) {
             if (lane < npair) {  // pair `lane` of this step
                 int p, q;
@@ -313,18 +316,14 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
                 V[k][q] = sn * vkp + c * vkq;
             }
             __syncthreads();
-            for (int idx = lane; idx < npair * M; idx += 64) {  // A <- J^T A
+            for (int idx = lane; idx < npair * M; idx += 64) {  // A <- J^T A; the rotated pair is exactly 0
                 const int r = idx / M, k = idx - r * M;
                 const int p = rot_p[r], q = rot_q[r];
                 const double c = rot_c[r], sn = rot_s[r];
                 const double apk = A[p][k], aqk = A[q][k];
-                A[p][k] = c * apk - sn * aqk;
-                A[q][k] = sn * apk + c * aqk;
-            }
-            __syncthreads();
-            if (lane < npair && rot_s[lane] != 0.0) {
-                A[rot_p[lane]][rot_q[lane]] = 0.0;
-                A[rot_q[lane]][rot_p[lane]] = 0.0;
+                const bool rotated = sn != 0.0;
+                A[p][k] = (rotated && k == q) ? 0.0 : c * apk - sn * aqk;
+                A[q][k] = (rotated && k == p) ? 0.0 : sn * apk + c * aqk;
             }
             __syncthreads();
         }
@@ -547,8 +546,9 @@ int nbx_huz_cycle_scalars(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int 
 
 int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
                               const double* d_vemb, const double* d_vhf, const double* d_hz, const double* d_dm,
-                              const double* d_dm_old, double* d_out) {
+                              const double* d_dm_old, double* d_out, const int* d_tail, int64_t tail_n) {
     NBX_CHECK_ARG(ctx && d_hcore && d_vhf && d_hz && d_dm && d_dm_old && d_out && nao > 0);
+    NBX_CHECK_ARG(tail_n >= 0 && tail_n <= 64 && (tail_n == 0 || d_tail != nullptr));
     NBX_CHECK_ARG(hcore_ndim == 2 || hcore_ndim == 3);
     const int64_t g = nbx_cdiv(nao, TILE);
     NBX_CHECK_ARG(g * g * 4 <= NBX_SCRATCH_DOUBLES - 64);
@@ -556,7 +556,7 @@ int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
                        hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch);
     NBX_LAUNCH_CHECK();
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_scratch, (int)(g * g), 4,
-                       d_out, 2);
+                       d_out, 2, d_tail, (int)tail_n);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

@@ -193,8 +193,15 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(int M, int N, int K, dou
                                                         const double* __restrict__ B, int64_t ldb, int64_t stride_b,
                                                         double beta, double* __restrict__ C, int64_t ldc,
                                                         int64_t stride_c, const int* __restrict__ gate, int gate_a,
-                                                        int gate_b) {
-    const int batch = blockIdx.z;
+                                                        int gate_b, const double* __restrict__ B2,
+                                                        double* __restrict__ C2, int split) {
+    // z >= split: second product of a pair sharing op(A) (C2 = op(A) op(B2)), same batch entries
+    int batch = blockIdx.z;
+    if (batch >= split) {
+        batch -= split;
+        B = B2;
+        C = C2;
+    }
     if (gate != nullptr) {  // device-side "run only if": see nbx_gemm_small_gated
         const int g = gate[batch];
         if (g != gate_a && g != gate_b) return;
@@ -297,15 +304,19 @@ bool nbx_gemm_small_supported(int64_t m, int64_t n, int64_t k, int64_t batch) {
 int nbx_gemm_small_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t n, int64_t k, double alpha,
                          const double* d_a, int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb,
                          int64_t stride_b, double beta, double* d_c, int64_t ldc, int64_t stride_c, int64_t batch,
-                         const int* d_gate, int gate_a, int gate_b) {
+                         const int* d_gate, int gate_a, int gate_b, const double* d_b2, double* d_c2) {
     NBX_CHECK_ARG(ctx && d_a && d_b && d_c && m > 0 && n > 0 && k > 0 && batch > 0);
     NBX_CHECK_ARG(nbx_gemm_small_supported(m, n, k, batch));
+    NBX_CHECK_ARG((d_b2 == nullptr) == (d_c2 == nullptr));
     const bool a_kc = !(trans_a == 'T' || trans_a == 't');
     const bool b_kc = (trans_b == 'T' || trans_b == 't');
-    dim3 grid((unsigned)nbx_cdiv(n, 16), (unsigned)nbx_cdiv(m, 16), (unsigned)batch);
+    const bool pair = d_b2 != nullptr;
+    dim3 grid((unsigned)nbx_cdiv(n, 16), (unsigned)nbx_cdiv(m, 16), (unsigned)(pair ? 2 * batch : batch));
+    const int split = pair ? (int)batch : (1 << 30);
 #define NBX_GEMM_SMALL(AK, BKC)                                                                               \
     hipLaunchKernelGGL((gemm_small_kernel<AK, BKC>), grid, dim3(64), 0, ctx->stream, (int)m, (int)n, (int)k, \
-                       alpha, d_a, lda, stride_a, d_b, ldb, stride_b, beta, d_c, ldc, stride_c, d_gate, gate_a, gate_b)
+                       alpha, d_a, lda, stride_a, d_b, ldb, stride_b, beta, d_c, ldc, stride_c, d_gate, gate_a, gate_b, \
+                       d_b2, d_c2, split)
     if (a_kc) {
         if (b_kc) NBX_GEMM_SMALL(true, true);
         else NBX_GEMM_SMALL(true, false);
@@ -354,7 +365,8 @@ extern "C" int nbx_gemm(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int
             dim3 grid((unsigned)nbx_cdiv(n, 16), (unsigned)nbx_cdiv(m, 16), (unsigned)nb);
 #define NBX_GEMM_SMALL(AK, BKC)                                                                               \
     hipLaunchKernelGGL((gemm_small_kernel<AK, BKC>), grid, dim3(64), 0, ctx->stream, (int)m, (int)n, (int)k, \
-                       alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c, nullptr, 0, 0)
+                       alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c, nullptr, 0, 0, nullptr, nullptr, \
+                       1 << 30)
             if (a_kc) {
                 if (b_kc) NBX_GEMM_SMALL(true, true);
                 else NBX_GEMM_SMALL(true, false);

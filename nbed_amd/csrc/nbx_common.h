@@ -35,6 +35,7 @@ struct nbx_ctx {
     double* d_scratch;      // small device scratch for reductions (NBX_SCRATCH_DOUBLES)
     double* h_pinned;       // pinned host mirror of the scratch
     bool profiling = false;
+    unsigned prof_mask = ~0u;
     nbx_prof_slot prof[NBX_PROF_SLOTS];
     std::vector<nbx_sched> sched;
 };
@@ -52,7 +53,8 @@ bool nbx_gemm_small_supported(int64_t m, int64_t n, int64_t k, int64_t batch);
 int nbx_gemm_small_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t n, int64_t k, double alpha,
                          const double* d_a, int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb,
                          int64_t stride_b, double beta, double* d_c, int64_t ldc, int64_t stride_c, int64_t batch,
-                         const int* d_gate, int gate_a, int gate_b);
+                         const int* d_gate, int gate_a, int gate_b, const double* d_b2 = nullptr,
+                         double* d_c2 = nullptr);
 
 // eigh_refine.hip
 bool nbx_eigh_refine_supported(int64_t n, int64_t batch);
@@ -74,7 +76,9 @@ struct nbx_prof_scope {
     int slot;
     hipEvent_t stop = nullptr;
     nbx_prof_scope(nbx_ctx* c, int s) : ctx(c), slot(s) {
-        if (!ctx->profiling || (int)ctx->prof[slot].start.size() >= NBX_PROF_MAX_EVENTS) return;
+        if (!ctx->profiling || !((ctx->prof_mask >> slot) & 1u) ||
+            (int)ctx->prof[slot].start.size() >= NBX_PROF_MAX_EVENTS)
+            return;
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess) return;
         if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
