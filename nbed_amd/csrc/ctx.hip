@@ -55,10 +55,15 @@ int nbx_ctx_create(int device, void* stream, int private_stream, nbx_ctx** out) 
     }
     c->d_scratch = nullptr;
     c->h_pinned = nullptr;
+    c->d_counters = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&c->d_scratch), NBX_SCRATCH_DOUBLES * sizeof(double)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), NBX_SCRATCH_DOUBLES * sizeof(double), 0) != hipSuccess) {
+        hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), NBX_SCRATCH_DOUBLES * sizeof(double), 0) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_counters), NBX_COUNTERS * sizeof(int)) != hipSuccess ||
+        hipMemsetAsync(c->d_counters, 0, NBX_COUNTERS * sizeof(int), c->stream) != hipSuccess) {
         nbx_set_error("nbx_ctx_create: scratch allocation failed");
         if (c->d_scratch) (void)hipFree(c->d_scratch);
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        if (c->d_counters) (void)hipFree(c->d_counters);
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return NBX_E_NOMEM;
@@ -79,6 +84,7 @@ int nbx_ctx_destroy(nbx_ctx* ctx) {
     }
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return NBX_OK;

@@ -22,36 +22,51 @@
 
 namespace {
 
-constexpr int RF_THREADS = 1024;
+constexpr int RF_THREADS = 256;
+constexpr int RF_WGS = 16;
 constexpr int RF_MAX_ITER = 3;
-constexpr int RF_UNROLL = 8;
+constexpr int RF_UNROLL = 4;
 constexpr double RF_TOL = 3.0e-8;       // accepted update has max|E| below this: error ~ tol^2
 constexpr double RF_GIVE_UP = 0.25;     // not in the contracting regime
 constexpr double RF_CLUSTER_NOISE = 1.0e-14;
 
-// One workgroup per matrix.  G = X^T X, S = X^T A X  ->  Ep = I + E, lambda, status.
+// G = X^T X, S = X^T A X  ->  Ep = I + E, lambda, status.  RF_WGS workgroups per matrix (grid
+// (RF_WGS, batch)); the two global quantities the element-wise work needs -- the norms behind
+// omega before it, max|E| after it -- go through agent-scope atomics: partial results are
+// published, a per-matrix counter is bumped, and (1) every workgroup waits until all RF_WGS have
+// arrived, then adds the partials up in fixed order (identical omega everywhere); (2) the last
+// workgroup to finish phase 2 reduces the maxima, writes the status word and clears the counter.
+// All RF_WGS * batch (<= 16 * 512 small) workgroups are co-resident, so the wait cannot deadlock.
+__device__ __forceinline__ void publish(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double peek(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const double* __restrict__ A,
                                                               const double* __restrict__ S,
                                                               const double* __restrict__ G, double* __restrict__ Ep,
                                                               double* __restrict__ lam_out, int* __restrict__ status,
-                                                              double* __restrict__ norm_a, int iter,
-                                                              int max_iter) {
+                                                              double* __restrict__ norm_a, int iter, int max_iter,
+                                                              double* __restrict__ partial, int* __restrict__ counters) {
     extern __shared__ double sm[];
     double* lam = sm;
-    double* red = sm + N;
-    const int b = blockIdx.x;
+    double* red = sm + N;  // 3 * RF_THREADS/64 + 8 doubles
+    const int b = blockIdx.y, wg = blockIdx.x, nwg = gridDim.x;
     if (iter > 0 && status[b] != 0) return;
     const int64_t n2 = (int64_t)N * N;
     A += b * n2;
     S += b * n2;
     G += b * n2;
     Ep += b * n2;
+    double* part = partial + (int64_t)b * nwg * 5;
+    int* counter = counters + b;
     for (int i = threadIdx.x; i < N; i += RF_THREADS) lam[i] = S[(int64_t)i * N + i] / G[(int64_t)i * N + i];
-    double off2 = 0.0, r2 = 0.0, a2 = 0.0;
-    // flat element index e = tid + k * RF_THREADS, RF_UNROLL of them per trip so that their loads
-    // are all in flight together (the matrices sit in L2; one workgroup is latency bound otherwise)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NW = RF_THREADS / 64;
     const int total = N * N;
+    const int first = wg * RF_THREADS + threadIdx.x, stride = nwg * RF_THREADS;
     const float inv_n = 1.0f / (float)N;
     auto row_of = [&](int e) {  // e / N for e < 2^24 without an integer division
         int i = (int)((float)e * inv_n);
@@ -59,11 +74,13 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
         i += ((i + 1) * N <= e) ? 1 : 0;
         return i;
     };
-    for (int e0 = threadIdx.x; e0 < total; e0 += RF_THREADS * RF_UNROLL) {
+    // ---- phase 1: ||S - diag||_F^2, ||R||_F^2 (and ||A||_F^2 once)
+    double off2 = 0.0, r2 = 0.0, a2 = 0.0;
+    for (int e0 = first; e0 < total; e0 += stride * RF_UNROLL) {
         double sv[RF_UNROLL], gv[RF_UNROLL], av[RF_UNROLL];
 #pragma unroll
         for (int u = 0; u < RF_UNROLL; ++u) {
-            const int e = e0 + u * RF_THREADS;
+            const int e = e0 + u * stride;
             const bool in = e < total;
             sv[u] = in ? S[e] : 0.0;
             gv[u] = in ? G[e] : 0.0;
@@ -71,7 +88,7 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
         }
 #pragma unroll
         for (int u = 0; u < RF_UNROLL; ++u) {
-            const int e = e0 + u * RF_THREADS;
+            const int e = e0 + u * stride;
             if (e < total) {
                 const int i = row_of(e), j = e - i * N;
                 const double r = (i == j) ? 1.0 - gv[u] : -gv[u];
@@ -81,45 +98,68 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
             }
         }
     }
-    // three sums with one pair of barriers: wave partials side by side in LDS
     off2 = nbx_wave_sum(off2);
     r2 = nbx_wave_sum(r2);
     a2 = nbx_wave_sum(a2);
     __syncthreads();
     if (lane == 0) {
         red[wave] = off2;
-        red[16 + wave] = r2;
-        red[32 + wave] = a2;
+        red[NW + wave] = r2;
+        red[2 * NW + wave] = a2;
     }
     __syncthreads();
-    off2 = r2 = a2 = 0.0;
-    for (int w = 0; w < RF_THREADS / 64; ++w) {
-        off2 += red[w];
-        r2 += red[16 + w];
-        a2 += red[32 + w];
+    if (threadIdx.x == 0) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < NW; ++w) {
+            t0 += red[w];
+            t1 += red[NW + w];
+            t2 += red[2 * NW + w];
+        }
+        publish(part + wg * 5 + 0, t0);
+        publish(part + wg * 5 + 1, t1);
+        publish(part + wg * 5 + 2, t2);
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // bounded wait (~50 ms): if a sibling never arrives the matrix is handed to Jacobi
+        int spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nwg && ++spins < (1 << 20))
+            __builtin_amdgcn_s_sleep(2);
+        red[3 * NW + 3] = (spins >= (1 << 20)) ? 1.0 : 0.0;
+        t0 = t1 = t2 = 0.0;
+        for (int w = 0; w < nwg; ++w) {
+            t0 += peek(part + w * 5 + 0);
+            t1 += peek(part + w * 5 + 1);
+            t2 += peek(part + w * 5 + 2);
+        }
+        red[3 * NW + 0] = t0;
+        red[3 * NW + 1] = t1;
+        red[3 * NW + 2] = t2;
     }
     __syncthreads();
+    off2 = red[3 * NW + 0];
+    r2 = red[3 * NW + 1];
+    a2 = red[3 * NW + 2];
     double na;
     if (iter == 0) {
         na = sqrt(a2);
-        if (threadIdx.x == 0) norm_a[b] = na;
+        if (wg == 0 && threadIdx.x == 0) norm_a[b] = na;
     } else {
         na = norm_a[b];
     }
     const double omega = 2.0 * (sqrt(off2) + na * sqrt(r2));
+    // ---- phase 2: E
     double emax = 0.0, cmax = 0.0;
-    for (int e0 = threadIdx.x; e0 < total; e0 += RF_THREADS * RF_UNROLL) {
+    for (int e0 = first; e0 < total; e0 += stride * RF_UNROLL) {
         double sv[RF_UNROLL], gv[RF_UNROLL];
 #pragma unroll
         for (int u = 0; u < RF_UNROLL; ++u) {
-            const int e = e0 + u * RF_THREADS;
+            const int e = e0 + u * stride;
             const bool in = e < total;
             sv[u] = in ? S[e] : 0.0;
             gv[u] = in ? G[e] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < RF_UNROLL; ++u) {
-            const int e = e0 + u * RF_THREADS;
+            const int e = e0 + u * stride;
             if (e < total) {
                 const int i = row_of(e), j = e - i * N;
                 const double sx = sv[u], g = gv[u];
@@ -148,26 +188,36 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
         emax = fmax(emax, __shfl_xor(emax, o));
         cmax = fmax(cmax, __shfl_xor(cmax, o));
     }
+    __syncthreads();
     if (lane == 0) {
         red[wave] = emax;
-        red[16 + wave] = cmax;
+        red[NW + wave] = cmax;
     }
     __syncthreads();
-    for (int w = 0; w < RF_THREADS / 64; ++w) {
-        emax = fmax(emax, red[w]);
-        cmax = fmax(cmax, red[16 + w]);
-    }
     if (threadIdx.x == 0) {
-        int st = 0;
-        if (!(emax < RF_GIVE_UP)) st = -1;  // also NaN
-        else if (emax < RF_TOL && cmax <= RF_CLUSTER_NOISE * na) st = iter + 1;
-        else if (iter == max_iter - 1) st = -1;
-        status[b] = st;
-#ifdef NBX_REFINE_DEBUG
-        printf("refine b=%d iter=%d emax=%.3e cmax=%.3e omega=%.3e na=%.3e off=%.3e r=%.3e st=%d\n", b, iter, emax, cmax, omega, na, sqrt(off2), sqrt(r2), st);
-#endif
+        for (int w = 0; w < NW; ++w) {
+            emax = fmax(emax, red[w]);
+            cmax = fmax(cmax, red[NW + w]);
+        }
+        if (red[3 * NW + 3] != 0.0) emax = 1.0e300;  // timed out above: force the fallback
+        publish(part + wg * 5 + 3, emax);
+        publish(part + wg * 5 + 4, cmax);
+        const int arrived = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == 2 * nwg - 1) {  // last workgroup of this matrix
+            for (int w = 0; w < nwg; ++w) {
+                emax = fmax(emax, peek(part + w * 5 + 3));
+                cmax = fmax(cmax, peek(part + w * 5 + 4));
+            }
+            int st = 0;
+            if (!(emax < RF_GIVE_UP)) st = -1;  // also NaN
+            else if (emax < RF_TOL && cmax <= RF_CLUSTER_NOISE * na) st = iter + 1;
+            else if (iter == max_iter - 1) st = -1;
+            status[b] = st;
+            __hip_atomic_store(counter, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    for (int i = threadIdx.x; i < N; i += RF_THREADS) lam_out[(int64_t)b * N + i] = lam[i];
+    if (wg == 0)
+        for (int i = threadIdx.x; i < N; i += RF_THREADS) lam_out[(int64_t)b * N + i] = lam[i];
 }
 
 // Accepted matrices: eigenvalues ascending, eigenvector columns permuted to match.
@@ -212,7 +262,7 @@ __global__ __launch_bounds__(256) void refine_finish_kernel(int N, const double*
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RefineLayout {
-    size_t xb0, xb1, y, s, g, ep, lam, norm, status, total;
+    size_t xb0, xb1, y, s, g, ep, lam, norm, partial, status, total;
 };
 
 RefineLayout rlayout(int64_t n, int64_t batch) {
@@ -227,6 +277,7 @@ RefineLayout rlayout(int64_t n, int64_t batch) {
     L.ep = off; off += mat;
     L.lam = off; off += align256((size_t)(n * batch) * sizeof(double));
     L.norm = off; off += align256((size_t)batch * sizeof(double));
+    L.partial = off; off += align256((size_t)(batch * RF_WGS * 5) * sizeof(double));
     L.status = off; off += align256((size_t)batch * sizeof(int));
     L.total = off;
     return L;
@@ -235,7 +286,7 @@ RefineLayout rlayout(int64_t n, int64_t batch) {
 }  // namespace
 
 bool nbx_eigh_refine_supported(int64_t n, int64_t batch) {
-    return n >= 2 && n <= 4096 && nbx_gemm_small_supported(n, n, n, batch) && (size_t)(n + 48) * sizeof(double) <= 64 * 1024;
+    return n >= 2 && n <= 4096 && batch <= NBX_COUNTERS && nbx_gemm_small_supported(n, n, n, batch);
 }
 
 size_t nbx_eigh_refine_worksize(int64_t n, int64_t batch) { return rlayout(n, batch).total; }
@@ -252,6 +303,7 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
     double* ep = reinterpret_cast<double*>(base + L.ep);
     double* lam = reinterpret_cast<double*>(base + L.lam);
     double* norm = reinterpret_cast<double*>(base + L.norm);
+    double* partial = reinterpret_cast<double*>(base + L.partial);
     int* status = reinterpret_cast<int*>(base + L.status);
     const int64_t n2 = n * n;
     for (int it = 0; it < max_iter; ++it) {
@@ -266,8 +318,9 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
         rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, y, n, n2, 0.0, s, n, n2, batch, gate, 0, 0,
                                   src, g);
         if (rc != NBX_OK) return rc;
-        hipLaunchKernelGGL(refine_e_kernel, dim3((unsigned)batch), dim3(RF_THREADS), (size_t)(n + 48) * sizeof(double),
-                           ctx->stream, (int)n, d_a, s, g, ep, lam, status, norm, it, max_iter);
+        hipLaunchKernelGGL(refine_e_kernel, dim3(RF_WGS, (unsigned)batch), dim3(RF_THREADS),
+                           (size_t)(n + 3 * (RF_THREADS / 64) + 8) * sizeof(double), ctx->stream, (int)n, d_a, s, g, ep,
+                           lam, status, norm, it, max_iter, partial, ctx->d_counters);
         NBX_LAUNCH_CHECK();
         rc = nbx_gemm_small_gated(ctx, 'N', 'N', n, n, n, 1.0, src, n, n2, ep, n, n2, 0.0, dst, n, n2, batch, status, 0,
                                   it + 1);

@@ -34,6 +34,8 @@ struct nbx_ctx {
     bool own_stream;
     double* d_scratch;      // small device scratch for reductions (NBX_SCRATCH_DOUBLES)
     double* h_pinned;       // pinned host mirror of the scratch
+    int* d_counters;        // NBX_COUNTERS zero-initialised ints: arrival counters of kernels that
+                            // synchronise across workgroups (each kernel leaves them zero again)
     bool profiling = false;
     unsigned prof_mask = ~0u;
     nbx_prof_slot prof[NBX_PROF_SLOTS];
@@ -93,6 +95,7 @@ struct nbx_prof_scope {
 };
 
 constexpr int NBX_SCRATCH_DOUBLES = 4096;
+constexpr int NBX_COUNTERS = 1024;
 
 void nbx_set_error(const char* fmt, ...);
 
