@@ -128,11 +128,15 @@ class _GpuSCF:
         slab = self.be.jk(self.eri_device(), dm_d, self.shards.lo, self.shards.hi)
         return self.shards.all_gather(self.be, slab, axis=1)
 
-    def _eig_device(self, fock_d):
-        """Generalised eigenproblem F C = S C e through Loewdin orthogonalisation."""
+    def _eig_device(self, fock_d, warm: dict | None = None):
+        """Generalised eigenproblem F C = S C e through Loewdin orthogonalisation.  ``warm``: a
+        dict carried across SCF cycles; the previous cycle's orthonormal eigenvectors kept in it
+        seed the solver (GEMM refinement / few sweeps instead of a cold Jacobi solve)."""
         x = self.x_device()
         fo = self.be.gemm(self.be.gemm(x, fock_d), x)
-        e, c = self.be.eigh(fo)
+        e, c = self.be.eigh(fo, v0=None if warm is None else warm.get("v"))
+        if warm is not None:
+            warm["v"] = c
         return e, self.be.gemm(x, c)
 
 
@@ -242,13 +246,14 @@ class GpuUHF(_GpuSCF, UHF):
 
         fock, e_tot, e1, e2 = fock_and_energy(dm_d)
         diis = CDIIS(be, self._s_d)
+        warm = {}
         conv_tol_grad = np.sqrt(self.conv_tol)
         self.converged = False
         mo_energy = mo_coeff = mo_occ = None
         for cycle in range(self.max_cycle):
             last_e = e_tot
             f_use = diis.update(dm_d, fock) if cycle >= 1 else fock
-            e_d, c_d = self._eig_device(f_use)
+            e_d, c_d = self._eig_device(f_use, warm)
             mo_energy = be.to_host(e_d)
             mo_occ = self.get_occ(mo_energy)
             dm_d = self.make_rdm1_device(c_d, mo_occ)
@@ -259,7 +264,7 @@ class GpuUHF(_GpuSCF, UHF):
                 self.converged = True
                 break
         if self.converged:
-            e_d, c_d = self._eig_device(fock)
+            e_d, c_d = self._eig_device(fock, warm)
             mo_energy = be.to_host(e_d)
             mo_occ = self.get_occ(mo_energy)
             dm_d = self.make_rdm1_device(c_d, mo_occ)
