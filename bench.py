@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--nact", type=int, default=128, help="embedded MOs kept for the transform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transform", action="store_true")
+    ap.add_argument("--no-n2000", action="store_true", help="skip the bounded N_AO=2000 streamed sample")
+    ap.add_argument("--n2000-rslabs", type=int, default=4, help="r-slabs of the N_AO=2000 transform per rank")
     ap.add_argument("--cpu-cycles", type=int, default=8)
     return ap.parse_args()
 
@@ -242,6 +244,60 @@ def main():
         }
         del outs
 
+    # ---------------- BASELINE configs[3]: N_AO = 2000, integrals generated in registers (a dense
+    # tensor would be 128 TB).  A bounded sample of the full job, sharded as the full job would be:
+    # each rank transforms its own `rslabs` values of r (partial tensors are summed by one
+    # all-reduce at the end of a full run) and builds J/K rows for its own `jrows` values of p.
+    n2000 = None
+    if not args.no_n2000:
+        NB, nb_act, rsl, jrows = 2000, 128, args.n2000_rslabs, 4
+        cb = be.asarray(np.ascontiguousarray(synth.sym_matrix(7, NB)[:, :nb_act]))
+        r0 = rank * rsl
+        be.ao2mo_synth(NB, cb, cb, cb, cb, r0=r0, r1=r0 + 1)  # first-touch of the workspaces
+        barrier()
+        be.profile(True, slots=[_nbx.PROF_AO2MO_Q1])
+        be.profile_reset()
+        t2 = time.perf_counter()
+        part = be.ao2mo_synth(NB, cb, cb, cb, cb, r0=r0, r1=r0 + rsl)
+        barrier()
+        dts = time.perf_counter() - t2
+        be.profile(False)
+        q1s_ms, q1s_cnt = be.profile_read(_nbx.PROF_AO2MO_Q1)
+        allreduce_ms = None
+        if distributed:
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            dist.all_reduce(part)
+            barrier()
+            allreduce_ms = (time.perf_counter() - t3) * 1e3
+        dmb = be.asarray(np.stack([synth.sym_matrix(8, NB), synth.sym_matrix(9, NB)]))
+        p0 = rank * jrows
+        be.jk_synth(NB, dmb, p0, p0 + 1)
+        barrier()
+        t4 = time.perf_counter()
+        be.jk_synth(NB, dmb, p0, p0 + jrows)
+        barrier()
+        dtj = time.perf_counter() - t4
+        if world > 1:
+            tm = torch.tensor([dts, dtj], dtype=torch.float64, device=be.device)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dts, dtj = float(tm[0].item()), float(tm[1].item())
+        fl_slab = transform_flops(NB, nb_act) / NB  # one r-slab of one spin block
+        q1_flops_slab = 2.0 * nb_act * NB**3
+        n2000 = {
+            "workload": f"BASELINE configs[3] sample: N_AO={NB}, n_act={nb_act}, (pq|rs) generated in registers; "
+                        f"{rsl} r-slabs and {jrows} J/K rows per rank (full job: {NB} of each)",
+            "transform_tflops": fl_slab * rsl * world / dts / 1e12,
+            "transform_quarter1_tflops_per_gpu": (q1_flops_slab * rsl / (q1s_ms * 1e-3) / 1e12) if q1s_cnt else None,
+            "transform_frac_of_fp64_mfma_peak": fl_slab * rsl / dts / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "projected_full_spin_block_s": dts * NB / (rsl * world),
+            "final_allreduce_ms": allreduce_ms,
+            "jk_gintegrals_per_s": jrows * world * float(NB) ** 3 / dtj / 1e9,
+            "projected_full_jk_build_s": dtj * NB / (jrows * world),
+        }
+        del part, dmb, cb
+        be.release_workspaces()
+
     # ---------------- CPU baseline (rank 0, N=1 only): the oracle on the host cores
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -318,6 +374,7 @@ def main():
             "breakdown_ms_per_cycle": {"jk_dense_kernel": jk_avg_ms, "everything_else": dt / args.steps * 1e3 - jk_avg_ms},
             "check": {"energy_last_cycle": e_last, "dm_change_last_cycle": dm_change_last},
             "transform": transform,
+            "n2000_streamed": n2000,
         }
         print(json.dumps(out))
     if distributed:

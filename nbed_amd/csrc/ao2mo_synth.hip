@@ -5,8 +5,8 @@
 //
 // The tensor is produced slab by slab from the counter hash (synth.hip) and consumed at once:
 //   for r:                                                        flop (summed over r, s)
-//     for s-chunks:  M[s][p,q] = (pq|rs)              generate   (hash, ALU)
-//                    Y[s] = C1^T M[s]   (n1 x N)      GEMM       2 n1 N^4
+//     for s-chunks:  Y[s] = C1^T M[s]   (n1 x N)      GEMM       2 n1 N^4     M[s][p,q] = (pq|rs)
+//                                                     generated in the GEMM's B-operand registers
 //                    Z[s] = Y[s] C2     (n1 x n2)     GEMM       2 n1 n2 N^3
 //     U[r] = C4^T Z   (n4 x n1 n2)                    GEMM       2 n1 n2 n4 N^2
 //   every RB r's:  acc += C3[rb]^T U[rb]  (n3 x n4 n1 n2)  GEMM  2 n1 n2 n3 n4 N
@@ -14,25 +14,15 @@
 // i.e. the same four quarter transforms and flop count as the dense path, with O(N^2 n^2 / N)
 // memory instead of O(N^4).  The r range is the multi-GPU shard axis here (partial sums are
 // all-reduced by the host): sharding the MO index i would make every rank regenerate the
-// whole tensor.  The generated slab still makes one round trip through HBM (8 N^2 bytes per
-// (r,s), written then read); fusing the generator into the GEMM operand staging is the next step.
+// whole tensor.  The integrals never exist in memory: gemm_f64_kernel<..., B_GEN> evaluates the
+// hash for the 16 x 128 B tile it is about to stage (4 values per thread per k-step, hidden
+// behind the 32 MFMAs per wave of that step).
 #include "nbx_common.h"
 #include "synth_device.h"
 
 namespace {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-// M[(s - s0)][p][q] = val(canon(p,q,r,s)) / N : one workgroup per (s, p) row
-__global__ __launch_bounds__(256) void synth_rs_kernel(double* __restrict__ M, int N, int r, int s0, uint64_t seed) {
-    const int sl = blockIdx.x / N;
-    const int p = blockIdx.x - sl * N;
-    const uint64_t rs = nbx_tri((uint64_t)r, (uint64_t)(s0 + sl));
-    const double scale = 1.0 / (double)N;
-    double* row = M + ((int64_t)sl * N + p) * N;
-    for (int q = threadIdx.x; q < N; q += blockDim.x)
-        row[q] = nbx_synth_val(0, nbx_tri(nbx_tri((uint64_t)p, (uint64_t)q), rs), seed) * scale;
-}
 
 struct SynthPlan {
     int64_t sc, rb;
@@ -41,13 +31,13 @@ struct SynthPlan {
 
 SynthPlan plan(int64_t N, int64_t n1, int64_t n2, int64_t n3, int64_t n4) {
     SynthPlan p;
-    int64_t sc = (int64_t)(2.0e9 / (8.0 * (double)N * (double)N));  // ~2 GB generated slab
+    int64_t sc = (int64_t)(4.0e9 / (8.0 * (double)N * (double)n1));  // ~4 GB of quarter-1 output
     if (sc < 1) sc = 1;
     if (sc > N) sc = N;
     p.sc = sc;
     p.rb = 8;
     size_t off = 0;
-    p.m_off = off; off += align256((size_t)(sc * N * N) * sizeof(double));
+    p.m_off = off;  // (no generated slab any more)
     p.y_off = off; off += align256((size_t)(sc * n1 * N) * sizeof(double));
     p.z_off = off; off += align256((size_t)(N * n1 * n2) * sizeof(double));
     p.u_off = off; off += align256((size_t)(p.rb * n4 * n1 * n2) * sizeof(double));
@@ -76,7 +66,6 @@ extern "C" int nbx_ao2mo_synth(nbx_ctx* ctx, int64_t nao, uint64_t seed, int64_t
         return NBX_E_NOMEM;
     }
     char* base = static_cast<char*>(d_work);
-    double* M = reinterpret_cast<double*>(base + pl.m_off);
     double* Y = reinterpret_cast<double*>(base + pl.y_off);
     double* Z = reinterpret_cast<double*>(base + pl.z_off);
     double* U = reinterpret_cast<double*>(base + pl.u_off);
@@ -88,12 +77,9 @@ extern "C" int nbx_ao2mo_synth(nbx_ctx* ctx, int64_t nao, uint64_t seed, int64_t
     for (int64_t r = r0; r < r1; ++r) {
         for (int64_t s0 = 0; s0 < N; s0 += pl.sc) {
             const int64_t ns = (N - s0) < pl.sc ? (N - s0) : pl.sc;
-            hipLaunchKernelGGL(synth_rs_kernel, dim3((unsigned)(ns * N)), dim3(256), 0, ctx->stream, M, (int)N, (int)r,
-                               (int)s0, seed);
-            NBX_LAUNCH_CHECK();
             {
                 nbx_prof_scope prof_q1(ctx, NBX_PROF_AO2MO_Q1);
-                rc = nbx_gemm(ctx, 'T', 'N', n1, N, N, 1.0, d_c1, n1, 0, M, N, N * N, 0.0, Y, N, n1 * N, ns);
+                rc = nbx_gemm_q1_synth(ctx, n1, N, N, d_c1, n1, seed, 1.0 / (double)N, r, s0, Y, N, n1 * N, ns);
             }
             if (rc != NBX_OK) return rc;
             rc = nbx_gemm(ctx, 'N', 'N', n1, n2, N, 1.0, Y, N, n1 * N, d_c2, n2, 0, 0.0, Z + s0 * n12, n2, n12, ns);

@@ -14,10 +14,19 @@
 // 256-byte bank row (conflict-free fragment reads).  The next k-tile is fetched into
 // registers while the current one feeds the MFMAs.
 #include "nbx_common.h"
+#include "synth_device.h"
 
 namespace {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// B operand produced by the counter hash instead of loaded (streamed quarter-1 of the synthetic
+// (pq|rs), ao2mo_synth.hip): batch entry z is the (p,q) matrix of the pair (r, s0 + z).
+struct GemmGen {
+    uint64_t seed;
+    double scale;
+    int r, s0;
+};
 
 constexpr int BK = 16;
 constexpr int PAD = 16;
@@ -71,6 +80,29 @@ struct Stager {
         }
     }
 
+    // same register tile, values generated: element (x, k) = val(canon(k, x, r, s)) * scale
+    __device__ __forceinline__ void generate(uint64_t rs, uint64_t seed, double scale, int x0, int k0, int xmax,
+                                             int kmax) {
+        static_assert(!KCONTIG, "generated operand is laid out along x");
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int item = threadIdx.x + i * GEMM_THREADS;
+            const int k = item / (BX / 2);
+            const int x = (item - k * (BX / 2)) * 2;
+            const int gx = x0 + x, gk = k0 + k;
+            double2 v = make_double2(0.0, 0.0);
+            if (gk < kmax) {
+                // pair indices fit 32 bits (N < 92681): 32 x 32 -> 64-bit products instead of 64 x 64
+                if (gx < xmax)
+                    v.x = nbx_synth_val(0, nbx_tri_u32(nbx_tri_pair_u32((uint32_t)gk, (uint32_t)gx), (uint32_t)rs), seed) * scale;
+                if (gx + 1 < xmax)
+                    v.y = nbx_synth_val(0, nbx_tri_u32(nbx_tri_pair_u32((uint32_t)gk, (uint32_t)(gx + 1)), (uint32_t)rs), seed) *
+                          scale;
+            }
+            reg[i] = v;
+        }
+    }
+
     __device__ __forceinline__ void store(double* __restrict__ tile /* [BK][BX+PAD] */) const {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
@@ -89,11 +121,11 @@ struct Stager {
     }
 };
 
-template <int BM, int BN, int WR, int WC, bool A_KC, bool B_KC>
+template <int BM, int BN, int WR, int WC, bool A_KC, bool B_KC, bool B_GEN = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
     int M, int N, int K, double alpha, const double* __restrict__ A, int64_t lda, int64_t stride_a,
     const double* __restrict__ B, int64_t ldb, int64_t stride_b, double beta, double* __restrict__ C,
-    int64_t ldc, int64_t stride_c, int vec_a, int vec_b) {
+    int64_t ldc, int64_t stride_c, int vec_a, int vec_b, GemmGen gen = GemmGen{}) {
     constexpr int GEMM_THREADS = 64 * WR * WC;
     constexpr int WM = BM / WR, WN = BN / WC;  // WR x WC waves
     constexpr int MT = WM / 16, NT = WN / 16;
@@ -102,8 +134,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
 
     const int batch = blockIdx.z;
     A += (int64_t)batch * stride_a;
-    B += (int64_t)batch * stride_b;
+    if (!B_GEN) B += (int64_t)batch * stride_b;
     C += (int64_t)batch * stride_c;
+    const uint64_t gen_rs = B_GEN ? nbx_tri((uint64_t)gen.r, (uint64_t)(gen.s0 + batch)) : 0;
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
 
@@ -123,7 +156,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
     Stager<BN, B_KC, GEMM_THREADS> sb;
     const int nkt = (K + BK - 1) / BK;
     sa.load(A, lda, m0, 0, M, K, vec_a);
-    sb.load(B, ldb, n0, 0, N, K, vec_b);
+    if constexpr (B_GEN) sb.generate(gen_rs, gen.seed, gen.scale, n0, 0, N, K);
+    else sb.load(B, ldb, n0, 0, N, K, vec_b);
     sa.store(As);
     sb.store(Bs);
     __syncthreads();
@@ -132,7 +166,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
         const bool more = kt + 1 < nkt;
         if (more) {
             sa.load(A, lda, m0, (kt + 1) * BK, M, K, vec_a);
-            sb.load(B, ldb, n0, (kt + 1) * BK, N, K, vec_b);
+            if constexpr (B_GEN) sb.generate(gen_rs, gen.seed, gen.scale, n0, (kt + 1) * BK, N, K);
+            else sb.load(B, ldb, n0, (kt + 1) * BK, N, K, vec_b);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
@@ -293,6 +328,32 @@ void launch(nbx_ctx* ctx, bool a_kc, bool b_kc, int M, int N, int K, double alph
 }
 
 }  // namespace
+
+// Y[z] (m x n) = op(A) (m x k) . G_z (k x n),  G_z[p][q] = val(canon(p, q, r, s0 + z)) * scale,
+// z < batch: quarter-1 of the streamed transform with the integrals born in the B-operand
+// registers of the GEMM (they never exist in memory).  A is (k x m) row-major ('T').
+int nbx_gemm_q1_synth(nbx_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* d_a, int64_t lda, uint64_t seed,
+                      double scale, int64_t r, int64_t s0, double* d_y, int64_t ldy, int64_t stride_y,
+                      int64_t batch) {
+    NBX_CHECK_ARG(ctx && d_a && d_y && m > 0 && n > 0 && k > 0 && batch > 0 && batch <= 65535 && lda >= m &&
+                  ldy >= n);
+    NBX_CHECK_ARG(m < (1ll << 31) && n < 92681 && k < 92681 && r + 1 < 92681 && s0 + batch < 92681);
+    GemmGen gen{seed, scale, (int)r, (int)s0};
+    const int vec_a = (aligned16(d_a) && lda % 2 == 0) ? 1 : 0;
+    if (m > 64 && n > 64) {
+        dim3 grid((unsigned)nbx_cdiv(n, 128), (unsigned)nbx_cdiv(m, 128), (unsigned)batch);
+        hipLaunchKernelGGL((gemm_f64_kernel<128, 128, 2, 4, false, false, true>), grid, dim3(512), 0, ctx->stream, (int)m,
+                           (int)n, (int)k, 1.0, d_a, lda, (int64_t)0, nullptr, (int64_t)0, (int64_t)0, 0.0, d_y, ldy,
+                           stride_y, vec_a, 0, gen);
+    } else {
+        dim3 grid((unsigned)nbx_cdiv(n, 64), (unsigned)nbx_cdiv(m, 64), (unsigned)batch);
+        hipLaunchKernelGGL((gemm_f64_kernel<64, 64, 2, 2, false, false, true>), grid, dim3(256), 0, ctx->stream, (int)m,
+                           (int)n, (int)k, 1.0, d_a, lda, (int64_t)0, nullptr, (int64_t)0, (int64_t)0, 0.0, d_y, ldy,
+                           stride_y, vec_a, 0, gen);
+    }
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
 
 bool nbx_gemm_small_supported(int64_t m, int64_t n, int64_t k, int64_t batch) {
     return batch <= 65535 && nbx_cdiv(m, 16) * nbx_cdiv(n, 16) * batch <= 512 && k <= 4096;

@@ -66,7 +66,7 @@ struct TileGen {
     uint64_t seed;
     double scale;
     __device__ __forceinline__ double val(int j, int a, int b) const {
-        return nbx_synth_val(0, nbx_tri(pq[j], nbx_tri((uint64_t)a, (uint64_t)b)), seed) * scale;
+        return nbx_synth_val(0, nbx_tri_u32((uint32_t)pq[j], nbx_tri_pair_u32((uint32_t)a, (uint32_t)b)), seed) * scale;
     }
     __device__ __forceinline__ double2 get2(int j, int64_t, int a, int b) const {
         return make_double2(val(j, a, b), val(j, a, b + 1));
