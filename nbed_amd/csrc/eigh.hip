@@ -247,9 +247,11 @@ static size_t eigh_jacobi_global_total(int64_t n, int64_t batch) {
 extern "C" size_t nbx_eigh_worksize(int64_t n, int64_t batch) {
     if (n <= 0 || batch <= 0) return 0;
     if (nbx_eigh_lds_supported(n)) return nbx_eigh_lds_worksize(n, batch);
-    // tridiagonal pipeline, then (only if needed) the Jacobi polisher, then a copy of V
+    // tridiagonal pipeline, then (only if needed) the Jacobi polisher, then a copy of V, then the
+    // warm-start refinement buffers
     return nbx_eigh_tridiag_worksize(n, batch) + eigh_jacobi_global_total(n, batch) +
-           align256((size_t)(n * n * batch) * sizeof(double));
+           align256((size_t)(n * n * batch) * sizeof(double)) +
+           (nbx_eigh_refine_supported(n, batch) ? nbx_eigh_refine_worksize(n, batch) : 0);
 }
 
 static int eigh_global(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
@@ -314,6 +316,29 @@ extern "C" int nbx_eigh_warm_ex(nbx_ctx* ctx, int64_t n, int64_t batch, const do
     const size_t td = nbx_eigh_tridiag_worksize(n, batch);
     char* jac = base + td;
     double* vcopy = reinterpret_cast<double*>(jac + eigh_jacobi_global_total(n, batch));
+    if (d_v0 != nullptr && refine_iters > 0 && nbx_eigh_refine_supported(n, batch)) {
+        // Warm start: the same GEMM-only refinement as for small N (~10 GEMMs instead of the
+        // whole tridiagonal pipeline).  The pipeline below is many launches with host decisions
+        // in between, so here the status words are read back (one short wait) to decide.
+        char* rf = reinterpret_cast<char*>(vcopy) + align256((size_t)(n * n * batch) * sizeof(double));
+        int* jstatus = reinterpret_cast<int*>(jac + align256((size_t)(4 * ((n + 1) & ~1ll) * ((n + 1) & ~1ll) * batch) *
+                                                              sizeof(double)));
+        const int* rstatus = nullptr;
+        int rc0;
+        {
+            nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
+            rc0 = nbx_eigh_refine(ctx, n, batch, d_a, d_v0, d_w, d_v, rf, jstatus, &rstatus,
+                                  refine_iters < NBX_EIGH_REFINE_ITERS ? refine_iters : NBX_EIGH_REFINE_ITERS);
+        }
+        if (rc0 != NBX_OK) return rc0;
+        std::vector<int> st((size_t)batch, 0);
+        rc0 = nbx_memcpy_d2h(ctx, st.data(), rstatus, (size_t)batch * sizeof(int));
+        if (rc0 != NBX_OK) return rc0;
+        bool all_ok = true;
+        for (int v : st) all_ok = all_ok && (v > 0);
+        if (all_ok) return NBX_OK;
+        // otherwise solve every matrix of the batch from scratch below (results overwrite)
+    }
     std::vector<double> quality((size_t)batch, 0.0);
     int rc = nbx_eigh_tridiag(ctx, n, batch, d_a, d_w, d_v, base, td, quality.data());
     if (rc != NBX_OK) return rc;

@@ -286,7 +286,7 @@ RefineLayout rlayout(int64_t n, int64_t batch) {
 }  // namespace
 
 bool nbx_eigh_refine_supported(int64_t n, int64_t batch) {
-    return n >= 2 && n <= 4096 && batch <= NBX_COUNTERS && nbx_gemm_small_supported(n, n, n, batch);
+    return n >= 2 && n <= 4096 && batch <= NBX_COUNTERS;
 }
 
 size_t nbx_eigh_refine_worksize(int64_t n, int64_t batch) { return rlayout(n, batch).total; }
@@ -306,24 +306,31 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
     double* partial = reinterpret_cast<double*>(base + L.partial);
     int* status = reinterpret_cast<int*>(base + L.status);
     const int64_t n2 = n * n;
+    const bool small = nbx_gemm_small_supported(n, n, n, batch);
     for (int it = 0; it < max_iter; ++it) {
         // iteration `it` reads src and writes dst; the first one reads V0 in place and its
         // GEMMs are not gated (its E kernel initialises the status words)
         const double* src = (it == 0) ? d_v0 : xb[it & 1];
         double* dst = xb[(it + 1) & 1];
         const int* gate = (it == 0) ? nullptr : status;
-        int rc = nbx_gemm_small_gated(ctx, 'N', 'N', n, n, n, 1.0, d_a, n, n2, src, n, n2, 0.0, y, n, n2, batch, gate, 0, 0);
+        int rc = nbx_gemm_gated(ctx, 'N', 'N', n, n, n, 1.0, d_a, n, n2, src, n, n2, 0.0, y, n, n2, batch, gate, 0, 0);
         if (rc != NBX_OK) return rc;
-        // S = X^T Y and G = X^T X in one launch (they share op(A) = X^T)
-        rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, y, n, n2, 0.0, s, n, n2, batch, gate, 0, 0,
-                                  src, g);
-        if (rc != NBX_OK) return rc;
+        if (small) {
+            // S = X^T Y and G = X^T X in one launch (they share op(A) = X^T)
+            rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, y, n, n2, 0.0, s, n, n2, batch, gate, 0, 0,
+                                      src, g);
+            if (rc != NBX_OK) return rc;
+        } else {
+            rc = nbx_gemm_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, y, n, n2, 0.0, s, n, n2, batch, gate, 0, 0);
+            if (rc != NBX_OK) return rc;
+            rc = nbx_gemm_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, src, n, n2, 0.0, g, n, n2, batch, gate, 0, 0);
+            if (rc != NBX_OK) return rc;
+        }
         hipLaunchKernelGGL(refine_e_kernel, dim3(RF_WGS, (unsigned)batch), dim3(RF_THREADS),
                            (size_t)(n + 3 * (RF_THREADS / 64) + 8) * sizeof(double), ctx->stream, (int)n, d_a, s, g, ep,
                            lam, status, norm, it, max_iter, partial, ctx->d_counters);
         NBX_LAUNCH_CHECK();
-        rc = nbx_gemm_small_gated(ctx, 'N', 'N', n, n, n, 1.0, src, n, n2, ep, n, n2, 0.0, dst, n, n2, batch, status, 0,
-                                  it + 1);
+        rc = nbx_gemm_gated(ctx, 'N', 'N', n, n, n, 1.0, src, n, n2, ep, n, n2, 0.0, dst, n, n2, batch, status, 0, it + 1);
         if (rc != NBX_OK) return rc;
     }
     hipLaunchKernelGGL(refine_finish_kernel, dim3((unsigned)nbx_cdiv(n, RF_ROWS), (unsigned)batch), dim3(256),

@@ -125,7 +125,8 @@ template <int BM, int BN, int WR, int WC, bool A_KC, bool B_KC, bool B_GEN = fal
 __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
     int M, int N, int K, double alpha, const double* __restrict__ A, int64_t lda, int64_t stride_a,
     const double* __restrict__ B, int64_t ldb, int64_t stride_b, double beta, double* __restrict__ C,
-    int64_t ldc, int64_t stride_c, int vec_a, int vec_b, GemmGen gen = GemmGen{}) {
+    int64_t ldc, int64_t stride_c, int vec_a, int vec_b, GemmGen gen = GemmGen{},
+    const int* __restrict__ gate = nullptr, int gate_a = 0, int gate_b = 0) {
     constexpr int GEMM_THREADS = 64 * WR * WC;
     constexpr int WM = BM / WR, WN = BN / WC;  // WR x WC waves
     constexpr int MT = WM / 16, NT = WN / 16;
@@ -133,6 +134,10 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
     __shared__ __attribute__((aligned(16))) double Bs[BK * (BN + PAD)];
 
     const int batch = blockIdx.z;
+    if (gate != nullptr) {  // device-side "run only if" (nbx_gemm_gated)
+        const int g = gate[batch];
+        if (g != gate_a && g != gate_b) return;
+    }
     A += (int64_t)batch * stride_a;
     if (!B_GEN) B += (int64_t)batch * stride_b;
     C += (int64_t)batch * stride_c;
@@ -311,12 +316,12 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <int BM, int BN, int WR, int WC>
 void launch(nbx_ctx* ctx, bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, int64_t lda,
             int64_t sa, const double* B, int64_t ldb, int64_t sb, double beta, double* C, int64_t ldc, int64_t sc,
-            int batch, int vec_a, int vec_b) {
+            int batch, int vec_a, int vec_b, const int* gate, int gate_a, int gate_b) {
     dim3 grid((unsigned)nbx_cdiv(N, BN), (unsigned)nbx_cdiv(M, BM), (unsigned)batch);
     dim3 block(64 * WR * WC);
 #define NBX_GEMM_GO(AK, BKC)                                                                                       \
     hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, WR, WC, AK, BKC>), grid, block, 0, ctx->stream, M, N, K, alpha, A, \
-                       lda, sa, B, ldb, sb, beta, C, ldc, sc, vec_a, vec_b)
+                       lda, sa, B, ldb, sb, beta, C, ldc, sc, vec_a, vec_b, GemmGen{}, gate, gate_a, gate_b)
     if (a_kc) {
         if (b_kc) NBX_GEMM_GO(true, true);
         else NBX_GEMM_GO(true, false);
@@ -394,7 +399,18 @@ extern "C" int nbx_gemm(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int
                         double alpha, const double* d_a, int64_t lda, int64_t stride_a, const double* d_b,
                         int64_t ldb, int64_t stride_b, double beta, double* d_c, int64_t ldc,
                         int64_t stride_c, int64_t batch) {
+    return nbx_gemm_gated(ctx, trans_a, trans_b, m, n, k, alpha, d_a, lda, stride_a, d_b, ldb, stride_b, beta, d_c, ldc,
+                          stride_c, batch, nullptr, 0, 0);
+}
+
+// nbx_gemm whose workgroups of batch entry b return at once unless d_gate[b] is gate_a or gate_b
+// when the kernel starts (d_gate == nullptr: plain nbx_gemm).  Any shape, any kernel.
+int nbx_gemm_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t n, int64_t k, double alpha,
+                   const double* d_a, int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb, int64_t stride_b,
+                   double beta, double* d_c, int64_t ldc, int64_t stride_c, int64_t batch, const int* d_gate,
+                   int gate_a, int gate_b) {
     NBX_CHECK_ARG(ctx != nullptr);
+    NBX_CHECK_ARG(d_gate == nullptr || batch <= 65535);
     NBX_CHECK_ARG(trans_a == 'N' || trans_a == 'T' || trans_a == 'n' || trans_a == 't');
     NBX_CHECK_ARG(trans_b == 'N' || trans_b == 'T' || trans_b == 'n' || trans_b == 't');
     NBX_CHECK_ARG(m >= 0 && n >= 0 && k >= 0 && batch >= 0);
@@ -426,8 +442,8 @@ extern "C" int nbx_gemm(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int
             dim3 grid((unsigned)nbx_cdiv(n, 16), (unsigned)nbx_cdiv(m, 16), (unsigned)nb);
 #define NBX_GEMM_SMALL(AK, BKC)                                                                               \
     hipLaunchKernelGGL((gemm_small_kernel<AK, BKC>), grid, dim3(64), 0, ctx->stream, (int)m, (int)n, (int)k, \
-                       alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c, nullptr, 0, 0, nullptr, nullptr, \
-                       1 << 30)
+                       alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c, d_gate, gate_a, gate_b, nullptr, \
+                       nullptr, 1 << 30)
             if (a_kc) {
                 if (b_kc) NBX_GEMM_SMALL(true, true);
                 else NBX_GEMM_SMALL(true, false);
@@ -438,13 +454,13 @@ extern "C" int nbx_gemm(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int
 #undef NBX_GEMM_SMALL
         } else if (tiles128 >= 512 && m > 64 && n > 64) {
             launch<128, 128, 2, 4>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
-                             beta, C, ldc, stride_c, nb, vec_a, vec_b);
+                             beta, C, ldc, stride_c, nb, vec_a, vec_b, d_gate, gate_a, gate_b);
         } else if (m <= 32 || n <= 32) {
             launch<32, 32, 2, 2>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
-                           beta, C, ldc, stride_c, nb, vec_a, vec_b);
+                           beta, C, ldc, stride_c, nb, vec_a, vec_b, d_gate, gate_a, gate_b);
         } else {
             launch<64, 64, 2, 2>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
-                           beta, C, ldc, stride_c, nb, vec_a, vec_b);
+                           beta, C, ldc, stride_c, nb, vec_a, vec_b, d_gate, gate_a, gate_b);
         }
         NBX_LAUNCH_CHECK();
     }

@@ -278,7 +278,7 @@ def eig_quality(a, w, v):
     return res, orth
 
 
-@pytest.mark.parametrize("n", [12, 37, 148, 196])
+@pytest.mark.parametrize("n", [12, 37, 148, 196, 230, 300])
 @pytest.mark.parametrize("eps", [1e-9, 1e-6, 1e-4])
 def test_eigh_warm_refinement_accepts_small_perturbations(be, n, eps):
     """Warm start from the eigenvectors of a nearby matrix: the GEMM refinement (status >= 1000)
@@ -343,6 +343,20 @@ def test_eigh_warm_refinement_falls_back(be):
     # (4) garbage start: not orthonormal at all
     w, v = be.eigh(be.asarray(a), check=True, v0=be.asarray(rnd(323, n, n)))
     assert be.last_eigh_sweeps[0] < 1000
+    # (5) N > 196 (fallback = the tridiagonal pipeline, chosen after reading the status back)
+    n2 = 230
+    a2 = symm(324, n2)
+    _, v2 = be.eigh(be.asarray(a2))
+    a2b = a2 + 0.5 * symm(325, n2)
+    w, v = be.eigh(be.asarray(a2b), check=True, v0=v2)
+    assert be.last_eigh_sweeps[0] < 1000
+    res, orth = eig_quality(a2b, be.to_host(w), be.to_host(v))
+    assert res < 1e-10 and orth < 1e-11, (res, orth)
+    np.testing.assert_allclose(be.to_host(w), np.linalg.eigvalsh(a2b), rtol=0, atol=1e-10)
+    # queued-iteration knob: results do not depend on it
+    for iters in (0, 1, 2):
+        w_i, v_i = be.eigh(be.asarray(a_big), v0=v0, refine_iters=iters)
+        np.testing.assert_allclose(be.to_host(w_i), np.linalg.eigvalsh(a_big), rtol=0, atol=1e-11)
 
 
 @pytest.mark.parametrize("n", [196, 197, 230, 431])
