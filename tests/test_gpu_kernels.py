@@ -464,3 +464,48 @@ def test_spinorb_scatter_golden(be):
     np.testing.assert_array_equal(be.to_host(h2), g["h2"])
     h1, h2 = be.spinorb_scatter(be.asarray(g["one_body"]), be.asarray(g["two_body"]), 1e-8, 0.5)
     np.testing.assert_array_equal(be.to_host(h2), 0.5 * g["h2"])
+
+
+def test_c_abi_error_behaviour(be):
+    """No exception crosses the C boundary: bad arguments, short workspaces and unsupported sizes
+    come back as negative NBX_E_* codes with a message (surfaced as NbxError by the binding); a
+    failed call leaves the context usable."""
+    import ctypes
+
+    from nbed_amd import _nbx
+
+    lib, ctx = be.lib, be.ctx
+    n = 8
+    a = be.asarray(symm(400, n))
+    dm = be.asarray(np.stack([symm(401, n), symm(402, n)]))
+    eri = be.synth_eri(n)
+    out = be.empty((3, n, n))
+    null = ctypes.c_void_p(0)
+
+    def code(name, *args):
+        return getattr(lib, name)(ctx, *args)
+
+    # null pointers / bad shapes -> NBX_E_INVALID
+    assert code("nbx_jk_dense", n, 0, n, null, be._p(dm), 2, be._p(out), null, 0) == -1
+    assert code("nbx_jk_dense", n, 0, n + 1, be._p(eri), be._p(dm), 2, be._p(out), null, 0) == -1
+    assert code("nbx_jk_dense", n, 0, n, be._p(eri), be._p(dm), 3, be._p(out), null, 0) == -1
+    assert code("nbx_gemm", b"X", b"N", n, n, n, 1.0, be._p(a), n, 0, be._p(a), n, 0, 0.0, be._p(out), n, 0, 1) == -1
+    assert code("nbx_gemm", b"N", b"N", n, n, n, 1.0, be._p(a), n - 1, 0, be._p(a), n, 0, 0.0, be._p(out), n, 0, 1) == -1
+    assert code("nbx_diis_update", 16, 6, 7, 1, be._p(a), be._p(a), be._p(a), be._p(a), be._p(a), be._p(a)) == -1
+    assert code("nbx_diis_update", 16, 17, 0, 1, be._p(a), be._p(a), be._p(a), be._p(a), be._p(a), be._p(a)) == -1
+    assert code("nbx_eigh_warm_ex", n, 1, be._p(a), null, be._p(out), be._p(out), be._p(out), 1 << 30, -1) == -1
+    # workspace too small -> NBX_E_NOMEM, with the required size in the message
+    need = lib.nbx_jk_dense_worksize(n, n, 2)
+    work = be.torch.empty(need, dtype=be.torch.uint8, device=be.device)
+    assert code("nbx_jk_dense", n, 0, n, be._p(eri), be._p(dm), 2, be._p(out), be._p(work), need - 1) == -3
+    assert str(need).encode() in lib.nbx_last_error()
+    assert code("nbx_eigh", n, 1, be._p(a), be._p(out), be._p(out), be._p(work), 8) == -3
+    # sizes the kernels do not cover -> NBX_E_UNSUPPORTED (never a silent wrong answer)
+    assert code("nbx_jk_synth", 2050, 0, 1, 1, be._p(dm), 2, be._p(out), be._p(work), need) in (-5, -3)
+    # the binding raises, and the context still works afterwards
+    with pytest.raises(_nbx.NbxError) as err:
+        be._call("nbx_axpby", 4, 1.0, null, 0.0, null)
+    assert err.value.code == -1
+    jk = be.jk(eri, dm)
+    eri_h = synth.eri_dense(n)
+    np.testing.assert_allclose(be.to_host(jk)[0], np.einsum("pqrs,rs->pq", eri_h, be.to_host(dm).sum(0)), atol=1e-13)
