@@ -235,6 +235,18 @@ int nbx_ao2mo(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c1
               int64_t i0, int64_t i1, const double* d_c2, int64_t n2, const double* d_c3,
               int64_t n3, const double* d_c4, int64_t n4, double* d_out, void* d_work,
               size_t work_bytes);
+/* Two tensors that share their first two MO indices in one pass,
+ *   out [i-i0,j,k,l] = (C1 C2 | C3 C4),   out2[i-i0,j,k,l] = (C1 C2 | C5 C6):
+ * quarters 1 and 2 are computed once.  The unrestricted Hamiltonian needs (aa|aa), (bb|bb) and
+ * (aa|bb) (nbed/ham_builder.py:127-133, three independent ao2mo.kernel calls in the reference):
+ * (aa|aa) and (aa|bb) are such a pair, which removes a third of the quarter-1 work.  Results are
+ * bitwise those of two nbx_ao2mo calls.  d_out2 == NULL: plain nbx_ao2mo.                    */
+size_t nbx_ao2mo_pair_worksize(int64_t nao, int64_t ni, int64_t n2, int64_t n3, int64_t n5);
+int nbx_ao2mo_pair(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c1, int64_t n1,
+                   int64_t i0, int64_t i1, const double* d_c2, int64_t n2, const double* d_c3,
+                   int64_t n3, const double* d_c4, int64_t n4, double* d_out, const double* d_c5,
+                   int64_t n5, const double* d_c6, int64_t n6, double* d_out2, void* d_work,
+                   size_t work_bytes);
 /* Streamed transform of the synthetic (pq|rs) of nbx_synth_eri, never stored (N_AO = 2000):
  *   out[i,j,k,l] = sum_{r in [r0,r1)} sum_pqs C1[p,i] C2[q,j] C3[r,k] C4[s,l] (pq|rs)
  * Same four quarter transforms / flop count as nbx_ao2mo.  [r0,r1) is the multi-GPU shard axis:

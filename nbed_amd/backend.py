@@ -410,6 +410,20 @@ class HipBackend:
                    self._p(c4), n4, self._p(out), self._p(work), work.numel())
         return out
 
+    def ao2mo_pair(self, eri, c1, c2, c3, c4, c5, c6, i0: int = 0, i1: int | None = None):
+        """((C1 C2|C3 C4), (C1 C2|C5 C6)) in one pass: quarters 1-2 shared (nbx_ao2mo_pair)."""
+        nao = c1.shape[0]
+        n1, n2, n3, n4, n5, n6 = (c.shape[1] for c in (c1, c2, c3, c4, c5, c6))
+        i1 = n1 if i1 is None else i1
+        nbytes = self.lib.nbx_ao2mo_pair_worksize(nao, i1 - i0, n2, n3, n5)
+        work = self._workspace("ao2mo", nbytes)
+        out = self.empty((i1 - i0, n2, n3, n4))
+        out2 = self.empty((i1 - i0, n2, n5, n6))
+        self._call("nbx_ao2mo_pair", nao, self._p(eri), self._p(c1), n1, i0, i1, self._p(c2), n2, self._p(c3), n3,
+                   self._p(c4), n4, self._p(out), self._p(c5), n5, self._p(c6), n6, self._p(out2), self._p(work),
+                   work.numel())
+        return out, out2
+
     def ao2mo_synth(self, nao: int, c1, c2, c3, c4, r0: int = 0, r1: int | None = None, seed: int = 20250829):
         """Streamed transform of the synthetic ERI (never stored); partial sum over r in [r0,r1)."""
         n1, n2, n3, n4 = c1.shape[1], c2.shape[1], c3.shape[1], c4.shape[1]

@@ -40,7 +40,22 @@ extern "C" size_t nbx_ao2mo_worksize(int64_t nao, int64_t ni, int64_t n2, int64_
 extern "C" int nbx_ao2mo(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c1, int64_t n1,
                          int64_t i0, int64_t i1, const double* d_c2, int64_t n2, const double* d_c3, int64_t n3,
                          const double* d_c4, int64_t n4, double* d_out, void* d_work, size_t work_bytes) {
+    return nbx_ao2mo_pair(ctx, nao, d_eri, d_c1, n1, i0, i1, d_c2, n2, d_c3, n3, d_c4, n4, d_out, nullptr, 0, nullptr,
+                          0, nullptr, d_work, work_bytes);
+}
+
+extern "C" size_t nbx_ao2mo_pair_worksize(int64_t nao, int64_t ni, int64_t n2, int64_t n3, int64_t n5) {
+    return nbx_ao2mo_worksize(nao, ni, n2, n3 > n5 ? n3 : n5, 0);
+}
+
+extern "C" int nbx_ao2mo_pair(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c1, int64_t n1,
+                              int64_t i0, int64_t i1, const double* d_c2, int64_t n2, const double* d_c3, int64_t n3,
+                              const double* d_c4, int64_t n4, double* d_out, const double* d_c5, int64_t n5,
+                              const double* d_c6, int64_t n6, double* d_out2, void* d_work, size_t work_bytes) {
+    const bool pair = d_out2 != nullptr;
     NBX_CHECK_ARG(ctx && d_eri && d_c1 && d_c2 && d_c3 && d_c4 && d_out);
+    NBX_CHECK_ARG(!pair || (d_c5 && d_c6 && n5 > 0 && n6 > 0));
+    if (!pair) n5 = 0;
     NBX_CHECK_ARG(nao > 0 && n1 > 0 && n2 > 0 && n3 > 0 && n4 > 0);
     NBX_CHECK_ARG(i0 >= 0 && i1 >= i0 && i1 <= n1);
     const int64_t ni = i1 - i0;
@@ -50,12 +65,12 @@ extern "C" int nbx_ao2mo(nbx_ctx* ctx, int64_t nao, const double* d_eri, const d
         nbx_set_error("nbx_ao2mo: dense path needs N^3 < 2^31 (N=%lld)", (long long)N);
         return NBX_E_UNSUPPORTED;
     }
-    const size_t need = nbx_ao2mo_worksize(N, ni, n2, n3, n4);
+    const size_t need = nbx_ao2mo_pair_worksize(N, ni, n2, n3, n5);
     if (d_work == nullptr || work_bytes < need) {
         nbx_set_error("nbx_ao2mo: workspace %zu < %zu bytes", work_bytes, need);
         return NBX_E_NOMEM;
     }
-    const Ao2moPlan p = plan(N, ni, n2, n3);
+    const Ao2moPlan p = plan(N, ni, n2, n3 > n5 ? n3 : n5);
     double* bufA = static_cast<double*>(d_work);
     double* bufB = reinterpret_cast<double*>(static_cast<char*>(d_work) + align256(p.a_doubles * sizeof(double)));
     const int64_t N2 = N * N, N3 = N2 * N;
@@ -75,5 +90,9 @@ extern "C" int nbx_ao2mo(nbx_ctx* ctx, int64_t nao, const double* d_eri, const d
     if (rc != NBX_OK) return rc;
     // Q4
     rc = nbx_gemm(ctx, 'N', 'N', ni * n2 * n3, n4, N, 1.0, bufA, N, 0, d_c4, n4, 0, 0.0, d_out, n4, 0, 1);
-    return rc;
+    if (rc != NBX_OK || !pair) return rc;
+    // second tensor of the pair: quarters 3 and 4 again from the X2 still sitting in bufB
+    rc = nbx_gemm(ctx, 'T', 'N', n5, N, N, 1.0, d_c5, n5, 0, bufB, N, N2, 0.0, bufA, N, n5 * N, ni * n2);
+    if (rc != NBX_OK) return rc;
+    return nbx_gemm(ctx, 'N', 'N', ni * n2 * n5, n6, N, 1.0, bufA, N, 0, d_c6, n6, 0, 0.0, d_out2, n6, 0, 1);
 }

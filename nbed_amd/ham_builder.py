@@ -96,9 +96,10 @@ class HamiltonianBuilder:
             raise HamiltonianBuilderError("Must localize the same number of alpha and beta orbitals.")
         eri = _ao_eri_device(self.scf_method, be)
         ca, cb = be.asarray(np.asarray(c[0])), be.asarray(np.asarray(c[1]))
-        aaaa = self._transform(eri, ca, ca, ca, ca)
+        # (aa|aa) and (aa|bb) share their first two quarter transforms -- a third of the quarter-1
+        # work of the reference's three independent ao2mo.kernel calls; bitwise the same results
+        aaaa, aabb = self._transform_pair(eri, ca, ca, cb)
         bbbb = self._transform(eri, cb, cb, cb, cb)
-        aabb = self._transform(eri, ca, ca, cb, cb)
         n = n_a
         # (bb|aa)[i,j,k,l] = (aa|bb)[k,l,i,j]: a transpose of the (n^2 x n^2) matrix
         bbaa = be.transpose(aabb.reshape(n * n, n * n)).reshape(n, n, n, n)
@@ -114,6 +115,17 @@ class HamiltonianBuilder:
             return self.be.ao2mo(eri, c1, c2, c3, c4)
         slab = self.be.ao2mo(eri, c1, c2, c3, c4, i0=sh.lo, i1=sh.hi)
         return sh.all_gather(self.be, slab, axis=0)
+
+    def _transform_pair(self, eri, c12, c34, c56):
+        """((c12 c12|c34 c34), (c12 c12|c56 c56)), quarters 1-2 computed once; sharded like _transform."""
+        be = self.be
+        if not hasattr(be, "ao2mo_pair"):
+            return self._transform(eri, c12, c12, c34, c34), self._transform(eri, c12, c12, c56, c56)
+        sh = self.shards
+        if sh is None or sh.world == 1:
+            return be.ao2mo_pair(eri, c12, c12, c34, c34, c56, c56)
+        s1, s2 = be.ao2mo_pair(eri, c12, c12, c34, c34, c56, c56, i0=sh.lo, i1=sh.hi)
+        return sh.all_gather(be, s1, axis=0), sh.all_gather(be, s2, axis=0)
 
     @property
     def _two_body_integrals(self) -> np.ndarray:

@@ -466,6 +466,24 @@ def test_spinorb_scatter_golden(be):
     np.testing.assert_array_equal(be.to_host(h2), 0.5 * g["h2"])
 
 
+def test_ao2mo_pair_equals_two_transforms_bitwise(be):
+    """(aa|aa) and (aa|bb) in one pass (quarters 1-2 shared) are bit for bit the two separate
+    transforms, full and per outer-index slab (the multi-GPU shard axis)."""
+    n, na = 24, 14
+    eri = be.synth_eri(n)
+    ca, cb = be.asarray(rnd(410, n, na)), be.asarray(rnd(411, n, na))
+    aa = be.to_host(be.ao2mo(eri, ca, ca, ca, ca))
+    ab = be.to_host(be.ao2mo(eri, ca, ca, cb, cb))
+    p1, p2 = be.ao2mo_pair(eri, ca, ca, ca, ca, cb, cb)
+    np.testing.assert_array_equal(be.to_host(p1), aa)
+    np.testing.assert_array_equal(be.to_host(p2), ab)
+    s1, s2 = be.ao2mo_pair(eri, ca, ca, ca, ca, cb, cb, i0=3, i1=9)
+    np.testing.assert_array_equal(be.to_host(s1), aa[3:9])
+    np.testing.assert_array_equal(be.to_host(s2), ab[3:9])
+    ref = hamiltonian.ao2mo_full(synth.eri_dense(n), be.to_host(ca), be.to_host(ca), be.to_host(cb), be.to_host(cb))
+    np.testing.assert_allclose(ab, ref, rtol=0, atol=1e-12)
+
+
 def test_c_abi_error_behaviour(be):
     """No exception crosses the C boundary: bad arguments, short workspaces and unsupported sizes
     come back as negative NBX_E_* codes with a message (surfaced as NbxError by the binding); a
