@@ -254,7 +254,8 @@ def main():
         NB, nb_act, rsl, jrows = 2000, 128, args.n2000_rslabs, 4
         cb = be.asarray(np.ascontiguousarray(synth.sym_matrix(7, NB)[:, :nb_act]))
         r0 = rank * rsl
-        be.ao2mo_synth(NB, cb, cb, cb, cb, r0=r0, r1=r0 + 1)  # first-touch of the workspaces
+        cb2 = be.asarray(np.ascontiguousarray(synth.sym_matrix(6, NB)[:, :nb_act]))
+        be.ao2mo_synth_pair(NB, cb, cb, cb, cb, cb2, cb2, r0=r0, r1=r0 + 1)  # first-touch of the workspaces
         barrier()
         be.profile(True, slots=[_nbx.PROF_AO2MO_Q1])
         be.profile_reset()
@@ -263,6 +264,13 @@ def main():
         barrier()
         dts = time.perf_counter() - t2
         be.profile(False)
+        # the three spin blocks of an unrestricted Hamiltonian: (aa|aa)+(aa|bb) as a pair, then (bb|bb)
+        t2 = time.perf_counter()
+        p_aa, p_ab = be.ao2mo_synth_pair(NB, cb, cb, cb, cb, cb2, cb2, r0=r0, r1=r0 + rsl)
+        p_bb = be.ao2mo_synth(NB, cb2, cb2, cb2, cb2, r0=r0, r1=r0 + rsl)
+        barrier()
+        dt3 = time.perf_counter() - t2
+        del p_aa, p_ab, p_bb
         q1s_ms, q1s_cnt = be.profile_read(_nbx.PROF_AO2MO_Q1)
         allreduce_ms = None
         if distributed:
@@ -280,9 +288,9 @@ def main():
         barrier()
         dtj = time.perf_counter() - t4
         if world > 1:
-            tm = torch.tensor([dts, dtj], dtype=torch.float64, device=be.device)
+            tm = torch.tensor([dts, dtj, dt3], dtype=torch.float64, device=be.device)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            dts, dtj = float(tm[0].item()), float(tm[1].item())
+            dts, dtj, dt3 = float(tm[0].item()), float(tm[1].item()), float(tm[2].item())
         fl_slab = transform_flops(NB, nb_act) / NB  # one r-slab of one spin block
         q1_flops_slab = 2.0 * nb_act * NB**3
         n2000 = {
@@ -292,11 +300,13 @@ def main():
             "transform_quarter1_tflops_per_gpu": (q1_flops_slab * rsl / (q1s_ms * 1e-3) / 1e12) if q1s_cnt else None,
             "transform_frac_of_fp64_mfma_peak": fl_slab * rsl / dts / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             "projected_full_spin_block_s": dts * NB / (rsl * world),
+            "uhf_three_blocks_reference_count_tflops": 3 * fl_slab * rsl * world / dt3 / 1e12,
+            "projected_full_uhf_three_blocks_s": dt3 * NB / (rsl * world),
             "final_allreduce_ms": allreduce_ms,
             "jk_gintegrals_per_s": jrows * world * float(NB) ** 3 / dtj / 1e9,
             "projected_full_jk_build_s": dtj * NB / (jrows * world),
         }
-        del part, dmb, cb
+        del part, dmb, cb, cb2
         be.release_workspaces()
 
     # ---------------- CPU baseline (rank 0, N=1 only): the oracle on the host cores

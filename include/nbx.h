@@ -252,6 +252,15 @@ int nbx_ao2mo_pair(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double*
  * Same four quarter transforms / flop count as nbx_ao2mo.  [r0,r1) is the multi-GPU shard axis:
  * the partial tensors of the ranks are SUMMED (all-reduce) by the host.                       */
 size_t nbx_ao2mo_synth_worksize(int64_t nao, int64_t n1, int64_t n2, int64_t n3, int64_t n4);
+/* ... and the pair form of it (see nbx_ao2mo_pair): out2 = (C1 C2|C5 C6) beside out, the generated
+ * integrals and quarters 1-2 shared.  d_out2 == NULL: nbx_ao2mo_synth.                        */
+size_t nbx_ao2mo_synth_pair_worksize(int64_t nao, int64_t n1, int64_t n2, int64_t n3, int64_t n4,
+                                     int64_t n5, int64_t n6);
+int nbx_ao2mo_synth_pair(nbx_ctx* ctx, int64_t nao, uint64_t seed, int64_t r0, int64_t r1,
+                         const double* d_c1, int64_t n1, const double* d_c2, int64_t n2,
+                         const double* d_c3, int64_t n3, const double* d_c4, int64_t n4, double* d_out,
+                         const double* d_c5, int64_t n5, const double* d_c6, int64_t n6, double* d_out2,
+                         void* d_work, size_t work_bytes);
 int nbx_ao2mo_synth(nbx_ctx* ctx, int64_t nao, uint64_t seed, int64_t r0, int64_t r1, const double* d_c1,
                     int64_t n1, const double* d_c2, int64_t n2, const double* d_c3, int64_t n3,
                     const double* d_c4, int64_t n4, double* d_out, void* d_work, size_t work_bytes);

@@ -435,6 +435,19 @@ class HipBackend:
                    self._p(c4), n4, self._p(out), self._p(work), work.numel())
         return out
 
+    def ao2mo_synth_pair(self, nao: int, c1, c2, c3, c4, c5, c6, r0: int = 0, r1: int | None = None,
+                         seed: int = 20250829):
+        """Streamed ((C1 C2|C3 C4), (C1 C2|C5 C6)): integrals and quarters 1-2 generated/computed once."""
+        n1, n2, n3, n4, n5, n6 = (c.shape[1] for c in (c1, c2, c3, c4, c5, c6))
+        r1 = nao if r1 is None else r1
+        nbytes = self.lib.nbx_ao2mo_synth_pair_worksize(nao, n1, n2, n3, n4, n5, n6)
+        work = self._workspace("ao2mo_synth", nbytes)
+        out, out2 = self.empty((n1, n2, n3, n4)), self.empty((n1, n2, n5, n6))
+        self._call("nbx_ao2mo_synth_pair", nao, seed, r0, r1, self._p(c1), n1, self._p(c2), n2, self._p(c3), n3,
+                   self._p(c4), n4, self._p(out), self._p(c5), n5, self._p(c6), n6, self._p(out2), self._p(work),
+                   work.numel())
+        return out, out2
+
     def chem_to_phys(self, x):
         n1, n2, n3, n4 = x.shape
         out = self.empty((n1, n3, n4, n2))

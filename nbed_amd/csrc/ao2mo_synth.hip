@@ -26,10 +26,11 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct SynthPlan {
     int64_t sc, rb;
-    size_t m_off, y_off, z_off, u_off, acc_off, total;
+    size_t m_off, y_off, z_off, u_off, acc_off, u2_off, acc2_off, total;
 };
 
-SynthPlan plan(int64_t N, int64_t n1, int64_t n2, int64_t n3, int64_t n4) {
+// n5, n6 > 0: a second tensor (C1 C2|C5 C6) accumulated beside the first one
+SynthPlan plan(int64_t N, int64_t n1, int64_t n2, int64_t n3, int64_t n4, int64_t n5 = 0, int64_t n6 = 0) {
     SynthPlan p;
     int64_t sc = (int64_t)(4.0e9 / (8.0 * (double)N * (double)n1));  // ~4 GB of quarter-1 output
     if (sc < 1) sc = 1;
@@ -42,6 +43,8 @@ SynthPlan plan(int64_t N, int64_t n1, int64_t n2, int64_t n3, int64_t n4) {
     p.z_off = off; off += align256((size_t)(N * n1 * n2) * sizeof(double));
     p.u_off = off; off += align256((size_t)(p.rb * n4 * n1 * n2) * sizeof(double));
     p.acc_off = off; off += align256((size_t)(n3 * n4 * n1 * n2) * sizeof(double));
+    p.u2_off = off; off += align256((size_t)(p.rb * n6 * n1 * n2) * sizeof(double));
+    p.acc2_off = off; off += align256((size_t)(n5 * n6 * n1 * n2) * sizeof(double));
     p.total = off;
     return p;
 }
@@ -56,11 +59,29 @@ extern "C" size_t nbx_ao2mo_synth_worksize(int64_t nao, int64_t n1, int64_t n2, 
 extern "C" int nbx_ao2mo_synth(nbx_ctx* ctx, int64_t nao, uint64_t seed, int64_t r0, int64_t r1, const double* d_c1,
                                int64_t n1, const double* d_c2, int64_t n2, const double* d_c3, int64_t n3,
                                const double* d_c4, int64_t n4, double* d_out, void* d_work, size_t work_bytes) {
+    return nbx_ao2mo_synth_pair(ctx, nao, seed, r0, r1, d_c1, n1, d_c2, n2, d_c3, n3, d_c4, n4, d_out, nullptr, 0,
+                                nullptr, 0, nullptr, d_work, work_bytes);
+}
+
+extern "C" size_t nbx_ao2mo_synth_pair_worksize(int64_t nao, int64_t n1, int64_t n2, int64_t n3, int64_t n4,
+                                                int64_t n5, int64_t n6) {
+    if (nao <= 0 || n1 <= 0 || n2 <= 0 || n3 <= 0 || n4 <= 0 || n5 < 0 || n6 < 0) return 0;
+    return plan(nao, n1, n2, n3, n4, n5, n6).total;
+}
+
+extern "C" int nbx_ao2mo_synth_pair(nbx_ctx* ctx, int64_t nao, uint64_t seed, int64_t r0, int64_t r1,
+                                    const double* d_c1, int64_t n1, const double* d_c2, int64_t n2, const double* d_c3,
+                                    int64_t n3, const double* d_c4, int64_t n4, double* d_out, const double* d_c5,
+                                    int64_t n5, const double* d_c6, int64_t n6, double* d_out2, void* d_work,
+                                    size_t work_bytes) {
+    const bool pair = d_out2 != nullptr;
     NBX_CHECK_ARG(ctx && d_c1 && d_c2 && d_c3 && d_c4 && d_out);
+    NBX_CHECK_ARG(!pair || (d_c5 && d_c6 && n5 > 0 && n6 > 0));
+    if (!pair) n5 = n6 = 0;
     NBX_CHECK_ARG(nao > 0 && n1 > 0 && n2 > 0 && n3 > 0 && n4 > 0 && r0 >= 0 && r1 >= r0 && r1 <= nao);
     const int64_t N = nao, n12 = n1 * n2;
-    NBX_CHECK_ARG(n4 * n12 < (1ll << 31) && N * N < (1ll << 31));
-    const SynthPlan pl = plan(N, n1, n2, n3, n4);
+    NBX_CHECK_ARG(n4 * n12 < (1ll << 31) && n6 * n12 < (1ll << 31) && N * N < (1ll << 31));
+    const SynthPlan pl = plan(N, n1, n2, n3, n4, n5, n6);
     if (d_work == nullptr || work_bytes < pl.total) {
         nbx_set_error("nbx_ao2mo_synth: workspace %zu < %zu bytes", work_bytes, pl.total);
         return NBX_E_NOMEM;
@@ -70,9 +91,15 @@ extern "C" int nbx_ao2mo_synth(nbx_ctx* ctx, int64_t nao, uint64_t seed, int64_t
     double* Z = reinterpret_cast<double*>(base + pl.z_off);
     double* U = reinterpret_cast<double*>(base + pl.u_off);
     double* acc = reinterpret_cast<double*>(base + pl.acc_off);
+    double* U2 = reinterpret_cast<double*>(base + pl.u2_off);
+    double* acc2 = reinterpret_cast<double*>(base + pl.acc2_off);
     nbx_prof_scope prof_all(ctx, NBX_PROF_AO2MO);
     int rc = nbx_memset(ctx, acc, 0, (size_t)(n3 * n4 * n12) * sizeof(double));
     if (rc != NBX_OK) return rc;
+    if (pair) {
+        rc = nbx_memset(ctx, acc2, 0, (size_t)(n5 * n6 * n12) * sizeof(double));
+        if (rc != NBX_OK) return rc;
+    }
     int64_t rb0 = r0;  // first r of the U block being filled
     for (int64_t r = r0; r < r1; ++r) {
         for (int64_t s0 = 0; s0 < N; s0 += pl.sc) {
@@ -88,15 +115,26 @@ extern "C" int nbx_ao2mo_synth(nbx_ctx* ctx, int64_t nao, uint64_t seed, int64_t
         // U[r - rb0] (n4 x n12) = C4^T (n4 x N) . Z (N x n12)
         rc = nbx_gemm(ctx, 'T', 'N', n4, n12, N, 1.0, d_c4, n4, 0, Z, n12, 0, 0.0, U + (r - rb0) * n4 * n12, n12, 0, 1);
         if (rc != NBX_OK) return rc;
+        if (pair) {  // the second tensor reuses Z: only quarters 3 and 4 are repeated
+            rc = nbx_gemm(ctx, 'T', 'N', n6, n12, N, 1.0, d_c6, n6, 0, Z, n12, 0, 0.0, U2 + (r - rb0) * n6 * n12, n12, 0, 1);
+            if (rc != NBX_OK) return rc;
+        }
         if (r - rb0 + 1 == pl.rb || r + 1 == r1) {
             const int64_t nr = r - rb0 + 1;
             // acc (n3 x n4 n12) += C3[rb0:rb0+nr]^T (n3 x nr) . U (nr x n4 n12)
             rc = nbx_gemm(ctx, 'T', 'N', n3, n4 * n12, nr, 1.0, d_c3 + rb0 * n3, n3, 0, U, n4 * n12, 0, 1.0, acc,
                           n4 * n12, 0, 1);
             if (rc != NBX_OK) return rc;
+            if (pair) {
+                rc = nbx_gemm(ctx, 'T', 'N', n5, n6 * n12, nr, 1.0, d_c5 + rb0 * n5, n5, 0, U2, n6 * n12, 0, 1.0, acc2,
+                              n6 * n12, 0, 1);
+                if (rc != NBX_OK) return rc;
+            }
             rb0 = r + 1;
         }
     }
     // acc[(k,l)][(i,j)] -> out[(i,j)][(k,l)]
-    return nbx_transpose(ctx, n3 * n4, n12, 1, acc, d_out);
+    rc = nbx_transpose(ctx, n3 * n4, n12, 1, acc, d_out);
+    if (rc != NBX_OK || !pair) return rc;
+    return nbx_transpose(ctx, n5 * n6, n12, 1, acc2, d_out2);
 }

@@ -484,6 +484,16 @@ def test_ao2mo_pair_equals_two_transforms_bitwise(be):
     np.testing.assert_allclose(ab, ref, rtol=0, atol=1e-12)
 
 
+def test_ao2mo_synth_pair_equals_two_streamed_transforms(be):
+    n, na = 20, 9
+    ca, cb = be.asarray(rnd(412, n, na)), be.asarray(rnd(413, n, na))
+    aa = be.to_host(be.ao2mo_synth(n, ca, ca, ca, ca, r0=2, r1=17))
+    ab = be.to_host(be.ao2mo_synth(n, ca, ca, cb, cb, r0=2, r1=17))
+    p1, p2 = be.ao2mo_synth_pair(n, ca, ca, ca, ca, cb, cb, r0=2, r1=17)
+    np.testing.assert_array_equal(be.to_host(p1), aa)
+    np.testing.assert_array_equal(be.to_host(p2), ab)
+
+
 def test_c_abi_error_behaviour(be):
     """No exception crosses the C boundary: bad arguments, short workspaces and unsupported sizes
     come back as negative NBX_E_* codes with a message (surfaced as NbxError by the binding); a
