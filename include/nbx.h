@@ -247,10 +247,14 @@ int nbx_ao2mo_pair(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double*
                    int64_t n3, const double* d_c4, int64_t n4, double* d_out, const double* d_c5,
                    int64_t n5, const double* d_c6, int64_t n6, double* d_out2, void* d_work,
                    size_t work_bytes);
-/* Streamed transform of the synthetic (pq|rs) of nbx_synth_eri, never stored (N_AO = 2000):
- *   out[i,j,k,l] = sum_{r in [r0,r1)} sum_pqs C1[p,i] C2[q,j] C3[r,k] C4[s,l] (pq|rs)
- * Same four quarter transforms / flop count as nbx_ao2mo.  [r0,r1) is the multi-GPU shard axis:
- * the partial tensors of the ranks are SUMMED (all-reduce) by the host.                       */
+/* Streamed transform of the synthetic (pq|rs) of nbx_synth_eri, never stored (N_AO = 2000).
+ * (pq|rs) = (pq|sr) is used: only the pairs s <= r are generated and half-transformed (the
+ * symmetry PySCF's ao2mo, which the reference calls, uses as well).  The call returns the part
+ * of the sum that belongs to r in [r0,r1), i.e. all pairs (r, s <= r) and their mirror images:
+ *   out[i,j,k,l] = sum_{r in [r0,r1)} sum_{s<=r} sum_pq C1[p,i] C2[q,j] (pq|rs)
+ *                                   (C3[r,k] C4[s,l] + [s<r] C3[s,k] C4[r,l])
+ * [r0,r1) is the multi-GPU shard axis: the partial tensors of the ranks are SUMMED (all-reduce)
+ * by the host; the work of a range grows with r, so equal-work ranges are not equal-length.   */
 size_t nbx_ao2mo_synth_worksize(int64_t nao, int64_t n1, int64_t n2, int64_t n3, int64_t n4);
 /* ... and the pair form of it (see nbx_ao2mo_pair): out2 = (C1 C2|C5 C6) beside out, the generated
  * integrals and quarters 1-2 shared.  d_out2 == NULL: nbx_ao2mo_synth.                        */
