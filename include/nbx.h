@@ -101,6 +101,19 @@ size_t nbx_jk_dense_worksize(int64_t nao, int64_t np, int64_t ndm);
 int nbx_jk_dense(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri,
                  const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes);
 
+/* Symmetric form: (pq|rs) = (qp|rs), so only the tiles q <= p of the slab are read -- half the
+ * bytes of nbx_jk_dense, which is HBM bound (PySCF's libcvhf, which the reference calls, works on
+ * 8-fold packed integrals).  The interface is ADDITIVE over slabs:
+ *   d_jk : out, ((1+ndm), N, N) full-size matrices holding the contribution of slab rows
+ *          p in [p0,p1): all pairs (p, q <= p) and their mirror images; [0] = J, [1+x] = K of
+ *          dm[x].  With p0 = 0, p1 = N they are the result; across GPUs the slabs' outputs are
+ *          summed (all-reduce).  The work of a slab grows with p: equal-work slabs are not
+ *          equal-height.
+ * Sizes the symmetric kernel does not cover (odd N, N > 512) go through nbx_jk_dense inside.  */
+size_t nbx_jk_dense_sym_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm);
+int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri,
+                     const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes);
+
 /* Same contraction with the synthetic (pq|rs) of nbx_synth_eri GENERATED in registers instead of
  * read from HBM (the N_AO = 2000 configuration: a dense tensor would be 128 TB).  Workspace as
  * nbx_jk_dense_worksize().  ALU-bound (one 64-bit counter hash per integral).               */

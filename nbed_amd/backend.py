@@ -182,6 +182,13 @@ class HipBackend:
         dist.all_gather_into_tensor(out, a.contiguous(), group=group)
         return out
 
+    def all_reduce_sum(self, a, group=None):
+        """RCCL all-reduce (sum) in place; every rank ends with the same bits."""
+        import torch.distributed as dist
+
+        dist.all_reduce(a, op=dist.ReduceOp.SUM, group=group)
+        return a
+
     def unstack_concat(self, stacked, axis: int, n: int):
         """(world, ..., chunk, ...) -> (..., world*chunk, ...)[:n] along ``axis``."""
         world = stacked.shape[0]
@@ -208,6 +215,20 @@ class HipBackend:
         work = self._workspace("jk", nbytes)
         out = self.empty((1 + ndm, p1 - p0, nao))
         self._call("nbx_jk_dense", nao, p0, p1, self._p(eri), self._p(dm3), ndm, self._p(out), self._p(work),
+                   work.numel())
+        return out
+
+    def jk_sym(self, eri, dm, p0: int = 0, p1: int | None = None):
+        """(1+ndm, N, N) full-size J/K contributions of slab rows [p0,p1) (nbx_jk_dense_sym: only the
+        tiles q <= p are read); with the whole tensor they are J and K, across slabs they add up."""
+        nao = dm.shape[-1]
+        p1 = nao if p1 is None else p1
+        dm3 = dm.reshape(-1, nao, nao)
+        ndm = dm3.shape[0]
+        nbytes = self.lib.nbx_jk_dense_sym_worksize(nao, p0, p1, ndm)
+        work = self._workspace("jk", nbytes)
+        out = self.empty((1 + ndm, nao, nao))
+        self._call("nbx_jk_dense_sym", nao, p0, p1, self._p(eri), self._p(dm3), ndm, self._p(out), self._p(work),
                    work.numel())
         return out
 

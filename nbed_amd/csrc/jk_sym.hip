@@ -1,0 +1,401 @@
+// libnbx: dense J/K contraction that reads every (pq| tile ONCE FOR BOTH (p,q) AND (q,p)
+// (include/nbx.h "J/K contraction, symmetric form").
+//
+//   (pq|rs) = (qp|rs): the N x N tile of (p,q) is the tile of (q,p).  Only the tiles q <= p are
+//   streamed -- half the bytes of jk.hip's kernel, which is HBM bound -- and each one feeds
+//       J_pq = J_qp = sum_ab T_ab Dtot_ab
+//       K^x_pb += sum_a T_ab D^x_qa                (row p: stays in registers while p is fixed)
+//       K^x_qb += sum_a T_ab D^x_pa   (q < p)      (row q: one partial row per tile)
+//   PySCF's own J/K (libcvhf, which the reference calls) works on 8-fold packed integrals; this is
+//   the part of that symmetry a streaming kernel gets for free.
+//
+// Work distribution as in jk.hip: persistent workgroups, one per occupancy slot, each owning an
+// equal contiguous range of the triangular tile sequence T(p,q) = p(p+1)/2 + q; 16-byte
+// non-temporal loads contiguous over the workgroup; thread t always sees the same column pair.
+// Everything is summed in a fixed order (bitwise reproducible):
+//   kpart1[w][slot][x][b]   row-p partials of workgroup w (flushed when its range crosses a row)
+//   kpart2[q][p_local][x][b] row-q partial of tile (p,q), reduced over p by jk_sym_reduce_kernel
+// The slab interface is additive: rows p in [p0,p1) of the tensor give PARTIAL full-size J and K
+// matrices; the sum over slabs (an all-reduce across GPUs) is the result.
+#include "nbx_common.h"
+
+namespace {
+
+constexpr int JS_THREADS = 256;
+// Tiles in flight per workgroup (QB) and the waves per SIMD the register budget is held to.  The
+// row-q accumulators cost 4 VGPRs per tile and spin on top of the plain kernel's: QB = 4 fits
+// 3 waves/SIMD (157 VGPRs), QB = 2 fits 4 (101).  Measured: QB = 2 wins for short rows
+// (N = 148: 0.389 vs 0.403 ms), QB = 4 for long ones (N = 256: 2.89 vs 3.07 ms).
+constexpr int js_waves(int qb) { return qb <= 2 ? 4 : 3; }
+constexpr int JS_CUS = 256;
+constexpr size_t JS_LDS_PER_CU = 160 * 1024;
+
+__device__ __forceinline__ void fma2(double2& acc, double s, double2 v) {
+    acc.x = fma(s, v.x, acc.x);
+    acc.y = fma(s, v.y, acc.y);
+}
+__device__ __forceinline__ double dot2(double acc, double2 a, double2 b) { return fma(a.y, b.y, fma(a.x, b.x, acc)); }
+__device__ __forceinline__ double2 ldnt(const double* p) {
+    typedef double nbx_d2 __attribute__((ext_vector_type(2)));
+    const nbx_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nbx_d2*>(p));
+    return make_double2(t.x, t.y);
+}
+
+__host__ __device__ __forceinline__ int64_t tri_index(int64_t p, int64_t q) { return p * (p + 1) / 2 + q; }
+// row of the triangular index T: largest p with p(p+1)/2 <= T
+__host__ __device__ __forceinline__ int tri_row(int64_t T) {
+    int64_t p = (int64_t)((sqrt(8.0 * (double)T + 1.0) - 1.0) * 0.5);
+    while (p * (p + 1) / 2 > T) --p;
+    while ((p + 1) * (p + 2) / 2 <= T) ++p;
+    return (int)p;
+}
+
+// One group of NQ tiles (p, q .. q+NQ-1): rows a = row0, row0 + rstep, ... of every tile.
+//   dsh[(x*(QB+1) + j)*N + a] = D^x[q+j][a] (j < QB), D^x[p][a] (j == QB)
+template <int NQ, int NDM, int QB>
+__device__ __forceinline__ void js_group(const double* __restrict__ tile0, int64_t n2, const double* __restrict__ dtot,
+                                         const double* dsh, int N, int row0, int rstep, int col,
+                                         double (&jacc)[QB], double2 (&kacc1)[NDM], double2 (&kacc2)[NDM][QB]) {
+    int a = row0;
+    for (; a + rstep < N; a += 2 * rstep) {
+        const int64_t o0 = (int64_t)a * N + col;
+        const int64_t o1 = o0 + (int64_t)rstep * N;
+        double2 t0[NQ], t1[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            t0[j] = ldnt(tile0 + j * n2 + o0);
+            t1[j] = ldnt(tile0 + j * n2 + o1);
+        }
+        const double2 d0 = *reinterpret_cast<const double2*>(dtot + o0);
+        const double2 d1 = *reinterpret_cast<const double2*>(dtot + o1);
+        double dp0[NDM], dp1[NDM];
+#pragma unroll
+        for (int x = 0; x < NDM; ++x) {
+            dp0[x] = dsh[(x * (QB + 1) + QB) * N + a];
+            dp1[x] = dsh[(x * (QB + 1) + QB) * N + a + rstep];
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            jacc[j] = dot2(jacc[j], t0[j], d0);
+            jacc[j] = dot2(jacc[j], t1[j], d1);
+#pragma unroll
+            for (int x = 0; x < NDM; ++x) {
+                fma2(kacc1[x], dsh[(x * (QB + 1) + j) * N + a], t0[j]);
+                fma2(kacc1[x], dsh[(x * (QB + 1) + j) * N + a + rstep], t1[j]);
+                fma2(kacc2[x][j], dp0[x], t0[j]);
+                fma2(kacc2[x][j], dp1[x], t1[j]);
+            }
+        }
+    }
+    if (a < N) {
+        const int64_t o0 = (int64_t)a * N + col;
+        double2 t0[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) t0[j] = ldnt(tile0 + j * n2 + o0);
+        const double2 d0 = *reinterpret_cast<const double2*>(dtot + o0);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            jacc[j] = dot2(jacc[j], t0[j], d0);
+#pragma unroll
+            for (int x = 0; x < NDM; ++x) {
+                fma2(kacc1[x], dsh[(x * (QB + 1) + j) * N + a], t0[j]);
+                fma2(kacc2[x][j], dsh[(x * (QB + 1) + QB) * N + a], t0[j]);
+            }
+        }
+    }
+}
+
+template <int NDM, int QB>
+__global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(js_waves(QB), js_waves(QB))))
+void jk_sym_kernel(const double* __restrict__ eri, const double* __restrict__ dm, const double* __restrict__ dtot,
+                   double* __restrict__ jfull, double* __restrict__ kpart1, double* __restrict__ kpart2, int N,
+                   int p0, int np, int64_t t_begin, int64_t t_end, int L, int S) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // smem: dsh[NDM*(QB+1)*N] | kred[R*NDM*QB*N] | red[17]
+    double* dsh = smem;
+    double* kred = dsh + NDM * (QB + 1) * N;
+
+    int64_t T = t_begin + (int64_t)blockIdx.x * L;
+    const int64_t T_end = min(t_end, T + L);
+    if (T >= T_end) return;  // uniform for the whole workgroup
+    int p = tri_row(T);
+    int q = (int)(T - tri_index(p, 0));
+    const int p_first = p;
+
+    const int CX = N / 2;  // column pairs per row (N even)
+    const int R = max(1, JS_THREADS / CX);
+    const int rowg = threadIdx.x / CX;
+    const int cx = threadIdx.x - rowg * CX;
+    const bool active = rowg < R;
+    const int col = cx * 2;
+    double* red = kred + (size_t)R * NDM * QB * N;
+
+    double2 kacc1[NDM];
+#pragma unroll
+    for (int x = 0; x < NDM; ++x) kacc1[x] = make_double2(0.0, 0.0);
+    const int64_t n2 = (int64_t)N * N;
+
+    // row-p partials: reduce the R row groups through LDS, store, clear
+    auto flush1 = [&](int prow) {
+        double* kout = kpart1 + ((int64_t)blockIdx.x * S + (prow - p_first)) * NDM * N;
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int x = 0; x < NDM; ++x)
+                *reinterpret_cast<double2*>(kred + ((size_t)rowg * NDM + x) * N + col) = kacc1[x];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NDM * N; i += JS_THREADS) {
+            const int x = i / N, b = i - x * N;
+            double tot = 0.0;
+            for (int g = 0; g < R; ++g) tot += kred[((size_t)g * NDM + x) * N + b];
+            kout[i] = tot;
+        }
+#pragma unroll
+        for (int x = 0; x < NDM; ++x) kacc1[x] = make_double2(0.0, 0.0);
+    };
+
+    int p_cur = p_first;
+    while (T < T_end) {
+        if (p != p_cur) {
+            flush1(p_cur);
+            p_cur = p;
+        }
+        const int nq = (int)min((int64_t)min(QB, p - q + 1), T_end - T);
+        __syncthreads();  // previous group's dsh / kred reads are done
+        for (int i = threadIdx.x; i < NDM * (QB + 1) * N; i += JS_THREADS) {
+            const int x = i / ((QB + 1) * N);
+            const int rem = i - x * (QB + 1) * N;
+            const int j = rem / N;
+            const int a = rem - j * N;
+            const int row = (j == QB) ? p : q + j;
+            dsh[i] = (j == QB || j < nq) ? dm[(int64_t)x * n2 + (int64_t)row * N + a] : 0.0;
+        }
+        __syncthreads();
+        double jacc[QB];
+        double2 kacc2[NDM][QB];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            jacc[j] = 0.0;
+#pragma unroll
+            for (int x = 0; x < NDM; ++x) kacc2[x][j] = make_double2(0.0, 0.0);
+        }
+        if (active) {
+            const double* tile0 = eri + ((int64_t)(p - p0) * N + q) * n2;
+            if (nq == QB) {
+                js_group<QB, NDM, QB>(tile0, n2, dtot, dsh, N, rowg, R, col, jacc, kacc1, kacc2);
+            } else if (QB >= 4 && nq == 3) {
+                js_group<(QB >= 4 ? 3 : 1), NDM, QB>(tile0, n2, dtot, dsh, N, rowg, R, col, jacc, kacc1, kacc2);
+            } else if (QB >= 3 && nq == 2) {
+                js_group<(QB >= 3 ? 2 : 1), NDM, QB>(tile0, n2, dtot, dsh, N, rowg, R, col, jacc, kacc1, kacc2);
+            } else {
+                js_group<1, NDM, QB>(tile0, n2, dtot, dsh, N, rowg, R, col, jacc, kacc1, kacc2);
+            }
+        }
+        // J_{p,q+j} = J_{q+j,p}
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const double tot = nbx_block_sum(jacc[j], red);
+            if (threadIdx.x == 0 && j < nq) {
+                jfull[(int64_t)p * N + q + j] = tot;
+                jfull[(int64_t)(q + j) * N + p] = tot;
+            }
+        }
+        // row-(q+j) partials of the tiles below the diagonal
+        if (active) {
+#pragma unroll
+            for (int x = 0; x < NDM; ++x)
+#pragma unroll
+                for (int j = 0; j < QB; ++j)
+                    *reinterpret_cast<double2*>(kred + (((size_t)rowg * NDM + x) * QB + j) * N + col) = kacc2[x][j];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NDM * QB * N; i += JS_THREADS) {
+            const int x = i / (QB * N);
+            const int rem = i - x * QB * N;
+            const int j = rem / N;
+            const int b = rem - j * N;
+            if (j < nq && q + j < p) {
+                double tot = 0.0;
+                for (int g = 0; g < R; ++g) tot += kred[(((size_t)g * NDM + x) * QB + j) * N + b];
+                kpart2[(((int64_t)(q + j) * np + (p - p0)) * NDM + x) * N + b] = tot;
+            }
+        }
+        T += nq;
+        q += nq;
+        if (q > p) {
+            ++p;
+            q = 0;
+        }
+    }
+    flush1(p_cur);
+}
+
+// out[(1+x)][row][b] for all N rows = (row in slab ? sum of its kpart1 partials : 0)
+//                                     + sum over slab rows p > row of kpart2[row][p - p0][x][b]
+// grid (N, NDM), 256 threads = 4 row-chunks x 64 column lanes; fixed summation order.
+__global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __restrict__ kpart1,
+                                                            const double* __restrict__ kpart2,
+                                                            double* __restrict__ kout, int N, int p0, int np, int ndm,
+                                                            int64_t t_begin, int L, int S) {
+    __shared__ double part[4][64];
+    const int row = blockIdx.x, x = blockIdx.y;
+    const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+    const int pl_lo = max(0, row + 1 - p0);  // first local p with global p > row
+    for (int b0 = 0; b0 < N; b0 += 64) {
+        const int b = b0 + lane;
+        double t = 0.0;
+        if (b < N) {
+            for (int pl = pl_lo + chunk; pl < np; pl += 4)
+                t += kpart2[(((int64_t)row * np + pl) * ndm + x) * N + b];
+        }
+        part[chunk][lane] = t;
+        __syncthreads();
+        if (chunk == 0 && b < N) {
+            double tot = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+            if (row >= p0 && row < p0 + np) {
+                const int64_t w_lo = (tri_index(row, 0) - t_begin) / L, w_hi = (tri_index(row, row) - t_begin) / L;
+                for (int64_t w = w_lo; w <= w_hi; ++w) {
+                    const int slot = row - tri_row(t_begin + w * L);
+                    tot += kpart1[((w * S + slot) * ndm + x) * N + b];
+                }
+            }
+            kout[((int64_t)x * N + row) * N + b] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void js_dtot_kernel(const double* __restrict__ dm, double* __restrict__ dtot, int64_t n2, int ndm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    double t = dm[i];
+    for (int x = 1; x < ndm; ++x) t += dm[x * n2 + i];
+    dtot[i] = t;
+}
+
+struct JsPlan {
+    int wgs, L, S, R;
+    size_t lds_bytes, dtot_off, k1_off, k2_off, total;
+};
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int js_qb(int64_t N) { return N <= 192 ? 2 : 4; }
+
+JsPlan js_plan(int64_t N, int64_t p0, int64_t np, int64_t ndm) {
+    JsPlan pl;
+    const int QB = js_qb(N);
+    const int64_t CX = N / 2;
+    pl.R = (int)(JS_THREADS / CX > 0 ? JS_THREADS / CX : 1);
+    pl.lds_bytes = (size_t)(ndm * (QB + 1) * N + (int64_t)pl.R * ndm * QB * N + 17) * sizeof(double);
+    int64_t per_cu = js_waves(QB);  // workgroups of 4 waves per CU = waves per SIMD
+    const int64_t by_lds = (int64_t)(JS_LDS_PER_CU / (pl.lds_bytes + 256));
+    if (per_cu > by_lds) per_cu = by_lds > 0 ? by_lds : 1;
+    const int64_t slots = JS_CUS * per_cu;
+    const int64_t ntiles = tri_index(p0 + np, 0) - tri_index(p0, 0);
+    int64_t L = nbx_cdiv(ntiles, slots);
+    if (L < 1) L = 1;
+    pl.L = (int)L;
+    pl.wgs = (int)nbx_cdiv(ntiles, L);
+    pl.S = (int)sqrt(2.0 * (double)L) + 3;
+    size_t off = 0;
+    pl.dtot_off = off; off += align256((size_t)(N * N) * sizeof(double));
+    pl.k1_off = off; off += align256((size_t)((int64_t)pl.wgs * pl.S * ndm * N) * sizeof(double));
+    pl.k2_off = off; off += align256((size_t)(N * np * ndm * N) * sizeof(double));
+    pl.total = off;
+    return pl;
+}
+
+}  // namespace
+
+bool nbx_jk_sym_supported(int64_t nao) { return nao >= 2 && nao % 2 == 0 && nao / 2 <= JS_THREADS; }
+
+extern "C" size_t nbx_jk_dense_sym_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm) {
+    if (nao <= 0 || p0 < 0 || p1 < p0 || p1 > nao || ndm <= 0) return 0;
+    if (!nbx_jk_sym_supported(nao))  // falls back to the plain kernel + a scatter into full-size matrices
+        return align256(nbx_jk_dense_worksize(nao, p1 - p0, ndm)) +
+               align256((size_t)((1 + ndm) * (p1 - p0) * nao) * sizeof(double));
+    return js_plan(nao, p0, p1 - p0, ndm).total;
+}
+
+namespace {
+// fallback path: rows [p0,p1) of a slab result into the full-size (1+ndm, N, N) partial matrices
+__global__ void js_scatter_rows_kernel(const double* __restrict__ slab, double* __restrict__ full, int N, int p0, int np,
+                                       int nmat) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nmat * N * N) return;
+    const int b = (int)(i % N);
+    const int row = (int)((i / N) % N);
+    const int m = (int)(i / ((int64_t)N * N));
+    full[i] = (row >= p0 && row < p0 + np) ? slab[((int64_t)m * np + (row - p0)) * N + b] : 0.0;
+}
+}  // namespace
+
+extern "C" int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri,
+                                const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes) {
+    NBX_CHECK_ARG(ctx && d_eri && d_dm && d_jk);
+    NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
+    NBX_CHECK_ARG(ndm == 1 || ndm == 2);
+    const int64_t np = p1 - p0, N = nao, n2 = N * N;
+    const size_t need = nbx_jk_dense_sym_worksize(nao, p0, p1, ndm);
+    if (d_work == nullptr || work_bytes < need) {
+        nbx_set_error("nbx_jk_dense_sym: workspace %zu < %zu bytes", work_bytes, need);
+        return NBX_E_NOMEM;
+    }
+    NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_eri) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
+    if (np == 0) return nbx_memset(ctx, d_jk, 0, (size_t)((1 + ndm) * n2) * sizeof(double));
+    if (!nbx_jk_sym_supported(nao)) {
+        char* base = static_cast<char*>(d_work);
+        const size_t w0 = align256(nbx_jk_dense_worksize(nao, np, ndm));
+        double* slab = reinterpret_cast<double*>(base + w0);
+        int rc = nbx_jk_dense(ctx, nao, p0, p1, d_eri, d_dm, ndm, slab, base, w0);
+        if (rc != NBX_OK) return rc;
+        const int64_t tot = (1 + ndm) * n2;
+        hipLaunchKernelGGL(js_scatter_rows_kernel, dim3((unsigned)nbx_cdiv(tot, 256)), dim3(256), 0, ctx->stream, slab,
+                           d_jk, (int)N, (int)p0, (int)np, (int)(1 + ndm));
+        NBX_LAUNCH_CHECK();
+        return NBX_OK;
+    }
+    const JsPlan pl = js_plan(N, p0, np, ndm);
+    char* base = static_cast<char*>(d_work);
+    double* dtot = reinterpret_cast<double*>(base + pl.dtot_off);
+    double* k1 = reinterpret_cast<double*>(base + pl.k1_off);
+    double* k2 = reinterpret_cast<double*>(base + pl.k2_off);
+    if (np < N) {  // J entries this slab does not own must read as zero
+        const int rc = nbx_memset(ctx, d_jk, 0, (size_t)n2 * sizeof(double));
+        if (rc != NBX_OK) return rc;
+    }
+    hipLaunchKernelGGL(js_dtot_kernel, dim3((unsigned)nbx_cdiv(n2, 256)), dim3(256), 0, ctx->stream, d_dm, dtot, n2,
+                       (int)ndm);
+    NBX_LAUNCH_CHECK();
+    const int64_t t_begin = tri_index(p0, 0), t_end = tri_index(p1, 0);
+    {
+        nbx_prof_scope prof(ctx, NBX_PROF_JK_DENSE);
+#define NBX_JS_GO(NDM_, QB_)                                                                                          \
+    do {                                                                                                              \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jk_sym_kernel<NDM_, QB_>),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL((jk_sym_kernel<NDM_, QB_>), dim3((unsigned)pl.wgs), dim3(JS_THREADS), pl.lds_bytes,        \
+                           ctx->stream, d_eri, d_dm, dtot, d_jk, k1, k2, (int)N, (int)p0, (int)np, t_begin, t_end,    \
+                           pl.L, pl.S);                                                                               \
+    } while (0)
+        if (js_qb(N) == 2) {
+            if (ndm == 2) NBX_JS_GO(2, 2);
+            else NBX_JS_GO(1, 2);
+        } else {
+            if (ndm == 2) NBX_JS_GO(2, 4);
+            else NBX_JS_GO(1, 4);
+        }
+#undef NBX_JS_GO
+    }
+    NBX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm), dim3(256), 0, ctx->stream, k1, k2,
+                       d_jk + n2, (int)N, (int)p0, (int)np, (int)ndm, t_begin, pl.L, pl.S);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}

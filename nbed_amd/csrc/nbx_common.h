@@ -64,6 +64,9 @@ int nbx_gemm_small_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, in
                          const int* d_gate, int gate_a, int gate_b, const double* d_b2 = nullptr,
                          double* d_c2 = nullptr);
 
+// jk_sym.hip
+bool nbx_jk_sym_supported(int64_t nao);
+
 // eigh_refine.hip
 bool nbx_eigh_refine_supported(int64_t n, int64_t batch);
 size_t nbx_eigh_refine_worksize(int64_t n, int64_t batch);

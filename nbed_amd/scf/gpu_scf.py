@@ -124,9 +124,14 @@ class _GpuSCF:
         return self._x_d
 
     def jk_device(self, dm_d):
-        """(1+ndm, N, N) on device: J(sum dm), K(dm[x]); all-gathers row slabs if sharded."""
-        slab = self.be.jk(self.eri_device(), dm_d, self.shards.lo, self.shards.hi)
-        return self.shards.all_gather(self.be, slab, axis=1)
+        """(1+ndm, N, N) on device: J(sum dm), K(dm[x]).  The symmetric kernel reads only the tiles
+        q <= p of this rank's slab and returns full-size partial matrices, summed over ranks by one
+        all-reduce; a backend without it computes plain row slabs and all-gathers them."""
+        be, sh = self.be, self.shards
+        if hasattr(be, "jk_sym"):
+            return sh.all_reduce(be, be.jk_sym(self.eri_device(), dm_d, sh.lo, sh.hi))
+        slab = be.jk(self.eri_device(), dm_d, sh.lo, sh.hi)
+        return sh.all_gather(be, slab, axis=1)
 
     def _eig_device(self, fock_d, warm: dict | None = None):
         """Generalised eigenproblem F C = S C e through Loewdin orthogonalisation.  ``warm``: a
