@@ -30,7 +30,12 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     be = OracleBackend()
     pr = synth.problem(n, nocc, n_env)
-    sh = Shards.from_env(n)
+    mode = sys.argv[3] if len(sys.argv) > 3 else "uniform"
+    if mode == "triangular":  # the symmetric J/K path: equal-work slabs, full-size partials, all-reduce
+        be.use_sym = True
+        sh = Shards(n, world, rank, balance="triangular")
+    else:
+        sh = Shards.from_env(n)
     assert (sh.world, sh.rank) == (world, rank)
     eri_slab = synth.eri_block(n, sh.lo, sh.hi)  # this rank's rows only
     mf = GpuUHF(Mole(n, pr["nelec"]), pr["S"], pr["hcore"], eri_slab, backend=be, shards=sh)

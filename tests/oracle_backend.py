@@ -78,6 +78,12 @@ class OracleBackend:
         dist.all_gather(pieces, a.contiguous(), group=group)
         return torch.stack(pieces)
 
+    def all_reduce_sum(self, a, group=None):
+        import torch.distributed as dist
+
+        dist.all_reduce(a, op=dist.ReduceOp.SUM, group=group)
+        return a
+
     def unstack_concat(self, stacked, axis, n):
         world = stacked.shape[0]
         moved = stacked.movedim(0, axis)
@@ -102,6 +108,35 @@ class OracleBackend:
         out[0] = np.einsum("pqrs,rs->pq", e, dtot)
         for x in range(d.shape[0]):
             out[1 + x] = np.einsum("pqrs,qs->pr", e, d[x])
+        return self.asarray(out)
+
+    use_sym = False
+
+    def __getattribute__(self, name):
+        if name == "jk_sym" and not object.__getattribute__(self, "use_sym"):
+            raise AttributeError(name)
+        return object.__getattribute__(self, name)
+
+    def jk_sym(self, eri, dm, p0=0, p1=None):
+        """Additive slab form (nbx_jk_dense_sym): full-size J/K contributions of the pairs
+        (p in [p0,p1), q <= p) and their mirror images.  Enabled per instance (``use_sym``)."""
+        self._count("jk")
+        nao = dm.shape[-1]
+        p1 = nao if p1 is None else p1
+        e = self._np(eri)
+        d = self._np(dm).reshape(-1, nao, nao)
+        dtot = d.sum(axis=0)
+        out = np.zeros((1 + d.shape[0], nao, nao))
+        for p in range(p0, p1):
+            for q in range(p + 1):
+                t = e[p - p0, q]
+                j = float(np.sum(t * dtot))
+                out[0, p, q] = j
+                out[0, q, p] = j
+                for x in range(d.shape[0]):
+                    out[1 + x, p] += d[x, q] @ t
+                    if q < p:
+                        out[1 + x, q] += d[x, p] @ t
         return self.asarray(out)
 
     def gemm(self, a, b, ta="N", tb="N", alpha=1.0, beta=0.0, out=None):

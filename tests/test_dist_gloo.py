@@ -21,11 +21,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(tmp_path, world, n):
+def run_world(tmp_path, world, n, mode="uniform"):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(HERE / "_dist_worker.py"),
-           str(tmp_path), str(n)]
+           str(tmp_path), str(n), mode]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return [dict(np.load(tmp_path / f"rank{k}.npz")) for k in range(world)]
@@ -40,6 +40,35 @@ def test_shards_partition():
         for a, b in zip(bounds[:-1], bounds[1:]):
             assert a.hi == b.lo
         assert all(b.bounds(b.rank) == (b.lo, b.hi) for b in bounds)
+
+
+def test_triangular_shards_balance_the_symmetric_jk_work():
+    for n, world in [(10, 2), (10, 3), (148, 8), (7, 8)]:
+        bounds = [Shards(n, world, r, balance="triangular") for r in range(world)]
+        assert bounds[0].lo == 0 and bounds[-1].hi == n
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            assert a.hi == b.lo
+        assert all(b.bounds(b.rank) == (b.lo, b.hi) for b in bounds)
+    work = [sum(p + 1 for p in range(b.lo, b.hi)) for b in (Shards(148, 8, r, balance="triangular") for r in range(8))]
+    assert max(work) < 1.1 * (148 * 149 / 2 / 8)  # within 10 % of the ideal share
+    with pytest.raises(ValueError):
+        Shards(10, 2, 0, balance="nope")
+
+
+def test_symmetric_jk_slabs_all_reduce_match_single_rank(tmp_path):
+    """World-2 gloo run of the additive-slab J/K path (equal-work slabs, one all-reduce)."""
+    n = 10
+    (tmp_path / "w1").mkdir()
+    (tmp_path / "w2").mkdir()
+    single = run_world(tmp_path / "w1", 1, n)[0]
+    ranks = run_world(tmp_path / "w2", 2, n, mode="triangular")
+    assert (int(ranks[0]["lo"]), int(ranks[0]["hi"])) != (0, 5)  # not the uniform cut
+    for r in ranks:
+        assert bool(r["conv"])
+        for key in ("e", "d", "hz", "h1", "h2"):
+            np.testing.assert_allclose(r[key], single[key], rtol=0, atol=1e-10, err_msg=key)
+    for key in ("e", "d", "h2"):
+        np.testing.assert_array_equal(ranks[0][key], ranks[1][key])
 
 
 @pytest.mark.parametrize("world", [2, 3])
