@@ -233,7 +233,8 @@ void jk_sym_kernel(const double* __restrict__ eri, const double* __restrict__ dm
 
 // out[(1+x)][row][b] for all N rows = (row in slab ? sum of its kpart1 partials : 0)
 //                                     + sum over slab rows p > row of kpart2[row][p - p0][x][b]
-// grid (N, NDM), 256 threads = 4 row-chunks x 64 column lanes; fixed summation order.
+// grid (N, NDM, ceil(N/64)); 256 threads = 4 row-chunks x 64 column lanes, 8 independent loads in
+// flight per thread; fixed summation order.
 __global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __restrict__ kpart1,
                                                             const double* __restrict__ kpart2,
                                                             double* __restrict__ kout, int N, int p0, int np, int ndm,
@@ -241,28 +242,34 @@ __global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __rest
     __shared__ double part[4][64];
     const int row = blockIdx.x, x = blockIdx.y;
     const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+    const int b = blockIdx.z * 64 + lane;
     const int pl_lo = max(0, row + 1 - p0);  // first local p with global p > row
-    for (int b0 = 0; b0 < N; b0 += 64) {
-        const int b = b0 + lane;
-        double t = 0.0;
-        if (b < N) {
-            for (int pl = pl_lo + chunk; pl < np; pl += 4)
-                t += kpart2[(((int64_t)row * np + pl) * ndm + x) * N + b];
+    double t = 0.0;
+    if (b < N) {
+        const double* src = kpart2 + (((int64_t)row * np) * ndm + x) * N + b;
+        const int64_t stride = (int64_t)ndm * N;
+        int pl = pl_lo + chunk;
+        for (; pl + 28 < np; pl += 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(pl + 4 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
         }
-        part[chunk][lane] = t;
-        __syncthreads();
-        if (chunk == 0 && b < N) {
-            double tot = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-            if (row >= p0 && row < p0 + np) {
-                const int64_t w_lo = (tri_index(row, 0) - t_begin) / L, w_hi = (tri_index(row, row) - t_begin) / L;
-                for (int64_t w = w_lo; w <= w_hi; ++w) {
-                    const int slot = row - tri_row(t_begin + w * L);
-                    tot += kpart1[((w * S + slot) * ndm + x) * N + b];
-                }
+        for (; pl < np; pl += 4) t += src[pl * stride];
+    }
+    part[chunk][lane] = t;
+    __syncthreads();
+    if (chunk == 0 && b < N) {
+        double tot = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        if (row >= p0 && row < p0 + np) {
+            const int64_t w_lo = (tri_index(row, 0) - t_begin) / L, w_hi = (tri_index(row, row) - t_begin) / L;
+            for (int64_t w = w_lo; w <= w_hi; ++w) {
+                const int slot = row - tri_row(t_begin + w * L);
+                tot += kpart1[((w * S + slot) * ndm + x) * N + b];
             }
-            kout[((int64_t)x * N + row) * N + b] = tot;
         }
-        __syncthreads();
+        kout[((int64_t)x * N + row) * N + b] = tot;
     }
 }
 
@@ -394,7 +401,8 @@ extern "C" int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p
 #undef NBX_JS_GO
     }
     NBX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm), dim3(256), 0, ctx->stream, k1, k2,
+    hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
+                       ctx->stream, k1, k2,
                        d_jk + n2, (int)N, (int)p0, (int)np, (int)ndm, t_begin, pl.L, pl.S);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
