@@ -77,11 +77,6 @@ int nbx_ctx_destroy(nbx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)nbx_profile_reset(ctx);
-    for (auto& sc : ctx->sched) {
-        if (sc.d_blocks) (void)hipFree(sc.d_blocks);
-        if (sc.d_pairs) (void)hipFree(sc.d_pairs);
-        if (sc.d_pq) (void)hipFree(sc.d_pq);
-    }
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);

@@ -20,14 +20,6 @@ struct nbx_prof_slot {
     int64_t count = 0;
 };
 
-// Round-robin Jacobi schedule tables of one (even) matrix order, device resident (eigh_lds.hip)
-struct nbx_sched {
-    int np;
-    void* d_blocks;  // ushort4 [steps][m(m-1)/2]: packed-LDS indices of each 2x2 block
-    void* d_pairs;   // ushort4 [steps][m]: packed indices of (pp, qq, pq)
-    void* d_pq;      // ushort2 [steps][m]: the pair (p, q)
-};
-
 struct nbx_ctx {
     int device;
     hipStream_t stream;
@@ -39,7 +31,6 @@ struct nbx_ctx {
     bool profiling = false;
     unsigned prof_mask = ~0u;
     nbx_prof_slot prof[NBX_PROF_SLOTS];
-    std::vector<nbx_sched> sched;
 };
 
 // eigh_lds.hip

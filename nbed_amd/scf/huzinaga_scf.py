@@ -167,18 +167,12 @@ def huzinaga_scf(
     # fused path: the eigensolver returns ascending eigenvalues, so aufbau occupation
     # (get_occ: the n_alpha / n_beta lowest, as the reference's UHF object does) is a fixed
     # vector and the MO energies need not leave the device inside the loop
-    lookahead = fused and (not ks) and nb == 2 and hasattr(be, "huz_cycle_scalars_async")
-    occ_fixed = None
-    if lookahead:
-        occ_fixed = np.zeros((2, s_h.shape[0]))
-        occ_fixed[0, : scf_method.mol.nelec[0]] = 1
-        occ_fixed[1, : scf_method.mol.nelec[1]] = 1
-        occ_fixed_d = be.asarray(occ_fixed)
-    lookahead = lookahead and hasattr(be, "density_occ")
+    lookahead = (fused and (not ks) and nb == 2 and hasattr(be, "huz_cycle_scalars_async")
+                 and hasattr(be, "density_occ"))
 
     def occupations(e_d, c_d):
         if lookahead:
-            return e_d, occ_fixed_d
+            return e_d, None  # density() takes the leading n_alpha / n_beta columns
         e_h = be.to_host(e_d)
         if fused:
             return e_h, scf_method.get_occ(e_h)
