@@ -173,6 +173,17 @@ int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
 int nbx_diis_update(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_t nd,
                     const double* d_x, double* d_xprev, double* d_xs, double* d_es, double* d_h,
                     double* d_coef);
+/* The same step with the error vector supplied by the caller (d_err, n doubles) instead of
+ * x - xprev: pyscf.scf.diis.CDIIS (error S D F - F D S, space 8) behind scf.hf.kernel, which the
+ * mu-shift path runs (nbed/driver.py:533).  d_xprev only receives the extrapolated vector.     */
+int nbx_diis_update_err(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_t nd,
+                        const double* d_x, const double* d_err, double* d_xprev, double* d_xs,
+                        double* d_es, double* d_h, double* d_coef);
+/* d_out[x] = sum_{a >= nocc_x, i < nocc_x} fmo[x][a][i]^2 for the (2,N,N) MO-basis Fock matrix
+ * C^T F C: the squared norm of the orbital gradient PySCF's scf.hf.kernel tests for convergence
+ * (get_grad + norm/sqrt(size), behind nbed/driver.py:533).  Device output, no synchronisation.  */
+int nbx_vo_sumsq(nbx_ctx* ctx, int64_t nao, const double* d_fmo, int64_t nocc_a, int64_t nocc_b,
+                 double* d_out);
 /* y = a*x + b*y over n doubles. */
 int nbx_axpby(nbx_ctx* ctx, int64_t n, double a, const double* d_x, double b, double* d_y);
 /* out = sum_k coef[k] * vecs[k] (k < nvec; vecs[k] = d_vecs + k*stride), DIIS extrapolation

@@ -70,6 +70,8 @@ SIGNATURES = {
     "nbx_huz_cycle_scalars": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, _P, POINTER(c_double)]),
     "nbx_huz_cycle_scalars_dev": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64]),
     "nbx_diis_update": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),
+    "nbx_diis_update_err": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "nbx_vo_sumsq": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P]),
     "nbx_axpby": (c_int, [_P, c_int64, c_double, _P, c_double, _P]),
     "nbx_lincomb": (c_int, [_P, c_int64, c_int64, POINTER(c_double), _P, c_int64, _P]),
     "nbx_dots": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, POINTER(c_double)]),

@@ -41,7 +41,8 @@ def set_backend(backend) -> None:
 class _PendingScalars:
     """A few doubles on their way from HBM to pinned host memory (stream-ordered copy + event)."""
 
-    def __init__(self, torch, d_vals, ntail=0):
+    def __init__(self, torch, d_vals, ntail=0, ncore=4):
+        self._ncore = ncore
         self._host = torch.empty(d_vals.shape, dtype=d_vals.dtype, pin_memory=True)
         self._host.copy_(d_vals, non_blocking=True)
         self._event = torch.cuda.Event()
@@ -52,14 +53,14 @@ class _PendingScalars:
     def get(self) -> np.ndarray:
         self._event.synchronize()
         self._keep = None
-        return self._host.numpy()[:4].copy()
+        return self._host.numpy()[: self._ncore].copy()
 
     def get_extra(self):
         """The appended status words (as ints), or None."""
         self._event.synchronize()
         if not self._ntail:
             return None
-        return self._host.numpy()[4:4 + self._ntail].astype(np.int64)
+        return self._host.numpy()[self._ncore:self._ncore + self._ntail].astype(np.int64)
 
 
 class HipBackend:
@@ -328,11 +329,27 @@ class HipBackend:
                    self._p(hz), self._p(dm), self._p(dm_old), self._p(d_out), self._p(extra), ntail)
         return _PendingScalars(self.torch, d_out, ntail)
 
+    def async_to_host(self, d_vals):
+        """Stream-ordered copy of a small device tensor to pinned memory; ``.get()`` waits for it only."""
+        return _PendingScalars(self.torch, d_vals, 0, ncore=int(d_vals.numel()))
+
     def diis_update(self, space: int, slot: int, nd: int, x, xprev, xs, es, h, coef):
         """Device-resident pyscf.lib.diis.DIIS.update step; ``xprev`` becomes the extrapolated vector."""
         self._call("nbx_diis_update", x.numel(), space, slot, nd, self._p(x), self._p(xprev), self._p(xs),
                    self._p(es), self._p(h), self._p(coef))
         return xprev
+
+    def diis_update_err(self, space: int, slot: int, nd: int, x, err, out, xs, es, h, coef):
+        """pyscf.lib.diis.DIIS.update(x, xerr) on the device (CDIIS); ``out`` receives the extrapolation."""
+        self._call("nbx_diis_update_err", x.numel(), space, slot, nd, self._p(x), self._p(err), self._p(out),
+                   self._p(xs), self._p(es), self._p(h), self._p(coef))
+        return out
+
+    def vo_sumsq(self, fmo, nocc):
+        """Device (2,) tensor: squared Frobenius norm of the virtual-occupied block of each fmo[x]."""
+        out = self.empty(2)
+        self._call("nbx_vo_sumsq", fmo.shape[-1], self._p(fmo), int(nocc[0]), int(nocc[1]), self._p(out))
+        return out
 
     def axpby(self, a: float, x, b: float, y):
         self._call("nbx_axpby", x.numel(), a, self._p(x), b, self._p(y))

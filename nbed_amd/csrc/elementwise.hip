@@ -187,17 +187,17 @@ __global__ void dots_kernel(int64_t n, int nvec, const double* __restrict__ x, c
 constexpr int DIIS_MAX_SPACE = 16;
 constexpr int DIIS_M = DIIS_MAX_SPACE + 1;
 
-// xs[slot] = x, es[slot] = e = x - xprev, partial[blk*nd + k] = sum_i e[i] * es[k][i]
+// xs[slot] = x, es[slot] = e = (err given ? err : x - xprev), partial[blk*nd + k] = sum_i e[i] * es[k][i]
 __global__ void diis_push_kernel(int64_t n, int nd, int slot, const double* __restrict__ x,
-                                 const double* __restrict__ xprev, double* __restrict__ xs,
-                                 double* __restrict__ es, double* __restrict__ partial) {
+                                 const double* __restrict__ xprev, const double* __restrict__ err,
+                                 double* __restrict__ xs, double* __restrict__ es, double* __restrict__ partial) {
     __shared__ double red[17];
     double acc[DIIS_MAX_SPACE];
 #pragma unroll
     for (int k = 0; k < DIIS_MAX_SPACE; ++k) acc[k] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double xv = x[i];
-        const double e = xv - xprev[i];
+        const double e = (err != nullptr) ? err[i] : xv - xprev[i];
         xs[(int64_t)slot * n + i] = xv;
         es[(int64_t)slot * n + i] = e;
 #pragma unroll
@@ -418,6 +418,25 @@ __global__ void transpose_kernel(const double* __restrict__ A, double* __restric
     }
 }
 
+// out[x] = sum over a >= nocc[x], i < nocc[x] of fmo[x][a][i]^2: the squared norm of the
+// virtual-occupied block of the MO-basis Fock matrix (the orbital gradient of PySCF's kernel)
+__global__ void vo_sumsq_kernel(const double* __restrict__ fmo, int N, int nocc_a, int nocc_b,
+                                double* __restrict__ partial) {
+    __shared__ double red[17];
+    const int x = blockIdx.y;
+    const int nocc = x == 0 ? nocc_a : nocc_b;
+    const int nvir = N - nocc;
+    const int64_t total = (int64_t)nvir * nocc;
+    double t = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int a = nocc + (int)(e / nocc), i = (int)(e % nocc);
+        const double v = fmo[((int64_t)x * N + a) * N + i];
+        t = fma(v, v, t);
+    }
+    t = nbx_block_sum(t, red);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * 2 + x] = t;
+}
+
 __global__ void scale_cols_kernel(int64_t rows, int64_t cols, const double* __restrict__ s, double* __restrict__ a) {
     const int64_t b = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -563,19 +582,36 @@ int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
 
 int nbx_diis_update(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_t nd, const double* d_x,
                     double* d_xprev, double* d_xs, double* d_es, double* d_h, double* d_coef) {
+    return nbx_diis_update_err(ctx, n, space, slot, nd, d_x, nullptr, d_xprev, d_xs, d_es, d_h, d_coef);
+}
+
+int nbx_diis_update_err(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_t nd, const double* d_x,
+                        const double* d_err, double* d_xprev, double* d_xs, double* d_es, double* d_h,
+                        double* d_coef) {
     NBX_CHECK_ARG(ctx && d_x && d_xprev && d_xs && d_es && d_h && d_coef && n > 0);
     NBX_CHECK_ARG(space >= 1 && space <= DIIS_MAX_SPACE && slot >= 0 && slot < space && nd >= 1 && nd <= space &&
                   slot < nd);
     const unsigned blocks = grid1d(n, 256, 128);
     NBX_CHECK_ARG((int64_t)blocks * nd <= NBX_SCRATCH_DOUBLES - 64);
     hipLaunchKernelGGL(diis_push_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, (int)nd, (int)slot, d_x,
-                       d_xprev, d_xs, d_es, ctx->d_scratch);
+                       d_xprev, d_err, d_xs, d_es, ctx->d_scratch);
     NBX_LAUNCH_CHECK();
     hipLaunchKernelGGL(diis_solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scratch, (int)blocks, (int)nd,
                        (int)slot, d_h, (int)(space + 1), d_coef);
     NBX_LAUNCH_CHECK();
     hipLaunchKernelGGL(lincomb_dev_kernel, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, n, (int)nd, d_coef, d_xs,
                        n, d_xprev);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+int nbx_vo_sumsq(nbx_ctx* ctx, int64_t nao, const double* d_fmo, int64_t nocc_a, int64_t nocc_b, double* d_out) {
+    NBX_CHECK_ARG(ctx && d_fmo && d_out && nao > 0 && nocc_a >= 0 && nocc_a <= nao && nocc_b >= 0 && nocc_b <= nao);
+    const int blocks = 32;
+    hipLaunchKernelGGL(vo_sumsq_kernel, dim3(blocks, 2), dim3(256), 0, ctx->stream, d_fmo, (int)nao, (int)nocc_a,
+                       (int)nocc_b, ctx->d_scratch);
+    NBX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_scratch, blocks, 2, d_out, 2);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

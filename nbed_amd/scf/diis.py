@@ -95,12 +95,31 @@ class CDIIS:
         self.space = space
         self._fs = []
         self._es = []
+        self._dev = None  # device-resident ring (HIP backend)
+        self._head = 0
+        self._nd = 0
 
     def update(self, dm_d, fock_d):
         be = self.be
         sdf = be.gemm(be.gemm(self.s_d, dm_d), fock_d)  # S D F  (batched over spin)
         err = be.transpose(sdf)
         be.axpby(-1.0, sdf, 1.0, err)  # (SDF)^T - SDF = FDS - SDF
+        if hasattr(be, "diis_update_err"):
+            # one nbx_diis_update_err call: ring slot, Pulay row, solve and extrapolation on the device
+            flat, eflat = fock_d.reshape(-1), err.reshape(-1)
+            if self._dev is None:
+                h = np.zeros((self.space + 1, self.space + 1))
+                h[0, 1:] = h[1:, 0] = 1
+                self._dev = {
+                    "xs": be.empty((self.space, flat.numel())), "es": be.empty((self.space, flat.numel())),
+                    "h": be.asarray(h), "coef": be.zeros(self.space), "out": be.empty(flat.numel()),
+                }
+            slot = self._head % self.space
+            self._head += 1
+            self._nd = min(self._nd + 1, self.space)
+            d = self._dev
+            be.diis_update_err(self.space, slot, self._nd, flat, eflat, d["out"], d["xs"], d["es"], d["h"], d["coef"])
+            return d["out"].reshape(fock_d.shape)  # valid until the next update
         self._fs.append(be.copy(fock_d).reshape(-1))
         self._es.append(err.reshape(-1))
         if len(self._fs) > self.space:

@@ -236,6 +236,10 @@ class GpuUHF(_GpuSCF, UHF):
         from .diis import CDIIS
 
         be = self.be
+        patched = any(k in vars(self) for k in ("get_veff", "get_occ", "make_rdm1", "get_fock"))
+        if not patched and all(hasattr(be, a) for a in ("huz_cycle_scalars_async", "density_occ", "vo_sumsq",
+                                                       "async_to_host")):
+            return self._kernel_device(dm0)
         h1e = np.asarray(self.get_hcore())  # possibly patched by the driver: evaluated once
         if h1e.ndim == 2:
             h1e = np.array((h1e, h1e))
@@ -279,6 +283,93 @@ class GpuUHF(_GpuSCF, UHF):
         self.mo_energy, self.mo_occ = mo_energy, mo_occ
         self.e_tot = e_tot
         self.scf_summary["e1"], self.scf_summary["e2"] = e1, e2
+        return e_tot
+
+    def _kernel_device(self, dm0=None):
+        """The same control flow with nothing in a cycle waiting for the host (HIP backend): CDIIS,
+        energy and orbital-gradient norm are computed on the device, the scalars come back through
+        stream-ordered copies and cycle i is judged after cycle i+1 has been queued (dropped if
+        cycle i had converged); occupations are the fixed aufbau vector because the eigensolver
+        returns ascending eigenvalues.  Same numbers as the synchronous loop."""
+        from .diis import CDIIS
+
+        be = self.be
+        h1e = np.asarray(self.get_hcore())  # possibly patched by the driver: evaluated once
+        if h1e.ndim == 2:
+            h1e = np.array((h1e, h1e))
+        h_d = be.asarray(h1e)
+        n = h1e.shape[-1]
+        nelec = tuple(int(x) for x in self.mol.nelec)
+        zero = be.zeros((2, n, n))
+        gsize = max(sum((n - k) * k for k in nelec), 1)
+        e_nuc = self.energy_nuc()
+        dm_d = be.asarray(self.get_init_guess() if dm0 is None else np.asarray(dm0))
+
+        def build(dm_dev, c_dev=None):
+            """Fock from dm_dev, its energy and (given the orbitals) the gradient norm, all queued."""
+            fock, vhf = be.fock_uhf(h_d, None, self.jk_device(dm_dev))
+            pend_e = be.huz_cycle_scalars_async(h_d, None, vhf, zero, dm_dev, dm_dev)
+            pend_g = None
+            if c_dev is not None:
+                fmo = be.gemm(be.gemm(c_dev, fock, "T", "N"), c_dev)
+                pend_g = be.async_to_host(be.vo_sumsq(fmo, nelec))
+            return fock, vhf, pend_e, pend_g
+
+        def energy(pend_e):
+            return float(pend_e.get()[:2].sum() + e_nuc)
+
+        fock, vhf, pend_e, _ = build(dm_d)
+        last_e = energy(pend_e)  # energy of the starting density
+        diis = CDIIS(be, self._s_d)
+        warm = {}
+        conv_tol_grad = np.sqrt(self.conv_tol)
+        self.converged = False
+        prev = {"dm": dm_d, "fock": fock, "vhf": vhf}
+        pending = final = None
+        e_tot = last_e
+
+        def judge(st):
+            nonlocal last_e, e_tot
+            e_now = energy(st["pend_e"])
+            norm_gorb = float(np.sqrt(st["pend_g"].get().sum()) / np.sqrt(gsize))
+            self.cycles = st["cycle"] + 1
+            ok = abs(e_now - last_e) < self.conv_tol and norm_gorb < conv_tol_grad
+            last_e = e_tot = e_now
+            return ok
+
+        for cycle in range(self.max_cycle):
+            f_use = diis.update(prev["dm"], prev["fock"]) if cycle >= 1 else prev["fock"]
+            e_d, c_d = self._eig_device(f_use, warm)
+            dm_new = be.density_occ(c_d, nelec)
+            fock_new, vhf_new, pe, pg = build(dm_new, c_d)
+            cur = {"cycle": cycle, "dm": dm_new, "fock": fock_new, "vhf": vhf_new, "e": e_d, "c": c_d, "pend_e": pe,
+                   "pend_g": pg}
+            if pending is not None and judge(pending):
+                self.converged, final = True, pending
+                break
+            pending = prev = cur
+        if not self.converged and pending is not None:
+            self.converged = judge(pending)
+            final = pending
+        if final is None:  # max_cycle == 0
+            final = {"dm": dm_d, "fock": fock, "vhf": vhf, "e": None, "c": None}
+        if self.converged:  # one DIIS-free cycle from the converged Fock matrix (conv_check)
+            e_d, c_d = self._eig_device(final["fock"], warm)
+            dm_f = be.density_occ(c_d, nelec)
+            fock_f, vhf_f, pe, _ = build(dm_f)
+            e_tot = energy(pe)
+            final = {"dm": dm_f, "fock": fock_f, "vhf": vhf_f, "e": e_d, "c": c_d}
+        mo_occ = np.zeros((2, n))
+        mo_occ[0, : nelec[0]] = 1
+        mo_occ[1, : nelec[1]] = 1
+        if final["c"] is not None:
+            c_h = be.to_host(final["c"])
+            self.mo_coeff = np.array([_sign_fix(c_h[0]), _sign_fix(c_h[1])])
+            self.mo_energy = be.to_host(final["e"])
+        self.mo_occ = mo_occ
+        self.e_tot = e_tot
+        self.scf_summary["e1"] = float(be.trace_prod(h_d, final["dm"]).sum())
+        self.scf_summary["e2"] = float(0.5 * be.trace_prod(final["vhf"], final["dm"]).sum())
         return e_tot
 
     def _grad_norm(self, c_d, mo_occ, fock_d) -> float:
