@@ -529,6 +529,27 @@ def test_jk_sym_fallback_sizes_and_full_size(be):
     np.testing.assert_array_equal(a[0], a[0].T)  # J is written once per pair: exactly symmetric
 
 
+def test_cdiis_device_and_orbital_gradient_norm(be):
+    """nbx_diis_update_err (CDIIS ring on the device) against the oracle's pyscf.scf.diis.CDIIS
+    restatement over 11 updates (space 8: the ring wraps), and nbx_vo_sumsq against numpy."""
+    from nbed_amd.scf.diis import CDIIS as DeviceCDIIS
+    from oracle.pyscf_like import CDIIS as OracleCDIIS
+
+    n = 21
+    s_h = synth.overlap(n)
+    dev, ref = DeviceCDIIS(be, be.asarray(s_h)), OracleCDIIS()
+    for it in range(11):
+        d = np.stack([symm(440 + 2 * it, n), symm(441 + 2 * it, n)]) * 0.3
+        f = np.stack([symm(470 + 2 * it, n), symm(471 + 2 * it, n)])
+        got = be.to_host(dev.update(be.asarray(d), be.asarray(f)))
+        want = ref.update(s_h, d, f)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * np.max(np.abs(want)), err_msg=f"update {it}")
+    fmo = rnd(499, 2, n, n)
+    nocc = (7, 5)
+    g2 = be.to_host(be.vo_sumsq(be.asarray(fmo), nocc))
+    np.testing.assert_allclose(g2, [np.sum(fmo[x][nocc[x]:, : nocc[x]] ** 2) for x in range(2)], rtol=1e-13)
+
+
 def test_c_abi_error_behaviour(be):
     """No exception crosses the C boundary: bad arguments, short workspaces and unsupported sizes
     come back as negative NBX_E_* codes with a message (surfaced as NbxError by the binding); a
