@@ -53,7 +53,9 @@ extern "C" int nbx_ao2mo_pair(nbx_ctx* ctx, int64_t nao, const double* d_eri, co
                               const double* d_c4, int64_t n4, double* d_out, const double* d_c5, int64_t n5,
                               const double* d_c6, int64_t n6, double* d_out2, void* d_work, size_t work_bytes) {
     const bool pair = d_out2 != nullptr;
-    NBX_CHECK_ARG(ctx && d_eri && d_c1 && d_c2 && d_c3 && d_c4 && d_out);
+    NBX_CHECK_ARG(ctx != nullptr && i0 >= 0 && i1 >= i0);
+    if (i1 == i0) return NBX_OK;  // an empty outer-index slab has no output storage
+    NBX_CHECK_ARG(d_eri && d_c1 && d_c2 && d_c3 && d_c4 && d_out);
     NBX_CHECK_ARG(!pair || (d_c5 && d_c6 && n5 > 0 && n6 > 0));
     if (!pair) n5 = 0;
     NBX_CHECK_ARG(nao > 0 && n1 > 0 && n2 > 0 && n3 > 0 && n4 > 0);

@@ -356,8 +356,9 @@ static void jk_launch(nbx_ctx* ctx, const JkPlan& pl, const double* eri, const d
 
 static int jk_impl(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri, bool gen, uint64_t seed,
                    const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes) {
-    NBX_CHECK_ARG(ctx != nullptr && (gen || d_eri != nullptr) && d_dm != nullptr && d_jk != nullptr);
+    NBX_CHECK_ARG(ctx != nullptr && d_dm != nullptr);
     NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
+    NBX_CHECK_ARG(p0 == p1 || ((gen || d_eri != nullptr) && d_jk != nullptr));  // an empty slab has no storage
     NBX_CHECK_ARG(ndm == 1 || ndm == 2);
     const int64_t np = p1 - p0;
     if (np == 0) return NBX_OK;

@@ -341,8 +341,9 @@ __global__ void js_scatter_rows_kernel(const double* __restrict__ slab, double* 
 
 extern "C" int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri,
                                 const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes) {
-    NBX_CHECK_ARG(ctx && d_eri && d_dm && d_jk);
+    NBX_CHECK_ARG(ctx && d_dm && d_jk);
     NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
+    NBX_CHECK_ARG(d_eri != nullptr || p0 == p1);  // an empty slab has no storage
     NBX_CHECK_ARG(ndm == 1 || ndm == 2);
     const int64_t np = p1 - p0, N = nao, n2 = N * N;
     const size_t need = nbx_jk_dense_sym_worksize(nao, p0, p1, ndm);

@@ -550,6 +550,38 @@ def test_cdiis_device_and_orbital_gradient_norm(be):
     np.testing.assert_allclose(g2, [np.sum(fmo[x][nocc[x]:, : nocc[x]] ** 2) for x in range(2)], rtol=1e-13)
 
 
+def test_degenerate_shapes(be):
+    """Empty slabs, single-element problems and zero inner dimensions through the C ABI."""
+    n = 6
+    eri = be.synth_eri(n)
+    dm = be.asarray(np.stack([symm(500, n), symm(501, n)]))
+    # empty row slab: the additive form contributes zeros, the row-slab form has no rows
+    assert float(be.jk_sym(eri[:0], dm, 3, 3).abs().max()) == 0.0
+    assert be.jk(eri[:0], dm, 3, 3).shape == (3, 0, n)
+    # empty outer-index slab of the transform
+    c = be.asarray(rnd(502, n, 4))
+    assert be.ao2mo(eri, c, c, c, c, i0=2, i1=2).shape == (0, 4, 4, 4)
+    a1, a2 = be.ao2mo_pair(eri, c, c, c, c, c, c, i0=1, i1=1)
+    assert a1.shape == (0, 4, 4, 4) and a2.shape == (0, 4, 4, 4)
+    # 1 x 1 eigenproblem, cold and warm
+    one = be.asarray(np.array([[2.5]]))
+    w, v = be.eigh(one)
+    assert float(w[0]) == 2.5 and abs(abs(float(v[0, 0])) - 1.0) < 1e-15
+    w, v = be.eigh(one, v0=v)
+    assert float(w[0]) == 2.5
+    # k = 0 product: beta * C
+    cm = be.asarray(rnd(503, 5, 7))
+    out = be.gemm(be.asarray(np.zeros((5, 0))), be.asarray(np.zeros((0, 7))), beta=2.0, out=be.copy(cm))
+    np.testing.assert_allclose(be.to_host(out), 2.0 * be.to_host(cm), rtol=0, atol=0)
+    # N = 2 symmetric J/K (one column pair per row)
+    e2 = synth.eri_dense(2)
+    d2 = np.stack([symm(504, 2), symm(505, 2)])
+    vj, vk = get_jk(e2, d2)
+    got = be.to_host(be.jk_sym(be.asarray(e2), be.asarray(d2)))
+    np.testing.assert_allclose(got[0], vj.sum(0), atol=1e-14)
+    np.testing.assert_allclose(got[1:], vk, atol=1e-14)
+
+
 def test_c_abi_error_behaviour(be):
     """No exception crosses the C boundary: bad arguments, short workspaces and unsupported sizes
     come back as negative NBX_E_* codes with a message (surfaced as NbxError by the binding); a
