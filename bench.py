@@ -125,9 +125,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # Rehearsal knob for a one-GPU box: NBED_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses
+        # gloo (RCCL refuses two ranks on one device), to exercise the N > 1 code path end to end.
+        rehearse = os.environ.get("NBED_BENCH_REHEARSE") == "1"
+        dev_index = 0 if rehearse else local_rank
+        torch.cuda.set_device(dev_index)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
 
     from nbed_amd import _nbx
@@ -136,7 +144,7 @@ def main():
     from nbed_amd.scf import GpuUHF, Mole
     from nbed_amd import synth
 
-    be = HipBackend(local_rank if distributed else 0)
+    be = HipBackend(dev_index)
     N, n_act = args.nao, args.nact
     pr = synth.problem(be, N, (args.nocc, args.nocc), args.nenv)
 

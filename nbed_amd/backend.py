@@ -179,9 +179,11 @@ class HipBackend:
         import torch.distributed as dist
 
         world = dist.get_world_size(group)
-        out = self.empty((world,) + tuple(a.shape))
-        dist.all_gather_into_tensor(out, a.contiguous(), group=group)
-        return out
+        a = a.contiguous()
+        # output in the concatenated form (world * n0, ...): the one every backend accepts
+        out = self.empty((world * a.shape[0],) + tuple(a.shape[1:]))
+        dist.all_gather_into_tensor(out, a, group=group)
+        return out.view((world,) + tuple(a.shape))
 
     def all_reduce_sum(self, a, group=None):
         """RCCL all-reduce (sum) in place; every rank ends with the same bits."""
