@@ -291,13 +291,15 @@ def main():
             barrier()
             allreduce_ms = (time.perf_counter() - t3) * 1e3
         dmb = be.asarray(np.stack([synth.sym_matrix(8, NB), synth.sym_matrix(9, NB)]))
-        p0 = rank * jrows
-        be.jk_synth(NB, dmb, p0, p0 + 1)
+        # symmetric form: row p generates the p + 1 tiles q <= p, so rows around N/2 cost the average
+        p0 = NB // 2 - (jrows * world) // 2 + rank * jrows
+        be.jk_synth_sym(NB, dmb, p0, p0 + 1)
         barrier()
         t4 = time.perf_counter()
-        be.jk_synth(NB, dmb, p0, p0 + jrows)
+        be.jk_synth_sym(NB, dmb, p0, p0 + jrows)
         barrier()
         dtj = time.perf_counter() - t4
+        generated = sum((p + 1) for p in range(p0, p0 + jrows)) * float(NB) ** 2
         if world > 1:
             tm = torch.tensor([dts, dtj, dt3], dtype=torch.float64, device=be.device)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -319,7 +321,8 @@ def main():
             "uhf_three_blocks_reference_count_tflops": 3 * fl_slab * rsl * world / dt3 / 1e12,
             "projected_full_uhf_three_blocks_s": dt3 * NB / (rsl * world),
             "final_allreduce_ms": allreduce_ms,
-            "jk_gintegrals_per_s": jrows * world * float(NB) ** 3 / dtj / 1e9,
+            "jk_generated_gintegrals_per_s": generated * world / dtj / 1e9,
+            "jk_full_tensor_equivalent_gintegrals_per_s": jrows * world * float(NB) ** 3 / dtj / 1e9,
             "projected_full_jk_build_s": dtj * NB / (jrows * world),
         }
         del part, dmb, cb, cb2

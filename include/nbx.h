@@ -120,6 +120,13 @@ int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const do
 int nbx_jk_synth(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, uint64_t seed, const double* d_dm,
                  int64_t ndm, double* d_jk, void* d_work, size_t work_bytes);
 
+/* nbx_jk_synth in the additive, symmetric form of nbx_jk_dense_sym: only the tiles q <= p are
+ * generated (half the hash evaluations; the kernel is VALU bound).  Even N <= 2048.  d_jk: out,
+ * ((1+ndm), N, N) full-size contributions of slab rows [p0,p1), summed across slabs by the host. */
+size_t nbx_jk_synth_sym_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm);
+int nbx_jk_synth_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, uint64_t seed,
+                     const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes);
+
 /* ------------------------------------------------------------------ dense products (MFMA fp64)
  * C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b], row-major, op = 'N' or 'T'.
  * Replaces the OpenBLAS dgemm behind numpy matmul/einsum at

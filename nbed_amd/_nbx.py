@@ -61,6 +61,8 @@ SIGNATURES = {
     "nbx_jk_dense": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
     "nbx_jk_dense_sym_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
     "nbx_jk_dense_sym": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
+    "nbx_jk_synth_sym_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "nbx_jk_synth_sym": (c_int, [_P, c_int64, c_int64, c_int64, c_uint64, _P, c_int64, _P, _P, c_size_t]),
     "nbx_jk_synth": (c_int, [_P, c_int64, c_int64, c_int64, c_uint64, _P, c_int64, _P, _P, c_size_t]),
     "nbx_gemm": (c_int, [_P, c_char, c_char, c_int64, c_int64, c_int64, c_double, _P, c_int64, c_int64,
                          _P, c_int64, c_int64, c_double, _P, c_int64, c_int64, c_int64]),

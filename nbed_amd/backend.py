@@ -246,6 +246,19 @@ class HipBackend:
         self._call("nbx_jk_synth", nao, p0, p1, seed, self._p(dm3), ndm, self._p(out), self._p(work), work.numel())
         return out
 
+    def jk_synth_sym(self, nao: int, dm, p0: int = 0, p1: int | None = None, seed: int = 20250829):
+        """Additive symmetric form of jk_synth: (1+ndm, N, N) contributions of slab rows [p0,p1),
+        only the tiles q <= p generated (nbx_jk_synth_sym)."""
+        p1 = nao if p1 is None else p1
+        dm3 = dm.reshape(-1, nao, nao)
+        ndm = dm3.shape[0]
+        nbytes = self.lib.nbx_jk_synth_sym_worksize(nao, p0, p1, ndm)
+        work = self._workspace("jk", nbytes)
+        out = self.empty((1 + ndm, nao, nao))
+        self._call("nbx_jk_synth_sym", nao, p0, p1, seed, self._p(dm3), ndm, self._p(out), self._p(work),
+                   work.numel())
+        return out
+
     # ------------------------------------------------------------------ GEMM
     def gemm(self, a, b, ta: str = "N", tb: str = "N", alpha: float = 1.0, beta: float = 0.0, out=None):
         """op(a) @ op(b) for 2-D operands, or batched over a shared leading axis (3-D)."""

@@ -18,6 +18,7 @@
 // The slab interface is additive: rows p in [p0,p1) of the tensor give PARTIAL full-size J and K
 // matrices; the sum over slabs (an all-reduce across GPUs) is the result.
 #include "nbx_common.h"
+#include "synth_device.h"
 
 namespace {
 
@@ -238,7 +239,7 @@ void jk_sym_kernel(const double* __restrict__ eri, const double* __restrict__ dm
 __global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __restrict__ kpart1,
                                                             const double* __restrict__ kpart2,
                                                             double* __restrict__ kout, int N, int p0, int np, int ndm,
-                                                            int64_t t_begin, int L, int S) {
+                                                            int64_t t_begin, int L, int S, int accumulate) {
     __shared__ double part[4][64];
     const int row = blockIdx.x, x = blockIdx.y;
     const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
@@ -269,8 +270,148 @@ __global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __rest
                 tot += kpart1[((w * S + slot) * ndm + x) * N + b];
             }
         }
-        kout[((int64_t)x * N + row) * N + b] = tot;
+        double* dst = kout + ((int64_t)x * N + row) * N + b;
+        *dst = accumulate ? *dst + tot : tot;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same contraction with the synthetic (pq|rs) of nbx_synth_eri GENERATED in registers (the
+// N_AO = 2000 configuration): with the tiles q <= p only, half the hash evaluations of
+// nbx_jk_synth, which is VALU bound.  One thread owns column pairs c, c + 256, ... (CS of them);
+// the column-segment loop is the outer one, so only the row-p accumulators of all CS segments
+// persist (and nothing needs a cross-thread reduction: a thread sees every row of its columns).
+// The density rows a group needs are staged through LDS in chunks of GS_AC rows.
+constexpr int GS_QB = 4;
+constexpr int GS_AC = 256;
+
+template <int NDM, int CS>
+__global__ __launch_bounds__(JS_THREADS) void jk_synth_sym_kernel(
+    const double* __restrict__ dm, const double* __restrict__ dtot, double* __restrict__ jfull,
+    double* __restrict__ kpart1, double* __restrict__ kpart2, int N, int p0, int np, int64_t t_begin, int64_t t_end,
+    int L, int S, uint64_t seed) {
+    __shared__ double dsh[NDM * (GS_QB + 1) * GS_AC];
+    __shared__ double red[17];
+    int64_t T = t_begin + (int64_t)blockIdx.x * L;
+    const int64_t T_end = min(t_end, T + L);
+    if (T >= T_end) return;  // uniform for the whole workgroup
+    int p = tri_row(T);
+    int q = (int)(T - tri_index(p, 0));
+    const int p_first = p;
+    const int CXp = N / 2;
+    const double scale = 1.0 / (double)N;
+    const int64_t n2 = (int64_t)N * N;
+
+    double2 kacc1[NDM][CS];
+#pragma unroll
+    for (int x = 0; x < NDM; ++x)
+#pragma unroll
+        for (int sg = 0; sg < CS; ++sg) kacc1[x][sg] = make_double2(0.0, 0.0);
+
+    auto flush1 = [&](int prow) {
+        double* kout = kpart1 + ((int64_t)blockIdx.x * S + (prow - p_first)) * NDM * N;
+#pragma unroll
+        for (int sg = 0; sg < CS; ++sg) {
+            const int c = threadIdx.x + sg * JS_THREADS;
+            if (c < CXp) {
+#pragma unroll
+                for (int x = 0; x < NDM; ++x) *reinterpret_cast<double2*>(kout + (int64_t)x * N + 2 * c) = kacc1[x][sg];
+            }
+#pragma unroll
+            for (int x = 0; x < NDM; ++x) kacc1[x][sg] = make_double2(0.0, 0.0);
+        }
+    };
+
+    int p_cur = p_first;
+    while (T < T_end) {
+        if (p != p_cur) {
+            flush1(p_cur);
+            p_cur = p;
+        }
+        const int nq = (int)min((int64_t)min(GS_QB, p - q + 1), T_end - T);
+        uint32_t pq[GS_QB];
+#pragma unroll
+        for (int j = 0; j < GS_QB; ++j) pq[j] = nbx_tri_pair_u32((uint32_t)p, (uint32_t)min(q + j, p));
+        double jacc[GS_QB];
+#pragma unroll
+        for (int j = 0; j < GS_QB; ++j) jacc[j] = 0.0;
+#pragma unroll
+        for (int sg = 0; sg < CS; ++sg) {
+            const int c = threadIdx.x + sg * JS_THREADS;
+            const bool mine = c < CXp;
+            const int col = 2 * c;
+            double2 kacc2[NDM][GS_QB];
+#pragma unroll
+            for (int x = 0; x < NDM; ++x)
+#pragma unroll
+                for (int j = 0; j < GS_QB; ++j) kacc2[x][j] = make_double2(0.0, 0.0);
+            for (int a0 = 0; a0 < N; a0 += GS_AC) {
+                const int na = min(GS_AC, N - a0);
+                __syncthreads();  // the previous chunk has been consumed
+                for (int i = threadIdx.x; i < NDM * (GS_QB + 1) * GS_AC; i += JS_THREADS) {
+                    const int x = i / ((GS_QB + 1) * GS_AC);
+                    const int rem = i - x * (GS_QB + 1) * GS_AC;
+                    const int j = rem / GS_AC;
+                    const int a = rem - j * GS_AC;
+                    const int row = (j == GS_QB) ? p : q + j;
+                    dsh[i] = ((j == GS_QB || j < nq) && a < na) ? dm[(int64_t)x * n2 + (int64_t)row * N + a0 + a] : 0.0;
+                }
+                __syncthreads();
+                if (mine) {
+                    for (int a = 0; a < na; ++a) {
+                        const int ag = a0 + a;
+                        const double2 d = *reinterpret_cast<const double2*>(dtot + (int64_t)ag * N + col);
+                        const uint32_t ab0 = nbx_tri_pair_u32((uint32_t)ag, (uint32_t)col);
+                        const uint32_t ab1 = nbx_tri_pair_u32((uint32_t)ag, (uint32_t)(col + 1));
+                        double dp[NDM];
+#pragma unroll
+                        for (int x = 0; x < NDM; ++x) dp[x] = dsh[(x * (GS_QB + 1) + GS_QB) * GS_AC + a];
+#pragma unroll
+                        for (int j = 0; j < GS_QB; ++j) {
+                            if (j < nq) {  // uniform
+                                double2 t;
+                                t.x = nbx_synth_val(0, nbx_tri_u32(pq[j], ab0), seed) * scale;
+                                t.y = nbx_synth_val(0, nbx_tri_u32(pq[j], ab1), seed) * scale;
+                                jacc[j] = dot2(jacc[j], t, d);
+#pragma unroll
+                                for (int x = 0; x < NDM; ++x) {
+                                    fma2(kacc1[x][sg], dsh[(x * (GS_QB + 1) + j) * GS_AC + a], t);
+                                    fma2(kacc2[x][j], dp[x], t);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // this segment's columns of the row-(q+j) partials: complete, straight to the partial buffer
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < GS_QB; ++j) {
+                    if (j < nq && q + j < p) {
+#pragma unroll
+                        for (int x = 0; x < NDM; ++x)
+                            *reinterpret_cast<double2*>(kpart2 + (((int64_t)(q + j) * np + (p - p0)) * NDM + x) * N + col) =
+                                kacc2[x][j];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GS_QB; ++j) {
+            const double tot = nbx_block_sum(jacc[j], red);
+            if (threadIdx.x == 0 && j < nq) {
+                jfull[(int64_t)p * N + q + j] = tot;
+                jfull[(int64_t)(q + j) * N + p] = tot;
+            }
+        }
+        T += nq;
+        q += nq;
+        if (q > p) {
+            ++p;
+            q = 0;
+        }
+    }
+    flush1(p_cur);
 }
 
 __global__ void js_dtot_kernel(const double* __restrict__ dm, double* __restrict__ dtot, int64_t n2, int ndm) {
@@ -404,7 +545,102 @@ extern "C" int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p
     NBX_LAUNCH_CHECK();
     hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
                        ctx->stream, k1, k2,
-                       d_jk + n2, (int)N, (int)p0, (int)np, (int)ndm, t_begin, pl.L, pl.S);
+                       d_jk + n2, (int)N, (int)p0, (int)np, (int)ndm, t_begin, pl.L, pl.S, 0);
     NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+// ------------------------------------------------------------------ streamed symmetric form
+namespace {
+struct GsPlan {
+    int wgs, L, S, cs;
+    int64_t pc;  // slab rows per pass (bounds the row-q partial buffer)
+    size_t dtot_off, k1_off, k2_off, total;
+};
+
+GsPlan gs_plan(int64_t N, int64_t np, int64_t ndm) {
+    GsPlan pl;
+    const int64_t CXp = N / 2;
+    pl.cs = CXp <= JS_THREADS ? 1 : (CXp <= 2 * JS_THREADS ? 2 : 4);
+    int64_t pc = (int64_t)(4.0e9 / ((double)N * (double)N * (double)ndm * 8.0));
+    if (pc < 1) pc = 1;
+    if (pc > np) pc = np > 0 ? np : 1;
+    pl.pc = pc;
+    // geometry of the largest pass (the last rows are the longest): used for every pass
+    const int64_t slots = JS_CUS * (pl.cs == 4 ? 3 : 4);  // 142 VGPRs at 4 segments: 3 workgroups per CU
+    const int64_t ntiles_max = tri_index(N, 0) - tri_index(N - pc, 0);
+    int64_t L = nbx_cdiv(ntiles_max, slots);
+    if (L < 1) L = 1;
+    pl.L = (int)L;
+    pl.wgs = (int)nbx_cdiv(ntiles_max, L);
+    pl.S = (int)sqrt(2.0 * (double)L) + 3;
+    size_t off = 0;
+    pl.dtot_off = off; off += align256((size_t)(N * N) * sizeof(double));
+    pl.k1_off = off; off += align256((size_t)((int64_t)pl.wgs * pl.S * ndm * N) * sizeof(double));
+    pl.k2_off = off; off += align256((size_t)(N * pc * ndm * N) * sizeof(double));
+    pl.total = off;
+    return pl;
+}
+}  // namespace
+
+bool nbx_jk_synth_sym_supported(int64_t nao) { return nao >= 2 && nao % 2 == 0 && nao / 2 <= 4 * JS_THREADS; }
+
+extern "C" size_t nbx_jk_synth_sym_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm) {
+    if (nao <= 0 || p0 < 0 || p1 < p0 || p1 > nao || ndm <= 0 || !nbx_jk_synth_sym_supported(nao)) return 0;
+    return gs_plan(nao, p1 - p0, ndm).total;
+}
+
+extern "C" int nbx_jk_synth_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, uint64_t seed, const double* d_dm,
+                                int64_t ndm, double* d_jk, void* d_work, size_t work_bytes) {
+    NBX_CHECK_ARG(ctx && d_dm && d_jk);
+    NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
+    NBX_CHECK_ARG(ndm == 1 || ndm == 2);
+    if (!nbx_jk_synth_sym_supported(nao)) {
+        nbx_set_error("nbx_jk_synth_sym: N=%lld is not covered (even N <= 2048)", (long long)nao);
+        return NBX_E_UNSUPPORTED;
+    }
+    const int64_t N = nao, n2 = N * N, np_all = p1 - p0;
+    const size_t need = nbx_jk_synth_sym_worksize(nao, p0, p1, ndm);
+    if (d_work == nullptr || work_bytes < need) {
+        nbx_set_error("nbx_jk_synth_sym: workspace %zu < %zu bytes", work_bytes, need);
+        return NBX_E_NOMEM;
+    }
+    NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
+    int rc = nbx_memset(ctx, d_jk, 0, (size_t)((1 + ndm) * n2) * sizeof(double));
+    if (rc != NBX_OK || np_all == 0) return rc;
+    const GsPlan pl = gs_plan(N, np_all, ndm);
+    char* base = static_cast<char*>(d_work);
+    double* dtot = reinterpret_cast<double*>(base + pl.dtot_off);
+    double* k1 = reinterpret_cast<double*>(base + pl.k1_off);
+    double* k2 = reinterpret_cast<double*>(base + pl.k2_off);
+    hipLaunchKernelGGL(js_dtot_kernel, dim3((unsigned)nbx_cdiv(n2, 256)), dim3(256), 0, ctx->stream, d_dm, dtot, n2,
+                       (int)ndm);
+    NBX_LAUNCH_CHECK();
+    for (int64_t c0 = p0; c0 < p1; c0 += pl.pc) {
+        const int64_t c1 = (c0 + pl.pc < p1) ? c0 + pl.pc : p1;
+        const int64_t np = c1 - c0;
+        const int64_t t_begin = tri_index(c0, 0), t_end = tri_index(c1, 0);
+        const unsigned wgs = (unsigned)nbx_cdiv(t_end - t_begin, pl.L);
+        {
+            nbx_prof_scope prof(ctx, NBX_PROF_JK_DENSE);
+#define NBX_GS_GO(NDM_, CS_)                                                                                        \
+    hipLaunchKernelGGL((jk_synth_sym_kernel<NDM_, CS_>), dim3(wgs), dim3(JS_THREADS), 0, ctx->stream, d_dm, dtot, d_jk, \
+                       k1, k2, (int)N, (int)c0, (int)np, t_begin, t_end, pl.L, pl.S, seed)
+            if (ndm == 2) {
+                if (pl.cs == 1) NBX_GS_GO(2, 1);
+                else if (pl.cs == 2) NBX_GS_GO(2, 2);
+                else NBX_GS_GO(2, 4);
+            } else {
+                if (pl.cs == 1) NBX_GS_GO(1, 1);
+                else if (pl.cs == 2) NBX_GS_GO(1, 2);
+                else NBX_GS_GO(1, 4);
+            }
+#undef NBX_GS_GO
+        }
+        NBX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
+                           ctx->stream, k1, k2, d_jk + n2, (int)N, (int)c0, (int)np, (int)ndm, t_begin, pl.L, pl.S, 1);
+        NBX_LAUNCH_CHECK();
+    }
     return NBX_OK;
 }

@@ -582,6 +582,37 @@ def test_degenerate_shapes(be):
     np.testing.assert_allclose(got[1:], vk, atol=1e-14)
 
 
+@pytest.mark.parametrize("n", [2, 6, 24, 38])
+@pytest.mark.parametrize("ndm", [1, 2])
+def test_jk_synth_sym_vs_oracle(be, n, ndm):
+    """Generated-integral J/K with the tiles q <= p only: against einsum on the dense synthetic
+    tensor; slabs add up."""
+    eri_h = synth.eri_dense(n)
+    dm = np.stack([symm(520 + x, n) for x in range(ndm)])
+    vj, vk = get_jk(eri_h, dm)
+    got = be.to_host(be.jk_synth_sym(n, be.asarray(dm)))
+    np.testing.assert_allclose(got[0], vj.sum(0) if vj.ndim == 3 else vj, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(got[1:], vk.reshape(ndm, n, n), rtol=0, atol=1e-12)
+    if n >= 6:
+        cut = n // 2 + 1
+        parts = be.to_host(be.jk_synth_sym(n, be.asarray(dm), 0, cut)) + be.to_host(be.jk_synth_sym(n, be.asarray(dm), cut, n))
+        np.testing.assert_allclose(parts, got, rtol=0, atol=1e-12)
+
+
+def test_jk_synth_sym_wide_rows_match_plain_kernel(be):
+    """N = 600 and 1100: two and four column segments per thread; a few slab rows against nbx_jk_synth."""
+    for n, rows in ((600, (297, 300)), (1100, (548, 550))):
+        dm = be.asarray(np.stack([symm(530, n), symm(531, n)]))
+        p0, p1 = rows
+        sym = be.to_host(be.jk_synth_sym(n, dm, p0, p1))
+        plain = be.to_host(be.jk_synth(n, dm, p0, p1))  # rows p0..p1 of J and K
+        # the additive form holds the pairs (p, q <= p): compare what both determine completely,
+        # J[p, q <= p] and the K rows of the LAST slab row restricted to ... use J only + symmetry
+        for i, p in enumerate(range(p0, p1)):
+            np.testing.assert_allclose(sym[0, p, : p + 1], plain[0, i, : p + 1], rtol=0, atol=1e-11)
+            np.testing.assert_allclose(sym[0, : p + 1, p], plain[0, i, : p + 1], rtol=0, atol=1e-11)
+
+
 def test_c_abi_error_behaviour(be):
     """No exception crosses the C boundary: bad arguments, short workspaces and unsupported sizes
     come back as negative NBX_E_* codes with a message (surfaced as NbxError by the binding); a
