@@ -52,7 +52,8 @@ __host__ __device__ __forceinline__ int tri_row(int64_t T) {
 }
 
 // One group of NQ tiles (p, q .. q+NQ-1): rows a = row0, row0 + rstep, ... of every tile.
-//   dsh[(x*(QB+1) + j)*N + a] = D^x[q+j][a] (j < QB), D^x[p][a] (j == QB)
+//   dsh[a*NDM*(QB+1) + x*(QB+1) + j] = D^x[q+j][a] (j < QB), D^x[p][a] (j == QB): what a row needs
+//   sits at constant offsets from one address (no per-read address arithmetic; -12 % at N = 192)
 template <int NQ, int NDM, int QB>
 __device__ __forceinline__ void js_group(const double* __restrict__ tile0, int64_t n2, const double* __restrict__ dtot,
                                          const double* dsh, int N, int row0, int rstep, int col,
@@ -72,8 +73,8 @@ __device__ __forceinline__ void js_group(const double* __restrict__ tile0, int64
         double dp0[NDM], dp1[NDM];
 #pragma unroll
         for (int x = 0; x < NDM; ++x) {
-            dp0[x] = dsh[(x * (QB + 1) + QB) * N + a];
-            dp1[x] = dsh[(x * (QB + 1) + QB) * N + a + rstep];
+            dp0[x] = dsh[a * (NDM * (QB + 1)) + x * (QB + 1) + QB];
+            dp1[x] = dsh[(a + rstep) * (NDM * (QB + 1)) + x * (QB + 1) + QB];
         }
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
@@ -81,8 +82,8 @@ __device__ __forceinline__ void js_group(const double* __restrict__ tile0, int64
             jacc[j] = dot2(jacc[j], t1[j], d1);
 #pragma unroll
             for (int x = 0; x < NDM; ++x) {
-                fma2(kacc1[x], dsh[(x * (QB + 1) + j) * N + a], t0[j]);
-                fma2(kacc1[x], dsh[(x * (QB + 1) + j) * N + a + rstep], t1[j]);
+                fma2(kacc1[x], dsh[a * (NDM * (QB + 1)) + x * (QB + 1) + j], t0[j]);
+                fma2(kacc1[x], dsh[(a + rstep) * (NDM * (QB + 1)) + x * (QB + 1) + j], t1[j]);
                 fma2(kacc2[x][j], dp0[x], t0[j]);
                 fma2(kacc2[x][j], dp1[x], t1[j]);
             }
@@ -99,8 +100,8 @@ __device__ __forceinline__ void js_group(const double* __restrict__ tile0, int64
             jacc[j] = dot2(jacc[j], t0[j], d0);
 #pragma unroll
             for (int x = 0; x < NDM; ++x) {
-                fma2(kacc1[x], dsh[(x * (QB + 1) + j) * N + a], t0[j]);
-                fma2(kacc2[x][j], dsh[(x * (QB + 1) + QB) * N + a], t0[j]);
+                fma2(kacc1[x], dsh[a * (NDM * (QB + 1)) + x * (QB + 1) + j], t0[j]);
+                fma2(kacc2[x][j], dsh[a * (NDM * (QB + 1)) + x * (QB + 1) + QB], t0[j]);
             }
         }
     }
@@ -112,7 +113,7 @@ void jk_sym_kernel(const double* __restrict__ eri, const double* __restrict__ dm
                    double* __restrict__ jfull, double* __restrict__ kpart1, double* __restrict__ kpart2, int N,
                    int p0, int np, int64_t t_begin, int64_t t_end, int L, int S) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    // smem: dsh[NDM*(QB+1)*N] | kred[R*NDM*QB*N] | red[17]
+    // smem: dsh[N][NDM][QB+1] | kred[R*NDM*QB*N] | red[17]
     double* dsh = smem;
     double* kred = dsh + NDM * (QB + 1) * N;
 
@@ -170,7 +171,8 @@ void jk_sym_kernel(const double* __restrict__ eri, const double* __restrict__ dm
             const int j = rem / N;
             const int a = rem - j * N;
             const int row = (j == QB) ? p : q + j;
-            dsh[i] = (j == QB || j < nq) ? dm[(int64_t)x * n2 + (int64_t)row * N + a] : 0.0;
+            dsh[a * (NDM * (QB + 1)) + x * (QB + 1) + j] =
+                (j == QB || j < nq) ? dm[(int64_t)x * n2 + (int64_t)row * N + a] : 0.0;
         }
         __syncthreads();
         double jacc[QB];
