@@ -275,6 +275,16 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
         }
         off = nbx_wave_sum(off);
         if (off <= 1e-31 * fro) break;  // eigenvalue error ~ off^2 / gap: far below 1e-16 |H|
+        {
+            // Early exit: every eigenvalue lies within ||offdiag||_F of a diagonal entry (Weyl), so
+            // once min|a_kk| - ||offdiag||_F > 1e-14 no eigenvalue can be below PySCF's threshold:
+            // the LU branch is certain and the remaining sweeps (and the vectors) are not needed.
+            double mind = 1.0e300;
+            for (int k = lane; k < m; k += 64) mind = fmin(mind, fabs(A[k][k]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mind = fmin(mind, __shfl_xor(mind, o));
+            if (mind - sqrt(2.0 * off) > 1.0e-14) break;
+        }
         for (int step = 0; step < M - 1; ++step) {
             if (lane < npair) {  // pair `lane` of this step
                 int p, q;
