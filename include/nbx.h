@@ -272,7 +272,7 @@ int nbx_ao2mo(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c1
  * (aa|bb) (nbed/ham_builder.py:127-133, three independent ao2mo.kernel calls in the reference):
  * (aa|aa) and (aa|bb) are such a pair, which removes a third of the quarter-1 work.  Results are
  * bitwise those of two nbx_ao2mo calls.  d_out2 == NULL: plain nbx_ao2mo.                    */
-size_t nbx_ao2mo_pair_worksize(int64_t nao, int64_t ni, int64_t n2, int64_t n3, int64_t n5);
+size_t nbx_ao2mo_pair_worksize(int64_t nao, int64_t ni, int64_t n2, int64_t n4, int64_t n6);
 int nbx_ao2mo_pair(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c1, int64_t n1,
                    int64_t i0, int64_t i1, const double* d_c2, int64_t n2, const double* d_c3,
                    int64_t n3, const double* d_c4, int64_t n4, double* d_out, const double* d_c5,

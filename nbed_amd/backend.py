@@ -468,7 +468,7 @@ class HipBackend:
         nao = c1.shape[0]
         n1, n2, n3, n4, n5, n6 = (c.shape[1] for c in (c1, c2, c3, c4, c5, c6))
         i1 = n1 if i1 is None else i1
-        nbytes = self.lib.nbx_ao2mo_pair_worksize(nao, i1 - i0, n2, n3, n5)
+        nbytes = self.lib.nbx_ao2mo_pair_worksize(nao, i1 - i0, n2, n4, n6)
         work = self._workspace("ao2mo", nbytes)
         out = self.empty((i1 - i0, n2, n3, n4))
         out2 = self.empty((i1 - i0, n2, n5, n6))

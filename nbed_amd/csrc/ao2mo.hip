@@ -5,8 +5,10 @@
 // Four sequential quarter transforms, each one (batched) fp64 MFMA GEMM (gemm.hip):
 //   Q1  X1[i,(qrs)]   = C1^T (ni x N)   . ERI  (N x N^3)                 2 ni N^4      flop
 //   Q2  X2[i][j,(rs)] = C2^T (n2 x N)   . X1[i] (N x N^2)    batch ni     2 ni n2 N^3
-//   Q3  X3[ij][k,s]   = C3^T (n3 x N)   . X2[ij] (N x N)     batch ni*n2  2 ni n2 n3 N^2
-//   Q4  out[(ijk),l]  = X3 (ni n2 n3 x N) . C4 (N x n4)                   2 ni n2 n3 n4 N
+//   Q3  W[(ijr),l]    = X2 (ni n2 N x N) . C4 (N x n4)                    2 ni n2 n4 N^2
+//   Q4  out[ij][k,l]  = C3^T (n3 x N)   . W[ij] (N x n4)     batch ni*n2  2 ni n2 n3 n4 N
+// (s is contracted before r: the batched product then has n4 columns -- one full 128-wide tile
+// for n = 128 -- instead of N = 148 columns, of which a second 128-wide tile would be 84 % empty.)
 // No permutational symmetry is used (SURVEY.md section 8d flop count).  The contiguous ERI
 // index s stays the fastest index of every intermediate, so all GEMM operand loads are
 // coalesced.  The outer MO index i is the multi-GPU shard axis: a rank transforms its own
@@ -20,10 +22,10 @@ struct Ao2moPlan {
     size_t a_doubles, b_doubles;
 };
 
-Ao2moPlan plan(int64_t N, int64_t ni, int64_t n2, int64_t n3) {
+Ao2moPlan plan(int64_t N, int64_t ni, int64_t n2, int64_t n4) {
     Ao2moPlan p;
     const size_t x1 = (size_t)ni * N * N * N;
-    const size_t x3 = (size_t)ni * n2 * n3 * N;
+    const size_t x3 = (size_t)ni * n2 * N * n4;  // W
     p.a_doubles = x1 > x3 ? x1 : x3;
     p.b_doubles = (size_t)ni * n2 * N * N;
     return p;
@@ -31,9 +33,9 @@ Ao2moPlan plan(int64_t N, int64_t ni, int64_t n2, int64_t n3) {
 }  // namespace
 
 extern "C" size_t nbx_ao2mo_worksize(int64_t nao, int64_t ni, int64_t n2, int64_t n3, int64_t n4) {
-    (void)n4;
-    if (nao <= 0 || ni <= 0 || n2 <= 0 || n3 <= 0) return 0;
-    const Ao2moPlan p = plan(nao, ni, n2, n3);
+    (void)n3;
+    if (nao <= 0 || ni <= 0 || n2 <= 0 || n4 < 0) return 0;
+    const Ao2moPlan p = plan(nao, ni, n2, n4);
     return align256(p.a_doubles * sizeof(double)) + align256(p.b_doubles * sizeof(double));
 }
 
@@ -44,8 +46,8 @@ extern "C" int nbx_ao2mo(nbx_ctx* ctx, int64_t nao, const double* d_eri, const d
                           0, nullptr, d_work, work_bytes);
 }
 
-extern "C" size_t nbx_ao2mo_pair_worksize(int64_t nao, int64_t ni, int64_t n2, int64_t n3, int64_t n5) {
-    return nbx_ao2mo_worksize(nao, ni, n2, n3 > n5 ? n3 : n5, 0);
+extern "C" size_t nbx_ao2mo_pair_worksize(int64_t nao, int64_t ni, int64_t n2, int64_t n4, int64_t n6) {
+    return nbx_ao2mo_worksize(nao, ni, n2, 0, n4 > n6 ? n4 : n6);
 }
 
 extern "C" int nbx_ao2mo_pair(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c1, int64_t n1,
@@ -67,12 +69,12 @@ extern "C" int nbx_ao2mo_pair(nbx_ctx* ctx, int64_t nao, const double* d_eri, co
         nbx_set_error("nbx_ao2mo: dense path needs N^3 < 2^31 (N=%lld)", (long long)N);
         return NBX_E_UNSUPPORTED;
     }
-    const size_t need = nbx_ao2mo_pair_worksize(N, ni, n2, n3, n5);
+    const size_t need = nbx_ao2mo_pair_worksize(N, ni, n2, n4, pair ? n6 : 0);
     if (d_work == nullptr || work_bytes < need) {
         nbx_set_error("nbx_ao2mo: workspace %zu < %zu bytes", work_bytes, need);
         return NBX_E_NOMEM;
     }
-    const Ao2moPlan p = plan(N, ni, n2, n3 > n5 ? n3 : n5);
+    const Ao2moPlan p = plan(N, ni, n2, (pair && n6 > n4) ? n6 : n4);
     double* bufA = static_cast<double*>(d_work);
     double* bufB = reinterpret_cast<double*>(static_cast<char*>(d_work) + align256(p.a_doubles * sizeof(double)));
     const int64_t N2 = N * N, N3 = N2 * N;
@@ -87,14 +89,14 @@ extern "C" int nbx_ao2mo_pair(nbx_ctx* ctx, int64_t nao, const double* d_eri, co
     // Q2
     rc = nbx_gemm(ctx, 'T', 'N', n2, N2, N, 1.0, d_c2, n2, 0, bufA, N2, N3, 0.0, bufB, N2, n2 * N2, ni);
     if (rc != NBX_OK) return rc;
-    // Q3
-    rc = nbx_gemm(ctx, 'T', 'N', n3, N, N, 1.0, d_c3, n3, 0, bufB, N, N2, 0.0, bufA, N, n3 * N, ni * n2);
+    // Q3: s -> l
+    rc = nbx_gemm(ctx, 'N', 'N', ni * n2 * N, n4, N, 1.0, bufB, N, 0, d_c4, n4, 0, 0.0, bufA, n4, 0, 1);
     if (rc != NBX_OK) return rc;
-    // Q4
-    rc = nbx_gemm(ctx, 'N', 'N', ni * n2 * n3, n4, N, 1.0, bufA, N, 0, d_c4, n4, 0, 0.0, d_out, n4, 0, 1);
+    // Q4: r -> k, batched over (i,j)
+    rc = nbx_gemm(ctx, 'T', 'N', n3, n4, N, 1.0, d_c3, n3, 0, bufA, n4, N * n4, 0.0, d_out, n4, n3 * n4, ni * n2);
     if (rc != NBX_OK || !pair) return rc;
     // second tensor of the pair: quarters 3 and 4 again from the X2 still sitting in bufB
-    rc = nbx_gemm(ctx, 'T', 'N', n5, N, N, 1.0, d_c5, n5, 0, bufB, N, N2, 0.0, bufA, N, n5 * N, ni * n2);
+    rc = nbx_gemm(ctx, 'N', 'N', ni * n2 * N, n6, N, 1.0, bufB, N, 0, d_c6, n6, 0, 0.0, bufA, n6, 0, 1);
     if (rc != NBX_OK) return rc;
-    return nbx_gemm(ctx, 'N', 'N', ni * n2 * n5, n6, N, 1.0, bufA, N, 0, d_c6, n6, 0, 0.0, d_out2, n6, 0, 1);
+    return nbx_gemm(ctx, 'T', 'N', n5, n6, N, 1.0, d_c5, n5, 0, bufA, n6, N * n6, 0.0, d_out2, n6, n5 * n6, ni * n2);
 }
