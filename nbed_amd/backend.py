@@ -14,6 +14,7 @@ libnbx.so or without a GPU ``get_backend()`` raises ``NbxUnavailableError``.
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_double, c_int
 
 import numpy as np
@@ -120,8 +121,61 @@ class HipBackend:
 
     def to_host(self, a) -> np.ndarray:
         if isinstance(a, self.torch.Tensor):
+            if a.is_cuda and a.dtype == self.torch.float64 and a.numel() >= (1 << 26):
+                return self._to_host_pipelined(a)
             return a.detach().cpu().numpy()
         return np.asarray(a)
+
+    def _to_host_pipelined(self, a, chunk: int = 32 * 1024 * 1024, nbuf: int = 3) -> np.ndarray:
+        """Large device -> host copy (the (2n)^4 spin-orbital tensor is tens of GB): asynchronous
+        chunks into a ring of pinned buffers on a copy stream, drained into the pageable result by a
+        few host threads (numpy releases the GIL while copying).  ~54 GB/s against ~12.5 GB/s for
+        ``tensor.cpu()`` on an MI355X host."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        torch = self.torch
+        src = a.detach().contiguous().reshape(-1)
+        n = src.numel()
+        out = np.empty(n, dtype=np.float64)
+        try:
+            threads = max(1, min(8, len(os.sched_getaffinity(0))))
+        except AttributeError:
+            threads = 4
+        bufs = [torch.empty(chunk, dtype=torch.float64, pin_memory=True) for _ in range(nbuf)]
+        events = [torch.cuda.Event() for _ in range(nbuf)]
+        stream = torch.cuda.Stream(device=self.device)
+        stream.wait_stream(torch.cuda.current_stream(self.device_index))
+        nchunks = (n + chunk - 1) // chunk
+        pending = [None] * nbuf
+
+        def drain(pool, k):
+            b = k % nbuf
+            lo, hi = k * chunk, min(n, (k + 1) * chunk)
+            events[b].synchronize()
+            piece = bufs[b].numpy()[: hi - lo]
+            step = (hi - lo + threads - 1) // threads
+            return [pool.submit(np.copyto, out[lo + i * step: min(hi, lo + (i + 1) * step)],
+                                piece[i * step: min(hi - lo, (i + 1) * step)]) for i in range(threads)]
+
+        with ThreadPoolExecutor(threads) as pool:
+            for k in range(nchunks + nbuf - 1):
+                if k < nchunks:
+                    b = k % nbuf
+                    if pending[b] is not None:
+                        for f in pending[b]:
+                            f.result()
+                    lo, hi = k * chunk, min(n, (k + 1) * chunk)
+                    with torch.cuda.stream(stream):
+                        bufs[b][: hi - lo].copy_(src[lo:hi], non_blocking=True)
+                        events[b].record()
+                j = k - (nbuf - 1)
+                if j >= 0:
+                    pending[j % nbuf] = drain(pool, j)
+            for p in pending:
+                if p is not None:
+                    for f in p:
+                        f.result()
+        return out.reshape(tuple(a.shape))
 
     def copy(self, a):
         return a.clone()

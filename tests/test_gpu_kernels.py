@@ -613,6 +613,20 @@ def test_jk_synth_sym_wide_rows_match_plain_kernel(be):
             np.testing.assert_allclose(sym[0, : p + 1, p], plain[0, i, : p + 1], rtol=0, atol=1e-11)
 
 
+def test_large_device_to_host_copy_is_exact(be):
+    """Tensors of 512 MB and more come back through the pinned-buffer pipeline: bit-exact, any shape,
+    including a ragged last chunk."""
+    n = (1 << 26) + 12345
+    a = be.torch.arange(n, dtype=be.torch.float64, device=be.device) * 0.5
+    h = be.to_host(a)
+    assert h.shape == (n,) and h.dtype == np.float64
+    np.testing.assert_array_equal(h[:5], [0.0, 0.5, 1.0, 1.5, 2.0])
+    assert h[-1] == (n - 1) * 0.5 and h[33554432] == 33554432 * 0.5 and h[33554431] == 33554431 * 0.5
+    assert float(np.sum(h[::4097])) == float(a[::4097].sum())
+    b = a[: 1 << 26].reshape(64, 1024, 1024)
+    np.testing.assert_array_equal(be.to_host(b)[63, 1023, 1020:], be.to_host(b[63, 1023, 1020:]))
+
+
 def test_c_abi_error_behaviour(be):
     """No exception crosses the C boundary: bad arguments, short workspaces and unsupported sizes
     come back as negative NBX_E_* codes with a message (surfaced as NbxError by the binding); a
