@@ -117,7 +117,48 @@ class HipBackend:
         t = self.torch
         if isinstance(a, t.Tensor):
             return a.to(device=self.device, dtype=t.float64).contiguous()
-        return t.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+        h = np.ascontiguousarray(a, dtype=np.float64)
+        if h.size >= (1 << 26):
+            return self._to_device_pipelined(h)
+        return t.from_numpy(h).to(self.device)
+
+    def _to_device_pipelined(self, h: np.ndarray, chunk: int = 32 * 1024 * 1024, nbuf: int = 3):
+        """Large host -> device copy (a dense (pq|rs) from the integral provider is GBs): host threads
+        fill a ring of pinned buffers, each shipped by an asynchronous copy on a copy stream."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        torch = self.torch
+        flat = h.reshape(-1)
+        n = flat.size
+        out = torch.empty(n, dtype=torch.float64, device=self.device)
+        try:
+            threads = max(1, min(8, len(os.sched_getaffinity(0))))
+        except AttributeError:
+            threads = 4
+        bufs = [torch.empty(chunk, dtype=torch.float64, pin_memory=True) for _ in range(nbuf)]
+        events = [None] * nbuf
+        stream = torch.cuda.Stream(device=self.device)
+        nchunks = (n + chunk - 1) // chunk
+        with ThreadPoolExecutor(threads) as pool:
+            for k in range(nchunks):
+                b = k % nbuf
+                lo, hi = k * chunk, min(n, (k + 1) * chunk)
+                if events[b] is not None:
+                    events[b].synchronize()  # the copy that last read this buffer is done
+                piece = bufs[b].numpy()[: hi - lo]
+                step = (hi - lo + threads - 1) // threads
+                for f in [pool.submit(np.copyto, piece[i * step: min(hi - lo, (i + 1) * step)],
+                                      flat[lo + i * step: min(hi, lo + (i + 1) * step)]) for i in range(threads)]:
+                    f.result()
+                with torch.cuda.stream(stream):
+                    out[lo:hi].copy_(bufs[b][: hi - lo], non_blocking=True)
+                    events[b] = torch.cuda.Event()
+                    events[b].record()
+        torch.cuda.current_stream(self.device_index).wait_stream(stream)
+        for ev in events:
+            if ev is not None:
+                ev.synchronize()  # the pinned buffers are about to be released
+        return out.reshape(tuple(h.shape))
 
     def to_host(self, a) -> np.ndarray:
         if isinstance(a, self.torch.Tensor):

@@ -625,6 +625,9 @@ def test_large_device_to_host_copy_is_exact(be):
     assert float(np.sum(h[::4097])) == float(a[::4097].sum())
     b = a[: 1 << 26].reshape(64, 1024, 1024)
     np.testing.assert_array_equal(be.to_host(b)[63, 1023, 1020:], be.to_host(b[63, 1023, 1020:]))
+    # and the way up: a large host array through the same kind of pipeline
+    up = be.asarray(h)
+    assert up.shape == (n,) and bool((up == a).all())
 
 
 def test_c_abi_error_behaviour(be):
