@@ -308,6 +308,13 @@ int nbx_chem_to_phys(nbx_ctx* ctx, int64_t n1, int64_t n2, int64_t n3, int64_t n
  * entries with |x| < tol are zeroed; h2 is multiplied by h2_scale afterwards.            */
 int nbx_spinorb_scatter(nbx_ctx* ctx, int64_t n, const double* d_one_body, const double* d_two_body,
                         double tol, double h2_scale, double* d_h1, double* d_h2);
+/* Elements [idx0, idx0 + count) of the flattened (2n)^4 tensor only, into d_h2_part[0..count): lets
+ * a host that wants the result in its own memory stream it out piece by piece instead of holding
+ * the whole tensor (60 GB at n = 147) on the device first; nbx_spinorb_scatter_h1 is the one-body
+ * part alone (nbed/ham_builder.py:180-214, as nbx_spinorb_scatter).                             */
+int nbx_spinorb_scatter_h1(nbx_ctx* ctx, int64_t n, const double* d_one_body, double tol, double* d_h1);
+int nbx_spinorb_scatter_range(nbx_ctx* ctx, int64_t n, const double* d_two_body, double tol,
+                              double h2_scale, int64_t idx0, int64_t count, double* d_h2_part);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,8 @@ SIGNATURES = {
     "nbx_ao2mo_synth": (c_int, [_P, c_int64, c_uint64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P,
                                 c_int64, _P, _P, c_size_t]),
     "nbx_chem_to_phys": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P]),
+    "nbx_spinorb_scatter_h1": (c_int, [_P, c_int64, _P, c_double, _P]),
+    "nbx_spinorb_scatter_range": (c_int, [_P, c_int64, _P, c_double, c_double, c_int64, c_int64, _P]),
     "nbx_spinorb_scatter": (c_int, [_P, c_int64, _P, _P, c_double, c_double, _P, _P]),
 }
 

@@ -602,6 +602,75 @@ class HipBackend:
         self._call("nbx_chem_to_phys", n1, n2, n3, n4, self._p(x), self._p(out))
         return out
 
+    def spinorb_scatter_to_host(self, one_body, two_body, tol: float, h2_scale: float, chunk: int = 32 * 1024 * 1024,
+                                nbuf: int = 3):
+        """(h1, h2) as numpy arrays with h2 streamed out in pieces: each piece of the flattened
+        (2n)^4 tensor is produced into a small device buffer (nbx_spinorb_scatter_range), copied to a
+        pinned buffer and drained into the result by host threads -- the tensor is never held on the
+        device (60 GB at n = 147) and the copy runs at the pinned-pipeline rate."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        torch = self.torch
+        n = one_body.shape[-1]
+        nq = 2 * n
+        total = nq**4
+        if total < (1 << 26):
+            h1, h2 = self.spinorb_scatter(one_body, two_body, tol, h2_scale)
+            return self.to_host(h1), self.to_host(h2)
+        h1 = self.empty((nq, nq))
+        self._call("nbx_spinorb_scatter_h1", n, self._p(one_body), tol, self._p(h1))
+        out = np.empty(total, dtype=np.float64)
+        try:
+            threads = max(1, min(8, len(os.sched_getaffinity(0))))
+        except AttributeError:
+            threads = 4
+        dbufs = [self.empty(chunk) for _ in range(nbuf)]
+        pbufs = [torch.empty(chunk, dtype=torch.float64, pin_memory=True) for _ in range(nbuf)]
+        made = [torch.cuda.Event() for _ in range(nbuf)]
+        copied = [torch.cuda.Event() for _ in range(nbuf)]
+        main = torch.cuda.current_stream(self.device_index)
+        copy_stream = torch.cuda.Stream(device=self.device)
+        nchunks = (total + chunk - 1) // chunk
+        pending = [None] * nbuf
+        used = [False] * nbuf
+
+        def drain(pool, k):
+            b = k % nbuf
+            lo, hi = k * chunk, min(total, (k + 1) * chunk)
+            copied[b].synchronize()
+            piece = pbufs[b].numpy()[: hi - lo]
+            step = (hi - lo + threads - 1) // threads
+            return [pool.submit(np.copyto, out[lo + i * step: min(hi, lo + (i + 1) * step)],
+                                piece[i * step: min(hi - lo, (i + 1) * step)]) for i in range(threads)]
+
+        with ThreadPoolExecutor(threads) as pool:
+            for k in range(nchunks + nbuf - 1):
+                if k < nchunks:
+                    b = k % nbuf
+                    if pending[b] is not None:
+                        for f in pending[b]:
+                            f.result()  # pinned buffer b has been drained
+                    if used[b]:
+                        main.wait_event(copied[b])  # device buffer b has been copied out
+                    lo, hi = k * chunk, min(total, (k + 1) * chunk)
+                    self._call("nbx_spinorb_scatter_range", n, self._p(two_body), tol, h2_scale, lo, hi - lo,
+                               self._p(dbufs[b]))
+                    made[b].record(main)
+                    with torch.cuda.stream(copy_stream):
+                        copy_stream.wait_event(made[b])
+                        pbufs[b][: hi - lo].copy_(dbufs[b][: hi - lo], non_blocking=True)
+                        copied[b].record(copy_stream)
+                    used[b] = True
+                j = k - (nbuf - 1)
+                if j >= 0:
+                    pending[j % nbuf] = drain(pool, j)
+            for p in pending:
+                if p is not None:
+                    for f in p:
+                        f.result()
+        main.wait_stream(copy_stream)
+        return self.to_host(h1), out.reshape((nq,) * 4)
+
     def spinorb_scatter(self, one_body, two_body, tol: float, h2_scale: float):
         n = one_body.shape[-1]
         h1 = self.empty((2 * n, 2 * n))

@@ -455,12 +455,14 @@ __global__ void scale_cols_kernel(int64_t rows, int64_t cols, const double* __re
 }
 
 // h2[P,Q,R,S] over the (2n)^4 output, coalesced stores (nbed/ham_builder.py:180-214)
+// elements [idx0, idx0 + count) of the flattened tensor go to h2[0 .. count)
 __global__ void spinorb_h2_kernel(int n, const double* __restrict__ tb, double tol, double scale,
-                                  double* __restrict__ h2, int64_t total) {
+                                  double* __restrict__ h2, int64_t idx0, int64_t count) {
     const int64_t nq = 2 * (int64_t)n;
     const int64_t n4 = (int64_t)n * n * n * n;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t off = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; off < count;
+         off += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t idx = idx0 + off;
         const int64_t S = idx % nq;
         int64_t t = idx / nq;
         const int64_t R = t % nq;
@@ -479,7 +481,7 @@ __global__ void spinorb_h2_kernel(int n, const double* __restrict__ tb, double t
             if (fabs(v) < tol) v = 0.0;
             v *= scale;
         }
-        h2[idx] = v;
+        h2[off] = v;
     }
 }
 
@@ -698,7 +700,29 @@ int nbx_spinorb_scatter(nbx_ctx* ctx, int64_t n, const double* d_one_body, const
     NBX_LAUNCH_CHECK();
     const int64_t total = nq * nq * nq * nq;
     hipLaunchKernelGGL(spinorb_h2_kernel, dim3(grid1d(total, 256, 8192)), dim3(256), 0, ctx->stream, (int)n,
-                       d_two_body, tol, h2_scale, d_h2, total);
+                       d_two_body, tol, h2_scale, d_h2, (int64_t)0, total);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+int nbx_spinorb_scatter_h1(nbx_ctx* ctx, int64_t n, const double* d_one_body, double tol, double* d_h1) {
+    NBX_CHECK_ARG(ctx && n > 0 && n < 1024 && d_one_body && d_h1);
+    const int64_t nq = 2 * n;
+    hipLaunchKernelGGL(spinorb_h1_kernel, dim3((unsigned)nbx_cdiv(nq * nq, 256)), dim3(256), 0, ctx->stream, (int)n,
+                       d_one_body, tol, d_h1);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+int nbx_spinorb_scatter_range(nbx_ctx* ctx, int64_t n, const double* d_two_body, double tol, double h2_scale,
+                              int64_t idx0, int64_t count, double* d_h2_part) {
+    NBX_CHECK_ARG(ctx && n > 0 && n < 1024 && d_two_body && idx0 >= 0 && count >= 0);
+    const int64_t nq = 2 * n;
+    NBX_CHECK_ARG(idx0 + count <= nq * nq * nq * nq);
+    if (count == 0) return NBX_OK;
+    NBX_CHECK_ARG(d_h2_part != nullptr);
+    hipLaunchKernelGGL(spinorb_h2_kernel, dim3(grid1d(count, 256, 8192)), dim3(256), 0, ctx->stream, (int)n,
+                       d_two_body, tol, h2_scale, d_h2_part, idx0, count);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

@@ -147,6 +147,9 @@ class HamiltonianBuilder:
         logger.info("Building Hamiltonian")
         one = be.asarray(self._one_body_integrals)
         two = self._two_body_device()
+        if hasattr(be, "spinorb_scatter_to_host"):  # large tensors are streamed out piece by piece
+            h1_h, h2_h = be.spinorb_scatter_to_host(one, two, EQ_TOLERANCE, 0.5)
+            return self.constant_e_shift, h1_h, h2_h
         h1, h2 = be.spinorb_scatter(one, two, EQ_TOLERANCE, 0.5)
         return self.constant_e_shift, be.to_host(h1), be.to_host(h2)
 

@@ -630,6 +630,20 @@ def test_large_device_to_host_copy_is_exact(be):
     assert up.shape == (n,) and bool((up == a).all())
 
 
+def test_spinorb_scatter_streamed_equals_dense(be):
+    """The piecewise (streamed-to-host) scatter against the one-shot kernel, at a size that takes the
+    streaming path (n = 46: 92^4 = 71.6 M elements, three pieces with a ragged last one)."""
+    n = 46
+    one = be.asarray(rnd(540, 2, n, n))
+    two = be.asarray(rnd(541, 4, n, n, n, n) * 1e-3)
+    h1_d, h2_d = be.spinorb_scatter(one, two, 1e-8, 0.5)
+    h1_h, h2_h = be.spinorb_scatter_to_host(one, two, 1e-8, 0.5)
+    np.testing.assert_array_equal(h1_h, be.to_host(h1_d))
+    ref = h2_d.cpu().numpy()
+    assert h2_h.shape == ref.shape
+    np.testing.assert_array_equal(h2_h, ref)
+
+
 def test_c_abi_error_behaviour(be):
     """No exception crosses the C boundary: bad arguments, short workspaces and unsupported sizes
     come back as negative NBX_E_* codes with a message (surfaced as NbxError by the binding); a
