@@ -27,6 +27,7 @@
 // (quadratic convergence: the next sweep's rotations would be < 1e-16).
 #include <algorithm>
 
+#include "jacobi_ring.h"
 #include "nbx_common.h"
 
 namespace {
@@ -36,18 +37,6 @@ constexpr int JL_MAXR = 5;          // block rounds per thread: m(m-1)/2 <= 5 * 
 constexpr int JL_MAX_SWEEPS = 24;
 constexpr int JL_MAX_NP = 196;
 constexpr double JL_PAD_VALUE = 1.0e300;
-
-// ---- tournament ring geometry (NP even, m = NP/2 pairs, R = NP-1 ring positions) ----------
-// t = 0: pair k = (top_k, bot_k) = (2k, 2k+1); top_0 = index 0 never moves; ring position r holds
-//   top_{r+1} for r <= m-2 and bot_{2m-2-r} for r >= m-1; every step turns the ring by +1.
-__host__ __device__ inline int ring_pos_top(int k) { return k - 1; }               // k >= 1
-__host__ __device__ inline int ring_pos_bot(int k, int m) { return 2 * m - 2 - k; }
-__host__ __device__ inline int ring_index0(int r, int m) {  // original index at ring position r, t = 0
-    return r <= m - 2 ? 2 * (r + 1) : 2 * (2 * m - 2 - r) + 1;
-}
-__host__ __device__ inline int ring_pos_of(int i, int m) {  // inverse of ring_index0, i >= 1
-    return (i & 1) ? 2 * m - 2 - (i >> 1) : (i >> 1) - 1;
-}
 
 // Address of the element at ring positions (P, Q) as base + offset, offset in [0, R).
 // P or Q == -1 denotes the fixed index 0.  Layout: diagonal d (0..m-1) at d*R + a, then the
@@ -306,7 +295,8 @@ __global__ __launch_bounds__(64) void eigh_apply_rot_kernel(const double* __rest
                                                             const int* __restrict__ nsteps_in,
                                                             const int* __restrict__ rank_in,
                                                             double* __restrict__ v_out, int64_t rot_stride,
-                                                            int64_t flag_stride, const int* __restrict__ gate) {
+                                                            int64_t flag_stride, const int* __restrict__ gate,
+                                                            int transpose_out) {
     if (gate != nullptr && gate[blockIdx.y] > 0) return;
     extern __shared__ __attribute__((aligned(16))) double row[];
     const int b = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
@@ -383,7 +373,7 @@ __global__ __launch_bounds__(64) void eigh_apply_rot_kernel(const double* __rest
     __syncthreads();
     for (int i = lane; i < NP; i += 64) {
         const int rk = rank_in[i];
-        if (rk < N) v_out[(int64_t)r * N + rk] = row[i];
+        if (rk < N) v_out[transpose_out ? (int64_t)rk * N + r : (int64_t)r * N + rk] = row[i];
     }
 }
 
@@ -483,7 +473,7 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
         NBX_LAUNCH_CHECK();
         hipLaunchKernelGGL(eigh_apply_rot_kernel, dim3((unsigned)N, (unsigned)batch), dim3(64),
                            (size_t)NP * sizeof(double), ctx->stream, d_v0, N, NP, steps, rot, flags, nsteps, rank, d_v,
-                           L.rot_stride, L.flag_stride, gate);
+                           L.rot_stride, L.flag_stride, gate, 0);
         NBX_LAUNCH_CHECK();
     }
     return NBX_OK;
@@ -493,4 +483,15 @@ size_t nbx_eigh_lds_status_offset(int64_t n, int64_t batch) { return layout(n, b
 
 const int* nbx_eigh_lds_status_ptr(int64_t n, int64_t batch, const void* d_work) {
     return reinterpret_cast<const int*>(static_cast<const char*>(d_work) + layout(n, batch).status_off);
+}
+
+// V^T (rows = accumulated columns, reordered by rank) of the identity under a recorded rotation
+// sequence: the deferred right-vector accumulation of the LDS one-sided Jacobi SVD (svd.hip).
+int nbx_apply_rotation_log_t(nbx_ctx* ctx, int n, int np_even, int steps, const void* d_rot, const int* d_flags,
+                             const int* d_nsteps, const int* d_rank, double* d_vt) {
+    hipLaunchKernelGGL(eigh_apply_rot_kernel, dim3((unsigned)n, 1u), dim3(64), (size_t)np_even * sizeof(double),
+                       ctx->stream, (const double*)nullptr, n, np_even, steps, static_cast<const double2*>(d_rot), d_flags,
+                       d_nsteps, d_rank, d_vt, (int64_t)0, (int64_t)0, (const int*)nullptr, 1);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
 }

@@ -40,6 +40,8 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
                  double* d_v, void* d_work, size_t work_bytes, int refine_iters);
 const int* nbx_eigh_lds_status_ptr(int64_t n, int64_t batch, const void* d_work);
 size_t nbx_eigh_lds_status_offset(int64_t n, int64_t batch);
+int nbx_apply_rotation_log_t(nbx_ctx* ctx, int n, int np_even, int steps, const void* d_rot, const int* d_flags,
+                             const int* d_nsteps, const int* d_rank, double* d_vt);
 
 // gemm.hip
 int nbx_gemm_q1_synth(nbx_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* d_a, int64_t lda, uint64_t seed,
