@@ -114,6 +114,26 @@ size_t nbx_jk_dense_sym_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t nd
 int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri,
                      const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes);
 
+/* Packed form: (pq|rs) = (qp|rs) = (pq|sr), so only q <= p and s <= r are stored and read -- a
+ * quarter of the dense tensor (PySCF holds `mf._eri` 8-fold packed and libcvhf, which the
+ * reference reaches through get_veff at nbed/scf/huzinaga_scf.py:156, contracts it packed).
+ * nbx_eri_pack converts slab rows [p0,p1) of the dense tensor ONCE (the integrals do not change
+ * during an SCF); nbx_jk_packed then reads nbx_eri_packed_bytes() per call instead of
+ * 8 N^4 (p1-p0)/N.  Storage: the tiles T(p,q) = p(p+1)/2 + q, q <= p, in sequence; a tile is the
+ * lower triangle of its (r,s) matrix cut into NB = 2 (N <= 128) or 4 blocks of s = N/NB rows:
+ * first the NB diagonal triangles (row-major, packed), then for r = 1..NB-1 the rectangles
+ * (I, J = I ^ r), I > J, ordered by J, row-major with row stride s|1 (zero pad); each of the NB
+ * chunks padded to an even number of doubles.
+ *   nbx_jk_packed_supported : 1 for even N <= 256 with N % NB == 0, else 0 (use nbx_jk_dense_sym)
+ *   d_jk   : out, ((1+ndm), N, N): ADDITIVE over slabs exactly as nbx_jk_dense_sym
+ *   d_work : nbx_jk_packed_worksize() bytes                                                  */
+int nbx_jk_packed_supported(int64_t nao);
+size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1);
+int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
+size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm);
+int nbx_jk_packed(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed,
+                  const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes);
+
 /* Same contraction with the synthetic (pq|rs) of nbx_synth_eri GENERATED in registers instead of
  * read from HBM (the N_AO = 2000 configuration: a dense tensor would be 128 TB).  Workspace as
  * nbx_jk_dense_worksize().  ALU-bound (one 64-bit counter hash per integral).               */

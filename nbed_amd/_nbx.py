@@ -60,6 +60,11 @@ SIGNATURES = {
     "nbx_jk_dense_worksize": (c_size_t, [c_int64, c_int64, c_int64]),
     "nbx_jk_dense": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
     "nbx_jk_dense_sym_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "nbx_jk_packed_supported": (c_int, [c_int64]),
+    "nbx_eri_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "nbx_eri_pack": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
+    "nbx_jk_packed_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "nbx_jk_packed": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
     "nbx_jk_dense_sym": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
     "nbx_jk_synth_sym_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
     "nbx_jk_synth_sym": (c_int, [_P, c_int64, c_int64, c_int64, c_uint64, _P, c_int64, _P, _P, c_size_t]),

@@ -330,6 +330,34 @@ class HipBackend:
                    work.numel())
         return out
 
+    def jk_packed_supported(self, nao: int) -> bool:
+        return bool(self.lib.nbx_jk_packed_supported(nao))
+
+    def eri_pack(self, eri, nao: int, p0: int = 0, p1: int | None = None):
+        """Slab rows [p0,p1) of the dense tensor in the 4-fold packed tile format of nbx_jk_packed
+        (q <= p, s <= r: a quarter of the bytes).  Done once per SCF: the integrals are constant."""
+        p1 = nao if p1 is None else p1
+        nbytes = self.lib.nbx_eri_packed_bytes(nao, p0, p1)
+        if p1 > p0 and nbytes == 0:
+            raise ValueError(f"nbx_eri_pack does not cover N = {nao}")
+        out = self.empty((max(nbytes // 8, 2),))
+        self._call("nbx_eri_pack", nao, p0, p1, self._p(eri) if p1 > p0 else None, self._p(out))
+        return out
+
+    def jk_packed(self, packed, dm, p0: int = 0, p1: int | None = None):
+        """(1+ndm, N, N) J/K contributions of slab rows [p0,p1) from the packed tiles of eri_pack
+        (nbx_jk_packed); additive over slabs like jk_sym."""
+        nao = dm.shape[-1]
+        p1 = nao if p1 is None else p1
+        dm3 = dm.reshape(-1, nao, nao)
+        ndm = dm3.shape[0]
+        nbytes = self.lib.nbx_jk_packed_worksize(nao, p0, p1, ndm)
+        work = self._workspace("jk", nbytes)
+        out = self.empty((1 + ndm, nao, nao))
+        self._call("nbx_jk_packed", nao, p0, p1, self._p(packed) if p1 > p0 else None, self._p(dm3), ndm,
+                   self._p(out), self._p(work), work.numel())
+        return out
+
     def jk_synth(self, nao: int, dm, p0: int = 0, p1: int | None = None, seed: int = 20250829):
         """J/K against the synthetic (pq|rs) generated in registers (no ERI in memory)."""
         p1 = nao if p1 is None else p1

@@ -1,0 +1,546 @@
+// libnbx: J/K contraction on 4-fold packed integrals (include/nbx.h "J/K contraction, packed form").
+//
+//   (pq|rs) = (qp|rs) = (pq|sr): only the pairs q <= p AND s <= r are stored and read -- a quarter
+//   of the dense tensor, half of what jk_sym.hip reads.  (PySCF keeps `mf._eri` 8-fold packed and
+//   libcvhf, which the reference calls through get_veff, contracts it in that form.)
+//
+// A tile is the lower triangle L[a][b], b <= a, of the (r,s) matrix of one pair (p,q); it feeds
+//       J_pq = J_qp  = sum_{ab} Lsym_ab Dtot_ab
+//       K^x_p[t]    += sum_c Lsym[t][c] D^x_q[c]     K^x_q[t] += sum_c Lsym[t][c] D^x_p[c]   (q < p)
+// i.e. two symmetric matrix x vector products per spin with the matrix stored once.  Thread t owns
+// output element t and walks the whole symmetric row t (the row part L[t][c], c <= t, and the
+// column part L[c][t], c > t): every thread does N steps, nothing is reduced across threads, the
+// density values of a step are wave-uniform (scalar loads, SGPR operands).
+//
+// Blocked triangle: the walk needs a tile resident in LDS, and a whole tile (N = 148: 88 KB)
+// leaves no room to stream the next one.  The index range is cut into NB blocks of s = N / NB
+// (one wave per block); a tile is stored as NB chunks,
+//       chunk 0      : the NB diagonal triangles            (wave w walks its own triangle)
+//       chunk r >= 1 : the NB/2 rectangles (I, J = I ^ r)   (wave w walks the rectangle it shares
+//                      with wave w ^ r: one as the row side, the other as the column side)
+// -- the rounds of a round-robin tournament: in every chunk every wave does exactly s steps.
+// Chunks (N = 148: 22 KB) are double buffered in LDS; the next tile streams into registers with
+// non-temporal 16-byte loads while the current one is walked.  Rectangle rows have an odd stride
+// (s | 1) in the stored format so that the row-side walk is LDS-bank-conflict free.
+//
+// Work distribution, partial buffers and the final reduction are those of jk_sym.hip: persistent
+// workgroups own equal contiguous ranges of the tile sequence T(p,q) = p(p+1)/2 + q; everything
+// is summed in a fixed order (bitwise reproducible).  The slab interface is additive.
+#include "nbx_common.h"
+
+namespace {
+
+constexpr int S4_CUS = 256;
+constexpr size_t S4_LDS_PER_CU = 160 * 1024;
+
+__host__ __device__ __forceinline__ int64_t s4_tri(int64_t k) { return k * (k + 1) / 2; }
+__host__ __device__ __forceinline__ int s4_tri_row(int64_t T) {
+    int64_t p = (int64_t)((sqrt(8.0 * (double)T + 1.0) - 1.0) * 0.5);
+    while (p * (p + 1) / 2 > T) --p;
+    while ((p + 1) * (p + 2) / 2 <= T) ++p;
+    return (int)p;
+}
+
+struct S4Geom {
+    int N, NB, s, ls, tri;
+    int E0, Er;  // doubles in the diagonal chunk / in a rectangle chunk (both even)
+    int64_t M;   // doubles per tile
+};
+
+__host__ __device__ __forceinline__ S4Geom s4_geom(int N, int NB) {
+    S4Geom g;
+    g.N = N;
+    g.NB = NB;
+    g.s = N / NB;
+    g.ls = g.s | 1;
+    g.tri = g.s * (g.s + 1) / 2;
+    g.E0 = (NB * g.tri + 1) & ~1;
+    g.Er = ((NB / 2) * g.s * g.ls + 1) & ~1;
+    g.M = (int64_t)g.E0 + (int64_t)(NB - 1) * g.Er;
+    return g;
+}
+
+// position of the rectangle (lo, lo ^ r), lo < lo ^ r, among the NB/2 rectangles of round r
+__host__ __device__ __forceinline__ int s4_slot(int lo, int r) {
+    int hb = 0;
+    while ((r >> (hb + 1)) != 0) ++hb;  // highest set bit of r: clear in lo
+    return ((lo >> (hb + 1)) << hb) | (lo & ((1 << hb) - 1));
+}
+
+// offset of (a, b), b <= a, inside a tile
+__host__ __device__ __forceinline__ int64_t s4_flat(const S4Geom& g, int a, int b) {
+    const int I = a / g.s, J = b / g.s, ai = a - I * g.s, bi = b - J * g.s;
+    if (I == J) return (int64_t)I * g.tri + s4_tri(ai) + bi;
+    const int r = I ^ J;
+    return (int64_t)g.E0 + (int64_t)(r - 1) * g.Er + (int64_t)s4_slot(J, r) * g.s * g.ls + (int64_t)ai * g.ls + bi;
+}
+
+__device__ __forceinline__ double2 s4_ldnt(const double* p) {
+    typedef double nbx_d2 __attribute__((ext_vector_type(2)));
+    const nbx_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nbx_d2*>(p));
+    return make_double2(t.x, t.y);
+}
+
+// dense slab rows [p0,p1) -> packed tiles T(p,q), q <= p (the buffer was zeroed: pads stay 0)
+__global__ __launch_bounds__(256) void s4_pack_kernel(const double* __restrict__ eri, double* __restrict__ out, int N,
+                                                      int NB, int p0, int64_t t_begin) {
+    const S4Geom g = s4_geom(N, NB);
+    const int64_t T = t_begin + blockIdx.x;
+    const int p = s4_tri_row(T), q = (int)(T - s4_tri(p));
+    const double* src = eri + ((int64_t)(p - p0) * N + q) * (int64_t)N * N;
+    double* dst = out + (int64_t)blockIdx.x * g.M;
+    for (int a = 0; a < N; ++a)
+        for (int b = threadIdx.x; b <= a; b += blockDim.x) dst[s4_flat(g, a, b)] = src[(int64_t)a * N + b];
+}
+
+// Staging slots.  Wave w moves a chunk's pairs (16 bytes) in LPT loads of 64 pairs: slot (w, k)
+// starts at pair 64 (LPT w + k); a slot that would run past the chunk end is pulled back to end
+// exactly there: its first lanes repeat pairs of the slot before it -- same bytes to the same LDS
+// address, and a zero weight in the J sum.  A slot that starts past the end (-1) reads a line that
+// is always in cache (the head of the Dtot' table) into an LDS scratch area, also with weight 0.
+// Everything is unconditional and wave-uniform: one address VGPR (the lane) serves every load.
+__host__ __device__ __forceinline__ int s4_slot_start(int ne, int lpt, int w, int k) {
+    const int np2 = ne >> 1, ps = 64 * (lpt * w + k);
+    return ps >= np2 ? -1 : (ps + 64 > np2 ? np2 - 64 : ps);
+}
+
+// (a, b) of the entry at offset f of chunk ch; false for a pad
+__device__ __forceinline__ bool s4_unflat(const S4Geom& g, int ch, int f, int& a, int& b) {
+    if (ch == 0) {
+        if (f >= g.NB * g.tri) return false;
+        const int I = f / g.tri, rem = f - I * g.tri, ai = s4_tri_row(rem);
+        a = I * g.s + ai;
+        b = I * g.s + rem - (int)s4_tri(ai);
+        return true;
+    }
+    const int slot = f / (g.s * g.ls), rem = f - slot * g.s * g.ls, ai = rem / g.ls, bi = rem - ai * g.ls;
+    if (slot >= g.NB / 2 || bi >= g.s) return false;
+    int hb = 0;
+    while ((ch >> (hb + 1)) != 0) ++hb;
+    const int lo = ((slot >> hb) << (hb + 1)) | (slot & ((1 << hb) - 1));  // inverse of s4_slot
+    a = (lo ^ ch) * g.s + ai;
+    b = lo * g.s + bi;
+    return true;
+}
+
+// Dtot' in the order the staging slots hold the tile: dts[ch][w][k][lane] = the pair of
+//   sum_x (D^x_ab + D^x_ba) (a != b), sum_x D^x_aa   for the two entries the lane stages,
+// 0 for pads, for the repeated lanes of a pulled-back slot and for empty slots -- the J sum then
+// needs no masks.  One thread per (slot, lane).
+__global__ __launch_bounds__(256) void s4_dtot_kernel(const double* __restrict__ dm, double* __restrict__ dts, int N,
+                                                      int NB, int lpt, int ndm) {
+    const S4Geom g = s4_geom(N, NB);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NB * NB * lpt * 64) return;
+    const int lane = i & 63, k = (i >> 6) % lpt, w = ((i >> 6) / lpt) % NB, ch = (i >> 6) / (lpt * NB);
+    const int ne = ch == 0 ? g.E0 : g.Er;
+    const int ps = s4_slot_start(ne, lpt, w, k);
+    const int64_t n2 = (int64_t)N * N;
+    double out[2] = {0.0, 0.0};
+    if (ps >= 0 && ps + lane >= 64 * (lpt * w + k)) {
+        for (int e = 0; e < 2; ++e) {
+            int a, b;
+            if (!s4_unflat(g, ch, 2 * (ps + lane) + e, a, b)) continue;
+            double v = 0.0;
+            for (int x = 0; x < ndm; ++x) {
+                v += dm[x * n2 + (int64_t)a * N + b];
+                if (a != b) v += dm[x * n2 + (int64_t)b * N + a];
+            }
+            out[e] = v;
+        }
+    }
+    *reinterpret_cast<double2*>(dts + 2 * (int64_t)i) = make_double2(out[0], out[1]);
+}
+
+// The walk of one chunk: s steps, thread-private element tv = Lsym[trow][u*s + c] from LDS and the
+// wave-uniform density values D_q[u*s + c], D_p[u*s + c] through scalar loads.  LDS and scalar
+// loads share one counter and scalar loads return out of order, so a wait for either is a wait
+// for everything: the loop is software pipelined by hand in groups of four steps -- wait, issue
+// the next group's loads, then do this group's FMAs -- with two register sets.  Groups are
+// uniform: the last one starts at s - 4 and masks the steps an earlier group has done.
+template <int NDM, bool DIAG>
+__device__ __forceinline__ void s4_walk(const double* lb, int step, int il, int tri_il, const double* xq,
+                                        const double* xp, int64_t n2, int s, double (&kp)[NDM], double (&kq)[NDM]) {
+    const int ng = (s + 3) >> 2;
+    auto load = [&](int g, double(&a)[NDM][4], double(&b)[NDM][4], double(&t)[4]) {
+        const int c0 = min(4 * g, s - 4);
+#pragma unroll
+        for (int x = 0; x < NDM; ++x)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[x][j] = xq[x * n2 + c0 + j];
+                b[x][j] = xp[x * n2 + c0 + j];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            int addr = c * step;
+            if (DIAG) {
+                const int below = tri_il + c, above = c * (c + 1) / 2 + il;
+                addr = il >= c ? below : above;
+            }
+            t[j] = lb[addr];
+        }
+    };
+    auto fmas = [&](const double(&a)[NDM][4], const double(&b)[NDM][4], const double(&t)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int x = 0; x < NDM; ++x) {
+                kp[x] = fma(t[j], a[x][j], kp[x]);
+                kq[x] = fma(t[j], b[x][j], kq[x]);
+            }
+    };
+    // the last group starts at s - 4: its first 4*ng - s steps belong to the group before it
+    auto fmas_last = [&](const double(&a)[NDM][4], const double(&b)[NDM][4], const double(&t)[4]) {
+        const int skip = 4 * ng - s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double tj = j >= skip ? t[j] : 0.0;
+#pragma unroll
+            for (int x = 0; x < NDM; ++x) {
+                kp[x] = fma(tj, a[x][j], kp[x]);
+                kq[x] = fma(tj, b[x][j], kq[x]);
+            }
+        }
+    };
+#define S4_WAIT_THEN(LOADS)                  \
+    __builtin_amdgcn_s_waitcnt(0xC07F);      \
+    __builtin_amdgcn_sched_barrier(0);       \
+    LOADS;                                   \
+    __builtin_amdgcn_sched_barrier(0)
+    double a0[NDM][4], b0[NDM][4], t0[4], a1[NDM][4], b1[NDM][4], t1[4];
+    load(0, a0, b0, t0);
+    int g = 0;
+    for (; g + 2 < ng; g += 2) {
+        S4_WAIT_THEN(load(g + 1, a1, b1, t1));
+        fmas(a0, b0, t0);
+        S4_WAIT_THEN(load(g + 2, a0, b0, t0));
+        fmas(a1, b1, t1);
+    }
+    if (g + 1 < ng) {  // two groups left: set 0 holds a full one
+        S4_WAIT_THEN(load(g + 1, a1, b1, t1));
+        fmas(a0, b0, t0);
+        S4_WAIT_THEN((void)0);
+        fmas_last(a1, b1, t1);
+    } else {
+        S4_WAIT_THEN((void)0);
+        fmas_last(a0, b0, t0);
+    }
+#undef S4_WAIT_THEN
+}
+
+// NB waves, LPT 16-byte loads per thread per chunk, PD chunks of prefetch distance (PD == NB: one
+// whole tile ahead), DT_REG: the thread's Dtot' entries (the same for every tile) live in registers.
+template <int NDM, int NB, int LPT, int PD, bool DT_REG, int WV>
+__global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV))) void jk_s4_kernel(const double* __restrict__ eri, const double* __restrict__ dm,
+                                                        const double* __restrict__ dts, double* __restrict__ jfull,
+                                                        double* __restrict__ kpart1, double* __restrict__ kpart2,
+                                                        int N, int p0, int np, int64_t t_begin, int64_t t_end, int L,
+                                                        int S) {
+    constexpr int NCH = NB, BUFD = LPT * NB * 128;
+    static_assert(PD == NCH || PD == 2 || PD == 1, "prefetch distance");
+    extern __shared__ __attribute__((aligned(16))) double smem[];  // buf[2][BUFD] | slack[128] | jred[2][NB]
+    double* slack = smem + 2 * BUFD;
+    double* jred = slack + 128;
+
+    int64_t T = t_begin + (int64_t)blockIdx.x * L;
+    const int64_t T_end = min(t_end, T + L);
+    if (T >= T_end) return;  // uniform for the whole workgroup
+    int p = s4_tri_row(T);
+    int q = (int)(T - s4_tri(p));
+    const int p_first = p;
+
+    const S4Geom g = s4_geom(N, NB);
+    const int s = g.s, ls = g.ls;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const bool live = lane < s;
+    const int il = live ? lane : s - 1;  // idle lanes shadow the last row (their results are dropped)
+    const int trow = w * s + il;
+    const int tri_il = il * (il + 1) / 2;
+    const int64_t n2 = (int64_t)N * N;
+
+    auto chunk_off = [&](int ch) { return ch == 0 ? 0 : g.E0 + (ch - 1) * g.Er; };
+    auto chunk_len = [&](int ch) { return ch == 0 ? g.E0 : g.Er; };
+
+    // staging slots (s4_slot_start): uniform start + 2 * lane
+    double2 stage[PD][LPT];
+    double2 dt[DT_REG ? NCH : 1][LPT];
+    auto issue = [&](double2(&st)[LPT], const double* tp, int ch) {
+        const double* cp = tp + chunk_off(ch);
+        const int ne = chunk_len(ch);
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) {
+            const int ps = s4_slot_start(ne, LPT, w, k);
+            st[k] = s4_ldnt((ps < 0 ? dts : cp + 2 * ps) + 2 * lane);
+        }
+    };
+    const double* dts_l = dts;
+    auto issue_dt = [&](double2(&d)[LPT], int ch) {
+        const double* cp = dts_l + ((ch * NB + w) * LPT) * 128;
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) d[k] = *reinterpret_cast<const double2*>(cp + k * 128 + 2 * lane);
+    };
+
+    const double* tile = eri + (T - t_begin) * g.M;
+#pragma unroll
+    for (int ch = 0; ch < PD; ++ch) issue(stage[ch], tile, ch);
+    if (DT_REG) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) issue_dt(dt[ch], ch);
+    } else {
+        issue_dt(dt[0], 0);
+    }
+
+    double kp[NDM];
+#pragma unroll
+    for (int x = 0; x < NDM; ++x) kp[x] = 0.0;
+    auto flush_p = [&](int prow) {
+        if (live) {
+            double* kout = kpart1 + ((int64_t)blockIdx.x * S + (prow - p_first)) * NDM * N;
+#pragma unroll
+            for (int x = 0; x < NDM; ++x) kout[x * N + trow] = kp[x];
+        }
+#pragma unroll
+        for (int x = 0; x < NDM; ++x) kp[x] = 0.0;
+    };
+    auto store_j = [&](int par, int pj, int qj) {  // thread 0, after a barrier that follows the jred writes
+        double tot = 0.0;
+#pragma unroll
+        for (int v = 0; v < NB; ++v) tot += jred[par * NB + v];
+        jfull[(int64_t)pj * N + qj] = tot;
+        jfull[(int64_t)qj * N + pj] = tot;
+    };
+
+    int p_cur = p_first, par = 0;
+    int pj = -1, qj = -1;  // the tile whose J partials sit in jred[par ^ 1]
+    while (T < T_end) {
+        if (p != p_cur) {
+            flush_p(p_cur);
+            p_cur = p;
+        }
+        const double* tile_next = T + 1 < T_end ? tile + g.M : tile;
+        // Dtot' is the same for every tile: without this the loads are hoisted out of the tile loop
+        // into NB * LPT double2 registers (which is DT_REG, for the sizes that can afford it)
+        if (!DT_REG) asm volatile("" : "+s"(dts_l));
+        double kq[NDM];
+#pragma unroll
+        for (int x = 0; x < NDM; ++x) kq[x] = 0.0;
+        double jacc = 0.0;
+        const double* dq = dm + (int64_t)q * N;
+        const double* dp = dm + (int64_t)p * N;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            double* buf = smem + (ch & 1) * BUFD;
+            double2(&st)[LPT] = stage[ch % PD];
+            double2(&dd)[LPT] = dt[DT_REG ? ch : 0];
+#pragma unroll
+            for (int k = 0; k < LPT; ++k) {
+                jacc = fma(st[k].x, dd[k].x, fma(st[k].y, dd[k].y, jacc));
+                const int ps = s4_slot_start(chunk_len(ch), LPT, w, k);
+                *reinterpret_cast<double2*>((ps < 0 ? slack : buf + 2 * ps) + 2 * lane) = st[k];
+            }
+            // refill the staging registers: chunk ch + PD of this tile, or of the next one (pinned
+            // after the stores above: hoisted loads would need a second set of registers)
+            __builtin_amdgcn_sched_barrier(0);
+            // (the last tile of the range re-reads itself: no tail case)
+            if (ch + PD < NCH) issue(st, tile, ch + PD);
+            else issue(st, tile_next, ch + PD - NCH);
+            if (!DT_REG) issue_dt(dd, (ch + 1) % NCH);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (ch == 0 && pj >= 0 && tid == 0) store_j(par ^ 1, pj, qj);
+
+            // ---- the walk: s steps, element Lsym[trow][u*s + c]
+            if (ch == 0) {
+                s4_walk<NDM, true>(buf + w * g.tri, 0, il, tri_il, dq + w * s, dp + w * s, n2, s, kp, kq);
+            } else {
+                const int u = w ^ ch;
+                const bool rowside = w > u;
+                const double* lb = buf + s4_slot(min(w, u), ch) * s * ls + (rowside ? il * ls : il);
+                s4_walk<NDM, false>(lb, rowside ? 1 : ls, il, tri_il, dq + u * s, dp + u * s, n2, s, kp, kq);
+            }
+        }
+        // J partial of this tile (summed by thread 0 after the next barrier)
+        jacc = nbx_wave_sum(jacc);
+        if (lane == 0) jred[par * NB + w] = jacc;
+        pj = p;
+        qj = q;
+        par ^= 1;
+        if (q < p && live) {
+            double* k2 = kpart2 + (((int64_t)q * np + (p - p0)) * NDM) * N + trow;
+#pragma unroll
+            for (int x = 0; x < NDM; ++x) k2[x * N] = kq[x];
+        }
+        ++T;
+        tile += g.M;
+        if (++q > p) {
+            ++p;
+            q = 0;
+        }
+    }
+    flush_p(p_cur);
+    __syncthreads();
+    if (tid == 0) store_j(par ^ 1, pj, qj);
+}
+
+struct S4Plan {
+    int NB, lpt, wgs, L, S, per_cu;
+    size_t lds_bytes, dtp_off, k1_off, k2_off, total;
+    S4Geom g;
+};
+
+size_t s4_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// four blocks when the chunks of N / 4 rows still fill a staging slot (128 doubles), else two
+int s4_nb(int64_t N) {
+    if (N % 4 == 0) {
+        const S4Geom g = s4_geom((int)N, 4);
+        if (g.E0 >= 128 && g.Er >= 128) return 4;
+    }
+    return 2;
+}
+
+// template instances: loads per thread per chunk
+int s4_lpt_class(int lpt, int NB) {
+    return lpt <= 2 ? 2 : lpt <= 6 ? 6 : lpt <= 10 ? 10 : (lpt <= 17 && NB == 4) ? 17 : 0;
+}
+
+bool s4_supported(int64_t N) {
+    if (N < 16 || N > 256 || N % 2 != 0) return false;  // a walk group is four steps: s >= 4
+    const int NB = s4_nb(N);
+    if (N % NB != 0 || N / NB > 64) return false;  // one wave walks a block
+    const S4Geom g = s4_geom((int)N, NB);
+    const int need = (int)nbx_cdiv((g.E0 > g.Er ? g.E0 : g.Er) / 2, NB * 64);
+    return s4_lpt_class(need, NB) != 0 && g.E0 >= 128 && g.Er >= 128;  // a staging slot is 64 pairs
+}
+
+S4Plan s4_plan(int64_t N, int64_t p0, int64_t np, int64_t ndm) {
+    S4Plan pl;
+    pl.NB = s4_nb(N);
+    pl.g = s4_geom((int)N, pl.NB);
+    const int nt = pl.NB * 64;
+    pl.lpt = s4_lpt_class((int)nbx_cdiv((pl.g.E0 > pl.g.Er ? pl.g.E0 : pl.g.Er) / 2, nt), pl.NB);
+    pl.lds_bytes = (size_t)(2 * pl.lpt * nt * 2 + 128 + 2 * pl.NB) * sizeof(double);
+    int64_t per_cu = (int64_t)(S4_LDS_PER_CU / (pl.lds_bytes + 256));
+    // two waves per SIMD (the staging registers need the budget), one for the long-row instances
+    const int64_t by_waves = (pl.lpt >= 10 ? 4 : 8) / pl.NB;
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu < 1) per_cu = 1;
+    pl.per_cu = (int)per_cu;
+    const int64_t slots = S4_CUS * per_cu;
+    const int64_t ntiles = s4_tri(p0 + np) - s4_tri(p0);
+    int64_t L = nbx_cdiv(ntiles, slots);
+    if (L < 1) L = 1;
+    pl.L = (int)L;
+    pl.wgs = (int)nbx_cdiv(ntiles, L);
+    pl.S = (int)sqrt(2.0 * (double)L) + 3;
+    size_t off = 0;
+    pl.dtp_off = off; off += s4_align256((size_t)(pl.NB * pl.NB * pl.lpt * 128) * sizeof(double));
+    pl.k1_off = off; off += s4_align256((size_t)((int64_t)pl.wgs * pl.S * ndm * N) * sizeof(double));
+    pl.k2_off = off; off += s4_align256((size_t)(N * np * ndm * N) * sizeof(double));
+    pl.total = off;
+    return pl;
+}
+
+}  // namespace
+
+extern "C" int nbx_jk_packed_supported(int64_t nao) { return s4_supported(nao) ? 1 : 0; }
+
+extern "C" size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1) {
+    if (!s4_supported(nao) || p0 < 0 || p1 < p0 || p1 > nao) return 0;
+    const S4Geom g = s4_geom((int)nao, s4_nb(nao));
+    return (size_t)((s4_tri(p1) - s4_tri(p0)) * g.M) * sizeof(double);
+}
+
+extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri, double* d_packed) {
+    NBX_CHECK_ARG(ctx);
+    NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
+    if (!s4_supported(nao)) {
+        nbx_set_error("nbx_eri_pack: N = %lld is not covered by the packed J/K kernel", (long long)nao);
+        return NBX_E_UNSUPPORTED;
+    }
+    if (p0 == p1) return NBX_OK;
+    NBX_CHECK_ARG(d_eri && d_packed);
+    const int64_t ntiles = s4_tri(p1) - s4_tri(p0);
+    int rc = nbx_memset(ctx, d_packed, 0, nbx_eri_packed_bytes(nao, p0, p1));
+    if (rc != NBX_OK) return rc;
+    hipLaunchKernelGGL(s4_pack_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, d_eri, d_packed, (int)nao,
+                       s4_nb(nao), (int)p0, s4_tri(p0));
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+extern "C" size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm) {
+    if (!s4_supported(nao) || p0 < 0 || p1 < p0 || p1 > nao || ndm <= 0) return 0;
+    return s4_plan(nao, p0, p1 - p0, ndm).total;
+}
+
+extern "C" int nbx_jk_packed(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed,
+                             const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes) {
+    NBX_CHECK_ARG(ctx && d_dm && d_jk);
+    NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
+    NBX_CHECK_ARG(d_packed != nullptr || p0 == p1);
+    NBX_CHECK_ARG(ndm == 1 || ndm == 2);
+    if (!s4_supported(nao)) {
+        nbx_set_error("nbx_jk_packed: N = %lld is not covered (even N <= 256, N %% 4 == 0 above 128)", (long long)nao);
+        return NBX_E_UNSUPPORTED;
+    }
+    const int64_t np = p1 - p0, N = nao, n2 = N * N;
+    const size_t need = nbx_jk_packed_worksize(nao, p0, p1, ndm);
+    if (d_work == nullptr || work_bytes < need) {
+        nbx_set_error("nbx_jk_packed: workspace %zu < %zu bytes", work_bytes, need);
+        return NBX_E_NOMEM;
+    }
+    NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
+    if (np == 0) return nbx_memset(ctx, d_jk, 0, (size_t)((1 + ndm) * n2) * sizeof(double));
+    const S4Plan pl = s4_plan(N, p0, np, ndm);
+    char* base = static_cast<char*>(d_work);
+    double* dtp = reinterpret_cast<double*>(base + pl.dtp_off);
+    double* k1 = reinterpret_cast<double*>(base + pl.k1_off);
+    double* k2 = reinterpret_cast<double*>(base + pl.k2_off);
+    if (np < N) {  // J entries this slab does not own must read as zero
+        const int rc = nbx_memset(ctx, d_jk, 0, (size_t)n2 * sizeof(double));
+        if (rc != NBX_OK) return rc;
+    }
+    hipLaunchKernelGGL(s4_dtot_kernel, dim3((unsigned)nbx_cdiv(pl.NB * pl.NB * pl.lpt * 64, 256)), dim3(256), 0,
+                       ctx->stream, d_dm, dtp, (int)N, pl.NB, pl.lpt, (int)ndm);
+    NBX_LAUNCH_CHECK();
+    const int64_t t_begin = s4_tri(p0), t_end = s4_tri(p1);
+    {
+        nbx_prof_scope prof(ctx, NBX_PROF_JK_DENSE);
+#define NBX_S4_GO(NDM_, NB_, LPT_, PD_, DT_, WV_)                                                                          \
+    do {                                                                                                              \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jk_s4_kernel<NDM_, NB_, LPT_, PD_, DT_, WV_>),        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL((jk_s4_kernel<NDM_, NB_, LPT_, PD_, DT_, WV_>), dim3((unsigned)pl.wgs), dim3(NB_ * 64),         \
+                           pl.lds_bytes, ctx->stream, d_packed, d_dm, dtp, d_jk, k1, k2, (int)N, (int)p0, (int)np,    \
+                           t_begin, t_end, pl.L, pl.S);                                                               \
+    } while (0)
+#define NBX_S4_NDM(NB_, LPT_, PD_, DT_, WV_)                                                                               \
+    do {                                                                                                              \
+        if (ndm == 2) NBX_S4_GO(2, NB_, LPT_, PD_, DT_, WV_);                                                              \
+        else NBX_S4_GO(1, NB_, LPT_, PD_, DT_, WV_);                                                                       \
+    } while (0)
+        if (pl.NB == 2) {
+            if (pl.lpt == 2) NBX_S4_NDM(2, 2, 2, true, 2);
+            else if (pl.lpt == 6) NBX_S4_NDM(2, 6, 2, true, 2);
+            else NBX_S4_NDM(2, 10, 2, true, 1);
+        } else {
+            if (pl.lpt == 2) NBX_S4_NDM(4, 2, 4, true, 2);
+            else if (pl.lpt == 6) NBX_S4_NDM(4, 6, 2, true, 2);
+            else if (pl.lpt == 10) NBX_S4_NDM(4, 10, 2, true, 1);   // one workgroup per CU (LDS): 512 registers
+            else NBX_S4_NDM(4, 17, 1, false, 1);
+        }
+#undef NBX_S4_NDM
+#undef NBX_S4_GO
+    }
+    NBX_LAUNCH_CHECK();
+    return nbx_jk_sym_reduce(ctx, k1, k2, d_jk + n2, N, p0, np, ndm, t_begin, pl.L, pl.S);
+}

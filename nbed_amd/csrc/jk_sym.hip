@@ -461,6 +461,15 @@ JsPlan js_plan(int64_t N, int64_t p0, int64_t np, int64_t ndm) {
 
 bool nbx_jk_sym_supported(int64_t nao) { return nao >= 2 && nao % 2 == 0 && nao / 2 <= JS_THREADS; }
 
+// K[x][row][b] from the row-p / row-q partial buffers (shared with jk_s4.hip, same layouts)
+int nbx_jk_sym_reduce(nbx_ctx* ctx, const double* k1, const double* k2, double* d_k, int64_t N, int64_t p0, int64_t np,
+                      int64_t ndm, int64_t t_begin, int L, int S) {
+    hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
+                       ctx->stream, k1, k2, d_k, (int)N, (int)p0, (int)np, (int)ndm, t_begin, L, S, 0);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
 extern "C" size_t nbx_jk_dense_sym_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm) {
     if (nao <= 0 || p0 < 0 || p1 < p0 || p1 > nao || ndm <= 0) return 0;
     if (!nbx_jk_sym_supported(nao))  // falls back to the plain kernel + a scatter into full-size matrices

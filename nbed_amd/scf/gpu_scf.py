@@ -59,6 +59,11 @@ class Mole:
         return self._e_nuc
 
 
+# Below this many basis functions the packed J/K kernel has no edge over the symmetric one (both
+# are launch bound) and the packed copy would only cost memory.
+PACKED_JK_MIN_NAO = 100
+
+
 def _sign_fix(c: np.ndarray) -> np.ndarray:
     """PySCF ``hf.eig``: make each eigenvector's largest-|component| positive."""
     idx = np.argmax(np.abs(c), axis=0)
@@ -85,6 +90,7 @@ class _GpuSCF:
                     f"ERI slab has shape {tuple(eri.shape)}, expected {(self.shards.size, nao, nao, nao)}"
                 )
         self._eri_d = eri
+        self._eri_packed_d = None  # 4-fold packed copy of the slab for the J/K kernel, made on first use
         self._x_d = None  # S^-1/2, built on first use
         self.mo_coeff = None
         self.mo_occ = None
@@ -123,11 +129,25 @@ class _GpuSCF:
             self._x_d = self.be.sym_pow(self._s_d, -0.5)
         return self._x_d
 
+    def eri_packed_device(self):
+        """This rank's slab in the packed tile format of nbx_jk_packed (q <= p, s <= r: a quarter of
+        the dense bytes; PySCF holds ``mf._eri`` packed too), made once -- the integrals are
+        constant over the SCF.  None where the packed kernel does not apply."""
+        be = self.be
+        nao = self._s_h.shape[0]
+        if self._eri_packed_d is None and self._eri_d is not None and hasattr(be, "jk_packed"):
+            if nao >= PACKED_JK_MIN_NAO and be.jk_packed_supported(nao):
+                self._eri_packed_d = be.eri_pack(self._eri_d, nao, self.shards.lo, self.shards.hi)
+        return self._eri_packed_d
+
     def jk_device(self, dm_d):
-        """(1+ndm, N, N) on device: J(sum dm), K(dm[x]).  The symmetric kernel reads only the tiles
-        q <= p of this rank's slab and returns full-size partial matrices, summed over ranks by one
-        all-reduce; a backend without it computes plain row slabs and all-gathers them."""
+        """(1+ndm, N, N) on device: J(sum dm), K(dm[x]).  The packed / symmetric kernels read only the
+        tiles q <= p of this rank's slab and return full-size partial matrices, summed over ranks
+        by one all-reduce; a backend without them computes plain row slabs and all-gathers them."""
         be, sh = self.be, self.shards
+        packed = self.eri_packed_device()
+        if packed is not None:
+            return sh.all_reduce(be, be.jk_packed(packed, dm_d, sh.lo, sh.hi))
         if hasattr(be, "jk_sym"):
             return sh.all_reduce(be, be.jk_sym(self.eri_device(), dm_d, sh.lo, sh.hi))
         slab = be.jk(self.eri_device(), dm_d, sh.lo, sh.hi)

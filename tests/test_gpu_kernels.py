@@ -529,6 +529,100 @@ def test_jk_sym_fallback_sizes_and_full_size(be):
     np.testing.assert_array_equal(a[0], a[0].T)  # J is written once per pair: exactly symmetric
 
 
+def s4_layout(n):
+    """The packed tile format of nbx_eri_pack (include/nbx.h), restated in numpy: offsets of the
+    entries (a, b <= a) of one tile and the tile length."""
+    def supported(nb):
+        s = n // nb
+        ls = s | 1
+        e0 = (nb * s * (s + 1) // 2 + 1) & ~1
+        er = ((nb // 2) * s * ls + 1) & ~1
+        return n % nb == 0 and e0 >= 128 and er >= 128, s, ls, e0, er
+    ok4, *_ = supported(4)
+    nb = 4 if n % 4 == 0 and ok4 else 2
+    _, s, ls, e0, er = supported(nb)
+    tri = s * (s + 1) // 2
+    off = np.full((n, n), -1, dtype=np.int64)
+    for a in range(n):
+        for b in range(a + 1):
+            i, j, ai, bi = a // s, b // s, a % s, b % s
+            if i == j:
+                off[a, b] = i * tri + ai * (ai + 1) // 2 + bi
+            else:
+                r = i ^ j
+                hb = r.bit_length() - 1
+                slot = ((j >> (hb + 1)) << hb) | (j & ((1 << hb) - 1))
+                off[a, b] = e0 + (r - 1) * er + slot * s * ls + ai * ls + bi
+    return off, e0 + (nb - 1) * er
+
+
+@pytest.mark.parametrize("n", [24, 32, 50, 72])
+def test_eri_pack_layout(be, n):
+    """nbx_eri_pack against the numpy restatement of the documented format: bit-identical values at
+    the documented offsets, zero pads, tiles q <= p in sequence, slabs start at T(p0, 0)."""
+    assert be.jk_packed_supported(n)
+    eri_h = synth.eri_dense(n)
+    off, m = s4_layout(n)
+    want = np.zeros((n * (n + 1) // 2, m))
+    ia, ib = np.tril_indices(n)
+    t = 0
+    for p in range(n):
+        for q in range(p + 1):
+            want[t, off[ia, ib]] = eri_h[p, q][ia, ib]
+            t += 1
+    got = be.to_host(be.eri_pack(be.asarray(eri_h), n))
+    np.testing.assert_array_equal(got.reshape(-1, m), want)
+    p0, p1 = n // 3, n // 3 + 5
+    slab = be.to_host(be.eri_pack(be.asarray(eri_h[p0:p1]), n, p0, p1))
+    np.testing.assert_array_equal(slab.reshape(-1, m), want[p0 * (p0 + 1) // 2 : p1 * (p1 + 1) // 2])
+
+
+@pytest.mark.parametrize("n,ndm", [(24, 2), (24, 1), (32, 2), (50, 2), (72, 2), (72, 1), (98, 2)])
+def test_jk_packed_vs_oracle(be, n, ndm):
+    """Packed J/K (q <= p and s <= r read: a quarter of the tensor) against the einsum definition;
+    slabs add up; the result is reproducible bit for bit."""
+    eri_h = synth.eri_dense(n)
+    dm = np.stack([symm(520 + x, n) for x in range(ndm)])
+    vj, vk = get_jk(eri_h, dm)
+    eri = be.asarray(eri_h)
+    packed = be.eri_pack(eri, n)
+    got = be.to_host(be.jk_packed(packed, be.asarray(dm)))
+    np.testing.assert_allclose(got[0], vj.sum(0) if vj.ndim == 3 else vj, rtol=0, atol=2e-12)
+    np.testing.assert_allclose(got[1:], vk.reshape(ndm, n, n), rtol=0, atol=2e-12)
+    np.testing.assert_array_equal(got[0], got[0].T)
+    np.testing.assert_array_equal(be.to_host(be.jk_packed(packed, be.asarray(dm))), got)
+    cut = n // 3 + 1
+    parts = (be.to_host(be.jk_packed(be.eri_pack(eri[:cut], n, 0, cut), be.asarray(dm), 0, cut))
+             + be.to_host(be.jk_packed(be.eri_pack(eri[cut:], n, cut, n), be.asarray(dm), cut, n)))
+    np.testing.assert_allclose(parts, got, rtol=0, atol=2e-12)
+    # empty slab: contributes zeros
+    assert float(be.jk_packed(be.eri_pack(eri[:0], n, 3, 3), be.asarray(dm), 3, 3).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n", [128, 148, 192, 256])
+def test_jk_packed_full_size(be, n):
+    """The four kernel instances of the larger sizes (N = 148 is the bench size) against the plain
+    streaming kernel on the generated tensor, both spins."""
+    eri = be.synth_eri(n)
+    dmd = be.asarray(np.stack([symm(532, n), symm(533, n)]))
+    a = be.to_host(be.jk_packed(be.eri_pack(eri, n), dmd))
+    b = be.to_host(be.jk(eri, dmd))
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-11 * (n / 148) ** 2)
+    np.testing.assert_array_equal(a[0], a[0].T)
+
+
+def test_jk_packed_unsupported_sizes(be):
+    """Sizes outside the packed kernel's coverage are refused loudly (the host then keeps the
+    symmetric kernel): odd N, blocks longer than a wave, tiny chunks."""
+    from nbed_amd._nbx import NbxError
+
+    for n in (7, 13, 16, 22, 102, 150, 258):
+        assert not be.jk_packed_supported(n)
+    eri = be.synth_eri(13)
+    with pytest.raises((ValueError, NbxError)):
+        be.eri_pack(eri, 13)
+
+
 def test_cdiis_device_and_orbital_gradient_norm(be):
     """nbx_diis_update_err (CDIIS ring on the device) against the oracle's pyscf.scf.diis.CDIIS
     restatement over 11 updates (space 8: the ring wraps), and nbx_vo_sumsq against numpy."""
