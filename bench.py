@@ -363,13 +363,19 @@ def main():
         sym = (N % 2 == 0 and N <= 512)
         ntiles = (shards.hi * (shards.hi + 1) - shards.lo * (shards.lo + 1)) // 2 if sym else shards.size * N
         alg_bytes = 8.0 * N * N * ntiles
+        # The packed kernel (the one GpuUHF uses where it applies) reads q <= p AND s <= r: the packed
+        # slab, once per build.
+        packed = mf.eri_packed_device() is not None
+        if packed:
+            alg_bytes = float(be.lib.nbx_eri_packed_bytes(N, shards.lo, shards.hi))
+        jk_kernel = "jk_s4_kernel" if packed else ("jk_sym_kernel" if sym else "jk_dense_kernel")
         achieved = alg_bytes / (jk_avg_ms * 1e-3) / 1e9 if jk_cnt else None
         traffic = None
         tfile = REPO / "profiles" / "jk_traffic.json"
         if tfile.exists() and world == 1 and N == 148:
             try:
                 tj = json.loads(tfile.read_text())
-                if ("jk_sym" in tj.get("kernel", "")) == sym:  # measured on the kernel this run uses
+                if tj.get("kernel", "").startswith(jk_kernel):  # measured on the kernel this run uses
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -388,7 +394,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"synthetic octane/6-31G*-shaped embedded UHF (BASELINE configs[2]): N_AO={N}, "
-                            f"n_occ=({args.nocc},{args.nocc}), n_env={args.nenv}, n_act_mo={n_act}; dense (pq|rs) in HBM",
+                            f"n_occ=({args.nocc},{args.nocc}), n_env={args.nenv}, n_act_mo={n_act}; (pq|rs) in HBM"
+                            + (", 4-fold packed for J/K (packed once, outside the timed region)" if packed else ""),
                 "nao": N,
                 "eri_bytes": 8 * N**4,
                 "parallelism": f"equal-work p-row slabs x{world} + RCCL all-reduce" if world > 1 else "single GPU",
@@ -396,15 +403,19 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "jk_sym_kernel" if sym else "jk_dense_kernel",
+                "kernel": jk_kernel,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "algorithmic_bytes_note": "tiles q <= p of the dense (pq|rs) slab, read once: (pq|rs) = (qp|rs) halves "
-                                          "SURVEY 8d's 8 N^4; dense_equivalent_gbs prices the same launch at 8 N^4",
+                "algorithmic_bytes_note": (
+                    "the 4-fold packed slab (q <= p, s <= r; (pq|rs) = (qp|rs) = (pq|sr)), read once per build: a "
+                    "quarter of SURVEY 8d's 8 N^4; dense_equivalent_gbs prices the same launch at 8 N^4"
+                    if packed else
+                    "tiles q <= p of the dense (pq|rs) slab, read once: (pq|rs) = (qp|rs) halves "
+                    "SURVEY 8d's 8 N^4; dense_equivalent_gbs prices the same launch at 8 N^4"),
                 "dense_equivalent_gbs": (8.0 * shards.size * N**3) / (jk_avg_ms * 1e-3) / 1e9 if jk_cnt else None,
                 "avg_launch_ms": jk_avg_ms,
                 "launches": jk_cnt,
