@@ -180,10 +180,13 @@ int nbx_trace_prod(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_a, 
 int nbx_huz_cycle_scalars(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
                           const double* d_vemb, const double* d_vhf, const double* d_hz,
                           const double* d_dm, const double* d_dm_old, double* h_out);
-/* Same scalars, left in device memory (d_out[4 + tail_n], square roots applied) with no
- * synchronisation, so that the host can queue the next SCF cycle before it reads them.
+/* Same scalars (d_out[4 + tail_n], square roots applied) with no synchronisation, so that the
+ * host can queue the next SCF cycle before it reads them.  One launch: the workgroup that arrives
+ * last does the second stage.  d_out is device memory or pinned (device-mapped) host memory --
+ * stored to host memory directly the values need no copy; they are complete once the stream has
+ * passed the launch (record an event).
  * d_tail (optional): tail_n <= 64 device ints appended as doubles, e.g. the eigensolver status
- * words, so that they reach the host in the same copy.                                        */
+ * words, so that they reach the host together.                                                */
 int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
                               const double* d_vemb, const double* d_vhf, const double* d_hz,
                               const double* d_dm, const double* d_dm_old, double* d_out,

@@ -40,12 +40,17 @@ def set_backend(backend) -> None:
 
 
 class _PendingScalars:
-    """A few doubles on their way from HBM to pinned host memory (stream-ordered copy + event)."""
+    """A few doubles on their way to pinned host memory: either a stream-ordered copy of ``d_vals``
+    or, with ``host`` given, values a queued kernel stores there itself (pinned memory is mapped
+    into the device's address space); an event marks the point after which they can be read."""
 
-    def __init__(self, torch, d_vals, ntail=0, ncore=4):
+    def __init__(self, torch, d_vals, ntail=0, ncore=4, host=None):
         self._ncore = ncore
-        self._host = torch.empty(d_vals.shape, dtype=d_vals.dtype, pin_memory=True)
-        self._host.copy_(d_vals, non_blocking=True)
+        if host is None:
+            self._host = torch.empty(d_vals.shape, dtype=d_vals.dtype, pin_memory=True)
+            self._host.copy_(d_vals, non_blocking=True)
+        else:
+            self._host = host
         self._event = torch.cuda.Event()
         self._event.record()
         self._keep = d_vals  # the source must outlive the copy
@@ -462,10 +467,12 @@ class HipBackend:
         ``extra``: a small device tensor to bring back with them (``get_extra()``)."""
         nao = dm.shape[-1]
         ntail = 0 if extra is None else int(extra.numel())
-        d_out = self.empty(4 + ntail)
+        # the kernel's last workgroup stores the results straight into pinned host memory: no copy
+        # (a device-to-host copy per cycle costs a launch and a cache flush in the middle of the chain)
+        h_out = self.torch.empty(4 + ntail, dtype=self.torch.float64, pin_memory=True)
         self._call("nbx_huz_cycle_scalars_dev", nao, self._p(hcore), hcore.dim(), self._p(vemb), self._p(vhf),
-                   self._p(hz), self._p(dm), self._p(dm_old), self._p(d_out), self._p(extra), ntail)
-        return _PendingScalars(self.torch, d_out, ntail)
+                   self._p(hz), self._p(dm), self._p(dm_old), self._p(h_out), self._p(extra), ntail)
+        return _PendingScalars(self.torch, None, ntail, host=h_out)
 
     def async_to_host(self, d_vals):
         """Stream-ordered copy of a small device tensor to pinned memory; ``.get()`` waits for it only."""

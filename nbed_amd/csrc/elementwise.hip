@@ -108,12 +108,20 @@ __global__ void huzinaga_sym_kernel(const double* __restrict__ fds, int N, doubl
 }
 
 // partial[blk*4 + {0,1}] = sum (h + v + 0.5 vhf + hz)[x][i,j] * D[x][j,i];  [2,3] = sum (D-Dold)^2
+// With `out`: the workgroup that arrives last (device-scope counter, left at zero) also does the
+// second stage in the fixed order of final_reduce_kernel -- out[0,1] the sums, out[2,3] the square
+// roots, then `tail_n` status words as doubles -- so the cycle's scalars cost one launch.  `out`
+// may be pinned host memory: the values then need no copy.
 __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const double* __restrict__ vemb,
                                    const double* __restrict__ vhf, const double* __restrict__ hz,
                                    const double* __restrict__ dm, const double* __restrict__ dm_old, int N,
-                                   double* __restrict__ partial) {
+                                   double* __restrict__ partial, double* __restrict__ out_final = nullptr,
+                                   const int* __restrict__ tail = nullptr, int tail_n = 0,
+                                   int* __restrict__ counter = nullptr) {
     __shared__ double dt[TILE][TILE + 1];
     __shared__ double red[4][4];
+    __shared__ double red2[17];
+    __shared__ int last;
     const int64_t n2 = (int64_t)N * N;
     const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
@@ -147,6 +155,34 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
         double t = 0.0;
         for (int w = 0; w < (int)(blockDim.x * blockDim.y) / 64; ++w) t += red[w][tid];
         partial[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + tid] = t;
+    }
+    if (out_final == nullptr) return;
+    const int nblocks = gridDim.x * gridDim.y;
+    __threadfence();  // the partials above are visible device-wide before the arrival is
+    __syncthreads();
+    if (tid == 0) {
+        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = prev == nblocks - 1;
+        if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const int nthr = blockDim.x * blockDim.y;
+    if (tid < tail_n) out_final[4 + tid] = (double)tail[tid];
+    for (int o = 0; o < 4; ++o) {
+        double t = 0.0;
+        for (int b = tid; b < nblocks; b += nthr)
+            t += __hip_atomic_load(partial + (int64_t)b * 4 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = nbx_wave_sum(t);  // (the workgroup is 2-D: nbx_block_sum's indexing does not apply)
+        if ((tid & 63) == 0) red2[tid >> 6] = t;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < nthr / 64; ++w) tot += red2[w];
+            out_final[o] = (o >= 2) ? sqrt(tot) : tot;
+        }
+        __syncthreads();
     }
 }
 
@@ -584,10 +620,8 @@ int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
     const int64_t g = nbx_cdiv(nao, TILE);
     NBX_CHECK_ARG(g * g * 4 <= NBX_SCRATCH_DOUBLES - 64);
     hipLaunchKernelGGL(huz_scalars_kernel, dim3((unsigned)g, (unsigned)g), dim3(TILE, 8), 0, ctx->stream, d_hcore,
-                       hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch);
-    NBX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_scratch, (int)(g * g), 4,
-                       d_out, 2, d_tail, (int)tail_n);
+                       hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch, d_out,
+                       d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
