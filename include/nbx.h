@@ -134,6 +134,14 @@ size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm);
 int nbx_jk_packed(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed,
                   const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes);
 
+/* nbx_jk_packed over the whole tensor (p0 = 0, p1 = N, two spin densities) with the Fock
+ * assembly of nbx_fock_uhf done by its reduction kernel (one launch less per SCF cycle):
+ *   d_hv : (2,N,N) hcore + V_emb;  d_fock[x] = d_hv[x] + J - K[x];  d_vhf[x] = J - K[x] (may be
+ *   NULL);  d_jk as nbx_jk_packed.  nbed/scf/huzinaga_scf.py:156-160.                        */
+int nbx_jk_packed_fock(nbx_ctx* ctx, int64_t nao, const double* d_packed, const double* d_dm,
+                       const double* d_hv, double* d_jk, double* d_fock, double* d_vhf, void* d_work,
+                       size_t work_bytes);
+
 /* Same contraction with the synthetic (pq|rs) of nbx_synth_eri GENERATED in registers instead of
  * read from HBM (the N_AO = 2000 configuration: a dense tensor would be 128 TB).  Workspace as
  * nbx_jk_dense_worksize().  ALU-bound (one 64-bit counter hash per integral).               */
@@ -275,6 +283,22 @@ int nbx_sym_pow(nbx_ctx* ctx, int64_t n, const double* d_s, double p, double* d_
 size_t nbx_svd_worksize(int64_t m, int64_t n);
 int nbx_svd_right(nbx_ctx* ctx, int64_t m, int64_t n, const double* d_a, double* d_s, double* d_vt,
                   void* d_work, size_t work_bytes);
+/* Generalised symmetric eigenproblem F C = S C eps by iterative refinement of the PREVIOUS SCF
+ * cycle's solution (Ogita-Aishima on the pencil: G = C^T S C, S~ = C^T F C, C <- C (I + E)), all
+ * GEMMs -- what scipy.linalg.eigh(F, S) / the Loewdin route of nbed/scf/huzinaga_scf.py:166-169
+ * computes, once an SCF is under way.  batch matrices: d_f, d_s (the overlap, repeated per batch
+ * entry), d_c0 (S-orthonormal start vectors), all (batch, n, n) row-major.
+ *   d_status[b] = 1000 + iterations used: accepted, d_w[b] (ascending) and d_c[b] written;
+ *               <= 0: not converged within max_iter (1..3) or near-degenerate cluster coupled --
+ *                     outputs untouched.  There is NO fallback solver behind this entry: the
+ *                     caller checks the status (the SCF loops do, one cycle late, and redo the run
+ *                     on nbx_eigh_warm_ex if it ever fails).
+ * Nothing synchronises.  d_work: nbx_geig_refine_worksize() bytes.                              */
+size_t nbx_geig_refine_worksize(int64_t n, int64_t batch);
+int nbx_geig_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_f, const double* d_s,
+                    const double* d_c0, double* d_w, double* d_c, int* d_status, void* d_work,
+                    size_t work_bytes, int max_iter);
+
 /* Sweep count of the last nbx_svd_right on this workspace (synchronises); NBX_E_NOCONV if the
  * sweep limit was hit. */
 int nbx_svd_status(nbx_ctx* ctx, int64_t m, int64_t n, const void* d_work, int* h_sweeps);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "nbx_eri_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "nbx_eri_pack": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     "nbx_jk_packed_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "nbx_jk_packed_fock": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t]),
     "nbx_jk_packed": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
     "nbx_jk_dense_sym": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
     "nbx_jk_synth_sym_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
@@ -87,6 +88,8 @@ SIGNATURES = {
     "nbx_eigh_worksize": (c_size_t, [c_int64, c_int64]),
     "nbx_eigh": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, c_size_t]),
     "nbx_eigh_warm": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, c_size_t]),
+    "nbx_geig_refine_worksize": (c_size_t, [c_int64, c_int64]),
+    "nbx_geig_refine": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int]),
     "nbx_eigh_warm_ex": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, c_size_t, c_int]),
     "nbx_eigh_status_offset": (c_size_t, [c_int64, c_int64]),
     "nbx_eigh_status": (c_int, [_P, c_int64, c_int64, _P, POINTER(c_int)]),

@@ -363,6 +363,19 @@ class HipBackend:
                    self._p(out), self._p(work), work.numel())
         return out
 
+    def jk_packed_fock(self, packed, dm, hv, want_vhf: bool = True):
+        """UHF Fock matrices straight from the packed J/K build of the whole tensor
+        (nbx_jk_packed_fock): returns (fock, vhf) = (hv + J - K[x], J - K[x])."""
+        nao = dm.shape[-1]
+        nbytes = self.lib.nbx_jk_packed_worksize(nao, 0, nao, 2)
+        work = self._workspace("jk", nbytes)
+        jk = self.empty((3, nao, nao))
+        fock = self.empty((2, nao, nao))
+        vhf = self.empty((2, nao, nao)) if want_vhf else None
+        self._call("nbx_jk_packed_fock", nao, self._p(packed), self._p(dm), self._p(hv), self._p(jk), self._p(fock),
+                   self._p(vhf), self._p(work), work.numel())
+        return fock, vhf
+
     def jk_synth(self, nao: int, dm, p0: int = 0, p1: int | None = None, seed: int = 20250829):
         """J/K against the synthetic (pq|rs) generated in registers (no ERI in memory)."""
         p1 = nao if p1 is None else p1
@@ -557,6 +570,23 @@ class HipBackend:
             self._call("nbx_eigh_status", n, batch, self._p(work), sweeps)
             self.last_eigh_sweeps = list(sweeps)
         return w, v
+
+    def geig_refine(self, fock, ovlp_b, c0, refine_iters: int = 1):
+        """Eigenpairs of the pencil (fock[b], S) refined from the previous cycle's S-orthonormal
+        vectors ``c0`` (nbx_geig_refine: GEMMs only, no Loewdin transform, NO fallback solver).
+        ``ovlp_b``: the overlap repeated per batch entry.  Sets ``last_eigh_status_d``
+        (1000 + iterations: accepted; <= 0: not -- the outputs are then meaningless)."""
+        n = fock.shape[-1]
+        batch = 1 if fock.dim() == 2 else fock.shape[0]
+        nbytes = self.lib.nbx_geig_refine_worksize(n, batch)
+        work = self._workspace("geig", nbytes)
+        w = self.empty(fock.shape[:-1])
+        c = self.torch.empty_like(fock)
+        status = self.torch.empty(batch, dtype=self.torch.int32, device=self.device)
+        self._call("nbx_geig_refine", n, batch, self._p(fock), self._p(ovlp_b), self._p(c0), self._p(w), self._p(c),
+                   self._p(status), self._p(work), work.numel(), int(refine_iters))
+        self.last_eigh_status_d = status
+        return w, c
 
     def sym_pow(self, s, p: float):
         n = s.shape[-1]

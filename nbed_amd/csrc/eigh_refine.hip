@@ -56,7 +56,7 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
     const int b = blockIdx.y, wg = blockIdx.x, nwg = gridDim.x;
     if (iter > 0 && status[b] != 0) return;
     const int64_t n2 = (int64_t)N * N;
-    A += b * n2;
+    if (A != nullptr) A += b * n2;  // nullptr: ||S||_F stands in for ||A||_F (S is A in a nearly orthonormal basis)
     S += b * n2;
     G += b * n2;
     Ep += b * n2;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
             const bool in = e < total;
             sv[u] = in ? S[e] : 0.0;
             gv[u] = in ? G[e] : 0.0;
-            av[u] = (in && iter == 0) ? A[e] : 0.0;
+            av[u] = (in && iter == 0) ? (A != nullptr ? A[e] : sv[u]) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < RF_UNROLL; ++u) {
@@ -233,7 +233,10 @@ __global__ __launch_bounds__(256) void refine_finish_kernel(int N, const double*
     int* rank = reinterpret_cast<int*>(sm + N);
     const int b = blockIdx.y;
     const int st = status[b];
-    if (st <= 0) return;
+    if (st <= 0) {  // not accepted: say so (a fallback solver that follows overwrites the word)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && jacobi_status != nullptr) jacobi_status[b] = st < 0 ? st : -2;
+        return;
+    }
     const int64_t n2 = (int64_t)N * N;
     const double* X = ((st & 1) ? xb1 : xb0) + b * n2;
     for (int i = threadIdx.x; i < N; i += blockDim.x) lam[i] = lam_in[(int64_t)b * N + i];
@@ -338,5 +341,103 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
                        status, d_w, d_v, d_jacobi_status);
     NBX_LAUNCH_CHECK();
     *d_status_out = status;
+    return NBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same iteration on the generalised problem F C = S C eps, started from the previous SCF
+// cycle's MO coefficients C0 (S-orthonormal eigenvectors of a nearby F):
+//     G = C^T S C  (R = I - G)      S~ = C^T F C      lambda_i = S~_ii / G_ii      C <- C (I + E)
+// No Loewdin transform of F, no back-transform of the vectors and NO fallback solver behind it:
+// four launches per iteration plus the sort -- {Yt = C^T F, Zt = C^T S} and {S~ = C^T Yt^T,
+// G = C^T Zt^T} are pairs sharing op(A) = C^T.  d_status[b] = 1000 + iterations when matrix b was
+// accepted (d_w, d_c written), <= 0 when not (outputs untouched): the caller must check it.
+namespace {
+struct GeigLayout {
+    size_t cb0, cb1, yt, zt, s, g, ep, lam, norm, partial, status, total;
+};
+GeigLayout glayout(int64_t n, int64_t batch) {
+    GeigLayout L;
+    const size_t mat = align256((size_t)(n * n * batch) * sizeof(double));
+    size_t off = 0;
+    L.cb0 = off; off += mat;
+    L.cb1 = off; off += mat;
+    L.yt = off; off += mat;
+    L.zt = off; off += mat;
+    L.s = off; off += mat;
+    L.g = off; off += mat;
+    L.ep = off; off += mat;
+    L.lam = off; off += align256((size_t)(n * batch) * sizeof(double));
+    L.norm = off; off += align256((size_t)batch * sizeof(double));
+    L.partial = off; off += align256((size_t)(batch * RF_WGS * 5) * sizeof(double));
+    L.status = off; off += align256((size_t)batch * sizeof(int));
+    L.total = off;
+    return L;
+}
+}  // namespace
+
+extern "C" size_t nbx_geig_refine_worksize(int64_t n, int64_t batch) {
+    if (n <= 0 || batch <= 0) return 0;
+    return glayout(n, batch).total;
+}
+
+extern "C" int nbx_geig_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_f, const double* d_s,
+                               const double* d_c0, double* d_w, double* d_c, int* d_status, void* d_work,
+                               size_t work_bytes, int max_iter) {
+    NBX_CHECK_ARG(ctx && d_f && d_s && d_c0 && d_w && d_c && d_status);
+    NBX_CHECK_ARG(n >= 2 && n <= 4096 && batch >= 1 && batch <= NBX_COUNTERS);
+    NBX_CHECK_ARG(max_iter >= 1 && max_iter <= RF_MAX_ITER);
+    const GeigLayout L = glayout(n, batch);
+    if (d_work == nullptr || work_bytes < L.total) {
+        nbx_set_error("nbx_geig_refine: workspace %zu < %zu bytes", work_bytes, L.total);
+        return NBX_E_NOMEM;
+    }
+    char* base = static_cast<char*>(d_work);
+    double* cb[2] = {reinterpret_cast<double*>(base + L.cb0), reinterpret_cast<double*>(base + L.cb1)};
+    double* yt = reinterpret_cast<double*>(base + L.yt);
+    double* zt = reinterpret_cast<double*>(base + L.zt);
+    double* s = reinterpret_cast<double*>(base + L.s);
+    double* g = reinterpret_cast<double*>(base + L.g);
+    double* ep = reinterpret_cast<double*>(base + L.ep);
+    double* lam = reinterpret_cast<double*>(base + L.lam);
+    double* norm = reinterpret_cast<double*>(base + L.norm);
+    double* partial = reinterpret_cast<double*>(base + L.partial);
+    int* status = reinterpret_cast<int*>(base + L.status);
+    const int64_t n2 = n * n;
+    const bool pair = nbx_gemm_small_supported(n, n, n, 2 * batch);
+    for (int it = 0; it < max_iter; ++it) {
+        const double* src = (it == 0) ? d_c0 : cb[it & 1];
+        double* dst = cb[(it + 1) & 1];
+        const int* gate = (it == 0) ? nullptr : status;
+        int rc;
+        if (pair) {
+            rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, d_f, n, n2, 0.0, yt, n, n2, batch, gate, 0,
+                                      0, d_s, zt);
+            if (rc != NBX_OK) return rc;
+            rc = nbx_gemm_small_gated(ctx, 'T', 'T', n, n, n, 1.0, src, n, n2, yt, n, n2, 0.0, s, n, n2, batch, gate, 0, 0,
+                                      zt, g);
+            if (rc != NBX_OK) return rc;
+        } else {
+            rc = nbx_gemm_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, d_f, n, n2, 0.0, yt, n, n2, batch, gate, 0, 0);
+            if (rc != NBX_OK) return rc;
+            rc = nbx_gemm_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, d_s, n, n2, 0.0, zt, n, n2, batch, gate, 0, 0);
+            if (rc != NBX_OK) return rc;
+            rc = nbx_gemm_gated(ctx, 'T', 'T', n, n, n, 1.0, src, n, n2, yt, n, n2, 0.0, s, n, n2, batch, gate, 0, 0);
+            if (rc != NBX_OK) return rc;
+            rc = nbx_gemm_gated(ctx, 'T', 'T', n, n, n, 1.0, src, n, n2, zt, n, n2, 0.0, g, n, n2, batch, gate, 0, 0);
+            if (rc != NBX_OK) return rc;
+        }
+        hipLaunchKernelGGL(refine_e_kernel, dim3(RF_WGS, (unsigned)batch), dim3(RF_THREADS),
+                           (size_t)(n + 3 * (RF_THREADS / 64) + 8) * sizeof(double), ctx->stream, (int)n,
+                           static_cast<const double*>(nullptr), s, g, ep, lam, status, norm, it, max_iter, partial,
+                           ctx->d_counters);
+        NBX_LAUNCH_CHECK();
+        rc = nbx_gemm_gated(ctx, 'N', 'N', n, n, n, 1.0, src, n, n2, ep, n, n2, 0.0, dst, n, n2, batch, status, 0, it + 1);
+        if (rc != NBX_OK) return rc;
+    }
+    hipLaunchKernelGGL(refine_finish_kernel, dim3((unsigned)nbx_cdiv(n, RF_ROWS), (unsigned)batch), dim3(256),
+                       (size_t)n * sizeof(double) + (size_t)n * sizeof(int), ctx->stream, (int)n, cb[0], cb[1], lam,
+                       status, d_w, d_c, d_status);
+    NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

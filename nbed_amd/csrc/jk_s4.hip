@@ -478,8 +478,25 @@ extern "C" size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, in
     return s4_plan(nao, p0, p1 - p0, ndm).total;
 }
 
+static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm,
+                 int64_t ndm, double* d_jk, void* d_work, size_t work_bytes, const double* d_hv, double* d_fock,
+                 double* d_vhf);
+
 extern "C" int nbx_jk_packed(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed,
                              const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes) {
+    return s4_jk(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, work_bytes, nullptr, nullptr, nullptr);
+}
+
+extern "C" int nbx_jk_packed_fock(nbx_ctx* ctx, int64_t nao, const double* d_packed, const double* d_dm,
+                                  const double* d_hv, double* d_jk, double* d_fock, double* d_vhf, void* d_work,
+                                  size_t work_bytes) {
+    NBX_CHECK_ARG(d_hv && d_fock);
+    return s4_jk(ctx, nao, 0, nao, d_packed, d_dm, 2, d_jk, d_work, work_bytes, d_hv, d_fock, d_vhf);
+}
+
+static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm,
+                 int64_t ndm, double* d_jk, void* d_work, size_t work_bytes, const double* d_hv, double* d_fock,
+                 double* d_vhf) {
     NBX_CHECK_ARG(ctx && d_dm && d_jk);
     NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
     NBX_CHECK_ARG(d_packed != nullptr || p0 == p1);
@@ -542,5 +559,5 @@ extern "C" int nbx_jk_packed(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, 
 #undef NBX_S4_GO
     }
     NBX_LAUNCH_CHECK();
-    return nbx_jk_sym_reduce(ctx, k1, k2, d_jk + n2, N, p0, np, ndm, t_begin, pl.L, pl.S);
+    return nbx_jk_sym_reduce(ctx, k1, k2, d_jk + n2, N, p0, np, ndm, t_begin, pl.L, pl.S, d_jk, d_hv, d_fock, d_vhf);
 }

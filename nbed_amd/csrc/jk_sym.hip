@@ -241,7 +241,11 @@ void jk_sym_kernel(const double* __restrict__ eri, const double* __restrict__ dm
 __global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __restrict__ kpart1,
                                                             const double* __restrict__ kpart2,
                                                             double* __restrict__ kout, int N, int p0, int np, int ndm,
-                                                            int64_t t_begin, int L, int S, int accumulate) {
+                                                            int64_t t_begin, int L, int S, int accumulate,
+                                                            const double* __restrict__ jfull = nullptr,
+                                                            const double* __restrict__ hv = nullptr,
+                                                            double* __restrict__ fock = nullptr,
+                                                            double* __restrict__ vhf = nullptr) {
     __shared__ double part[4][64];
     const int row = blockIdx.x, x = blockIdx.y;
     const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
@@ -274,6 +278,12 @@ __global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __rest
         }
         double* dst = kout + ((int64_t)x * N + row) * N + b;
         *dst = accumulate ? *dst + tot : tot;
+        if (fock != nullptr) {  // Fock epilogue (whole tensor on this device): F = hv + J - K, vhf = J - K
+            const int64_t o = ((int64_t)x * N + row) * N + b;
+            const double v = jfull[(int64_t)row * N + b] - tot;
+            fock[o] = hv[o] + v;
+            if (vhf != nullptr) vhf[o] = v;
+        }
     }
 }
 
@@ -463,9 +473,11 @@ bool nbx_jk_sym_supported(int64_t nao) { return nao >= 2 && nao % 2 == 0 && nao 
 
 // K[x][row][b] from the row-p / row-q partial buffers (shared with jk_s4.hip, same layouts)
 int nbx_jk_sym_reduce(nbx_ctx* ctx, const double* k1, const double* k2, double* d_k, int64_t N, int64_t p0, int64_t np,
-                      int64_t ndm, int64_t t_begin, int L, int S) {
+                      int64_t ndm, int64_t t_begin, int L, int S, const double* d_j, const double* d_hv, double* d_fock,
+                      double* d_vhf) {
     hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
-                       ctx->stream, k1, k2, d_k, (int)N, (int)p0, (int)np, (int)ndm, t_begin, L, S, 0);
+                       ctx->stream, k1, k2, d_k, (int)N, (int)p0, (int)np, (int)ndm, t_begin, L, S, 0, d_j, d_hv, d_fock,
+                       d_vhf);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

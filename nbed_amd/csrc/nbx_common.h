@@ -60,7 +60,8 @@ int nbx_gemm_small_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, in
 // jk_sym.hip
 bool nbx_jk_sym_supported(int64_t nao);
 int nbx_jk_sym_reduce(nbx_ctx* ctx, const double* k1, const double* k2, double* d_k, int64_t N, int64_t p0, int64_t np,
-                      int64_t ndm, int64_t t_begin, int L, int S);
+                      int64_t ndm, int64_t t_begin, int L, int S, const double* d_j = nullptr,
+                      const double* d_hv = nullptr, double* d_fock = nullptr, double* d_vhf = nullptr);
 
 // eigh_refine.hip
 bool nbx_eigh_refine_supported(int64_t n, int64_t batch);

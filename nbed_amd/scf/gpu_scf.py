@@ -153,6 +153,16 @@ class _GpuSCF:
         slab = be.jk(self.eri_device(), dm_d, sh.lo, sh.hi)
         return sh.all_gather(be, slab, axis=1)
 
+    def fock_device(self, dm_d, hv_d):
+        """(fock, vhf) = (hv + J - K[x], J - K[x]) of a two-spin density: one J/K build; on a single
+        device with the packed kernel the Fock assembly rides on its reduction kernel."""
+        be, sh = self.be, self.shards
+        packed = self.eri_packed_device()
+        single = sh.world == 1 and not sh.force_collective
+        if packed is not None and single and hasattr(be, "jk_packed_fock") and hv_d.dim() == 3:
+            return be.jk_packed_fock(packed, dm_d, hv_d)
+        return be.fock_uhf(hv_d, None, self.jk_device(dm_d))
+
     def _eig_device(self, fock_d, warm: dict | None = None):
         """Generalised eigenproblem F C = S C e through Loewdin orthogonalisation.  ``warm``: a
         dict carried across SCF cycles; the previous cycle's orthonormal eigenvectors kept in it

@@ -25,6 +25,7 @@ Two execution paths, same arithmetic:
 from __future__ import annotations
 
 import logging
+import os
 from typing import Optional
 
 import numpy as np
@@ -102,6 +103,10 @@ def _is_fused(scf_method) -> bool:
     return not any(k in d for k in ("get_veff", "get_hcore", "get_occ", "make_rdm1"))
 
 
+class _TrackedEigensolveFailed(Exception):
+    """A cycle solved by unguarded refinement (nbx_geig_refine) was not accepted."""
+
+
 def huzinaga_scf(
     scf_method,
     embedding_potential: np.ndarray,
@@ -120,7 +125,26 @@ def huzinaga_scf(
     (nbed/scf/huzinaga_scf.py:206).  Not in the reference's signature: ``backend``; ``history``
     collects (energy, dm_diff) per cycle; ``callback(i)`` is called on the host before cycle
     ``i`` is queued (bench.py uses it to separate warm-up cycles from timed ones).
+
+    The fused device loop solves the eigenproblem of a cycle by refining the previous cycle's
+    vectors with no fallback solver queued behind it once a cycle has shown that refinement is
+    accepted at once ("tracked" cycles: 5 launches instead of 12).  Acceptance is checked on the
+    host one cycle late like everything else; in the (not yet observed) case that a tracked cycle
+    is rejected the whole run is repeated with the guarded solver, which gives the same numbers.
     """
+    args = (scf_method, embedding_potential, dm_environment_occupied, dm_environment_virtual, dm_conv_tol,
+            dm_initial_guess, use_DIIS, backend, history, callback)
+    try:
+        return _huzinaga_scf(*args, allow_tracked=os.environ.get("NBED_TRACKED_EIG", "1") != "0")
+    except _TrackedEigensolveFailed:
+        logger.warning("tracked eigensolve rejected a cycle: repeating the SCF with the guarded solver")
+        if history is not None:
+            del history[:]
+        return _huzinaga_scf(*args, allow_tracked=False)
+
+
+def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_environment_virtual, dm_conv_tol,
+                  dm_initial_guess, use_DIIS, backend, history, callback, allow_tracked):
     if not (is_ks(scf_method) or is_hf(scf_method)):
         raise TypeError("Cannot run Huzinaga SCF with type %s" % type(scf_method))
     be = backend if backend is not None else (getattr(scf_method, "be", None) or get_backend())
@@ -151,9 +175,18 @@ def huzinaga_scf(
         be.axpby(1.0, hcore_d if hcore_d.dim() == 2 else hcore_d[x], 1.0, hv[x])
         be.axpby(1.0, vemb_d if vemb_d.dim() == 2 else vemb_d[x], 1.0, hv[x])
 
-    warm = {"v": None, "iters": 3}
+    warm = {"v": None, "iters": 3, "tracked": False, "c": None}
+    s_b = None  # the overlap once per spin, for the tracked solver
 
     def diagonalise(fock3):
+        nonlocal s_b
+        if warm["tracked"] and warm["c"] is not None:
+            # refine (eps, C) of the previous cycle on the pencil (F, S) directly
+            if s_b is None:
+                s_b = be.asarray(np.stack([s_h] * nb))
+            e_d, c_new = be.geig_refine(fock3, s_b, warm["c"], refine_iters=warm["iters"])
+            warm["c"] = c_new
+            return e_d, c_new
         # Loewdin step (:166-169).  The previous cycle's orthonormal eigenvectors seed the
         # solver: X F X is nearly diagonal in that basis once the SCF is under way.
         fo = be.gemm(be.gemm(x_d, fock3), x_d)
@@ -162,13 +195,16 @@ def huzinaga_scf(
         else:
             e_d, c_ortho = be.eigh(fo, v0=warm["v"])
         warm["v"] = c_ortho
-        return e_d, be.gemm(x_d, c_ortho)
+        warm["c"] = be.gemm(x_d, c_ortho)
+        return e_d, warm["c"]
 
     # fused path: the eigensolver returns ascending eigenvalues, so aufbau occupation
     # (get_occ: the n_alpha / n_beta lowest, as the reference's UHF object does) is a fixed
     # vector and the MO energies need not leave the device inside the loop
     lookahead = (fused and (not ks) and nb == 2 and hasattr(be, "huz_cycle_scalars_async")
                  and hasattr(be, "density_occ"))
+
+    can_track = lookahead and hasattr(be, "geig_refine")
 
     def occupations(e_d, c_d):
         if lookahead:
@@ -218,7 +254,12 @@ def huzinaga_scf(
         # (anything it does not finish falls through to Jacobi on the device); otherwise three
         st = handle.get_extra()
         if st is not None:
+            if state[6] and np.any(st <= 0):
+                raise _TrackedEigensolveFailed(f"cycle {cycle}: status {st.tolist()}")
             warm["iters"] = 1 if np.all(st == 1001) else 3
+            # every matrix accepted after one iteration: from the next cycle queued on, refine
+            # without the guard; anything else (re-)arms the guarded solver
+            warm["tracked"] = bool(allow_tracked and can_track and np.all(st == 1001))
         scf_energy = sc[:2].copy()
         norm_dm_diff = float(np.max(sc[2:]))
         run_diff = np.max(np.abs(scf_energy - scf_energy_prev))
@@ -237,8 +278,10 @@ def huzinaga_scf(
             callback(i)
         # ---- Fock build (:156-160)
         if fused:
-            jk = scf_method.jk_device(dm_d)
-            fock, vhf = be.fock_uhf(hv, None, jk)
+            if nb == 2 and hasattr(scf_method, "fock_device"):
+                fock, vhf = scf_method.fock_device(dm_d, hv)
+            else:
+                fock, vhf = be.fock_uhf(hv, None, scf_method.jk_device(dm_d))
         else:
             vhf_h = scf_method.get_veff(dm=unbatch(be.to_host(dm_d)))
             vhf = _as3(be, np.asarray(vhf_h))
@@ -249,6 +292,7 @@ def huzinaga_scf(
         if use_DIIS and (i > 1):
             fock = adiis.update(fock)
 
+        tracked_now = bool(warm["tracked"] and warm["c"] is not None)
         e_d, c_d = diagonalise(fock)
         mo_energy_h, occ_h = occupations(e_d, c_d)
         dm_old = dm_d
@@ -281,7 +325,7 @@ def huzinaga_scf(
 
         if lookahead:
             # judge the PREVIOUS cycle now that this one is queued behind it
-            state_now = (i, pending_now, c_d, mo_energy_h, dm_d, hz)
+            state_now = (i, pending_now, c_d, mo_energy_h, dm_d, hz, tracked_now)
             if pending is not None and judge(pending):
                 break
             pending = state_now
@@ -300,7 +344,7 @@ def huzinaga_scf(
         if not conv_flag and pending is not None:
             judge(pending)  # the last cycle queued
         if result["state"] is not None:
-            _, _, c_d, mo_energy_d, dm_d, hz = result["state"]
+            _, _, c_d, mo_energy_d, dm_d, hz, _ = result["state"]
             mo_energy_h = be.to_host(mo_energy_d)
 
     if conv_flag is False:

@@ -529,6 +529,36 @@ def test_jk_sym_fallback_sizes_and_full_size(be):
     np.testing.assert_array_equal(a[0], a[0].T)  # J is written once per pair: exactly symmetric
 
 
+@pytest.mark.parametrize("n", [24, 148, 200])
+def test_geig_refine_tracks_perturbed_pencil(be, n):
+    """nbx_geig_refine: eigenpairs of (F, S) refined from the solution of a nearby pencil (what the
+    SCF loop hands it) against scipy.linalg.eigh; S-orthonormal output; statuses."""
+    import scipy.linalg
+
+    s_h = synth.overlap(n)
+    f0 = np.stack([symm(540, n) - np.diag(np.arange(n) * 0.7), symm(541, n) - np.diag(np.arange(n) * 0.9)])
+    c0 = np.stack([scipy.linalg.eigh(f0[x], s_h)[1] for x in range(2)])
+    # (the perturbation has to stay below the level spacing: a cluster threshold omega of the size
+    # of the gaps would -- correctly -- refuse the matrix)
+    f1 = f0 + (1e-3 if n < 100 else 2e-5) * np.stack([symm(542, n), symm(543, n)])
+    s_b = be.asarray(np.stack([s_h, s_h]))
+    w, c = be.geig_refine(be.asarray(f1), s_b, be.asarray(c0), refine_iters=3)
+    st = be.to_host(be.last_eigh_status_d)
+    assert np.all(st > 1000), st
+    w, c = be.to_host(w), be.to_host(c)
+    for x in range(2):
+        we, _ = scipy.linalg.eigh(f1[x], s_h)
+        np.testing.assert_allclose(w[x], we, rtol=0, atol=1e-11 * n)
+        np.testing.assert_allclose(c[x].T @ s_h @ c[x], np.eye(n), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(f1[x] @ c[x], s_h @ c[x] * w[x], rtol=0, atol=1e-10 * n)
+    # a start that is nowhere near: refused (status <= 0), never a silent wrong answer
+    q = np.linalg.qr(rnd(544, n, n))[0]
+    x_h = np.linalg.inv(scipy.linalg.sqrtm(s_h).real)
+    bad = np.stack([x_h @ q, x_h @ q])
+    be.geig_refine(be.asarray(f1), s_b, be.asarray(bad), refine_iters=3)
+    assert np.all(be.to_host(be.last_eigh_status_d) <= 0)
+
+
 def s4_layout(n):
     """The packed tile format of nbx_eri_pack (include/nbx.h), restated in numpy: offsets of the
     entries (a, b <= a) of one tile and the tile length."""

@@ -86,6 +86,54 @@ def test_huzinaga_scf_vs_oracle_converged(be, n, nocc, n_env):
         np.testing.assert_allclose(d[x] @ s @ d[x], d[x], rtol=0, atol=1e-9)
 
 
+def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch):
+    """The unguarded refinement cycles (nbx_geig_refine, no fallback queued) give the run the guarded
+    solver gives; a rejected tracked cycle makes the loop repeat the run guarded (same numbers)."""
+    import nbed_amd.scf.huzinaga_scf as mod
+    from nbed_amd.scf import GpuUHF, Mole, huzinaga_scf
+
+    n, nocc, n_env = 64, (12, 11), 5
+    pr = synth.problem(n, nocc, n_env)
+
+    def run():
+        mf = GpuUHF(Mole(n, pr["nelec"]), pr["S"], pr["hcore"], be.synth_eri(n), backend=be)
+        mf.max_cycle, mf.conv_tol = 100, 1e-11
+        hist = []
+        out = huzinaga_scf(mf, pr["V_emb"], pr["D_env"], dm_conv_tol=1e-9, history=hist)
+        return out, hist
+
+    calls = {"n": 0}
+    orig = be.geig_refine
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+
+    monkeypatch.setattr(be, "geig_refine", counting)
+    (c1, e1, d1, hz1, conv1), h1 = run()
+    assert conv1 and calls["n"] > 3  # the tracked solver did most of the cycles
+    monkeypatch.setenv("NBED_TRACKED_EIG", "0")
+    used = calls["n"]
+    (c0, e0, d0, hz0, conv0), h0 = run()
+    assert conv0 and calls["n"] == used
+    assert len(h0) == len(h1)
+    np.testing.assert_allclose(e1, e0, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(d1, d0, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(hz1, hz0, rtol=0, atol=1e-10)
+    # a tracked cycle that reports failure: the run is repeated with the guarded solver
+    monkeypatch.setenv("NBED_TRACKED_EIG", "1")
+
+    def failing(fock, s_b, c0_, refine_iters=1):
+        w, c = orig(fock, s_b, c0_, refine_iters=refine_iters)
+        be.last_eigh_status_d = be.last_eigh_status_d * 0 - 1
+        return w, c
+
+    monkeypatch.setattr(be, "geig_refine", failing)
+    (c2, e2, d2, hz2, conv2), h2 = run()
+    assert conv2 and len(h2) == len(h0)
+    np.testing.assert_array_equal(d2, d0)
+
+
 def test_gpu_uhf_kernel_vs_oracle(be):
     from nbed_amd.scf import GpuUHF, Mole
 
