@@ -176,7 +176,7 @@ __device__ __forceinline__ void s4_walk(const double* lb, int step, int il, int 
             const int c = c0 + j;
             int addr = c * step;
             if (DIAG) {
-                const int below = tri_il + c, above = c * (c + 1) / 2 + il;
+                const int below = tri_il + c, above = (int)(((unsigned)c * (unsigned)(c + 1)) >> 1) + il;
                 addr = il >= c ? below : above;
             }
             t[j] = lb[addr];
