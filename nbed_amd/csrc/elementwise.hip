@@ -112,26 +112,30 @@ __global__ void huzinaga_sym_kernel(const double* __restrict__ fds, int N, doubl
 // second stage in the fixed order of final_reduce_kernel -- out[0,1] the sums, out[2,3] the square
 // roots, then `tail_n` status words as doubles -- so the cycle's scalars cost one launch.  `out`
 // may be pinned host memory: the values then need no copy.
+template <int T>  // tile edge: 16 x 16 tiles give N = 148 a hundred workgroups instead of 25
 __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const double* __restrict__ vemb,
                                    const double* __restrict__ vhf, const double* __restrict__ hz,
                                    const double* __restrict__ dm, const double* __restrict__ dm_old, int N,
                                    double* __restrict__ partial, double* __restrict__ out_final = nullptr,
                                    const int* __restrict__ tail = nullptr, int tail_n = 0,
                                    int* __restrict__ counter = nullptr) {
-    __shared__ double dt[TILE][TILE + 1];
+    __shared__ double dt[T][T + 1];
     __shared__ double red[4][4];
     __shared__ double red2[17];
     __shared__ int last;
     const int64_t n2 = (int64_t)N * N;
-    const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
+    const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     double out[4];
     for (int x = 0; x < 2; ++x) {
         __syncthreads();
-        load_tile(dm + x * n2, N, j0, i0, dt);
+        for (int r = threadIdx.y; r < T; r += blockDim.y) {  // dt[j][i] = D[x][j0+j][i0+i]
+            const int gr = j0 + r, gc = i0 + threadIdx.x;
+            dt[r][threadIdx.x] = (gr < N && gc < N) ? dm[x * n2 + (int64_t)gr * N + gc] : 0.0;
+        }
         __syncthreads();
         double e = 0.0, d2 = 0.0;
-        for (int r = threadIdx.y; r < TILE; r += blockDim.y) {
+        for (int r = threadIdx.y; r < T; r += blockDim.y) {
             const int gi = i0 + r, gj = j0 + threadIdx.x;
             if (gi < N && gj < N) {
                 const int64_t o = (int64_t)gi * N + gj;
@@ -601,7 +605,7 @@ int nbx_huz_cycle_scalars(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int 
     NBX_CHECK_ARG(hcore_ndim == 2 || hcore_ndim == 3);
     const int64_t g = nbx_cdiv(nao, TILE);
     NBX_CHECK_ARG(g * g * 4 <= NBX_SCRATCH_DOUBLES - 64);
-    hipLaunchKernelGGL(huz_scalars_kernel, dim3((unsigned)g, (unsigned)g), dim3(TILE, 8), 0, ctx->stream, d_hcore,
+    hipLaunchKernelGGL(huz_scalars_kernel<TILE>, dim3((unsigned)g, (unsigned)g), dim3(TILE, 8), 0, ctx->stream, d_hcore,
                        hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch);
     NBX_LAUNCH_CHECK();
     const int rc = finish_reduction(ctx, (int)(g * g), 4, h_out);
@@ -617,11 +621,18 @@ int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
     NBX_CHECK_ARG(ctx && d_hcore && d_vhf && d_hz && d_dm && d_dm_old && d_out && nao > 0);
     NBX_CHECK_ARG(tail_n >= 0 && tail_n <= 64 && (tail_n == 0 || d_tail != nullptr));
     NBX_CHECK_ARG(hcore_ndim == 2 || hcore_ndim == 3);
-    const int64_t g = nbx_cdiv(nao, TILE);
+    // 16 x 16 tiles while the partials fit the scratch (N <= 500): more workgroups for small N
+    const bool fine = nbx_cdiv(nao, 16) * nbx_cdiv(nao, 16) * 4 <= NBX_SCRATCH_DOUBLES - 64;
+    const int64_t g = nbx_cdiv(nao, fine ? 16 : TILE);
     NBX_CHECK_ARG(g * g * 4 <= NBX_SCRATCH_DOUBLES - 64);
-    hipLaunchKernelGGL(huz_scalars_kernel, dim3((unsigned)g, (unsigned)g), dim3(TILE, 8), 0, ctx->stream, d_hcore,
-                       hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch, d_out,
-                       d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1);
+    if (fine)
+        hipLaunchKernelGGL(huz_scalars_kernel<16>, dim3((unsigned)g, (unsigned)g), dim3(16, 8), 0, ctx->stream, d_hcore,
+                           hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch,
+                           d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1);
+    else
+        hipLaunchKernelGGL(huz_scalars_kernel<TILE>, dim3((unsigned)g, (unsigned)g), dim3(TILE, 8), 0, ctx->stream,
+                           d_hcore, hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao,
+                           ctx->d_scratch, d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

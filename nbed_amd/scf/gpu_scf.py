@@ -337,7 +337,7 @@ class GpuUHF(_GpuSCF, UHF):
 
         def build(dm_dev, c_dev=None):
             """Fock from dm_dev, its energy and (given the orbitals) the gradient norm, all queued."""
-            fock, vhf = be.fock_uhf(h_d, None, self.jk_device(dm_dev))
+            fock, vhf = self.fock_device(dm_dev, h_d)
             pend_e = be.huz_cycle_scalars_async(h_d, None, vhf, zero, dm_dev, dm_dev)
             pend_g = None
             if c_dev is not None:
