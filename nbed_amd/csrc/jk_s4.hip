@@ -153,47 +153,65 @@ __global__ __launch_bounds__(256) void s4_dtot_kernel(const double* __restrict__
 }
 
 // The walk of one chunk: s steps, thread-private element tv = Lsym[trow][u*s + c] from LDS and the
-// wave-uniform density values D_q[u*s + c], D_p[u*s + c] through scalar loads.  LDS and scalar
-// loads share one counter and scalar loads return out of order, so a wait for either is a wait
-// for everything: the loop is software pipelined by hand in groups of four steps -- wait, issue
-// the next group's loads, then do this group's FMAs -- with two register sets.  Groups are
-// uniform: the last one starts at s - 4 and masks the steps an earlier group has done.
-template <int NDM, bool DIAG>
+// wave-uniform density values D_q[u*s + c], D_p[u*s + c] through scalar loads.  A wavefront issues
+// at most one instruction every four cycles, whatever its kind, so the walk costs what its
+// instruction count costs: the scalar loads are written as s_load_dwordx8 with one running SGPR
+// offset (no pointer arithmetic per load), rows of the row side are read with immediate offsets.
+// LDS and scalar loads share one counter and scalar loads return out of order, so a wait for
+// either is a wait for everything: the loop is software pipelined by hand in groups of four steps
+// -- wait, issue the next group's loads, then do this group's FMAs -- with two register sets.
+// (The compiler does not track the inline-asm loads: every use below follows an explicit wait.)
+// The last group starts at s - 4 and masks the steps an earlier group has done.
+// KIND 0: diagonal triangle (per-lane row / column select), 1: rectangle, row side (consecutive
+// doubles), 2: rectangle, column side (stride `step` doubles).
+typedef double s4_v4d __attribute__((ext_vector_type(4)));
+
+template <int NDM, int KIND>
 __device__ __forceinline__ void s4_walk(const double* lb, int step, int il, int tri_il, const double* xq,
                                         const double* xp, int64_t n2, int s, double (&kp)[NDM], double (&kq)[NDM]) {
     const int ng = (s + 3) >> 2;
-    auto load = [&](int g, double(&a)[NDM][4], double(&b)[NDM][4], double(&t)[4]) {
-        const int c0 = min(4 * g, s - 4);
+    const double* xqs[NDM];
+    const double* xps[NDM];
 #pragma unroll
-        for (int x = 0; x < NDM; ++x)
+    for (int x = 0; x < NDM; ++x) {
+        xqs[x] = xq + x * n2;
+        xps[x] = xp + x * n2;
+    }
+    const char* lbc = reinterpret_cast<const char*>(lb);
+    const int il8 = il * 8;
+    auto load = [&](int g, s4_v4d(&a)[NDM], s4_v4d(&b)[NDM], double(&t)[4]) {
+        const int c0 = min(4 * g, s - 4);
+        const int off = c0 * 8;
+#pragma unroll
+        for (int x = 0; x < NDM; ++x) {
+            asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(a[x]) : "s"(xqs[x]), "s"(off));
+            asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(b[x]) : "s"(xps[x]), "s"(off));
+        }
+        if (KIND == 0) {
+            // row part (c <= il): L[il][c] at tri(il) + c; column part: L[c][il] at tri(c) + il
+            const int rb = tri_il * 8 + off;
+            int tric = (int)(((unsigned)c0 * (unsigned)(c0 + 1)) >> 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a[x][j] = xq[x * n2 + c0 + j];
-                b[x][j] = xp[x * n2 + c0 + j];
+                const int cb = (tric - j) * 8 + il8;  // minus j: the read below adds 8 j to both forms
+                const int ab = (il >= c0 + j) ? rb : cb;
+                t[j] = *reinterpret_cast<const double*>(lbc + ab + 8 * j);
+                tric += c0 + j + 1;
             }
+        } else if (KIND == 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = c0 + j;
-            int addr = c * step;
-            if (DIAG) {
-                const int below = tri_il + c, above = (int)(((unsigned)c * (unsigned)(c + 1)) >> 1) + il;
-                addr = il >= c ? below : above;
+            for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const double*>(lbc + off + 8 * j);
+        } else {
+            const int sb = step * 8;
+            int ab = c0 * sb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[j] = *reinterpret_cast<const double*>(lbc + ab);
+                ab += sb;
             }
-            t[j] = lb[addr];
         }
     };
-    auto fmas = [&](const double(&a)[NDM][4], const double(&b)[NDM][4], const double(&t)[4]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int x = 0; x < NDM; ++x) {
-                kp[x] = fma(t[j], a[x][j], kp[x]);
-                kq[x] = fma(t[j], b[x][j], kq[x]);
-            }
-    };
-    // the last group starts at s - 4: its first 4*ng - s steps belong to the group before it
-    auto fmas_last = [&](const double(&a)[NDM][4], const double(&b)[NDM][4], const double(&t)[4]) {
-        const int skip = 4 * ng - s;
+    auto fmas = [&](const s4_v4d(&a)[NDM], const s4_v4d(&b)[NDM], const double(&t)[4], int skip) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const double tj = j >= skip ? t[j] : 0.0;
@@ -209,23 +227,25 @@ __device__ __forceinline__ void s4_walk(const double* lb, int step, int il, int 
     __builtin_amdgcn_sched_barrier(0);       \
     LOADS;                                   \
     __builtin_amdgcn_sched_barrier(0)
-    double a0[NDM][4], b0[NDM][4], t0[4], a1[NDM][4], b1[NDM][4], t1[4];
+    s4_v4d a0[NDM], b0[NDM], a1[NDM], b1[NDM];
+    double t0[4], t1[4];
     load(0, a0, b0, t0);
     int g = 0;
     for (; g + 2 < ng; g += 2) {
         S4_WAIT_THEN(load(g + 1, a1, b1, t1));
-        fmas(a0, b0, t0);
+        fmas(a0, b0, t0, 0);
         S4_WAIT_THEN(load(g + 2, a0, b0, t0));
-        fmas(a1, b1, t1);
+        fmas(a1, b1, t1, 0);
     }
+    const int skip = 4 * ng - s;  // steps of the last group that belong to the one before it
     if (g + 1 < ng) {  // two groups left: set 0 holds a full one
         S4_WAIT_THEN(load(g + 1, a1, b1, t1));
-        fmas(a0, b0, t0);
+        fmas(a0, b0, t0, 0);
         S4_WAIT_THEN((void)0);
-        fmas_last(a1, b1, t1);
+        fmas(a1, b1, t1, skip);
     } else {
         S4_WAIT_THEN((void)0);
-        fmas_last(a0, b0, t0);
+        fmas(a0, b0, t0, skip);
     }
 #undef S4_WAIT_THEN
 }
@@ -355,12 +375,12 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
 
             // ---- the walk: s steps, element Lsym[trow][u*s + c]
             if (ch == 0) {
-                s4_walk<NDM, true>(buf + w * g.tri, 0, il, tri_il, dq + w * s, dp + w * s, n2, s, kp, kq);
+                s4_walk<NDM, 0>(buf + w * g.tri, 0, il, tri_il, dq + w * s, dp + w * s, n2, s, kp, kq);
             } else {
                 const int u = w ^ ch;
-                const bool rowside = w > u;
-                const double* lb = buf + s4_slot(min(w, u), ch) * s * ls + (rowside ? il * ls : il);
-                s4_walk<NDM, false>(lb, rowside ? 1 : ls, il, tri_il, dq + u * s, dp + u * s, n2, s, kp, kq);
+                const double* rect = buf + s4_slot(min(w, u), ch) * s * ls;
+                if (w > u) s4_walk<NDM, 1>(rect + il * ls, 1, il, tri_il, dq + u * s, dp + u * s, n2, s, kp, kq);
+                else s4_walk<NDM, 2>(rect + il, ls, il, tri_il, dq + u * s, dp + u * s, n2, s, kp, kq);
             }
         }
         // J partial of this tile (summed by thread 0 after the next barrier)
