@@ -178,7 +178,16 @@ __device__ __forceinline__ void s4_walk(const double* lb, int step, int il, int 
         xps[x] = xp + x * n2;
     }
     const char* lbc = reinterpret_cast<const char*>(lb);
-    const int il8 = il * 8;
+    // diagonal triangle: LDS byte addresses of the lane's row (L[il][0]) and of its column's head
+    // (L[0][il] if the rows above il were full); opaque, so that the uniform parts of the per-step
+    // addresses stay in scalar registers
+    typedef __attribute__((address_space(3))) const char* s4_lds_cp;
+    typedef __attribute__((address_space(3))) const double* s4_lds_dp;
+    int row_a = (int)(size_t)(s4_lds_cp)lbc + tri_il * 8, col_a = (int)(size_t)(s4_lds_cp)lbc + il * 8;
+    if (KIND == 0) {
+        asm volatile("" : "+v"(row_a));
+        asm volatile("" : "+v"(col_a));
+    }
     auto load = [&](int g, s4_v4d(&a)[NDM], s4_v4d(&b)[NDM], double(&t)[4]) {
         const int c0 = min(4 * g, s - 4);
         const int off = c0 * 8;
@@ -189,13 +198,13 @@ __device__ __forceinline__ void s4_walk(const double* lb, int step, int il, int 
         }
         if (KIND == 0) {
             // row part (c <= il): L[il][c] at tri(il) + c; column part: L[c][il] at tri(c) + il
-            const int rb = tri_il * 8 + off;
+            const int rb = row_a + off;
             int tric = (int)(((unsigned)c0 * (unsigned)(c0 + 1)) >> 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int cb = (tric - j) * 8 + il8;  // minus j: the read below adds 8 j to both forms
-                const int ab = (il >= c0 + j) ? rb : cb;
-                t[j] = *reinterpret_cast<const double*>(lbc + ab + 8 * j);
+                const int sj = (tric - j) * 8;  // minus j: the read below adds 8 j to both forms
+                const int ab = (il >= c0 + j) ? rb : col_a + sj;
+                t[j] = *(s4_lds_dp)(size_t)(ab + 8 * j);
                 tric += c0 + j + 1;
             }
         } else if (KIND == 1) {
