@@ -268,11 +268,22 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
     __shared__ int lu_failed;
     const int lane = threadIdx.x;
     const int m = nd + 1;
-    for (int k = 0; k < nd; ++k) {
-        double t = 0.0;
-        for (int b = lane; b < nblocks; b += 64) t += partial[(int64_t)b * nd + k];
-        t = nbx_wave_sum(t);
-        if (lane == 0) row[k] = t;
+    {
+        // all loads of the partial dot products in flight before the first sum needs one (one trip
+        // to L2 instead of nd of them: this kernel is a single wave on the critical path)
+        double acc[DIIS_MAX_SPACE];
+#pragma unroll
+        for (int k = 0; k < DIIS_MAX_SPACE; ++k) acc[k] = 0.0;
+        for (int b = lane; b < nblocks; b += 64) {
+#pragma unroll
+            for (int k = 0; k < DIIS_MAX_SPACE; ++k)
+                if (k < nd) acc[k] += partial[(int64_t)b * nd + k];
+        }
+#pragma unroll
+        for (int k = 0; k < DIIS_MAX_SPACE; ++k) {
+            const double t = nbx_wave_sum(acc[k]);
+            if (lane == 0 && k < nd) row[k] = t;
+        }
     }
     __syncthreads();
     if (lane < nd) {
@@ -307,6 +318,12 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
         fro = fma(v, v, fro);
     }
     fro = nbx_wave_sum(fro);
+    // This kernel is ONE wavefront on the SCF's critical path: it issues an instruction every four
+    // cycles, so what counts is the instruction count.  The element a lane updates in the rotation
+    // passes is fixed: its indices are computed once (no integer division per step), and the rotation
+    // is computed without forming tau (one square root, one reciprocal square root).
+    const int rr = lane / M, rk = lane - rr * M;
+    const int q64 = 64 / M, r64 = 64 - q64 * M;  // idx += 64 in (row, column) form
     for (int sweep = 0; sweep < 40; ++sweep) {
         double off = 0.0;
         for (int idx = lane; idx < m * m; idx += 64) {
@@ -343,9 +360,14 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
                 const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
                 double c = 1.0, sn = 0.0;
                 if (fabs(apq) > 1e-290) {
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + t * t);
+                    // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = d / (2 apq), written without tau:
+                    // t = 2 apq / (d + sgn(d) sqrt(d^2 + 4 apq^2)); scaled so the squares cannot underflow
+                    const double d = aqq - app, b = 2.0 * apq;
+                    const double sc = fmax(fabs(d), fabs(b));
+                    const double ds = d / sc, bs = b / sc;
+                    const double r = sqrt(fma(ds, ds, bs * bs));
+                    const double t = bs / (ds + (ds >= 0.0 ? r : -r));
+                    c = rsqrt(fma(t, t, 1.0));
                     sn = t * c;
                 }
                 rot_c[lane] = c;
@@ -354,8 +376,7 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
                 rot_q[lane] = q;
             }
             __syncthreads();
-            for (int idx = lane; idx < npair * M; idx += 64) {  // A <- A J, V <- V J
-                const int r = idx / M, k = idx - r * M;
+            for (int idx = lane, r = rr, k = rk; idx < npair * M; idx += 64) {  // A <- A J, V <- V J
                 const int p = rot_p[r], q = rot_q[r];
                 const double c = rot_c[r], sn = rot_s[r];
                 const double akp = A[k][p], akq = A[k][q];
@@ -364,16 +385,27 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
                 const double vkp = V[k][p], vkq = V[k][q];
                 V[k][p] = c * vkp - sn * vkq;
                 V[k][q] = sn * vkp + c * vkq;
+                r += q64;
+                k += r64;
+                if (k >= M) {
+                    k -= M;
+                    ++r;
+                }
             }
             __syncthreads();
-            for (int idx = lane; idx < npair * M; idx += 64) {  // A <- J^T A; the rotated pair is exactly 0
-                const int r = idx / M, k = idx - r * M;
+            for (int idx = lane, r = rr, k = rk; idx < npair * M; idx += 64) {  // A <- J^T A; rotated pair = 0
                 const int p = rot_p[r], q = rot_q[r];
                 const double c = rot_c[r], sn = rot_s[r];
                 const double apk = A[p][k], aqk = A[q][k];
                 const bool rotated = sn != 0.0;
                 A[p][k] = (rotated && k == q) ? 0.0 : c * apk - sn * aqk;
                 A[q][k] = (rotated && k == p) ? 0.0 : sn * apk + c * aqk;
+                r += q64;
+                k += r64;
+                if (k >= M) {
+                    k -= M;
+                    ++r;
+                }
             }
             __syncthreads();
         }

@@ -90,6 +90,84 @@ class PySCFProvider:
         return GpuUHF(embedded_mol, s, h, eri, backend=backend)
 
 
+class _TaggedVeff(np.ndarray):
+    """ndarray carrying .ecoul / .exc like PySCF's tagged Kohn-Sham veff."""
+
+
+class BuiltinHFProvider:
+    """The out-of-path pieces without PySCF, for what ``nbed_amd.integrals`` covers: molecules of
+    s/p-shell elements in STO-3G with the "functional" ``xc_functional='hf'`` (exact exchange:
+    HF-in-HF embedding, the DFT-free analogue of the reference's workflow; PySCF's ``dft.UKS``
+    accepts the same string).  Integrals come from the host-side McMurchie-Davidson engine, the
+    global mean field is the product's own ``GpuUHF``."""
+
+    def __init__(self, backend=None):
+        self._be = backend
+        self._cache = {}
+
+    @staticmethod
+    def supports(config: NbedConfig) -> bool:
+        from . import integrals
+
+        no_mm = None in [config.mm_charges, config.mm_coords, config.mm_radii]
+        return (str(config.xc_functional).lower() == "hf" and no_mm
+                and integrals.supports(config.geometry, str(config.basis)))
+
+    def _integrals(self, config: NbedConfig):
+        from . import integrals
+
+        key = (config.geometry, str(config.basis).lower(), str(config.unit))
+        if key not in self._cache:
+            self._cache[key] = integrals.molecule_integrals(config.geometry, str(config.basis), str(config.unit))
+        return self._cache[key]
+
+    def build_mol(self, config: NbedConfig):
+        from .scf import Mole
+
+        ints = self._integrals(config)
+        nelectron = ints["nelectron"] - int(config.charge)
+        spin = int(config.spin)
+        if (nelectron + spin) % 2:
+            raise NbedDriverError(f"{nelectron} electrons are incompatible with spin {spin}")
+        nelec = ((nelectron + spin) // 2, (nelectron - spin) // 2)
+        return Mole(ints["nao"], nelec, ao_slices=ints["ao_slices"], e_nuc=ints["e_nuc"], atom=config.geometry,
+                    basis=config.basis, charge=config.charge)
+
+    def global_ks(self, config: NbedConfig, run_qmmm: bool = False):
+        from .scf import GpuUHF
+
+        if run_qmmm or not self.supports(config):
+            raise NbedDriverError("BuiltinHFProvider covers xc_functional='hf', s/p elements in STO-3G, no QM/MM")
+        ints = self._integrals(config)
+
+        class GlobalHF(GpuUHF):
+            """UHF presented through the Kohn-Sham protocol: veff = J - K with ecoul = 1/2 tr(D J)
+            and exc = -1/2 sum_x tr(D_x K_x), as PySCF tags its UKS veff."""
+
+            xc = "hf"
+
+            def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
+                dm = self.make_rdm1() if dm is None else np.asarray(dm)
+                dm3 = np.array((dm * 0.5, dm * 0.5)) if dm.ndim == 2 else dm
+                vj, vk = self.get_jk(mol, dm3)
+                v = np.asarray(vj[0] + vj[1] - vk).view(_TaggedVeff)
+                v.ecoul = 0.5 * float(np.einsum("ij,ji->", vj[0] + vj[1], dm3[0] + dm3[1]))
+                v.exc = -0.5 * float(np.einsum("xij,xji->", vk, dm3))
+                return v
+
+        ks = GlobalHF(self.build_mol(config), ints["S"], ints["hcore"], ints["eri"], backend=self._be)
+        ks.conv_tol = config.convergence
+        ks.max_cycle = config.max_dft_cycles
+        ks.kernel()
+        return ks
+
+    def local_hf(self, config: NbedConfig, embedded_mol, backend=None):
+        from .scf import GpuUHF
+
+        ints = self._integrals(config)
+        return GpuUHF(embedded_mol, ints["S"], ints["hcore"], ints["eri"], backend=backend)
+
+
 class NbedDriver:
     """Run projection-based embedding and produce the embedded active-space Hamiltonian."""
 
@@ -117,7 +195,13 @@ class NbedDriver:
     @property
     def provider(self):
         if self._provider is None:
-            self._provider = PySCFProvider()
+            try:
+                self._provider = PySCFProvider()
+            except NbedDriverError:
+                # no PySCF: the built-in integrals cover HF-in-HF on small s/p molecules in STO-3G
+                if not BuiltinHFProvider.supports(self.config):
+                    raise
+                self._provider = BuiltinHFProvider(self._be)
         return self._provider
 
     def _build_mol(self):

@@ -26,6 +26,7 @@ from test_water_kat import (  # noqa: E402,F401
     test_hf_in_hf_embedding_of_water_is_exact,
     test_product_scf_reproduces_reference_uhf_literals,
 )
+from test_host_integrals import test_driver_on_builtin_provider_hf_in_hf_water  # noqa: E402,F401
 from test_host_scf import (  # noqa: E402,F401
     test_energy_elec_matches_reference,
     test_gpu_uhf_protocol_matches_oracle_scf,

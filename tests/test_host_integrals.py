@@ -1,0 +1,98 @@
+"""The product's host-side integral engine (nbed_amd/integrals.py) against the oracle's
+independent one (oracle/gto.py) and the committed water/STO-3G fixture -- whose SCF energy
+reproduces the literal values of the reference's own test (tests/test_driver.py:52-61, see
+test_water_kat.py) -- and the driver running end to end on the built-in provider (no PySCF, no
+test provider)."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import gto as oracle_gto
+from oracle_backend import OracleBackend
+
+from nbed_amd import NbedConfig, integrals, nbed
+from nbed_amd.driver import BuiltinHFProvider
+
+WATER_XYZ = "3\n\nO   0.0000  0.000  0.115\nH   0.0000  0.754  -0.459\nH   0.0000  -0.754  -0.459"
+H2O2_XYZ = ("4\n\nO   0.000  0.734  -0.052\nO   0.000  -0.734  -0.052\nH   0.839  0.881  0.419\n"
+            "H   -0.839  -0.881  0.419")
+H2_XYZ = "2\n\nH 0.0 0.0 0.0\nH 0.0 0.0 0.74"
+
+
+def test_water_integrals_match_the_fixture():
+    g = load_golden("water_sto3g")
+    m = integrals.molecule_integrals(WATER_XYZ)
+    assert m["nao"] == 7 and m["nelectron"] == 10
+    np.testing.assert_allclose(m["S"], g["S"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(m["T"], g["T"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(m["V"], g["V"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(m["eri"], g["eri"], rtol=0, atol=1e-12)
+    assert abs(m["e_nuc"] - float(g["ref_e_nuc"])) < 1e-12  # the reference's literal
+    # AO ranges per atom (columns 2:4 of aoslice_by_atom; the shell columns here count shells as
+    # PySCF does: O has three)
+    assert [list(r[2:]) for r in m["ao_slices"]] == [list(map(int, r[2:])) for r in g["ao_slices"]]
+    assert [list(r[:2]) for r in m["ao_slices"]] == [[0, 3], [3, 4], [4, 5]]
+
+
+@pytest.mark.parametrize("xyz", [H2_XYZ, H2O2_XYZ])
+def test_integrals_match_the_oracle_engine(xyz):
+    m = integrals.molecule_integrals(xyz)
+    atoms = oracle_gto.parse_xyz(xyz)
+    basis = oracle_gto.Basis(atoms)
+    s, t, v = oracle_gto.one_electron(basis)
+    np.testing.assert_allclose(m["S"], s, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(m["T"], t, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(m["V"], v, rtol=0, atol=1e-11)
+    eri = m["eri"]
+    n = m["nao"]
+    # permutational symmetry of the product's tensor, and a sample of elements against the oracle
+    np.testing.assert_array_equal(eri, eri.transpose(1, 0, 2, 3))
+    np.testing.assert_array_equal(eri, eri.transpose(2, 3, 0, 1))
+    if n <= 4:
+        np.testing.assert_allclose(eri, oracle_gto.two_electron(basis), rtol=0, atol=1e-12)
+    assert abs(m["e_nuc"] - oracle_gto.nuclear_repulsion(atoms)) < 1e-12
+    assert np.all(np.linalg.eigvalsh(s) > 0) and abs(np.diag(s) - 1).max() < 1e-12
+
+
+def test_supports():
+    assert integrals.supports(WATER_XYZ, "STO-3G") and integrals.supports(H2_XYZ, "sto-3g")
+    assert not integrals.supports(WATER_XYZ, "cc-pVDZ")
+    assert not integrals.supports("1\n\nC 0 0 0", "sto-3g")
+
+
+@pytest.fixture()
+def be():
+    return OracleBackend()
+
+
+@pytest.mark.parametrize("projector", ["mu", "huzinaga"])
+def test_driver_on_builtin_provider_hf_in_hf_water(be, projector):
+    """nbed(config) with nothing injected but the backend: built-in integrals, the product's own
+    global mean field.  HF-in-HF embedding is exact, and the global energy is the literal value
+    the reference's test asserts for water / STO-3G UHF."""
+    g = load_golden("water_sto3g")
+    cfg = NbedConfig(geometry=WATER_XYZ, n_active_atoms=2, basis="STO-3G", xc_functional="hf",
+                     projector=projector, convergence=1e-10, max_hf_cycles=100, max_dft_cycles=100,
+                     virtual_localization="cl")
+    drv = nbed(cfg, backend=be)
+    assert isinstance(drv.provider, BuiltinHFProvider)
+    res = drv.mu if projector == "mu" else drv.huzinaga
+    e_global = drv._global_ks.e_tot
+    assert abs(e_global - float(g["ref_uhf_e_tot"])) < 1e-8
+    assert abs(drv.e_nuc - float(g["ref_e_nuc"])) < 1e-12
+    assert res["scf"].converged
+    assert abs(res["e_rhf"] - e_global) < 2e-6
+    assert abs(drv.e_act + drv.e_env + drv.two_e_cross + drv.e_nuc - e_global) < 1e-8
+
+
+def test_builtin_provider_refuses_what_it_does_not_cover():
+    from nbed_amd.exceptions import NbedDriverError
+
+    cfg = NbedConfig(geometry=WATER_XYZ, n_active_atoms=2, basis="STO-3G", xc_functional="b3lyp",
+                     projector="mu", convergence=1e-8)
+    assert not BuiltinHFProvider.supports(cfg)
+    from nbed_amd.driver import NbedDriver
+
+    with pytest.raises(NbedDriverError):
+        NbedDriver(cfg, backend=OracleBackend()).provider
