@@ -6,7 +6,7 @@ nbed/localizers/virtual/concentric.py:83-88).  They are inputs of the hot path, 
 molecule; this module makes them without PySCF for contracted Cartesian s and p shells
 (McMurchie-Davidson: Hermite expansion of the pair densities, Boys function), vectorised over the
 primitive combinations of a shell block.  Enough for the reference's own CPU-runnable test case
-(water / STO-3G, BASELINE configs[0]) and the other H/O molecules of its test set; larger bases
+(water / STO-3G, BASELINE configs[0]) and the other H/C/N/O/F molecules of its test set in STO-3G; larger bases
 need the PySCF provider (``nbed_amd.driver.PySCFProvider``).
 
 Conventions are PySCF's: Bohr radius 0.52917721092 Angstrom, AO order per atom = shells in basis
@@ -26,18 +26,27 @@ BOHR = 0.52917721092
 _STO3G_1S = (0.15432897, 0.53532814, 0.44463454)
 _STO3G_2S = (-0.09996723, 0.39951283, 0.70011547)
 _STO3G_2P = (0.15591627, 0.60768372, 0.39195739)
+
+
+def _sto3g_second_row(core, valence):
+    return [(0, core, _STO3G_1S), (0, valence, _STO3G_2S), (1, valence, _STO3G_2P)]
+
+
 #: basis name -> element -> [(l, exponents, contraction coefficients)]
+#: STO-3G exponents are zeta^2 times the universal three-Gaussian fit of a Slater 1s / 2sp function
+#: (tests/test_host_integrals.py checks the table against that identity)
 BASIS_SETS = {
     "sto-3g": {
         "H": [(0, (3.42525091, 0.62391373, 0.16885540), _STO3G_1S)],
-        "O": [
-            (0, (130.7093200, 23.8088610, 6.4436083), _STO3G_1S),
-            (0, (5.0331513, 1.1695961, 0.3803890), _STO3G_2S),
-            (1, (5.0331513, 1.1695961, 0.3803890), _STO3G_2P),
-        ],
+        "C": _sto3g_second_row((71.6168370, 13.0450960, 3.5305122), (2.9412494, 0.6834831, 0.2222899)),
+        "N": _sto3g_second_row((99.1061690, 18.0523120, 4.8856602), (3.7804559, 0.8784966, 0.2857144)),
+        "O": _sto3g_second_row((130.7093200, 23.8088610, 6.4436083), (5.0331513, 1.1695961, 0.3803890)),
+        "F": _sto3g_second_row((166.6791300, 30.3608120, 8.2168207), (6.4648032, 1.5022812, 0.4885885)),
     }
 }
-NUCLEAR_CHARGE = {"H": 1, "O": 8}
+NUCLEAR_CHARGE = {"H": 1, "C": 6, "N": 7, "O": 8, "F": 9}
+#: Slater exponents behind the table (1s, 2sp)
+STO3G_ZETA = {"H": (1.24, None), "C": (5.67, 1.72), "N": (6.67, 1.95), "O": (7.66, 2.25), "F": (8.65, 2.55)}
 _CART = {0: [(0, 0, 0)], 1: [(1, 0, 0), (0, 1, 0), (0, 0, 1)]}
 
 

@@ -58,7 +58,25 @@ def test_integrals_match_the_oracle_engine(xyz):
 def test_supports():
     assert integrals.supports(WATER_XYZ, "STO-3G") and integrals.supports(H2_XYZ, "sto-3g")
     assert not integrals.supports(WATER_XYZ, "cc-pVDZ")
-    assert not integrals.supports("1\n\nC 0 0 0", "sto-3g")
+    assert not integrals.supports("1\n\nS 0 0 0", "sto-3g")
+
+
+def test_sto3g_table_is_zeta_scaled_universal_fit():
+    """Every STO-3G exponent is zeta^2 times the universal fit of a Slater function: guards the
+    table of the elements that have no reference literal (C, N, F) against typos."""
+    fit_1s = np.array([2.227660584, 0.405771156, 0.109818])
+    fit_2sp = np.array([0.994203, 0.231031, 0.0751386])
+    for sym, (z1, z2) in integrals.STO3G_ZETA.items():
+        shells = integrals.BASIS_SETS["sto-3g"][sym]
+        np.testing.assert_allclose(shells[0][1], z1 * z1 * fit_1s, rtol=2e-5)
+        if z2 is not None:
+            assert shells[1][1] == shells[2][1] and shells[1][0] == 0 and shells[2][0] == 1
+            np.testing.assert_allclose(shells[1][1], z2 * z2 * fit_2sp, rtol=2e-5)
+    # methyl radical (the reference's open-shell test molecule): 8 basis functions, normalised
+    m = integrals.molecule_integrals("4\n\nC 0 0 0\nH 1.079 0 0\nH -0.5395 0.9344 0\nH -0.5395 -0.9344 0")
+    assert m["nao"] == 8 and m["nelectron"] == 9
+    np.testing.assert_allclose(np.diag(m["S"]), 1.0, atol=1e-12)
+    assert np.all(np.linalg.eigvalsh(m["S"]) > 0)
 
 
 @pytest.fixture()
