@@ -254,12 +254,19 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         # (anything it does not finish falls through to Jacobi on the device); otherwise three
         st = handle.get_extra()
         if st is not None:
+            logger.debug("cycle %s eigensolver status %s tracked=%s", cycle, st.tolist(), state[6])
             if state[6] and np.any(st <= 0):
                 raise _TrackedEigensolveFailed(f"cycle {cycle}: status {st.tolist()}")
-            warm["iters"] = 1 if np.all(st == 1001) else 3
-            # every matrix accepted after one iteration: from the next cycle queued on, refine
-            # without the guard; anything else (re-)arms the guarded solver
-            warm["tracked"] = bool(allow_tracked and can_track and np.all(st == 1001))
+            # every matrix accepted by refinement within two iterations: from the next cycle queued
+            # on, refine without the guard -- with one iteration in reserve while the density still
+            # moves; anything else (re-)arms the guarded solver
+            accepted = bool(np.all(st >= 1001))
+            needed = int(np.max(st)) - 1000 if accepted else 99
+            warm["tracked"] = bool(allow_tracked and can_track and needed <= 2)
+            if warm["tracked"]:
+                warm["iters"] = min(3, needed + (1 if float(np.max(sc[2:])) > 1e-8 else 0))
+            else:
+                warm["iters"] = 1 if needed == 1 else 3
         scf_energy = sc[:2].copy()
         norm_dm_diff = float(np.max(sc[2:]))
         run_diff = np.max(np.abs(scf_energy - scf_energy_prev))
