@@ -159,6 +159,7 @@ def main():
     shards = Shards(N, world, rank, force_collective=distributed, balance="triangular")
     eri = be.synth_eri(N, shards.lo, shards.hi)
     mf = GpuUHF(Mole(N, pr["nelec"]), pr["S"], pr["hcore"], eri, backend=be, shards=shards)
+    mf.eri_packed_device()  # the J/K kernel's packed copy of the slab: part of the resident inputs
     from nbed_amd.scf import huzinaga_scf
 
     mf.conv_tol = -1.0  # the stopping rule can never fire: exactly max_cycle cycles run
