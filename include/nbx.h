@@ -249,14 +249,14 @@ int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* 
              void* d_work, size_t work_bytes);
 /* Warm start: d_v0 (batch,N,N) holds approximate eigenvectors (orthonormal columns, e.g. the
  * previous SCF cycle's).  For N <= 196 the pair is first refined with GEMMs only (Ogita-Aishima
- * iteration, <= 3 steps, quadratically convergent); a matrix the refinement does not bring to
+ * iteration, 3 steps, quadratically convergent); a matrix the refinement does not bring to
  * max|E| < 3e-8 -- or that has coupled near-degenerate eigenvalues -- falls through, on the
  * device and with no host round trip, to Jacobi sweeps on V0^T A V0 (nearly diagonal: 1-4
  * sweeps instead of 8-10).  d_v0 == NULL is nbx_eigh.  Same outputs/workspace.               */
 int nbx_eigh_warm(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0,
                   double* d_w, double* d_v, void* d_work, size_t work_bytes);
 /* Same with the number of refinement iterations queued before the Jacobi fallback chosen by the
- * caller (0 = none ... 3 = default).  Results do not depend on it -- a matrix the queued
+ * caller (0 = none, 3 = the default of nbx_eigh_warm, 6 = most).  Results do not depend on it -- a matrix the queued
  * iterations do not finish is solved by the sweeps -- only the number of launches does: an SCF
  * driver that saw the last cycles accepted after one iteration queues one.                   */
 int nbx_eigh_warm_ex(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0,
@@ -289,7 +289,7 @@ int nbx_svd_right(nbx_ctx* ctx, int64_t m, int64_t n, const double* d_a, double*
  * computes, once an SCF is under way.  batch matrices: d_f, d_s (the overlap, repeated per batch
  * entry), d_c0 (S-orthonormal start vectors), all (batch, n, n) row-major.
  *   d_status[b] = 1000 + iterations used: accepted, d_w[b] (ascending) and d_c[b] written;
- *               <= 0: not converged within max_iter (1..3) or near-degenerate cluster coupled --
+ *               <= 0: not converged within max_iter (1..6) or near-degenerate cluster coupled --
  *                     outputs untouched.  There is NO fallback solver behind this entry: the
  *                     caller checks the status (the SCF loops do, one cycle late, and redo the run
  *                     on nbx_eigh_warm_ex if it ever fails).

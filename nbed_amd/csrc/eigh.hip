@@ -328,7 +328,7 @@ extern "C" int nbx_eigh_warm_ex(nbx_ctx* ctx, int64_t n, int64_t batch, const do
         {
             nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
             rc0 = nbx_eigh_refine(ctx, n, batch, d_a, d_v0, d_w, d_v, rf, jstatus, &rstatus,
-                                  refine_iters < NBX_EIGH_REFINE_ITERS ? refine_iters : NBX_EIGH_REFINE_ITERS);
+                                  refine_iters < NBX_EIGH_REFINE_MAX ? refine_iters : NBX_EIGH_REFINE_MAX);
         }
         if (rc0 != NBX_OK) return rc0;
         std::vector<int> st((size_t)batch, 0);

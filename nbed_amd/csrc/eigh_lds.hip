@@ -437,7 +437,7 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
             // status word says the refinement did not get there (decided on the device)
             nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
             rc = nbx_eigh_refine(ctx, n, batch, d_a, d_v0, d_w, d_v, base + L.refine_off, status, &gate,
-                                 refine_iters < NBX_EIGH_REFINE_ITERS ? refine_iters : NBX_EIGH_REFINE_ITERS);
+                                 refine_iters < NBX_EIGH_REFINE_MAX ? refine_iters : NBX_EIGH_REFINE_MAX);
             if (rc != NBX_OK) return rc;
             rc = nbx_gemm_gated(ctx, 'T', 'N', n, n, n, 1.0, d_v0, n, n * n, d_a, n, n * n, 0.0, tmp, n, n * n, batch, gate,
                                 0, -1);

@@ -24,7 +24,7 @@ namespace {
 
 constexpr int RF_THREADS = 256;
 constexpr int RF_WGS = 16;
-constexpr int RF_MAX_ITER = 3;
+constexpr int RF_MAX_ITER = 6;
 constexpr int RF_UNROLL = 4;
 constexpr double RF_TOL = 3.0e-8;       // accepted update has max|E| below this: error ~ tol^2
 constexpr double RF_GIVE_UP = 0.25;     // not in the contracting regime

@@ -70,7 +70,8 @@ size_t nbx_eigh_refine_worksize(int64_t n, int64_t batch);
 // for every matrix whose eigenpairs were accepted and written to d_w / d_v.
 int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0, double* d_w,
                     double* d_v, void* d_work, int* d_jacobi_status, const int** d_status_out, int max_iter);
-constexpr int NBX_EIGH_REFINE_ITERS = 3;
+constexpr int NBX_EIGH_REFINE_ITERS = 3;  // default of nbx_eigh_warm
+constexpr int NBX_EIGH_REFINE_MAX = 6;    // most a caller can queue (eigh_refine.hip RF_MAX_ITER)
 
 // eigh_tridiag.hip
 size_t nbx_eigh_tridiag_worksize(int64_t n, int64_t batch);

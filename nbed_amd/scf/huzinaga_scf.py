@@ -103,6 +103,9 @@ def _is_fused(scf_method) -> bool:
     return not any(k in d for k in ("get_veff", "get_hcore", "get_occ", "make_rdm1"))
 
 
+MAX_REFINE_ITERS = 6  # the library's limit (nbx_eigh_warm_ex / nbx_geig_refine)
+
+
 class _TrackedEigensolveFailed(Exception):
     """A cycle solved by unguarded refinement (nbx_geig_refine) was not accepted."""
 
@@ -175,7 +178,7 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         be.axpby(1.0, hcore_d if hcore_d.dim() == 2 else hcore_d[x], 1.0, hv[x])
         be.axpby(1.0, vemb_d if vemb_d.dim() == 2 else vemb_d[x], 1.0, hv[x])
 
-    warm = {"v": None, "iters": 3, "tracked": False, "c": None}
+    warm = {"v": None, "iters": MAX_REFINE_ITERS, "tracked": False, "c": None}
     s_b = None  # the overlap once per spin, for the tracked solver
 
     def diagonalise(fock3):
@@ -264,9 +267,11 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
             needed = int(np.max(st)) - 1000 if accepted else 99
             warm["tracked"] = bool(allow_tracked and can_track and needed <= 2)
             if warm["tracked"]:
-                warm["iters"] = min(3, needed + (1 if float(np.max(sc[2:])) > 1e-8 else 0))
-            else:
-                warm["iters"] = 1 if needed == 1 else 3
+                warm["iters"] = needed + (1 if float(np.max(sc[2:])) > 1e-8 else 0)
+            else:  # guarded: refinement converges quadratically from max|E| < 0.25, so up to six
+                # iterations (25 us each) are worth queueing ahead of a ~1 ms Jacobi solve
+                warm["iters"] = 1 if needed == 1 else (min(MAX_REFINE_ITERS, needed + 1) if accepted
+                                                       else MAX_REFINE_ITERS)
         scf_energy = sc[:2].copy()
         norm_dm_diff = float(np.max(sc[2:]))
         run_diff = np.max(np.abs(scf_energy - scf_energy_prev))
