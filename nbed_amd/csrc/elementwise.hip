@@ -226,6 +226,7 @@ __global__ void dots_kernel(int64_t n, int nvec, const double* __restrict__ x, c
 // ------------------------------------------------------------------ device-resident DIIS
 constexpr int DIIS_MAX_SPACE = 16;
 constexpr int DIIS_M = DIIS_MAX_SPACE + 1;
+constexpr int DIIS_SLOTS = ((DIIS_M + 1) * (DIIS_M + 1) + 63) / 64;  // matrix elements per lane
 
 // xs[slot] = x, es[slot] = e = (err given ? err : x - xprev), partial[blk*nd + k] = sum_i e[i] * es[k][i]
 __global__ void diis_push_kernel(int64_t n, int nd, int slot, const double* __restrict__ x,
@@ -263,14 +264,24 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
                                                         double* __restrict__ coef) {
     __shared__ double A[DIIS_M + 1][DIIS_M + 2], V[DIIS_M + 1][DIIS_M + 2], A0[DIIS_M][DIIS_M + 1];
     __shared__ double row[DIIS_MAX_SPACE], w[DIIS_M], c_out[DIIS_M];
-    __shared__ double rot_c[(DIIS_M + 1) / 2], rot_s[(DIIS_M + 1) / 2];
-    __shared__ int rot_p[(DIIS_M + 1) / 2], rot_q[(DIIS_M + 1) / 2];
+    __shared__ double kc[DIIS_M + 1], ks[DIIS_M + 1];
+    __shared__ int kmate[DIIS_M + 1];
     __shared__ int lu_failed;
     const int lane = threadIdx.x;
     const int m = nd + 1;
+    // One trip to L2 for everything the kernel reads: the old H entries (the row / column being
+    // replaced is patched from `row` below, and stored once A is built) and all partial sums.
+    double hold[DIIS_SLOTS];
+#pragma unroll
+    for (int e = 0; e < DIIS_SLOTS; ++e) {
+        const int idx = lane + 64 * e;
+        hold[e] = 0.0;
+        if (idx < m * m) {
+            const int r = idx / m, c = idx - r * m;
+            if (!((r == slot + 1 && c >= 1) || (c == slot + 1 && r >= 1))) hold[e] = H[(int64_t)r * ldh + c];
+        }
+    }
     {
-        // all loads of the partial dot products in flight before the first sum needs one (one trip
-        // to L2 instead of nd of them: this kernel is a single wave on the critical path)
         double acc[DIIS_MAX_SPACE];
 #pragma unroll
         for (int k = 0; k < DIIS_MAX_SPACE; ++k) acc[k] = 0.0;
@@ -286,19 +297,22 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
         }
     }
     __syncthreads();
+#pragma unroll
+    for (int e = 0; e < DIIS_SLOTS; ++e) {
+        const int idx = lane + 64 * e;
+        if (idx < m * m) {
+            const int r = idx / m, c = idx - r * m;
+            double v = hold[e];
+            if (r == slot + 1 && c >= 1) v = row[c - 1];
+            else if (c == slot + 1 && r >= 1) v = row[r - 1];
+            A[r][c] = v;
+            A0[r][c] = v;
+            V[r][c] = (r == c) ? 1.0 : 0.0;
+        }
+    }
     if (lane < nd) {
         H[(int64_t)(slot + 1) * ldh + lane + 1] = row[lane];
         H[(int64_t)(lane + 1) * ldh + slot + 1] = row[lane];
-    }
-    for (int idx = lane; idx < m * m; idx += 64) {
-        const int r = idx / m, c = idx - r * m;
-        double v;
-        if (r == slot + 1 && c >= 1) v = row[c - 1];
-        else if (c == slot + 1 && r >= 1) v = row[r - 1];
-        else v = H[(int64_t)r * ldh + c];
-        A[r][c] = v;
-        A0[r][c] = v;
-        V[r][c] = (r == c) ? 1.0 : 0.0;
     }
     __syncthreads();
     // Parallel-order (round-robin) Jacobi: M/2 disjoint rotations per step, M-1 steps per sweep;
@@ -320,16 +334,21 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
     fro = nbx_wave_sum(fro);
     // This kernel is ONE wavefront on the SCF's critical path: it issues an instruction every four
     // cycles, so what counts is the instruction count.  The element a lane updates in the rotation
-    // passes is fixed: its indices are computed once (no integer division per step), and the rotation
-    // is computed without forming tau (one square root, one reciprocal square root).
-    const int rr = lane / M, rk = lane - rr * M;
-    const int q64 = 64 / M, r64 = 64 - q64 * M;  // idx += 64 in (row, column) form
+    // pass is fixed: its indices are computed once (no integer division per step), the rotation is
+    // computed without forming tau (one square root, one reciprocal square root), and the column
+    // and row rotations are one pass over the matrix (three LDS round trips per step, not five).
+    int er[DIIS_SLOTS], ec[DIIS_SLOTS];  // the elements (row, column) this lane updates; row M: none
+#pragma unroll
+    for (int e = 0; e < DIIS_SLOTS; ++e) {
+        const int idx = lane + 64 * e;
+        er[e] = idx < M * M ? idx / M : M;
+        ec[e] = idx < M * M ? idx - (idx / M) * M : 0;
+    }
     for (int sweep = 0; sweep < 40; ++sweep) {
         double off = 0.0;
-        for (int idx = lane; idx < m * m; idx += 64) {
-            const int r = idx / m, c = idx - r * m;
-            if (r < c) off = fma(A[r][c], A[r][c], off);
-        }
+#pragma unroll
+        for (int e = 0; e < DIIS_SLOTS; ++e)
+            if (er[e] < ec[e] && ec[e] < m) off = fma(A[er[e]][ec[e]], A[er[e]][ec[e]], off);
         off = nbx_wave_sum(off);
         if (off <= 1e-31 * fro) break;  // eigenvalue error ~ off^2 / gap: far below 1e-16 |H|
         {
@@ -342,16 +361,12 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
             for (int o = 32; o > 0; o >>= 1) mind = fmin(mind, __shfl_xor(mind, o));
             if (mind - sqrt(2.0 * off) > 1.0e-14) break;
         }
+        // ring positions of this lane's pair: (step + lane) and (step - lane) mod (M - 1), both
+        // advanced by one per step (lane 0 pairs the fixed player M - 1 with `step`)
+        int ring_p = lane % (M - 1), ring_q = (M - 1 - lane % (M - 1)) % (M - 1);
         for (int step = 0; step < M - 1; ++step) {
             if (lane < npair) {  // pair `lane` of this step
-                int p, q;
-                if (lane == 0) {
-                    p = M - 1;
-                    q = step;
-                } else {
-                    p = (step + lane) % (M - 1);
-                    q = (step - lane + (M - 1)) % (M - 1);
-                }
+                int p = lane == 0 ? M - 1 : ring_p, q = lane == 0 ? step : ring_q;
                 if (p > q) {
                     const int tmp = p;
                     p = q;
@@ -362,49 +377,48 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
                 if (fabs(apq) > 1e-290) {
                     // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = d / (2 apq), written without tau:
                     // t = 2 apq / (d + sgn(d) sqrt(d^2 + 4 apq^2)); scaled so the squares cannot underflow
+                    // (t is scale invariant: an approximate reciprocal is as good as a division here)
                     const double d = aqq - app, b = 2.0 * apq;
-                    const double sc = fmax(fabs(d), fabs(b));
-                    const double ds = d / sc, bs = b / sc;
+                    const double inv = __builtin_amdgcn_rcp(fmax(fabs(d), fabs(b)));
+                    const double ds = d * inv, bs = b * inv;
                     const double r = sqrt(fma(ds, ds, bs * bs));
                     const double t = bs / (ds + (ds >= 0.0 ? r : -r));
                     c = rsqrt(fma(t, t, 1.0));
                     sn = t * c;
                 }
-                rot_c[lane] = c;
-                rot_s[lane] = sn;
-                rot_p[lane] = p;
-                rot_q[lane] = q;
+                // per index: column k of A J is kc[k] * col_k + ks[k] * col_mate(k)
+                kc[p] = c;
+                ks[p] = -sn;
+                kmate[p] = q;
+                kc[q] = c;
+                ks[q] = sn;
+                kmate[q] = p;
             }
+            ring_p = ring_p + 1 == M - 1 ? 0 : ring_p + 1;
+            ring_q = ring_q + 1 == M - 1 ? 0 : ring_q + 1;
             __syncthreads();
-            for (int idx = lane, r = rr, k = rk; idx < npair * M; idx += 64) {  // A <- A J, V <- V J
-                const int p = rot_p[r], q = rot_q[r];
-                const double c = rot_c[r], sn = rot_s[r];
-                const double akp = A[k][p], akq = A[k][q];
-                A[k][p] = c * akp - sn * akq;
-                A[k][q] = sn * akp + c * akq;
-                const double vkp = V[k][p], vkq = V[k][q];
-                V[k][p] = c * vkp - sn * vkq;
-                V[k][q] = sn * vkp + c * vkq;
-                r += q64;
-                k += r64;
-                if (k >= M) {
-                    k -= M;
-                    ++r;
+            // A <- J^T A J and V <- V J in one pass: every element from the old matrices ...
+            double na[DIIS_SLOTS], nv[DIIS_SLOTS];
+#pragma unroll
+            for (int e = 0; e < DIIS_SLOTS; ++e) {
+                const int r = er[e], c = ec[e];
+                if (r < M) {
+                    const int mr = kmate[r], mc = kmate[c];
+                    const double cc = kc[c], sc = ks[c], cr = kc[r], sr = ks[r];
+                    const double x = cc * A[r][c] + sc * A[r][mc];    // (A J)[r][c]
+                    const double y = cc * A[mr][c] + sc * A[mr][mc];  // (A J)[mate(r)][c]
+                    na[e] = (sr != 0.0 && mr == c) ? 0.0 : cr * x + sr * y;  // the rotated pair is exactly 0
+                    nv[e] = cc * V[r][c] + sc * V[r][mc];
                 }
             }
             __syncthreads();
-            for (int idx = lane, r = rr, k = rk; idx < npair * M; idx += 64) {  // A <- J^T A; rotated pair = 0
-                const int p = rot_p[r], q = rot_q[r];
-                const double c = rot_c[r], sn = rot_s[r];
-                const double apk = A[p][k], aqk = A[q][k];
-                const bool rotated = sn != 0.0;
-                A[p][k] = (rotated && k == q) ? 0.0 : c * apk - sn * aqk;
-                A[q][k] = (rotated && k == p) ? 0.0 : sn * apk + c * aqk;
-                r += q64;
-                k += r64;
-                if (k >= M) {
-                    k -= M;
-                    ++r;
+            // ... then stored
+#pragma unroll
+            for (int e = 0; e < DIIS_SLOTS; ++e) {
+                const int r = er[e], c = ec[e];
+                if (r < M) {
+                    A[r][c] = na[e];
+                    V[r][c] = nv[e];
                 }
             }
             __syncthreads();
