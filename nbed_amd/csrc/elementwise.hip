@@ -255,6 +255,58 @@ __global__ void diis_push_kernel(int64_t n, int nd, int slot, const double* __re
     }
 }
 
+// Parallel-order Jacobi on a matrix of order <= 8 held ONE ELEMENT PER LANE (lane = 8 r + c: a =
+// A[r][c], v = V[r][c]; rows / columns >= m are a decoupled zero pad): the rotation parameters and
+// the partner elements travel by lane shuffles, no LDS arrays, no barriers -- about half the
+// instructions of the LDS version per step.  Same round-robin pairing (with M = 8), same
+// rotations, same stopping rules.
+__device__ __forceinline__ void diis_jacobi_reg8(double& a, double& v, int m, double fro, int lane) {
+    const int r = lane >> 3, c = lane & 7;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = (r < c) ? a * a : 0.0;
+        off = nbx_wave_sum(off);
+        if (off <= 1e-31 * fro) break;
+        double mind = (r == c && r < m) ? fabs(a) : 1.0e300;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mind = fmin(mind, __shfl_xor(mind, o));
+        if (mind - sqrt(2.0 * off) > 1.0e-14) break;  // Weyl: see the LDS version below
+        for (int step = 0; step < 7; ++step) {
+            // player 7 is fixed and meets `step`; k = step +- l (mod 7) meet each other
+            auto mate = [&](int k) {
+                if (k == 7) return step;
+                if (k == step) return 7;
+                int x = 2 * step - k;
+                x += x < 0 ? 7 : 0;
+                x -= x >= 7 ? 7 : 0;
+                return x;
+            };
+            const int mc = mate(c), mr = mate(r);
+            const int p = min(c, mc), q = max(c, mc);
+            const double app = __shfl(a, 9 * p), aqq = __shfl(a, 9 * q), apq = __shfl(a, 8 * p + q);
+            const double a_rmc = __shfl(a, 8 * r + mc), a_mrc = __shfl(a, 8 * mr + c), a_mrmc = __shfl(a, 8 * mr + mc);
+            const double v_rmc = __shfl(v, 8 * r + mc);
+            double cs = 1.0, sn = 0.0;
+            if (fabs(apq) > 1e-290) {
+                const double d = aqq - app, b = 2.0 * apq;
+                const double inv = __builtin_amdgcn_rcp(fmax(fabs(d), fabs(b)));
+                const double ds = d * inv, bs = b * inv;
+                const double rt = sqrt(fma(ds, ds, bs * bs));
+                const double t = bs / (ds + (ds >= 0.0 ? rt : -rt));
+                cs = rsqrt(fma(t, t, 1.0));
+                sn = t * cs;
+            }
+            // column c of A J is kc * col_c + ks * col_mate(c); the row pair's parameters are those
+            // of column r, which lane (0, r) has just computed
+            const double kc_c = cs, ks_c = (c < mc) ? -sn : sn;
+            const double kc_r = __shfl(kc_c, r), ks_r = __shfl(ks_c, r);
+            const double x = kc_c * a + ks_c * a_rmc;       // (A J)[r][c]
+            const double y = kc_c * a_mrc + ks_c * a_mrmc;  // (A J)[mate(r)][c]
+            a = (ks_r != 0.0 && mr == c) ? 0.0 : kc_r * x + ks_r * y;  // the rotated pair is exactly 0
+            v = kc_c * v + ks_c * v_rmc;
+        }
+    }
+}
+
 // One wavefront: finish the dot products, update H, solve the Pulay system as PySCF does.
 //   eigenvalues by parallel-order Jacobi in LDS;
 //   any |w| < 1e-14  ->  c = V_keep diag(1/w_keep) V_keep^T g      (g = e_0)
@@ -344,7 +396,19 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
         er[e] = idx < M * M ? idx / M : M;
         ec[e] = idx < M * M ? idx - (idx / M) * M : 0;
     }
-    for (int sweep = 0; sweep < 40; ++sweep) {
+    if (m <= 8) {  // the usual case (pyscf.lib.diis space 6): one element per lane, no LDS traffic
+        const int r8 = lane >> 3, c8 = lane & 7;
+        double a = (r8 < m && c8 < m) ? A[r8][c8] : 0.0;
+        double v = (r8 == c8) ? 1.0 : 0.0;
+        diis_jacobi_reg8(a, v, m, fro, lane);
+        __syncthreads();
+        if (r8 < m && c8 < m) {
+            A[r8][c8] = a;
+            V[r8][c8] = v;
+        }
+        __syncthreads();
+    }
+    for (int sweep = 0; sweep < (m <= 8 ? 0 : 40); ++sweep) {
         double off = 0.0;
 #pragma unroll
         for (int e = 0; e < DIIS_SLOTS; ++e)
