@@ -180,6 +180,11 @@ int nbx_huzinaga_sym(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_f
                      double* d_hz, double* d_fock_io);
 /* out[b] = sum_ij A[b,i,j] * B[b,j,i]   (einsum "ij,ji->"; huzinaga_scf.py:185,
  * embedded_hcore_funcs.py:38-42, driver.py:957-962).  h_out: host, synchronises.          */
+/* The same operator from F and DS = D_env S directly, product and symmetrisation in one launch
+ * (huzinaga_scf.py:78-81 as one kernel): d_hz[b] = -kappa (F[b] DS[b] + (F[b] DS[b])^T) and, if
+ * d_fock_out is not NULL, d_fock_out[b] = F[b] + d_hz[b] (out of place: must not alias d_f).  */
+int nbx_huzinaga_fused(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_f, const double* d_ds, double kappa,
+                       double* d_hz, double* d_fock_out);
 int nbx_trace_prod(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_a, const double* d_b,
                    double* h_out);
 /* Per-cycle scalars of the Huzinaga HF branch (huzinaga_scf.py:181-194):

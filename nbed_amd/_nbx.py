@@ -64,6 +64,7 @@ SIGNATURES = {
     "nbx_eri_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "nbx_eri_pack": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     "nbx_jk_packed_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "nbx_huzinaga_fused": (c_int, [_P, c_int64, c_int64, _P, _P, c_double, _P, _P]),
     "nbx_jk_packed_fock": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t]),
     "nbx_jk_packed": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
     "nbx_jk_dense_sym": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),

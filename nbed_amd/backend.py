@@ -458,6 +458,16 @@ class HipBackend:
         self._call("nbx_huzinaga_sym", nao, batch, self._p(fds), kappa, self._p(hz), self._p(fock_io))
         return hz
 
+    def huzinaga_fused(self, fock, ds, kappa: float, want_fock: bool = True):
+        """(hz, fock + hz) with hz = -kappa (F DS + (F DS)^T): product and symmetrisation in one
+        launch (nbx_huzinaga_fused); ``fock`` itself is left untouched."""
+        nao = fock.shape[-1]
+        batch = 1 if fock.dim() == 2 else fock.shape[0]
+        hz = self.torch.empty_like(fock)
+        out = self.torch.empty_like(fock) if want_fock else None
+        self._call("nbx_huzinaga_fused", nao, batch, self._p(fock), self._p(ds), kappa, self._p(hz), self._p(out))
+        return hz, out
+
     def trace_prod(self, a, b) -> np.ndarray:
         """einsum('...ij,...ji->...') on device; returns host floats."""
         nao = a.shape[-1]

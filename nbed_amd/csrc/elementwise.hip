@@ -84,6 +84,81 @@ __global__ void fock_uhf_kernel(const double* __restrict__ h, int h3d, const dou
     }
 }
 
+// Hz = -kappa (F DS + (F DS)^T) and F' = F + Hz in ONE launch (the product and its symmetrisation
+// were a GEMM and an element-wise kernel: one launch less on the SCF's critical path).  One
+// wavefront per pair of 16 x 16 tiles (I, J <= I): T1 = F[I,:] DS[:,J] and T2 = F[J,:] DS[:,I] on the
+// matrix cores (k-slot order of gemm_small_kernel), Hz[I,J] = -kappa (T1 + T2^T) and its mirror image
+// through a 16 x 17 LDS tile.  Out of place: every workgroup reads all of F.
+typedef double ew_v4f64 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void huzinaga_fused_kernel(const double* __restrict__ F,
+                                                            const double* __restrict__ DS, int N, double kappa,
+                                                            double* __restrict__ hz, double* __restrict__ fock_out) {
+    __shared__ double t2[16][17], hv[16][17];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int64_t n2 = (int64_t)N * N;
+    F += blockIdx.z * n2;
+    DS += blockIdx.z * n2;
+    hz += blockIdx.z * n2;
+    if (fock_out != nullptr) fock_out += blockIdx.z * n2;
+    const int lane = threadIdx.x, fr = lane & 15, fk = lane >> 4;
+    const int ri = ti * 16 + fr, rj = tj * 16 + fr;  // A-fragment rows of the two products = B-fragment columns
+    const bool oki = ri < N, okj = rj < N;
+    const double* fi = F + (int64_t)(oki ? ri : 0) * N;  // row ri of F (k contiguous)
+    const double* fj = F + (int64_t)(okj ? rj : 0) * N;
+    const double* dsj = DS + (okj ? rj : 0);  // column rj of DS (k strided by N)
+    const double* dsi = DS + (oki ? ri : 0);
+    ew_v4f64 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+    const bool diag = ti == tj;
+    for (int k0 = 0; k0 < N; k0 += 16) {
+        double a1[4], b1[4], a2[4], b2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + 4 * j + fk;
+            const bool in = k < N;
+            a1[j] = (in && oki) ? fi[k] : 0.0;
+            b1[j] = (in && okj) ? dsj[(int64_t)k * N] : 0.0;
+            a2[j] = (in && okj && !diag) ? fj[k] : 0.0;
+            b2[j] = (in && oki && !diag) ? dsi[(int64_t)k * N] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], b1[j], acc1, 0, 0, 0);
+            if (!diag) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[j], b2[j], acc2, 0, 0, 0);
+        }
+    }
+    if (diag) acc2 = acc1;
+    // accumulator element r of a lane: tile row fk + 4 r, tile column fr
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t2[fk + 4 * r][fr] = acc2[r];
+    __syncthreads();
+    double val[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        val[r] = -kappa * (acc1[r] + t2[fr][fk + 4 * r]);  // T1[i][j] + T2[j][i]
+        hv[fk + 4 * r][fr] = val[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + fk + 4 * r, col = tj * 16 + fr;
+        if (row < N && col < N) {
+            const int64_t o = (int64_t)row * N + col;
+            hz[o] = val[r];
+            if (fock_out != nullptr) fock_out[o] = F[o] + val[r];
+        }
+        if (!diag) {  // the mirror tile: Hz[J rows][I columns], element [j][i] = value of [i][j]
+            const int mrow = tj * 16 + fk + 4 * r, mcol = ti * 16 + fr;
+            if (mrow < N && mcol < N) {
+                const int64_t o = (int64_t)mrow * N + mcol;
+                const double v = hv[fr][fk + 4 * r];
+                hz[o] = v;
+                if (fock_out != nullptr) fock_out[o] = F[o] + v;
+            }
+        }
+    }
+}
+
 // Hz = -kappa (FDS + FDS^T); optionally F += Hz
 __global__ void huzinaga_sym_kernel(const double* __restrict__ fds, int N, double kappa,
                                     double* __restrict__ hz, double* __restrict__ fock) {
@@ -688,6 +763,17 @@ int nbx_huzinaga_sym(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_f
     const unsigned g = (unsigned)nbx_cdiv(nao, TILE);
     hipLaunchKernelGGL(huzinaga_sym_kernel, dim3(g, g, (unsigned)batch), dim3(TILE, 8), 0, ctx->stream, d_fds,
                        (int)nao, kappa, d_hz, d_fock_io);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+int nbx_huzinaga_fused(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_f, const double* d_ds, double kappa,
+                       double* d_hz, double* d_fock_out) {
+    NBX_CHECK_ARG(ctx && d_f && d_ds && d_hz && nao > 0 && batch > 0 && batch < 65536);
+    NBX_CHECK_ARG(d_fock_out != d_f);  // every workgroup reads all of F: the update is out of place
+    const unsigned g = (unsigned)nbx_cdiv(nao, 16);
+    hipLaunchKernelGGL(huzinaga_fused_kernel, dim3(g, g, (unsigned)batch), dim3(64), 0, ctx->stream, d_f, d_ds,
+                       (int)nao, kappa, d_hz, d_fock_out);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

@@ -299,7 +299,10 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
             vhf = _as3(be, np.asarray(vhf_h))
             fock = be.copy(hv)
             be.axpby(1.0, vhf, 1.0, fock)
-        hz = _huzinaga_device(be, fock, ds_occ, ds_virt, kappa, fock_io=fock)
+        if ds_virt is None and hasattr(be, "huzinaga_fused"):
+            hz, fock = be.huzinaga_fused(fock, ds_occ, kappa)  # product + symmetrisation + F += Hz
+        else:
+            hz = _huzinaga_device(be, fock, ds_occ, ds_virt, kappa, fock_io=fock)
 
         if use_DIIS and (i > 1):
             fock = adiis.update(fock)

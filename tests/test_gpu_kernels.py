@@ -563,6 +563,26 @@ def test_geig_refine_tracks_perturbed_pencil(be, n):
     assert np.all(be.to_host(be.last_eigh_status_d) <= 0)
 
 
+@pytest.mark.parametrize("n", [7, 16, 24, 148])
+def test_huzinaga_fused_matches_two_kernel_path(be, n):
+    """nbx_huzinaga_fused (product + symmetrisation + F += Hz in one launch) against numpy and the
+    GEMM + nbx_huzinaga_sym pair it replaces; Hz comes out exactly symmetric."""
+    f = np.stack([symm(560, n), symm(561, n)])
+    ds = rnd(562, 2, n, n)
+    for kappa in (1.0, 0.5):
+        hz, fo = be.huzinaga_fused(be.asarray(f), be.asarray(ds), kappa)
+        fds = np.einsum("xij,xjk->xik", f, ds)
+        ref = -kappa * (fds + fds.transpose(0, 2, 1))
+        np.testing.assert_allclose(be.to_host(hz), ref, rtol=0, atol=1e-12 * n)
+        np.testing.assert_allclose(be.to_host(fo), f + ref, rtol=0, atol=1e-12 * n)
+        hz_h = be.to_host(hz)
+        np.testing.assert_array_equal(hz_h, hz_h.transpose(0, 2, 1))
+        old = be.to_host(be.huzinaga_sym(be.gemm(be.asarray(f), be.asarray(ds)), kappa))
+        np.testing.assert_allclose(hz_h, old, rtol=0, atol=1e-12 * n)
+    hz1, fo1 = be.huzinaga_fused(be.asarray(f[0]), be.asarray(ds[0]), 1.0)  # restricted (2-D) form
+    np.testing.assert_allclose(be.to_host(hz1), -(f[0] @ ds[0] + (f[0] @ ds[0]).T), rtol=0, atol=1e-12 * n)
+
+
 def s4_layout(n):
     """The packed tile format of nbx_eri_pack (include/nbx.h), restated in numpy: offsets of the
     entries (a, b <= a) of one tile and the tile length."""
