@@ -137,10 +137,15 @@ int nbx_jk_packed(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const doubl
 /* nbx_jk_packed over the whole tensor (p0 = 0, p1 = N, two spin densities) with the Fock
  * assembly of nbx_fock_uhf done by its reduction kernel (one launch less per SCF cycle):
  *   d_hv : (2,N,N) hcore + V_emb;  d_fock[x] = d_hv[x] + J - K[x];  d_vhf[x] = J - K[x] (may be
- *   NULL);  d_jk as nbx_jk_packed.  nbed/scf/huzinaga_scf.py:156-160.                        */
+ *   NULL);  d_jk as nbx_jk_packed.  nbed/scf/huzinaga_scf.py:156-160.
+ *   d_dts : NULL, or the Dtot' table of d_dm that nbx_huz_cycle_scalars_dts left behind when it
+ *   judged this density (saves the build its preparation launch): nbx_jk_dts_bytes() bytes, zeroed
+ *   ONCE with nbx_jk_dts_init (the entries it never writes are zero weights).               */
+size_t nbx_jk_dts_bytes(int64_t nao);
+int nbx_jk_dts_init(nbx_ctx* ctx, int64_t nao, double* d_dts);
 int nbx_jk_packed_fock(nbx_ctx* ctx, int64_t nao, const double* d_packed, const double* d_dm,
                        const double* d_hv, double* d_jk, double* d_fock, double* d_vhf, void* d_work,
-                       size_t work_bytes);
+                       size_t work_bytes, const double* d_dts);
 
 /* Same contraction with the synthetic (pq|rs) of nbx_synth_eri GENERATED in registers instead of
  * read from HBM (the N_AO = 2000 configuration: a dense tensor would be 128 TB).  Workspace as
@@ -204,6 +209,12 @@ int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
                               const double* d_vemb, const double* d_vhf, const double* d_hz,
                               const double* d_dm, const double* d_dm_old, double* d_out,
                               const int* d_tail, int64_t tail_n);
+/* nbx_huz_cycle_scalars_dev that also prepares the NEXT J/K build: with d_dts (see
+ * nbx_jk_packed_fock) the kernel, which reads D anyway, leaves Dtot' of d_dm in the table.     */
+int nbx_huz_cycle_scalars_dts(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
+                              const double* d_vemb, const double* d_vhf, const double* d_hz,
+                              const double* d_dm, const double* d_dm_old, double* d_out, const int* d_tail,
+                              int64_t tail_n, double* d_dts);
 /* One pyscf.lib.diis.DIIS.update step (behind huzinaga_scf.py:130,164) with nothing leaving
  * the device.  State: d_xs, d_es = (space, n) trial / error vectors, d_h = the
  * (space+1)x(space+1) Pulay matrix (row 0 / column 0 = 1, H[0][0] = 0; the caller initialises

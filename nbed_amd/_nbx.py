@@ -65,7 +65,9 @@ SIGNATURES = {
     "nbx_eri_pack": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     "nbx_jk_packed_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
     "nbx_huzinaga_fused": (c_int, [_P, c_int64, c_int64, _P, _P, c_double, _P, _P]),
-    "nbx_jk_packed_fock": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t]),
+    "nbx_jk_packed_fock": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "nbx_jk_dts_bytes": (c_size_t, [c_int64]),
+    "nbx_jk_dts_init": (c_int, [_P, c_int64, _P]),
     "nbx_jk_packed": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
     "nbx_jk_dense_sym": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
     "nbx_jk_synth_sym_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
@@ -78,6 +80,7 @@ SIGNATURES = {
     "nbx_trace_prod": (c_int, [_P, c_int64, c_int64, _P, _P, POINTER(c_double)]),
     "nbx_huz_cycle_scalars": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, _P, POINTER(c_double)]),
     "nbx_huz_cycle_scalars_dev": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64]),
+    "nbx_huz_cycle_scalars_dts": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "nbx_diis_update": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),
     "nbx_diis_update_err": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "nbx_vo_sumsq": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P]),

@@ -363,9 +363,19 @@ class HipBackend:
                    self._p(out), self._p(work), work.numel())
         return out
 
-    def jk_packed_fock(self, packed, dm, hv, want_vhf: bool = True):
+    def jk_dts_new(self, nao: int):
+        """A zeroed Dtot' table for nbx_jk_packed_fock / nbx_huz_cycle_scalars_dts (one per SCF)."""
+        nbytes = self.lib.nbx_jk_dts_bytes(nao)
+        if nbytes == 0:
+            raise ValueError(f"no packed J/K kernel for N = {nao}")
+        dts = self.empty((nbytes // 8,))
+        self._call("nbx_jk_dts_init", nao, self._p(dts))
+        return dts
+
+    def jk_packed_fock(self, packed, dm, hv, want_vhf: bool = True, dts=None):
         """UHF Fock matrices straight from the packed J/K build of the whole tensor
-        (nbx_jk_packed_fock): returns (fock, vhf) = (hv + J - K[x], J - K[x])."""
+        (nbx_jk_packed_fock): returns (fock, vhf) = (hv + J - K[x], J - K[x]).  ``dts``: the Dtot'
+        table of ``dm`` left by ``huz_cycle_scalars_async(..., dts=)`` (skips one launch)."""
         nao = dm.shape[-1]
         nbytes = self.lib.nbx_jk_packed_worksize(nao, 0, nao, 2)
         work = self._workspace("jk", nbytes)
@@ -373,7 +383,7 @@ class HipBackend:
         fock = self.empty((2, nao, nao))
         vhf = self.empty((2, nao, nao)) if want_vhf else None
         self._call("nbx_jk_packed_fock", nao, self._p(packed), self._p(dm), self._p(hv), self._p(jk), self._p(fock),
-                   self._p(vhf), self._p(work), work.numel())
+                   self._p(vhf), self._p(work), work.numel(), self._p(dts))
         return fock, vhf
 
     def jk_synth(self, nao: int, dm, p0: int = 0, p1: int | None = None, seed: int = 20250829):
@@ -484,7 +494,7 @@ class HipBackend:
                    self._p(hz), self._p(dm), self._p(dm_old), out)
         return np.array(out[:], dtype=np.float64)
 
-    def huz_cycle_scalars_async(self, hcore, vemb, vhf, hz, dm, dm_old, extra=None):
+    def huz_cycle_scalars_async(self, hcore, vemb, vhf, hz, dm, dm_old, extra=None, dts=None):
         """Same four scalars without stalling the stream: returns a handle whose ``get()`` waits
         for (only) the copy of those 32 bytes, so later work can be queued before it is read.
         ``extra``: a small device tensor to bring back with them (``get_extra()``)."""
@@ -493,8 +503,10 @@ class HipBackend:
         # the kernel's last workgroup stores the results straight into pinned host memory: no copy
         # (a device-to-host copy per cycle costs a launch and a cache flush in the middle of the chain)
         h_out = self.torch.empty(4 + ntail, dtype=self.torch.float64, pin_memory=True)
-        self._call("nbx_huz_cycle_scalars_dev", nao, self._p(hcore), hcore.dim(), self._p(vemb), self._p(vhf),
-                   self._p(hz), self._p(dm), self._p(dm_old), self._p(h_out), self._p(extra), ntail)
+        # ``dts``: a table from jk_dts_new() that the kernel fills with Dtot' of ``dm`` for the next
+        # packed J/K build
+        self._call("nbx_huz_cycle_scalars_dts", nao, self._p(hcore), hcore.dim(), self._p(vemb), self._p(vhf),
+                   self._p(hz), self._p(dm), self._p(dm_old), self._p(h_out), self._p(extra), ntail, self._p(dts))
         return _PendingScalars(self.torch, None, ntail, host=h_out)
 
     def async_to_host(self, d_vals):

@@ -4,6 +4,7 @@
 // accesses, transposed operands staged through a padded LDS tile, wavefront
 // reductions for the scalar outputs.
 #include "nbx_common.h"
+#include "jk_s4_layout.h"
 
 namespace {
 
@@ -193,7 +194,8 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
                                    const double* __restrict__ dm, const double* __restrict__ dm_old, int N,
                                    double* __restrict__ partial, double* __restrict__ out_final = nullptr,
                                    const int* __restrict__ tail = nullptr, int tail_n = 0,
-                                   int* __restrict__ counter = nullptr) {
+                                   int* __restrict__ counter = nullptr, double* __restrict__ dts = nullptr,
+                                   int s4_nb_ = 0, int s4_lpt_ = 0) {
     __shared__ double dt[T][T + 1];
     __shared__ double red[4][4];
     __shared__ double red2[17];
@@ -202,6 +204,12 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
     const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     double out[4];
+    // With `dts`: this kernel also leaves Dtot' of D (the density the NEXT J/K build contracts) in
+    // the staging order of nbx_jk_packed -- sum_x (D_ab + D_ba) below the diagonal, sum_x D_aa on it
+    // -- which saves that build its preparation launch.  Tiles on or below the diagonal write.
+    double dsum[T / 8], tsum[T / 8];
+#pragma unroll
+    for (int k = 0; k < T / 8; ++k) dsum[k] = tsum[k] = 0.0;
     for (int x = 0; x < 2; ++x) {
         __syncthreads();
         for (int r = threadIdx.y; r < T; r += blockDim.y) {  // dt[j][i] = D[x][j0+j][i0+i]
@@ -217,8 +225,11 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
                 double ham = h[h3d ? x * n2 + o : o] + 0.5 * vhf[x * n2 + o] + hz[x * n2 + o];
                 if (vemb) ham += vemb[x * n2 + o];
                 e = fma(ham, dt[threadIdx.x][r], e);
-                const double dd = dm[x * n2 + o] - dm_old[x * n2 + o];
+                const double dv = dm[x * n2 + o];
+                const double dd = dv - dm_old[x * n2 + o];
                 d2 = fma(dd, dd, d2);
+                dsum[r / 8] += dv;
+                tsum[r / 8] += dt[threadIdx.x][r];
             }
         }
         out[x] = e;
@@ -234,6 +245,14 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
         double t = 0.0;
         for (int w = 0; w < (int)(blockDim.x * blockDim.y) / 64; ++w) t += red[w][tid];
         partial[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + tid] = t;
+    }
+    if (dts != nullptr && i0 >= j0) {
+        const S4Geom g = s4_geom(N, s4_nb_);
+#pragma unroll
+        for (int k = 0; k < T / 8; ++k) {
+            const int gi = i0 + threadIdx.y + 8 * k, gj = j0 + threadIdx.x;
+            if (gi < N && gj <= gi) dts[s4_dts_index(g, s4_lpt_, gi, gj)] = gi == gj ? dsum[k] : dsum[k] + tsum[k];
+        }
     }
     if (out_final == nullptr) return;
     const int nblocks = gridDim.x * gridDim.y;
@@ -814,7 +833,17 @@ int nbx_huz_cycle_scalars(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int 
 int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
                               const double* d_vemb, const double* d_vhf, const double* d_hz, const double* d_dm,
                               const double* d_dm_old, double* d_out, const int* d_tail, int64_t tail_n) {
+    return nbx_huz_cycle_scalars_dts(ctx, nao, d_hcore, hcore_ndim, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, d_out, d_tail,
+                                     tail_n, nullptr);
+}
+
+int nbx_huz_cycle_scalars_dts(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
+                              const double* d_vemb, const double* d_vhf, const double* d_hz, const double* d_dm,
+                              const double* d_dm_old, double* d_out, const int* d_tail, int64_t tail_n,
+                              double* d_dts) {
     NBX_CHECK_ARG(ctx && d_hcore && d_vhf && d_hz && d_dm && d_dm_old && d_out && nao > 0);
+    const int nb4 = d_dts ? s4_nb(nao) : 0, lpt4 = d_dts ? s4_lpt(nao) : 0;
+    NBX_CHECK_ARG(d_dts == nullptr || lpt4 > 0);  // the table exists for sizes nbx_jk_packed covers
     NBX_CHECK_ARG(tail_n >= 0 && tail_n <= 64 && (tail_n == 0 || d_tail != nullptr));
     NBX_CHECK_ARG(hcore_ndim == 2 || hcore_ndim == 3);
     // 16 x 16 tiles while the partials fit the scratch (N <= 500): more workgroups for small N
@@ -824,11 +853,12 @@ int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
     if (fine)
         hipLaunchKernelGGL(huz_scalars_kernel<16>, dim3((unsigned)g, (unsigned)g), dim3(16, 8), 0, ctx->stream, d_hcore,
                            hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch,
-                           d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1);
+                           d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1, d_dts, nb4, lpt4);
     else
         hipLaunchKernelGGL(huz_scalars_kernel<TILE>, dim3((unsigned)g, (unsigned)g), dim3(TILE, 8), 0, ctx->stream,
                            d_hcore, hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao,
-                           ctx->d_scratch, d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1);
+                           ctx->d_scratch, d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1, d_dts, nb4,
+                           lpt4);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

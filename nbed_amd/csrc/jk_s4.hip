@@ -27,53 +27,12 @@
 // workgroups own equal contiguous ranges of the tile sequence T(p,q) = p(p+1)/2 + q; everything
 // is summed in a fixed order (bitwise reproducible).  The slab interface is additive.
 #include "nbx_common.h"
+#include "jk_s4_layout.h"
 
 namespace {
 
 constexpr int S4_CUS = 256;
 constexpr size_t S4_LDS_PER_CU = 160 * 1024;
-
-__host__ __device__ __forceinline__ int64_t s4_tri(int64_t k) { return k * (k + 1) / 2; }
-__host__ __device__ __forceinline__ int s4_tri_row(int64_t T) {
-    int64_t p = (int64_t)((sqrt(8.0 * (double)T + 1.0) - 1.0) * 0.5);
-    while (p * (p + 1) / 2 > T) --p;
-    while ((p + 1) * (p + 2) / 2 <= T) ++p;
-    return (int)p;
-}
-
-struct S4Geom {
-    int N, NB, s, ls, tri;
-    int E0, Er;  // doubles in the diagonal chunk / in a rectangle chunk (both even)
-    int64_t M;   // doubles per tile
-};
-
-__host__ __device__ __forceinline__ S4Geom s4_geom(int N, int NB) {
-    S4Geom g;
-    g.N = N;
-    g.NB = NB;
-    g.s = N / NB;
-    g.ls = g.s | 1;
-    g.tri = g.s * (g.s + 1) / 2;
-    g.E0 = (NB * g.tri + 1) & ~1;
-    g.Er = ((NB / 2) * g.s * g.ls + 1) & ~1;
-    g.M = (int64_t)g.E0 + (int64_t)(NB - 1) * g.Er;
-    return g;
-}
-
-// position of the rectangle (lo, lo ^ r), lo < lo ^ r, among the NB/2 rectangles of round r
-__host__ __device__ __forceinline__ int s4_slot(int lo, int r) {
-    int hb = 0;
-    while ((r >> (hb + 1)) != 0) ++hb;  // highest set bit of r: clear in lo
-    return ((lo >> (hb + 1)) << hb) | (lo & ((1 << hb) - 1));
-}
-
-// offset of (a, b), b <= a, inside a tile
-__host__ __device__ __forceinline__ int64_t s4_flat(const S4Geom& g, int a, int b) {
-    const int I = a / g.s, J = b / g.s, ai = a - I * g.s, bi = b - J * g.s;
-    if (I == J) return (int64_t)I * g.tri + s4_tri(ai) + bi;
-    const int r = I ^ J;
-    return (int64_t)g.E0 + (int64_t)(r - 1) * g.Er + (int64_t)s4_slot(J, r) * g.s * g.ls + (int64_t)ai * g.ls + bi;
-}
 
 __device__ __forceinline__ double2 s4_ldnt(const double* p) {
     typedef double nbx_d2 __attribute__((ext_vector_type(2)));
@@ -91,17 +50,6 @@ __global__ __launch_bounds__(256) void s4_pack_kernel(const double* __restrict__
     double* dst = out + (int64_t)blockIdx.x * g.M;
     for (int a = 0; a < N; ++a)
         for (int b = threadIdx.x; b <= a; b += blockDim.x) dst[s4_flat(g, a, b)] = src[(int64_t)a * N + b];
-}
-
-// Staging slots.  Wave w moves a chunk's pairs (16 bytes) in LPT loads of 64 pairs: slot (w, k)
-// starts at pair 64 (LPT w + k); a slot that would run past the chunk end is pulled back to end
-// exactly there: its first lanes repeat pairs of the slot before it -- same bytes to the same LDS
-// address, and a zero weight in the J sum.  A slot that starts past the end (-1) reads a line that
-// is always in cache (the head of the Dtot' table) into an LDS scratch area, also with weight 0.
-// Everything is unconditional and wave-uniform: one address VGPR (the lane) serves every load.
-__host__ __device__ __forceinline__ int s4_slot_start(int ne, int lpt, int w, int k) {
-    const int np2 = ne >> 1, ps = 64 * (lpt * w + k);
-    return ps >= np2 ? -1 : (ps + 64 > np2 ? np2 - 64 : ps);
 }
 
 // (a, b) of the entry at offset f of chunk ch; false for a pad
@@ -141,12 +89,14 @@ __global__ __launch_bounds__(256) void s4_dtot_kernel(const double* __restrict__
         for (int e = 0; e < 2; ++e) {
             int a, b;
             if (!s4_unflat(g, ch, 2 * (ps + lane) + e, a, b)) continue;
-            double v = 0.0;
+            // (sum_x D_ab) + (sum_x D_ba): the association nbx_huz_cycle_scalars_dts uses too, so
+            // that a build gives the same bits whichever kernel prepared its table
+            double v = 0.0, vt = 0.0;
             for (int x = 0; x < ndm; ++x) {
                 v += dm[x * n2 + (int64_t)a * N + b];
-                if (a != b) v += dm[x * n2 + (int64_t)b * N + a];
+                vt += dm[x * n2 + (int64_t)b * N + a];
             }
-            out[e] = v;
+            out[e] = a == b ? v : v + vt;
         }
     }
     *reinterpret_cast<double2*>(dts + 2 * (int64_t)i) = make_double2(out[0], out[1]);
@@ -423,29 +373,6 @@ struct S4Plan {
 
 size_t s4_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// four blocks when the chunks of N / 4 rows still fill a staging slot (128 doubles), else two
-int s4_nb(int64_t N) {
-    if (N % 4 == 0) {
-        const S4Geom g = s4_geom((int)N, 4);
-        if (g.E0 >= 128 && g.Er >= 128) return 4;
-    }
-    return 2;
-}
-
-// template instances: loads per thread per chunk
-int s4_lpt_class(int lpt, int NB) {
-    return lpt <= 2 ? 2 : lpt <= 6 ? 6 : lpt <= 10 ? 10 : (lpt <= 17 && NB == 4) ? 17 : 0;
-}
-
-bool s4_supported(int64_t N) {
-    if (N < 16 || N > 256 || N % 2 != 0) return false;  // a walk group is four steps: s >= 4
-    const int NB = s4_nb(N);
-    if (N % NB != 0 || N / NB > 64) return false;  // one wave walks a block
-    const S4Geom g = s4_geom((int)N, NB);
-    const int need = (int)nbx_cdiv((g.E0 > g.Er ? g.E0 : g.Er) / 2, NB * 64);
-    return s4_lpt_class(need, NB) != 0 && g.E0 >= 128 && g.Er >= 128;  // a staging slot is 64 pairs
-}
-
 S4Plan s4_plan(int64_t N, int64_t p0, int64_t np, int64_t ndm) {
     S4Plan pl;
     pl.NB = s4_nb(N);
@@ -509,7 +436,18 @@ extern "C" size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, in
 
 static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm,
                  int64_t ndm, double* d_jk, void* d_work, size_t work_bytes, const double* d_hv, double* d_fock,
-                 double* d_vhf);
+                 double* d_vhf, const double* d_dts = nullptr);
+
+extern "C" size_t nbx_jk_dts_bytes(int64_t nao) {
+    if (!s4_supported(nao)) return 0;
+    const int NB = s4_nb(nao);
+    return (size_t)(NB * NB * s4_lpt(nao) * 128) * sizeof(double);
+}
+
+extern "C" int nbx_jk_dts_init(nbx_ctx* ctx, int64_t nao, double* d_dts) {
+    NBX_CHECK_ARG(ctx && d_dts && s4_supported(nao));
+    return nbx_memset(ctx, d_dts, 0, nbx_jk_dts_bytes(nao));
+}
 
 extern "C" int nbx_jk_packed(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed,
                              const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes) {
@@ -518,14 +456,14 @@ extern "C" int nbx_jk_packed(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, 
 
 extern "C" int nbx_jk_packed_fock(nbx_ctx* ctx, int64_t nao, const double* d_packed, const double* d_dm,
                                   const double* d_hv, double* d_jk, double* d_fock, double* d_vhf, void* d_work,
-                                  size_t work_bytes) {
+                                  size_t work_bytes, const double* d_dts) {
     NBX_CHECK_ARG(d_hv && d_fock);
-    return s4_jk(ctx, nao, 0, nao, d_packed, d_dm, 2, d_jk, d_work, work_bytes, d_hv, d_fock, d_vhf);
+    return s4_jk(ctx, nao, 0, nao, d_packed, d_dm, 2, d_jk, d_work, work_bytes, d_hv, d_fock, d_vhf, d_dts);
 }
 
 static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm,
                  int64_t ndm, double* d_jk, void* d_work, size_t work_bytes, const double* d_hv, double* d_fock,
-                 double* d_vhf) {
+                 double* d_vhf, const double* d_dts) {
     NBX_CHECK_ARG(ctx && d_dm && d_jk);
     NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
     NBX_CHECK_ARG(d_packed != nullptr || p0 == p1);
@@ -551,9 +489,13 @@ static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double
         const int rc = nbx_memset(ctx, d_jk, 0, (size_t)n2 * sizeof(double));
         if (rc != NBX_OK) return rc;
     }
-    hipLaunchKernelGGL(s4_dtot_kernel, dim3((unsigned)nbx_cdiv(pl.NB * pl.NB * pl.lpt * 64, 256)), dim3(256), 0,
-                       ctx->stream, d_dm, dtp, (int)N, pl.NB, pl.lpt, (int)ndm);
-    NBX_LAUNCH_CHECK();
+    if (d_dts != nullptr) {  // the caller's table (left by nbx_huz_cycle_scalars_dts for this density)
+        dtp = const_cast<double*>(d_dts);
+    } else {
+        hipLaunchKernelGGL(s4_dtot_kernel, dim3((unsigned)nbx_cdiv(pl.NB * pl.NB * pl.lpt * 64, 256)), dim3(256), 0,
+                           ctx->stream, d_dm, dtp, (int)N, pl.NB, pl.lpt, (int)ndm);
+        NBX_LAUNCH_CHECK();
+    }
     const int64_t t_begin = s4_tri(p0), t_end = s4_tri(p1);
     {
         nbx_prof_scope prof(ctx, NBX_PROF_JK_DENSE);

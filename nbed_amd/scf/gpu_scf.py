@@ -153,14 +153,30 @@ class _GpuSCF:
         slab = be.jk(self.eri_device(), dm_d, sh.lo, sh.hi)
         return sh.all_gather(be, slab, axis=1)
 
-    def fock_device(self, dm_d, hv_d):
+    def fused_fock_available(self, hv_d) -> bool:
+        sh = self.shards
+        single = sh.world == 1 and not sh.force_collective
+        return (self.eri_packed_device() is not None and single and hasattr(self.be, "jk_packed_fock")
+                and hv_d.dim() == 3)
+
+    def dts_device(self):
+        """The Dtot' table the packed J/K build multiplies the staged tiles with; a loop that calls
+        ``huz_cycle_scalars_async(..., dts=this)`` on a density may pass ``dts_ready=True`` to
+        ``fock_device`` for the build on that same density (one launch less).  None if the fused
+        build does not apply."""
+        if getattr(self, "_dts_d", None) is None:
+            self._dts_d = None
+            if self.eri_packed_device() is not None and hasattr(self.be, "jk_dts_new"):
+                self._dts_d = self.be.jk_dts_new(self._s_h.shape[0])
+        return self._dts_d
+
+    def fock_device(self, dm_d, hv_d, dts_ready: bool = False):
         """(fock, vhf) = (hv + J - K[x], J - K[x]) of a two-spin density: one J/K build; on a single
         device with the packed kernel the Fock assembly rides on its reduction kernel."""
-        be, sh = self.be, self.shards
-        packed = self.eri_packed_device()
-        single = sh.world == 1 and not sh.force_collective
-        if packed is not None and single and hasattr(be, "jk_packed_fock") and hv_d.dim() == 3:
-            return be.jk_packed_fock(packed, dm_d, hv_d)
+        be = self.be
+        if self.fused_fock_available(hv_d):
+            dts = self.dts_device() if dts_ready else None
+            return be.jk_packed_fock(self.eri_packed_device(), dm_d, hv_d, dts=dts)
         return be.fock_uhf(hv_d, None, self.jk_device(dm_d))
 
     def _eig_device(self, fock_d, warm: dict | None = None):

@@ -239,6 +239,9 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
     else:
         dm_d = _as3(be, dm_initial_guess)
 
+    dts_d, dts_ready = None, False
+    if lookahead and hasattr(scf_method, "dts_device") and scf_method.fused_fock_available(hv):
+        dts_d = scf_method.dts_device()
     conv_flag = False
     scf_energy_prev = 0
     mo_energy_h = None
@@ -291,7 +294,7 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         # ---- Fock build (:156-160)
         if fused:
             if nb == 2 and hasattr(scf_method, "fock_device"):
-                fock, vhf = scf_method.fock_device(dm_d, hv)
+                fock, vhf = scf_method.fock_device(dm_d, hv, dts_ready=dts_ready)
             else:
                 fock, vhf = be.fock_uhf(hv, None, scf_method.jk_device(dm_d))
         else:
@@ -323,8 +326,10 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
             norm_dm_diff = float(np.max(np.sqrt(be.trace_prod(diff, be.transpose(diff)))))
         elif lookahead:
             scf_energy = norm_dm_diff = None
+            # (the scalars kernel reads D anyway: it also leaves the Dtot' table of the next build)
             pending_now = be.huz_cycle_scalars_async(hv, None, vhf, hz, dm_d, dm_old,
-                                                     extra=getattr(be, "last_eigh_status_d", None))
+                                                     extra=getattr(be, "last_eigh_status_d", None), dts=dts_d)
+            dts_ready = dts_d is not None
         elif nb == 2:
             sc = be.huz_cycle_scalars(hv, None, vhf, hz, dm_d, dm_old)
             scf_energy = sc[:2].copy()
