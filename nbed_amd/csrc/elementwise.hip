@@ -588,46 +588,77 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
     bool singular = false;
     for (int k = 0; k < m; ++k) singular = singular || (fabs(w[k]) < 1e-14);
     if (!singular) {
-        if (lane == 0) {  // Gaussian elimination with partial pivoting on A0, rhs e_0
-            double rhs[DIIS_M];
-            for (int i = 0; i < m; ++i) rhs[i] = (i == 0) ? 1.0 : 0.0;
-            for (int k = 0; k < m && !lu_failed; ++k) {
-                int piv = k;
-                double best = fabs(A0[k][k]);
-                for (int i = k + 1; i < m; ++i)
-                    if (fabs(A0[i][k]) > best) {
-                        best = fabs(A0[i][k]);
-                        piv = i;
-                    }
-                if (best == 0.0) {
-                    lu_failed = 1;
-                    break;
-                }
-                if (piv != k) {
-                    for (int j = 0; j < m; ++j) {
-                        const double tmp = A0[k][j];
-                        A0[k][j] = A0[piv][j];
-                        A0[piv][j] = tmp;
-                    }
-                    const double tmp = rhs[k];
-                    rhs[k] = rhs[piv];
-                    rhs[piv] = tmp;
-                }
-                const double inv = 1.0 / A0[k][k];
-                for (int i = k + 1; i < m; ++i) {
-                    const double f = A0[i][k] * inv;
-                    if (f != 0.0) {
-                        for (int j = k + 1; j < m; ++j) A0[i][j] -= f * A0[k][j];
-                        rhs[i] -= f * rhs[k];
-                    }
+        // Gaussian elimination with partial pivoting on A0, rhs e_0 (numpy.linalg.solve / dgesv),
+        // by the whole wavefront: pivot search by a lane reduction, the row swap and the rank-one
+        // update spread over the lanes (each element sees the same operations as in the serial
+        // right-looking elimination), back substitution with lane-parallel dot products.
+        __shared__ double rhs_s[DIIS_M];
+        if (lane < m) rhs_s[lane] = (lane == 0) ? 1.0 : 0.0;
+        __syncthreads();
+        for (int k = 0; k < m; ++k) {
+            // first row index with the largest |A0[i][k]|, i >= k
+            double best = (lane >= k && lane < m) ? fabs(A0[lane][k]) : -1.0;
+            int piv = lane;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o);
+                const int op = __shfl_xor(piv, o);
+                if (ob > best || (ob == best && op < piv)) {
+                    best = ob;
+                    piv = op;
                 }
             }
-            if (!lu_failed) {
-                for (int i = m - 1; i >= 0; --i) {
-                    double t = rhs[i];
-                    for (int j = i + 1; j < m; ++j) t -= A0[i][j] * c_out[j];
-                    c_out[i] = t / A0[i][i];
+            if (best == 0.0) {  // uniform: every lane holds the reduced values
+                if (lane == 0) lu_failed = 1;
+                break;
+            }
+            if (piv != k) {
+                if (lane < m) {
+                    const double tmp = A0[k][lane];
+                    A0[k][lane] = A0[piv][lane];
+                    A0[piv][lane] = tmp;
                 }
+                if (lane == 0) {
+                    const double tmp = rhs_s[k];
+                    rhs_s[k] = rhs_s[piv];
+                    rhs_s[piv] = tmp;
+                }
+            }
+            __syncthreads();
+            const double inv = 1.0 / A0[k][k];
+            const int rem = m - 1 - k;  // rows / columns below / right of the pivot
+            double upd[DIIS_SLOTS];
+            double rupd = 0.0;
+#pragma unroll
+            for (int e = 0; e < DIIS_SLOTS; ++e) {
+                const int idx = lane + 64 * e;
+                upd[e] = 0.0;
+                if (idx < rem * rem) {
+                    const int i = k + 1 + idx / rem, jj = k + 1 + idx % rem;
+                    const double f = A0[i][k] * inv;
+                    upd[e] = A0[i][jj] - f * A0[k][jj];
+                }
+            }
+            if (lane < rem) {
+                const double f = A0[k + 1 + lane][k] * inv;
+                rupd = rhs_s[k + 1 + lane] - f * rhs_s[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < DIIS_SLOTS; ++e) {
+                const int idx = lane + 64 * e;
+                if (idx < rem * rem) A0[k + 1 + idx / rem][k + 1 + idx % rem] = upd[e];
+            }
+            if (lane < rem) rhs_s[k + 1 + lane] = rupd;
+            __syncthreads();
+        }
+        __syncthreads();
+        if (!lu_failed) {
+            for (int i = m - 1; i >= 0; --i) {
+                double t = (lane > i && lane < m) ? A0[i][lane] * c_out[lane] : 0.0;
+                t = nbx_wave_sum(t);
+                if (lane == 0) c_out[i] = (rhs_s[i] - t) / A0[i][i];
+                __syncthreads();
             }
         }
         __syncthreads();
