@@ -241,12 +241,21 @@ __global__ __launch_bounds__(256) void refine_finish_kernel(int N, const double*
     const double* X = ((st & 1) ? xb1 : xb0) + b * n2;
     for (int i = threadIdx.x; i < N; i += blockDim.x) lam[i] = lam_in[(int64_t)b * N + i];
     __syncthreads();
+    // Refinement keeps column i with eigenvalue i, so between SCF cycles the order hardly ever
+    // changes: if the values are already ascending the ranks are the identity (N comparisons
+    // instead of N^2).
+    int unsorted = 0;
+    for (int i = threadIdx.x + 1; i < N; i += blockDim.x) unsorted |= lam[i - 1] > lam[i] ? 1 : 0;
+    unsorted = __syncthreads_or(unsorted);
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         const double li = lam[i];
-        int r = 0;
-        for (int j = 0; j < N; ++j) {
-            const double lj = lam[j];
-            r += (lj < li || (lj == li && j < i)) ? 1 : 0;
+        int r = i;
+        if (unsorted) {
+            r = 0;
+            for (int j = 0; j < N; ++j) {
+                const double lj = lam[j];
+                r += (lj < li || (lj == li && j < i)) ? 1 : 0;
+            }
         }
         rank[i] = r;
         if (blockIdx.x == 0) w[(int64_t)b * N + r] = li;
