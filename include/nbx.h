@@ -315,6 +315,17 @@ int nbx_geig_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_f, c
                     const double* d_c0, double* d_w, double* d_c, int* d_status, void* d_work,
                     size_t work_bytes, int max_iter);
 
+/* nbx_ao2mo_pair for C1 = C2 (one matrix d_c12, n columns) over the whole outer range:
+ * (ij|kl) = (ji|kl), so quarters 3 and 4 run on the pairs j <= i only and each finished (k,l)
+ * block is stored at (i,j) and (j,i).  Every ao2mo.kernel call of nbed/ham_builder.py:127-133
+ * has C1 = C2.  Same outputs as nbx_ao2mo_pair up to rounding ((i,j) and (j,i) are equal by
+ * construction here); d_out2 == NULL: one tensor.  Outer-index slabs: use nbx_ao2mo_pair.      */
+size_t nbx_ao2mo_pair_sym_worksize(int64_t nao, int64_t n, int64_t n4, int64_t n6);
+int nbx_ao2mo_pair_sym(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c12, int64_t n,
+                       const double* d_c3, int64_t n3, const double* d_c4, int64_t n4, double* d_out,
+                       const double* d_c5, int64_t n5, const double* d_c6, int64_t n6, double* d_out2,
+                       void* d_work, size_t work_bytes);
+
 /* Sweep count of the last nbx_svd_right on this workspace (synchronises); NBX_E_NOCONV if the
  * sweep limit was hit. */
 int nbx_svd_status(nbx_ctx* ctx, int64_t m, int64_t n, const void* d_work, int* h_sweeps);

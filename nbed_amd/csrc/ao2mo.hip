@@ -100,3 +100,113 @@ extern "C" int nbx_ao2mo_pair(nbx_ctx* ctx, int64_t nao, const double* d_eri, co
     if (rc != NBX_OK) return rc;
     return nbx_gemm(ctx, 'T', 'N', n5, n6, N, 1.0, d_c5, n5, 0, bufA, n6, N * n6, 0.0, d_out2, n6, n5 * n6, ni * n2);
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same transform(s) when C1 and C2 are THE SAME matrix and the whole outer range is done here:
+// (ij|kl) = (ji|kl), so quarters 3 and 4 run on the pairs j <= i only (a "triangular batch" of
+// the GEMM: batch entry i has (i+1) N rows, results stored compactly) and the finished (n3 x n4)
+// blocks are copied to both (i,j) and (j,i).  All three spin blocks of the unrestricted
+// Hamiltonian qualify (nbed/ham_builder.py:127-133: C1 = C2 in every ao2mo.kernel call).  Not
+// bit-identical to nbx_ao2mo_pair: there (i,j) and (j,i) are computed separately and agree to
+// rounding; here they are equal by construction.  Slabs (multi-GPU) use nbx_ao2mo_pair.
+namespace {
+__global__ __launch_bounds__(256) void ao2mo_expand_kernel(const double* __restrict__ outc, double* __restrict__ out,
+                                                           int n, int64_t blk) {
+    const int pair = blockIdx.x;
+    int i = (int)((sqrt(8.0 * (double)pair + 1.0) - 1.0) * 0.5);
+    while (i * (i + 1) / 2 > pair) --i;
+    while ((i + 1) * (i + 2) / 2 <= pair) ++i;
+    const int j = pair - i * (i + 1) / 2;
+    const double* src = outc + (int64_t)pair * blk;
+    double* d1 = out + ((int64_t)i * n + j) * blk;
+    double* d2 = out + ((int64_t)j * n + i) * blk;
+    for (int64_t e = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; e < blk; e += (int64_t)gridDim.y * blockDim.x) {
+        const double v = src[e];
+        d1[e] = v;
+        if (i != j) d2[e] = v;
+    }
+}
+
+struct Ao2moSymPlan {
+    size_t a_doubles, b_doubles, c_doubles;
+};
+Ao2moSymPlan sym_plan(int64_t N, int64_t n, int64_t n4, int64_t n6) {
+    Ao2moSymPlan p;
+    const size_t npairs = (size_t)(n * (n + 1) / 2);
+    const size_t x1 = (size_t)n * N * N * N, w = npairs * N * (size_t)n4;
+    p.a_doubles = x1 > w ? x1 : w;
+    p.b_doubles = (size_t)n * n * N * N;
+    p.c_doubles = npairs * N * (size_t)n6;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t nbx_ao2mo_pair_sym_worksize(int64_t nao, int64_t n, int64_t n4, int64_t n6) {
+    if (nao <= 0 || n <= 0 || n4 <= 0 || n6 < 0) return 0;
+    const Ao2moSymPlan p = sym_plan(nao, n, n4, n6);
+    return align256(p.a_doubles * sizeof(double)) + align256(p.b_doubles * sizeof(double)) +
+           align256(p.c_doubles * sizeof(double));
+}
+
+extern "C" int nbx_ao2mo_pair_sym(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c12, int64_t n,
+                                  const double* d_c3, int64_t n3, const double* d_c4, int64_t n4, double* d_out,
+                                  const double* d_c5, int64_t n5, const double* d_c6, int64_t n6, double* d_out2,
+                                  void* d_work, size_t work_bytes) {
+    const bool pair = d_out2 != nullptr;
+    NBX_CHECK_ARG(ctx && d_eri && d_c12 && d_c3 && d_c4 && d_out);
+    NBX_CHECK_ARG(nao > 0 && n > 0 && n3 > 0 && n4 > 0);
+    NBX_CHECK_ARG(!pair || (d_c5 && d_c6 && n5 > 0 && n6 > 0));
+    NBX_CHECK_ARG(n3 * n4 <= nao * nao && (!pair || n5 * n6 <= nao * nao));  // the compact results reuse X2's buffer
+    const int64_t N = nao;
+    if (N * N * N >= (1ll << 31)) {
+        nbx_set_error("nbx_ao2mo_pair_sym: dense path needs N^3 < 2^31 (N=%lld)", (long long)N);
+        return NBX_E_UNSUPPORTED;
+    }
+    const size_t need = nbx_ao2mo_pair_sym_worksize(N, n, n4, pair ? n6 : 0);
+    if (d_work == nullptr || work_bytes < need) {
+        nbx_set_error("nbx_ao2mo_pair_sym: workspace %zu < %zu bytes", work_bytes, need);
+        return NBX_E_NOMEM;
+    }
+    const Ao2moSymPlan p = sym_plan(N, n, n4, pair ? n6 : 0);
+    char* base = static_cast<char*>(d_work);
+    double* bufA = reinterpret_cast<double*>(base);
+    double* bufB = reinterpret_cast<double*>(base + align256(p.a_doubles * sizeof(double)));
+    double* bufC = reinterpret_cast<double*>(base + align256(p.a_doubles * sizeof(double)) +
+                                             align256(p.b_doubles * sizeof(double)));
+    const int64_t N2 = N * N, N3 = N2 * N, npairs = n * (n + 1) / 2;
+    int rc;
+    nbx_prof_scope prof_all(ctx, NBX_PROF_AO2MO);
+    {
+        nbx_prof_scope prof_q1(ctx, NBX_PROF_AO2MO_Q1);
+        rc = nbx_gemm(ctx, 'T', 'N', n, N3, N, 1.0, d_c12, n, 0, d_eri, N3, 0, 0.0, bufA, N3, 0, 1);
+    }
+    if (rc != NBX_OK) return rc;
+    rc = nbx_gemm(ctx, 'T', 'N', n, N2, N, 1.0, d_c12, n, 0, bufA, N2, N3, 0.0, bufB, N2, n * N2, n);
+    if (rc != NBX_OK) return rc;
+    // Q3 on the pairs j <= i: W[(i,j),r,l] = sum_s X2[i,j,r,s] C4[s,l]
+    rc = nbx_gemm_tri(ctx, N, 0, n, n4, N, bufB, N, n * N2, d_c4, n4, bufA, n4);
+    if (rc != NBX_OK) return rc;
+    if (pair) {
+        rc = nbx_gemm_tri(ctx, N, 0, n, n6, N, bufB, N, n * N2, d_c6, n6, bufC, n6);
+        if (rc != NBX_OK) return rc;
+    }
+    // Q4 per pair, each (n3 x n4) result stored at (i,j) and (j,i) by the GEMM's epilogue
+    if (npairs <= 65535) {
+        rc = nbx_gemm_pair_scatter(ctx, n, n3, n4, N, d_c3, n3, bufA, n4, N * n4, d_out);
+        if (rc != NBX_OK || !pair) return rc;
+        return nbx_gemm_pair_scatter(ctx, n, n5, n6, N, d_c5, n5, bufC, n6, N * n6, d_out2);
+    }
+    // (more pairs than a grid dimension holds: compact results in X2's buffer, dead now, then a copy)
+    rc = nbx_gemm(ctx, 'T', 'N', n3, n4, N, 1.0, d_c3, n3, 0, bufA, n4, N * n4, 0.0, bufB, n4, n3 * n4, npairs);
+    if (rc != NBX_OK) return rc;
+    hipLaunchKernelGGL(ao2mo_expand_kernel, dim3((unsigned)npairs, 4), dim3(256), 0, ctx->stream, bufB, d_out, (int)n,
+                       n3 * n4);
+    NBX_LAUNCH_CHECK();
+    if (!pair) return NBX_OK;
+    rc = nbx_gemm(ctx, 'T', 'N', n5, n6, N, 1.0, d_c5, n5, 0, bufC, n6, N * n6, 0.0, bufB, n6, n5 * n6, npairs);
+    if (rc != NBX_OK) return rc;
+    hipLaunchKernelGGL(ao2mo_expand_kernel, dim3((unsigned)npairs, 4), dim3(256), 0, ctx->stream, bufB, d_out2, (int)n,
+                       n5 * n6);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}

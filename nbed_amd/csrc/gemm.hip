@@ -26,6 +26,13 @@ struct GemmGen {
     uint64_t seed;
     double scale;
     int r, s0;
+    // "triangular batch" (tri_unit > 0): batch entry b has (tri_m0 + b + 1) * tri_unit rows and its
+    // C block follows those of the entries before it -- the (i, j <= i) pairs of a symmetric
+    // transform, stored compactly (ao2mo.hip)
+    int tri_unit = 0, tri_m0 = 0;
+    // "pair scatter" (pair_n > 0): batch entry b is the pair (i, j <= i), b = i (i+1)/2 + j; its C
+    // block (stride_c doubles) is stored at block index i * pair_n + j AND at j * pair_n + i
+    int pair_n = 0;
 };
 
 constexpr int BK = 16;
@@ -141,6 +148,21 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
     A += (int64_t)batch * stride_a;
     if (!B_GEN) B += (int64_t)batch * stride_b;
     C += (int64_t)batch * stride_c;
+    double* C2 = nullptr;
+    if (gen.pair_n > 0) {
+        int pi = (int)((sqrt(8.0 * (double)batch + 1.0) - 1.0) * 0.5);
+        while (pi * (pi + 1) / 2 > batch) --pi;
+        while ((pi + 1) * (pi + 2) / 2 <= batch) ++pi;
+        const int pj = batch - pi * (pi + 1) / 2;
+        C += ((int64_t)pi * gen.pair_n + pj - batch) * stride_c;  // (C already points at block `batch`)
+        if (pi != pj) C2 = C + ((int64_t)pj * gen.pair_n + pi - ((int64_t)pi * gen.pair_n + pj)) * stride_c;
+    }
+    if (gen.tri_unit > 0) {
+        const int64_t gi = gen.tri_m0 + batch, g0 = gen.tri_m0;
+        M = min(M, (int)((gi + 1) * gen.tri_unit));
+        C += (gi * (gi + 1) / 2 - g0 * (g0 + 1) / 2) * gen.tri_unit * ldc;
+        if ((int)blockIdx.y * BM >= M) return;  // uniform for the workgroup
+    }
     const uint64_t gen_rs = B_GEN ? nbx_tri((uint64_t)gen.r, (uint64_t)(gen.s0 + batch)) : 0;
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
@@ -210,6 +232,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
                     double* c = C + (int64_t)row * ldc + col;
                     const double v = alpha * acc[i][j][r];
                     *c = (beta == 0.0) ? v : fma(beta, *c, v);
+                    if (C2 != nullptr) C2[(int64_t)row * ldc + col] = v;  // pair scatter (beta = 0)
                 }
             }
         }
@@ -316,12 +339,12 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <int BM, int BN, int WR, int WC>
 void launch(nbx_ctx* ctx, bool a_kc, bool b_kc, int M, int N, int K, double alpha, const double* A, int64_t lda,
             int64_t sa, const double* B, int64_t ldb, int64_t sb, double beta, double* C, int64_t ldc, int64_t sc,
-            int batch, int vec_a, int vec_b, const int* gate, int gate_a, int gate_b) {
+            int batch, int vec_a, int vec_b, const int* gate, int gate_a, int gate_b, GemmGen gen = GemmGen{}) {
     dim3 grid((unsigned)nbx_cdiv(N, BN), (unsigned)nbx_cdiv(M, BM), (unsigned)batch);
     dim3 block(64 * WR * WC);
 #define NBX_GEMM_GO(AK, BKC)                                                                                       \
     hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, WR, WC, AK, BKC>), grid, block, 0, ctx->stream, M, N, K, alpha, A, \
-                       lda, sa, B, ldb, sb, beta, C, ldc, sc, vec_a, vec_b, GemmGen{}, gate, gate_a, gate_b)
+                       lda, sa, B, ldb, sb, beta, C, ldc, sc, vec_a, vec_b, gen, gate, gate_a, gate_b)
     if (a_kc) {
         if (b_kc) NBX_GEMM_GO(true, true);
         else NBX_GEMM_GO(true, false);
@@ -391,6 +414,47 @@ int nbx_gemm_small_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, in
         else NBX_GEMM_SMALL(false, false);
     }
 #undef NBX_GEMM_SMALL
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+// C_b = op(A_b) op(B_b) for a "triangular batch": entry b (global index tri_m0 + b) has
+// (tri_m0 + b + 1) * unit rows; A_b = A + b * stride_a (lda), the C blocks are stored one after the
+// other (row length ldc).  Operands 'N','N' row-major; 128 x 128 tiles.
+int nbx_gemm_tri(nbx_ctx* ctx, int64_t unit, int64_t tri_m0, int64_t nbatch, int64_t n, int64_t k, const double* d_a,
+                 int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb, double* d_c, int64_t ldc) {
+    NBX_CHECK_ARG(ctx && d_a && d_b && d_c && unit > 0 && tri_m0 >= 0 && nbatch > 0 && n > 0 && k > 0);
+    const int64_t m_max = (tri_m0 + nbatch) * unit;
+    NBX_CHECK_ARG(m_max < (1ll << 31) && nbatch <= 65535);
+    GemmGen gen{};
+    gen.tri_unit = (int)unit;
+    gen.tri_m0 = (int)tri_m0;
+    const int vec_a = (aligned16(d_a) && lda % 2 == 0 && stride_a % 2 == 0) ? 1 : 0;
+    const int vec_b = (aligned16(d_b) && ldb % 2 == 0) ? 1 : 0;
+    launch<128, 128, 2, 4>(ctx, true, false, (int)m_max, (int)n, (int)k, 1.0, d_a, lda, stride_a, d_b, ldb, 0, 0.0, d_c,
+                           ldc, 0, (int)nbatch, vec_a, vec_b, nullptr, 0, 0, gen);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+// C[(i,j)] = C[(j,i)] = A^T B_b for the pairs b = i(i+1)/2 + j, j <= i < pair_n: A is (k x m) shared,
+// B_b = B + b * stride_b (k x n, row length ldb), the (m x n) results are blocks of an
+// (pair_n, pair_n, m, n) tensor.
+int nbx_gemm_pair_scatter(nbx_ctx* ctx, int64_t pair_n, int64_t m, int64_t n, int64_t k, const double* d_a, int64_t lda,
+                          const double* d_b, int64_t ldb, int64_t stride_b, double* d_c) {
+    NBX_CHECK_ARG(ctx && d_a && d_b && d_c && pair_n > 0 && m > 0 && n > 0 && k > 0);
+    const int64_t npairs = pair_n * (pair_n + 1) / 2;
+    NBX_CHECK_ARG(npairs <= 65535 && m < (1ll << 31) && n < (1ll << 31));
+    GemmGen gen{};
+    gen.pair_n = (int)pair_n;
+    const int vec_a = (aligned16(d_a) && lda % 2 == 0) ? 1 : 0;
+    const int vec_b = (aligned16(d_b) && ldb % 2 == 0 && stride_b % 2 == 0) ? 1 : 0;
+    if (m > 64 && n > 64)
+        launch<128, 128, 2, 4>(ctx, false, false, (int)m, (int)n, (int)k, 1.0, d_a, lda, 0, d_b, ldb, stride_b, 0.0, d_c, n,
+                               m * n, (int)npairs, vec_a, vec_b, nullptr, 0, 0, gen);
+    else
+        launch<64, 64, 2, 2>(ctx, false, false, (int)m, (int)n, (int)k, 1.0, d_a, lda, 0, d_b, ldb, stride_b, 0.0, d_c, n,
+                             m * n, (int)npairs, vec_a, vec_b, nullptr, 0, 0, gen);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

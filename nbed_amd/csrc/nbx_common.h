@@ -47,6 +47,10 @@ int nbx_apply_rotation_log_t(nbx_ctx* ctx, int n, int np_even, int steps, const 
 int nbx_gemm_q1_synth(nbx_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* d_a, int64_t lda, uint64_t seed,
                       double scale, int64_t r, int64_t s0, double* d_y, int64_t ldy, int64_t stride_y, int64_t batch);
 bool nbx_gemm_small_supported(int64_t m, int64_t n, int64_t k, int64_t batch);
+int nbx_gemm_pair_scatter(nbx_ctx* ctx, int64_t pair_n, int64_t m, int64_t n, int64_t k, const double* d_a, int64_t lda,
+                          const double* d_b, int64_t ldb, int64_t stride_b, double* d_c);
+int nbx_gemm_tri(nbx_ctx* ctx, int64_t unit, int64_t tri_m0, int64_t nbatch, int64_t n, int64_t k, const double* d_a,
+                 int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb, double* d_c, int64_t ldc);
 int nbx_gemm_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t n, int64_t k, double alpha,
                    const double* d_a, int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb, int64_t stride_b,
                    double beta, double* d_c, int64_t ldc, int64_t stride_c, int64_t batch, const int* d_gate,

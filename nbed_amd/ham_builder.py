@@ -97,7 +97,8 @@ class HamiltonianBuilder:
         eri = _ao_eri_device(self.scf_method, be)
         ca, cb = be.asarray(np.asarray(c[0])), be.asarray(np.asarray(c[1]))
         # (aa|aa) and (aa|bb) share their first two quarter transforms -- a third of the quarter-1
-        # work of the reference's three independent ao2mo.kernel calls; bitwise the same results
+        # work of the reference's three independent ao2mo.kernel calls -- and on one device every
+        # block uses (ij|kl) = (ji|kl) for quarters 3-4
         aaaa, aabb = self._transform_pair(eri, ca, ca, cb)
         bbbb = self._transform(eri, cb, cb, cb, cb)
         n = n_a
@@ -112,6 +113,8 @@ class HamiltonianBuilder:
         """Dense (n1,n2,n3,n4) chemist-order block; outer index sharded over ranks if asked."""
         sh = self.shards
         if sh is None or sh.world == 1:
+            if c1 is c2 and hasattr(self.be, "ao2mo_pair_sym"):  # (ij|kl) = (ji|kl): pairs j <= i only
+                return self.be.ao2mo_pair_sym(eri, c1, c3, c4)
             return self.be.ao2mo(eri, c1, c2, c3, c4)
         slab = self.be.ao2mo(eri, c1, c2, c3, c4, i0=sh.lo, i1=sh.hi)
         return sh.all_gather(self.be, slab, axis=0)
@@ -123,6 +126,8 @@ class HamiltonianBuilder:
             return self._transform(eri, c12, c12, c34, c34), self._transform(eri, c12, c12, c56, c56)
         sh = self.shards
         if sh is None or sh.world == 1:
+            if hasattr(be, "ao2mo_pair_sym"):
+                return be.ao2mo_pair_sym(eri, c12, c34, c34, c56, c56)
             return be.ao2mo_pair(eri, c12, c12, c34, c34, c56, c56)
         s1, s2 = be.ao2mo_pair(eri, c12, c12, c34, c34, c56, c56, i0=sh.lo, i1=sh.hi)
         return sh.all_gather(be, s1, axis=0), sh.all_gather(be, s2, axis=0)

@@ -488,6 +488,26 @@ def test_ao2mo_pair_equals_two_transforms_bitwise(be):
     np.testing.assert_allclose(ab, ref, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("n,na,nb_", [(12, 5, 4), (24, 14, 14), (37, 20, 9)])
+def test_ao2mo_pair_sym_vs_oracle(be, n, na, nb_):
+    """(ij|kl) = (ji|kl) transform (quarters 3-4 on the pairs j <= i): against the einsum definition
+    and the unsymmetrised kernels, single tensor and pair; outputs exactly symmetric in (i, j)."""
+    eri_h = synth.eri_dense(n)
+    ca_h, cb_h = rnd(420, n, na), rnd(421, n, nb_)
+    eri, ca, cb = be.asarray(eri_h), be.asarray(ca_h), be.asarray(cb_h)
+    ref_aa = hamiltonian.ao2mo_full(eri_h, ca_h, ca_h, ca_h, ca_h)
+    ref_ab = hamiltonian.ao2mo_full(eri_h, ca_h, ca_h, cb_h, cb_h)
+    one = be.to_host(be.ao2mo_pair_sym(eri, ca, ca, ca))
+    np.testing.assert_allclose(one, ref_aa, rtol=0, atol=1e-12)
+    p1, p2 = be.ao2mo_pair_sym(eri, ca, ca, ca, cb, cb)
+    p1, p2 = be.to_host(p1), be.to_host(p2)
+    np.testing.assert_array_equal(p1, one)
+    np.testing.assert_allclose(p2, ref_ab, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(p1, p1.transpose(1, 0, 2, 3))
+    np.testing.assert_array_equal(p2, p2.transpose(1, 0, 2, 3))
+    np.testing.assert_allclose(p2, be.to_host(be.ao2mo(eri, ca, ca, cb, cb)), rtol=0, atol=1e-13)
+
+
 def test_ao2mo_synth_pair_equals_two_streamed_transforms(be):
     n, na = 20, 9
     ca, cb = be.asarray(rnd(412, n, na)), be.asarray(rnd(413, n, na))
