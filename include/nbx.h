@@ -321,6 +321,17 @@ int nbx_geig_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_f, c
  * has C1 = C2.  Same outputs as nbx_ao2mo_pair up to rounding ((i,j) and (j,i) are equal by
  * construction here); d_out2 == NULL: one tensor.  Outer-index slabs: use nbx_ao2mo_pair.      */
 size_t nbx_ao2mo_pair_sym_worksize(int64_t nao, int64_t n, int64_t n4, int64_t n6);
+/* ... and with (pq|rs) = (pq|sr) too: nbx_eri_pack_rs stores (r, s <= r) packed once per molecule
+ * (out[(p,q)][r(r+1)/2 + s], nbx_eri_rs_bytes() bytes -- PySCF's "s2kl" form of ao2mo's input);
+ * quarters 1 and 2 of nbx_ao2mo_pair_sym_rs then run on N(N+1)/2 columns instead of N^2 and
+ * quarter 3 reads the packed X2 in place.  Same results as nbx_ao2mo_pair_sym up to rounding.  */
+size_t nbx_eri_rs_bytes(int64_t nao);
+int nbx_eri_pack_rs(nbx_ctx* ctx, int64_t nao, const double* d_eri, double* d_out);
+size_t nbx_ao2mo_pair_sym_rs_worksize(int64_t nao, int64_t n, int64_t n4, int64_t n6);
+int nbx_ao2mo_pair_sym_rs(nbx_ctx* ctx, int64_t nao, const double* d_eri_rs, const double* d_c12, int64_t n,
+                          const double* d_c3, int64_t n3, const double* d_c4, int64_t n4, double* d_out,
+                          const double* d_c5, int64_t n5, const double* d_c6, int64_t n6, double* d_out2,
+                          void* d_work, size_t work_bytes);
 int nbx_ao2mo_pair_sym(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c12, int64_t n,
                        const double* d_c3, int64_t n3, const double* d_c4, int64_t n4, double* d_out,
                        const double* d_c5, int64_t n5, const double* d_c6, int64_t n6, double* d_out2,

@@ -111,6 +111,11 @@ SIGNATURES = {
     "nbx_ao2mo_pair_sym_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
     "nbx_ao2mo_pair_sym": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64,
                                    _P, _P, c_size_t]),
+    "nbx_eri_rs_bytes": (c_size_t, [c_int64]),
+    "nbx_eri_pack_rs": (c_int, [_P, c_int64, _P, _P]),
+    "nbx_ao2mo_pair_sym_rs_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "nbx_ao2mo_pair_sym_rs": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P,
+                                      c_int64, _P, _P, c_size_t]),
     "nbx_ao2mo_synth_pair_worksize": (c_size_t, [c_int64] * 7),
     "nbx_ao2mo_synth_pair": (c_int, [_P, c_int64, c_uint64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
                                      _P, c_int64, _P, _P, c_int64, _P, c_int64, _P, _P, c_size_t]),

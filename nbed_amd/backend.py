@@ -659,19 +659,27 @@ class HipBackend:
                    work.numel())
         return out, out2
 
-    def ao2mo_pair_sym(self, eri, c12, c3, c4, c5=None, c6=None):
+    def eri_pack_rs(self, eri, nao: int):
+        """(pq|rs) with (r, s <= r) packed: (N, N, N(N+1)/2), the input of ao2mo_pair_sym(rs_packed=True)."""
+        out = self.empty((nao, nao, nao * (nao + 1) // 2))
+        self._call("nbx_eri_pack_rs", nao, self._p(eri), self._p(out))
+        return out
+
+    def ao2mo_pair_sym(self, eri, c12, c3, c4, c5=None, c6=None, rs_packed: bool = False):
         """(C12 C12|C3 C4) [and (C12 C12|C5 C6)] over the whole outer range with (ij|kl) = (ji|kl):
-        quarters 3-4 on the pairs j <= i only (nbx_ao2mo_pair_sym).  Equal to ao2mo / ao2mo_pair up to
-        rounding; the outputs are exactly symmetric in (i, j)."""
+        quarters 3-4 on the pairs j <= i only (nbx_ao2mo_pair_sym).  ``rs_packed``: ``eri`` comes from
+        eri_pack_rs and quarters 1-2 use (pq|rs) = (pq|sr) as well.  Equal to ao2mo / ao2mo_pair up
+        to rounding; the outputs are exactly symmetric in (i, j)."""
         nao, n = c12.shape
         n3, n4 = c3.shape[1], c4.shape[1]
         pair = c5 is not None
         n5, n6 = (c5.shape[1], c6.shape[1]) if pair else (0, 0)
-        nbytes = self.lib.nbx_ao2mo_pair_sym_worksize(nao, n, n4, n6)
+        name = "nbx_ao2mo_pair_sym_rs" if rs_packed else "nbx_ao2mo_pair_sym"
+        nbytes = getattr(self.lib, name + "_worksize")(nao, n, n4, n6)
         work = self._workspace("ao2mo", nbytes)
         out = self.empty((n, n, n3, n4))
         out2 = self.empty((n, n, n5, n6)) if pair else None
-        self._call("nbx_ao2mo_pair_sym", nao, self._p(eri), self._p(c12), n, self._p(c3), n3, self._p(c4), n4,
+        self._call(name, nao, self._p(eri), self._p(c12), n, self._p(c3), n3, self._p(c4), n4,
                    self._p(out), self._p(c5), n5, self._p(c6), n6, self._p(out2), self._p(work), work.numel())
         return (out, out2) if pair else out
 

@@ -127,6 +127,20 @@ __global__ __launch_bounds__(256) void ao2mo_expand_kernel(const double* __restr
     }
 }
 
+// out[(p,q)][T(r,s)] = eri[p][q][r][s], s <= r, T = r(r+1)/2 + s
+__global__ __launch_bounds__(256) void eri_pack_rs_kernel(const double* __restrict__ eri, double* __restrict__ out, int N) {
+    const int64_t pq = blockIdx.x, nt = (int64_t)N * (N + 1) / 2;
+    const double* src = eri + pq * N * N;
+    double* dst = out + pq * nt;
+    // 16 rows per workgroup (grid.y), one 64-lane wave per row at a time
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int rr = wave; rr < 16; rr += 4) {
+        const int r = blockIdx.y * 16 + rr;
+        if (r >= N) break;
+        for (int s = lane; s <= r; s += 64) dst[(int64_t)r * (r + 1) / 2 + s] = src[(int64_t)r * N + s];
+    }
+}
+
 struct Ao2moSymPlan {
     size_t a_doubles, b_doubles, c_doubles;
 };
@@ -141,6 +155,14 @@ Ao2moSymPlan sym_plan(int64_t N, int64_t n, int64_t n4, int64_t n6) {
 }
 }  // namespace
 
+extern "C" size_t nbx_ao2mo_pair_sym_rs_worksize(int64_t nao, int64_t n, int64_t n4, int64_t n6) {
+    if (nao <= 0 || n <= 0 || n4 <= 0 || n6 < 0) return 0;
+    const Ao2moSymPlan p = sym_plan(nao, n, n4, n6);
+    // + the packed X2 (n^2 N(N+1)/2); the packed X1 is smaller than the dense one the plan sizes bufA for
+    return align256(p.a_doubles * sizeof(double)) + align256(p.b_doubles * sizeof(double)) +
+           align256(p.c_doubles * sizeof(double)) + align256((size_t)(n * n * (nao * (nao + 1) / 2)) * sizeof(double));
+}
+
 extern "C" size_t nbx_ao2mo_pair_sym_worksize(int64_t nao, int64_t n, int64_t n4, int64_t n6) {
     if (nao <= 0 || n <= 0 || n4 <= 0 || n6 < 0) return 0;
     const Ao2moSymPlan p = sym_plan(nao, n, n4, n6);
@@ -148,10 +170,43 @@ extern "C" size_t nbx_ao2mo_pair_sym_worksize(int64_t nao, int64_t n, int64_t n4
            align256(p.c_doubles * sizeof(double));
 }
 
+static int ao2mo_pair_sym_impl(nbx_ctx* ctx, int64_t nao, const double* d_eri, bool rs_packed, const double* d_c12,
+                               int64_t n, const double* d_c3, int64_t n3, const double* d_c4, int64_t n4, double* d_out,
+                               const double* d_c5, int64_t n5, const double* d_c6, int64_t n6, double* d_out2,
+                               void* d_work, size_t work_bytes);
+
 extern "C" int nbx_ao2mo_pair_sym(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_c12, int64_t n,
                                   const double* d_c3, int64_t n3, const double* d_c4, int64_t n4, double* d_out,
                                   const double* d_c5, int64_t n5, const double* d_c6, int64_t n6, double* d_out2,
                                   void* d_work, size_t work_bytes) {
+    return ao2mo_pair_sym_impl(ctx, nao, d_eri, false, d_c12, n, d_c3, n3, d_c4, n4, d_out, d_c5, n5, d_c6, n6, d_out2,
+                               d_work, work_bytes);
+}
+
+extern "C" int nbx_ao2mo_pair_sym_rs(nbx_ctx* ctx, int64_t nao, const double* d_eri_rs, const double* d_c12, int64_t n,
+                                     const double* d_c3, int64_t n3, const double* d_c4, int64_t n4, double* d_out,
+                                     const double* d_c5, int64_t n5, const double* d_c6, int64_t n6, double* d_out2,
+                                     void* d_work, size_t work_bytes) {
+    return ao2mo_pair_sym_impl(ctx, nao, d_eri_rs, true, d_c12, n, d_c3, n3, d_c4, n4, d_out, d_c5, n5, d_c6, n6, d_out2,
+                               d_work, work_bytes);
+}
+
+extern "C" size_t nbx_eri_rs_bytes(int64_t nao) {
+    return nao > 0 ? (size_t)(nao * nao * (nao * (nao + 1) / 2)) * sizeof(double) : 0;
+}
+
+extern "C" int nbx_eri_pack_rs(nbx_ctx* ctx, int64_t nao, const double* d_eri, double* d_out) {
+    NBX_CHECK_ARG(ctx && d_eri && d_out && nao > 0 && nao * nao < (1ll << 31));
+    hipLaunchKernelGGL(eri_pack_rs_kernel, dim3((unsigned)(nao * nao), (unsigned)nbx_cdiv(nao, 16)), dim3(256), 0,
+                       ctx->stream, d_eri, d_out, (int)nao);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+static int ao2mo_pair_sym_impl(nbx_ctx* ctx, int64_t nao, const double* d_eri, bool rs_packed, const double* d_c12,
+                               int64_t n, const double* d_c3, int64_t n3, const double* d_c4, int64_t n4, double* d_out,
+                               const double* d_c5, int64_t n5, const double* d_c6, int64_t n6, double* d_out2,
+                               void* d_work, size_t work_bytes) {
     const bool pair = d_out2 != nullptr;
     NBX_CHECK_ARG(ctx && d_eri && d_c12 && d_c3 && d_c4 && d_out);
     NBX_CHECK_ARG(nao > 0 && n > 0 && n3 > 0 && n4 > 0);
@@ -162,7 +217,8 @@ extern "C" int nbx_ao2mo_pair_sym(nbx_ctx* ctx, int64_t nao, const double* d_eri
         nbx_set_error("nbx_ao2mo_pair_sym: dense path needs N^3 < 2^31 (N=%lld)", (long long)N);
         return NBX_E_UNSUPPORTED;
     }
-    const size_t need = nbx_ao2mo_pair_sym_worksize(N, n, n4, pair ? n6 : 0);
+    const size_t need = rs_packed ? nbx_ao2mo_pair_sym_rs_worksize(N, n, n4, pair ? n6 : 0)
+                                  : nbx_ao2mo_pair_sym_worksize(N, n, n4, pair ? n6 : 0);
     if (d_work == nullptr || work_bytes < need) {
         nbx_set_error("nbx_ao2mo_pair_sym: workspace %zu < %zu bytes", work_bytes, need);
         return NBX_E_NOMEM;
@@ -176,19 +232,43 @@ extern "C" int nbx_ao2mo_pair_sym(nbx_ctx* ctx, int64_t nao, const double* d_eri
     const int64_t N2 = N * N, N3 = N2 * N, npairs = n * (n + 1) / 2;
     int rc;
     nbx_prof_scope prof_all(ctx, NBX_PROF_AO2MO);
-    {
-        nbx_prof_scope prof_q1(ctx, NBX_PROF_AO2MO_Q1);
-        rc = nbx_gemm(ctx, 'T', 'N', n, N3, N, 1.0, d_c12, n, 0, d_eri, N3, 0, 0.0, bufA, N3, 0, 1);
-    }
-    if (rc != NBX_OK) return rc;
-    rc = nbx_gemm(ctx, 'T', 'N', n, N2, N, 1.0, d_c12, n, 0, bufA, N2, N3, 0.0, bufB, N2, n * N2, n);
-    if (rc != NBX_OK) return rc;
-    // Q3 on the pairs j <= i: W[(i,j),r,l] = sum_s X2[i,j,r,s] C4[s,l]
-    rc = nbx_gemm_tri(ctx, N, 0, n, n4, N, bufB, N, n * N2, d_c4, n4, bufA, n4);
-    if (rc != NBX_OK) return rc;
-    if (pair) {
-        rc = nbx_gemm_tri(ctx, N, 0, n, n6, N, bufB, N, n * N2, d_c6, n6, bufC, n6);
+    if (rs_packed) {
+        // (pq|rs) = (pq|sr): the integrals come with (r, s <= r) packed (nbx_eri_pack_rs), quarters 1
+        // and 2 run on N(N+1)/2 columns instead of N^2, and quarter 3 reads the packed X2 through the
+        // GEMM's symmetric-packed A operand (no unpacked copy is ever made)
+        const int64_t Nt = N * (N + 1) / 2;
+        double* bufT = reinterpret_cast<double*>(reinterpret_cast<char*>(bufC) + align256(p.c_doubles * sizeof(double)));
+        {
+            nbx_prof_scope prof_q1(ctx, NBX_PROF_AO2MO_Q1);
+            rc = nbx_gemm(ctx, 'T', 'N', n, N * Nt, N, 1.0, d_c12, n, 0, d_eri, N * Nt, 0, 0.0, bufA, N * Nt, 0, 1);
+        }
         if (rc != NBX_OK) return rc;
+        rc = nbx_gemm(ctx, 'T', 'N', n, Nt, N, 1.0, d_c12, n, 0, bufA, Nt, N * Nt, 0.0, bufT, Nt, n * Nt, n);
+        if (rc != NBX_OK) return rc;
+        // quarter 3 reads the packed X2 directly (symmetric-packed A operand of the GEMM)
+        rc = nbx_gemm_tri(ctx, N, 0, n, n4, N, bufT, N, n * Nt, d_c4, n4, bufA, n4, N);
+        if (rc != NBX_OK) return rc;
+        if (pair) {
+            rc = nbx_gemm_tri(ctx, N, 0, n, n6, N, bufT, N, n * Nt, d_c6, n6, bufC, n6, N);
+            if (rc != NBX_OK) return rc;
+        }
+    } else {
+        {
+            nbx_prof_scope prof_q1(ctx, NBX_PROF_AO2MO_Q1);
+            rc = nbx_gemm(ctx, 'T', 'N', n, N3, N, 1.0, d_c12, n, 0, d_eri, N3, 0, 0.0, bufA, N3, 0, 1);
+        }
+        if (rc != NBX_OK) return rc;
+        rc = nbx_gemm(ctx, 'T', 'N', n, N2, N, 1.0, d_c12, n, 0, bufA, N2, N3, 0.0, bufB, N2, n * N2, n);
+        if (rc != NBX_OK) return rc;
+    }
+    // Q3 on the pairs j <= i: W[(i,j),r,l] = sum_s X2[i,j,r,s] C4[s,l]
+    if (!rs_packed) {
+        rc = nbx_gemm_tri(ctx, N, 0, n, n4, N, bufB, N, n * N2, d_c4, n4, bufA, n4);
+        if (rc != NBX_OK) return rc;
+        if (pair) {
+            rc = nbx_gemm_tri(ctx, N, 0, n, n6, N, bufB, N, n * N2, d_c6, n6, bufC, n6);
+            if (rc != NBX_OK) return rc;
+        }
     }
     // Q4 per pair, each (n3 x n4) result stored at (i,j) and (j,i) by the GEMM's epilogue
     if (npairs <= 65535) {

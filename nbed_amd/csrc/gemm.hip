@@ -33,6 +33,10 @@ struct GemmGen {
     // "pair scatter" (pair_n > 0): batch entry b is the pair (i, j <= i), b = i (i+1)/2 + j; its C
     // block (stride_c doubles) is stored at block index i * pair_n + j AND at j * pair_n + i
     int pair_n = 0;
+    // "symmetric-packed A" (a_symn = N > 0): row x of op(A) is row r = x % N of the symmetric N x N
+    // matrix number x / N, stored as its packed lower triangle (N(N+1)/2 doubles per matrix);
+    // element (r, k) is read from offset T(max(r,k), min(r,k)).  A 'N' operand only.
+    int a_symn = 0;
 };
 
 constexpr int BK = 16;
@@ -82,6 +86,32 @@ struct Stager {
                         if (gx + 1 < xmax) v.y = p[1];
                     }
                 }
+            }
+            reg[i] = v;
+        }
+    }
+
+    // KCONTIG operand whose rows are rows of packed symmetric matrices (GemmGen::a_symn)
+    __device__ __forceinline__ void load_sym(const double* __restrict__ base, int n, int x0, int k0, int xmax,
+                                             int kmax) {
+        static_assert(KCONTIG || BX > 0, "");
+        const int64_t nt = (int64_t)n * (n + 1) / 2;
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int item = threadIdx.x + i * GEMM_THREADS;
+            const int x = item / (BK / 2);
+            const int k = (item - x * (BK / 2)) * 2;
+            const int gx = x0 + x, gk = k0 + k;
+            double2 v = make_double2(0.0, 0.0);
+            if (gx < xmax) {
+                const int mat = gx / n, r = gx - mat * n;
+                const double* p = base + mat * nt;
+                auto at = [&](int kk) {
+                    const int hi = r > kk ? r : kk, lo = r > kk ? kk : r;
+                    return p[(int64_t)hi * (hi + 1) / 2 + lo];
+                };
+                if (gk < kmax) v.x = at(gk);
+                if (gk + 1 < kmax) v.y = at(gk + 1);
             }
             reg[i] = v;
         }
@@ -182,7 +212,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
     Stager<BM, A_KC, GEMM_THREADS> sa;
     Stager<BN, B_KC, GEMM_THREADS> sb;
     const int nkt = (K + BK - 1) / BK;
-    sa.load(A, lda, m0, 0, M, K, vec_a);
+    if (A_KC && gen.a_symn > 0) sa.load_sym(A, gen.a_symn, m0, 0, M, K);
+    else sa.load(A, lda, m0, 0, M, K, vec_a);
     if constexpr (B_GEN) sb.generate(gen_rs, gen.seed, gen.scale, n0, 0, N, K);
     else sb.load(B, ldb, n0, 0, N, K, vec_b);
     sa.store(As);
@@ -192,7 +223,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
     for (int kt = 0; kt < nkt; ++kt) {
         const bool more = kt + 1 < nkt;
         if (more) {
-            sa.load(A, lda, m0, (kt + 1) * BK, M, K, vec_a);
+            if (A_KC && gen.a_symn > 0) sa.load_sym(A, gen.a_symn, m0, (kt + 1) * BK, M, K);
+            else sa.load(A, lda, m0, (kt + 1) * BK, M, K, vec_a);
             if constexpr (B_GEN) sb.generate(gen_rs, gen.seed, gen.scale, n0, (kt + 1) * BK, N, K);
             else sb.load(B, ldb, n0, (kt + 1) * BK, N, K, vec_b);
         }
@@ -422,13 +454,15 @@ int nbx_gemm_small_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, in
 // (tri_m0 + b + 1) * unit rows; A_b = A + b * stride_a (lda), the C blocks are stored one after the
 // other (row length ldc).  Operands 'N','N' row-major; 128 x 128 tiles.
 int nbx_gemm_tri(nbx_ctx* ctx, int64_t unit, int64_t tri_m0, int64_t nbatch, int64_t n, int64_t k, const double* d_a,
-                 int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb, double* d_c, int64_t ldc) {
+                 int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb, double* d_c, int64_t ldc,
+                 int64_t a_symn) {
     NBX_CHECK_ARG(ctx && d_a && d_b && d_c && unit > 0 && tri_m0 >= 0 && nbatch > 0 && n > 0 && k > 0);
     const int64_t m_max = (tri_m0 + nbatch) * unit;
     NBX_CHECK_ARG(m_max < (1ll << 31) && nbatch <= 65535);
     GemmGen gen{};
     gen.tri_unit = (int)unit;
     gen.tri_m0 = (int)tri_m0;
+    gen.a_symn = (int)a_symn;  // > 0: the rows of A are rows of packed symmetric matrices of this order
     const int vec_a = (aligned16(d_a) && lda % 2 == 0 && stride_a % 2 == 0) ? 1 : 0;
     const int vec_b = (aligned16(d_b) && ldb % 2 == 0) ? 1 : 0;
     launch<128, 128, 2, 4>(ctx, true, false, (int)m_max, (int)n, (int)k, 1.0, d_a, lda, stride_a, d_b, ldb, 0, 0.0, d_c,

@@ -50,7 +50,8 @@ bool nbx_gemm_small_supported(int64_t m, int64_t n, int64_t k, int64_t batch);
 int nbx_gemm_pair_scatter(nbx_ctx* ctx, int64_t pair_n, int64_t m, int64_t n, int64_t k, const double* d_a, int64_t lda,
                           const double* d_b, int64_t ldb, int64_t stride_b, double* d_c);
 int nbx_gemm_tri(nbx_ctx* ctx, int64_t unit, int64_t tri_m0, int64_t nbatch, int64_t n, int64_t k, const double* d_a,
-                 int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb, double* d_c, int64_t ldc);
+                 int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb, double* d_c, int64_t ldc,
+                 int64_t a_symn = 0);
 int nbx_gemm_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t n, int64_t k, double alpha,
                    const double* d_a, int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb, int64_t stride_b,
                    double beta, double* d_c, int64_t ldc, int64_t stride_c, int64_t batch, const int* d_gate,

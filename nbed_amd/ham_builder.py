@@ -101,6 +101,7 @@ class HamiltonianBuilder:
         # block uses (ij|kl) = (ji|kl) for quarters 3-4
         aaaa, aabb = self._transform_pair(eri, ca, ca, cb)
         bbbb = self._transform(eri, cb, cb, cb, cb)
+        self._eri_rs = None  # (the packed copy is 0.5 N^4 doubles: not kept beyond the build)
         n = n_a
         # (bb|aa)[i,j,k,l] = (aa|bb)[k,l,i,j]: a transpose of the (n^2 x n^2) matrix
         bbaa = be.transpose(aabb.reshape(n * n, n * n)).reshape(n, n, n, n)
@@ -109,11 +110,23 @@ class HamiltonianBuilder:
             out[i].copy_(be.chem_to_phys(blk))
         return out
 
+    def _eri_rs_packed(self, eri):
+        """(pq|rs) with (r, s <= r) packed, made once per build (both transforms of the build use it:
+        quarters 1-2 on half the columns); None on a backend without the packed transform."""
+        if not hasattr(self.be, "eri_pack_rs"):
+            return None
+        if getattr(self, "_eri_rs", None) is None:
+            self._eri_rs = self.be.eri_pack_rs(eri, eri.shape[-1])
+        return self._eri_rs
+
     def _transform(self, eri, c1, c2, c3, c4):
         """Dense (n1,n2,n3,n4) chemist-order block; outer index sharded over ranks if asked."""
         sh = self.shards
         if sh is None or sh.world == 1:
             if c1 is c2 and hasattr(self.be, "ao2mo_pair_sym"):  # (ij|kl) = (ji|kl): pairs j <= i only
+                rs = self._eri_rs_packed(eri)
+                if rs is not None:
+                    return self.be.ao2mo_pair_sym(rs, c1, c3, c4, rs_packed=True)
                 return self.be.ao2mo_pair_sym(eri, c1, c3, c4)
             return self.be.ao2mo(eri, c1, c2, c3, c4)
         slab = self.be.ao2mo(eri, c1, c2, c3, c4, i0=sh.lo, i1=sh.hi)
@@ -127,6 +140,9 @@ class HamiltonianBuilder:
         sh = self.shards
         if sh is None or sh.world == 1:
             if hasattr(be, "ao2mo_pair_sym"):
+                rs = self._eri_rs_packed(eri)
+                if rs is not None:
+                    return be.ao2mo_pair_sym(rs, c12, c34, c34, c56, c56, rs_packed=True)
                 return be.ao2mo_pair_sym(eri, c12, c34, c34, c56, c56)
             return be.ao2mo_pair(eri, c12, c12, c34, c34, c56, c56)
         s1, s2 = be.ao2mo_pair(eri, c12, c12, c34, c34, c56, c56, i0=sh.lo, i1=sh.hi)

@@ -506,6 +506,15 @@ def test_ao2mo_pair_sym_vs_oracle(be, n, na, nb_):
     np.testing.assert_array_equal(p1, p1.transpose(1, 0, 2, 3))
     np.testing.assert_array_equal(p2, p2.transpose(1, 0, 2, 3))
     np.testing.assert_allclose(p2, be.to_host(be.ao2mo(eri, ca, ca, cb, cb)), rtol=0, atol=1e-13)
+    # ... and with (pq|rs) = (pq|sr) too: quarters 1-2 on the packed (r, s <= r) columns
+    eri_rs = be.eri_pack_rs(eri, n)
+    ir, js = np.tril_indices(n)
+    np.testing.assert_array_equal(be.to_host(eri_rs), eri_h[:, :, ir, js])
+    q1, q2 = be.ao2mo_pair_sym(eri_rs, ca, ca, ca, cb, cb, rs_packed=True)
+    np.testing.assert_allclose(be.to_host(q1), ref_aa, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(be.to_host(q2), ref_ab, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(be.to_host(be.ao2mo_pair_sym(eri_rs, cb, cb, cb, rs_packed=True)),
+                               hamiltonian.ao2mo_full(eri_h, cb_h, cb_h, cb_h, cb_h), rtol=0, atol=1e-12)
 
 
 def test_ao2mo_synth_pair_equals_two_streamed_transforms(be):
