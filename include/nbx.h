@@ -319,7 +319,8 @@ int nbx_geig_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_f, c
  * (ij|kl) = (ji|kl), so quarters 3 and 4 run on the pairs j <= i only and each finished (k,l)
  * block is stored at (i,j) and (j,i).  Every ao2mo.kernel call of nbed/ham_builder.py:127-133
  * has C1 = C2.  Same outputs as nbx_ao2mo_pair up to rounding ((i,j) and (j,i) are equal by
- * construction here); d_out2 == NULL: one tensor.  Outer-index slabs: use nbx_ao2mo_pair.      */
+ * construction here); d_out2 == NULL: one tensor.  Outer-index slabs, or n > 361 (more than 65535
+ * pairs: NBX_E_UNSUPPORTED): use nbx_ao2mo_pair.                                               */
 size_t nbx_ao2mo_pair_sym_worksize(int64_t nao, int64_t n, int64_t n4, int64_t n6);
 /* ... and with (pq|rs) = (pq|sr) too: nbx_eri_pack_rs stores (r, s <= r) packed once per molecule
  * (out[(p,q)][r(r+1)/2 + s], nbx_eri_rs_bytes() bytes -- PySCF's "s2kl" form of ao2mo's input);

@@ -110,23 +110,6 @@ extern "C" int nbx_ao2mo_pair(nbx_ctx* ctx, int64_t nao, const double* d_eri, co
 // bit-identical to nbx_ao2mo_pair: there (i,j) and (j,i) are computed separately and agree to
 // rounding; here they are equal by construction.  Slabs (multi-GPU) use nbx_ao2mo_pair.
 namespace {
-__global__ __launch_bounds__(256) void ao2mo_expand_kernel(const double* __restrict__ outc, double* __restrict__ out,
-                                                           int n, int64_t blk) {
-    const int pair = blockIdx.x;
-    int i = (int)((sqrt(8.0 * (double)pair + 1.0) - 1.0) * 0.5);
-    while (i * (i + 1) / 2 > pair) --i;
-    while ((i + 1) * (i + 2) / 2 <= pair) ++i;
-    const int j = pair - i * (i + 1) / 2;
-    const double* src = outc + (int64_t)pair * blk;
-    double* d1 = out + ((int64_t)i * n + j) * blk;
-    double* d2 = out + ((int64_t)j * n + i) * blk;
-    for (int64_t e = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; e < blk; e += (int64_t)gridDim.y * blockDim.x) {
-        const double v = src[e];
-        d1[e] = v;
-        if (i != j) d2[e] = v;
-    }
-}
-
 // out[(p,q)][T(r,s)] = eri[p][q][r][s], s <= r, T = r(r+1)/2 + s
 __global__ __launch_bounds__(256) void eri_pack_rs_kernel(const double* __restrict__ eri, double* __restrict__ out, int N) {
     const int64_t pq = blockIdx.x, nt = (int64_t)N * (N + 1) / 2;
@@ -211,7 +194,10 @@ static int ao2mo_pair_sym_impl(nbx_ctx* ctx, int64_t nao, const double* d_eri, b
     NBX_CHECK_ARG(ctx && d_eri && d_c12 && d_c3 && d_c4 && d_out);
     NBX_CHECK_ARG(nao > 0 && n > 0 && n3 > 0 && n4 > 0);
     NBX_CHECK_ARG(!pair || (d_c5 && d_c6 && n5 > 0 && n6 > 0));
-    NBX_CHECK_ARG(n3 * n4 <= nao * nao && (!pair || n5 * n6 <= nao * nao));  // the compact results reuse X2's buffer
+    if (n * (n + 1) / 2 > 65535) {  // one grid dimension holds the pairs
+        nbx_set_error("nbx_ao2mo_pair_sym: n = %lld gives more than 65535 pairs; use nbx_ao2mo_pair", (long long)n);
+        return NBX_E_UNSUPPORTED;
+    }
     const int64_t N = nao;
     if (N * N * N >= (1ll << 31)) {
         nbx_set_error("nbx_ao2mo_pair_sym: dense path needs N^3 < 2^31 (N=%lld)", (long long)N);
@@ -229,7 +215,7 @@ static int ao2mo_pair_sym_impl(nbx_ctx* ctx, int64_t nao, const double* d_eri, b
     double* bufB = reinterpret_cast<double*>(base + align256(p.a_doubles * sizeof(double)));
     double* bufC = reinterpret_cast<double*>(base + align256(p.a_doubles * sizeof(double)) +
                                              align256(p.b_doubles * sizeof(double)));
-    const int64_t N2 = N * N, N3 = N2 * N, npairs = n * (n + 1) / 2;
+    const int64_t N2 = N * N, N3 = N2 * N;
     int rc;
     nbx_prof_scope prof_all(ctx, NBX_PROF_AO2MO);
     if (rs_packed) {
@@ -271,22 +257,7 @@ static int ao2mo_pair_sym_impl(nbx_ctx* ctx, int64_t nao, const double* d_eri, b
         }
     }
     // Q4 per pair, each (n3 x n4) result stored at (i,j) and (j,i) by the GEMM's epilogue
-    if (npairs <= 65535) {
-        rc = nbx_gemm_pair_scatter(ctx, n, n3, n4, N, d_c3, n3, bufA, n4, N * n4, d_out);
-        if (rc != NBX_OK || !pair) return rc;
-        return nbx_gemm_pair_scatter(ctx, n, n5, n6, N, d_c5, n5, bufC, n6, N * n6, d_out2);
-    }
-    // (more pairs than a grid dimension holds: compact results in X2's buffer, dead now, then a copy)
-    rc = nbx_gemm(ctx, 'T', 'N', n3, n4, N, 1.0, d_c3, n3, 0, bufA, n4, N * n4, 0.0, bufB, n4, n3 * n4, npairs);
-    if (rc != NBX_OK) return rc;
-    hipLaunchKernelGGL(ao2mo_expand_kernel, dim3((unsigned)npairs, 4), dim3(256), 0, ctx->stream, bufB, d_out, (int)n,
-                       n3 * n4);
-    NBX_LAUNCH_CHECK();
-    if (!pair) return NBX_OK;
-    rc = nbx_gemm(ctx, 'T', 'N', n5, n6, N, 1.0, d_c5, n5, 0, bufC, n6, N * n6, 0.0, bufB, n6, n5 * n6, npairs);
-    if (rc != NBX_OK) return rc;
-    hipLaunchKernelGGL(ao2mo_expand_kernel, dim3((unsigned)npairs, 4), dim3(256), 0, ctx->stream, bufB, d_out2, (int)n,
-                       n5 * n6);
-    NBX_LAUNCH_CHECK();
-    return NBX_OK;
+    rc = nbx_gemm_pair_scatter(ctx, n, n3, n4, N, d_c3, n3, bufA, n4, N * n4, d_out);
+    if (rc != NBX_OK || !pair) return rc;
+    return nbx_gemm_pair_scatter(ctx, n, n5, n6, N, d_c5, n5, bufC, n6, N * n6, d_out2);
 }

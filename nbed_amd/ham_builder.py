@@ -110,6 +110,11 @@ class HamiltonianBuilder:
             out[i].copy_(be.chem_to_phys(blk))
         return out
 
+    def _sym_ok(self, c) -> bool:
+        """nbx_ao2mo_pair_sym covers up to 65535 (i, j <= i) pairs: 361 active MOs."""
+        n = c.shape[1]
+        return hasattr(self.be, "ao2mo_pair_sym") and n * (n + 1) // 2 <= 65535
+
     def _eri_rs_packed(self, eri):
         """(pq|rs) with (r, s <= r) packed, made once per build (both transforms of the build use it:
         quarters 1-2 on half the columns); None on a backend without the packed transform."""
@@ -123,7 +128,7 @@ class HamiltonianBuilder:
         """Dense (n1,n2,n3,n4) chemist-order block; outer index sharded over ranks if asked."""
         sh = self.shards
         if sh is None or sh.world == 1:
-            if c1 is c2 and hasattr(self.be, "ao2mo_pair_sym"):  # (ij|kl) = (ji|kl): pairs j <= i only
+            if c1 is c2 and self._sym_ok(c1):  # (ij|kl) = (ji|kl): pairs j <= i only
                 rs = self._eri_rs_packed(eri)
                 if rs is not None:
                     return self.be.ao2mo_pair_sym(rs, c1, c3, c4, rs_packed=True)
@@ -139,7 +144,7 @@ class HamiltonianBuilder:
             return self._transform(eri, c12, c12, c34, c34), self._transform(eri, c12, c12, c56, c56)
         sh = self.shards
         if sh is None or sh.world == 1:
-            if hasattr(be, "ao2mo_pair_sym"):
+            if self._sym_ok(c12):
                 rs = self._eri_rs_packed(eri)
                 if rs is not None:
                     return be.ao2mo_pair_sym(rs, c12, c34, c34, c56, c56, rs_packed=True)
