@@ -305,8 +305,9 @@ int nbx_svd_right(nbx_ctx* ctx, int64_t m, int64_t n, const double* d_a, double*
  * computes, once an SCF is under way.  batch matrices: d_f, d_s (the overlap, repeated per batch
  * entry), d_c0 (S-orthonormal start vectors), all (batch, n, n) row-major.
  *   d_status[b] = 1000 + iterations used: accepted, d_w[b] (ascending) and d_c[b] written;
- *               <= 0: not converged within max_iter (1..6) or near-degenerate cluster coupled --
- *                     outputs untouched.  There is NO fallback solver behind this entry: the
+ *               <= 0: not converged within max_iter (1..6), near-degenerate cluster coupled, or
+ *                     (max_iter = 1, where no sorting pass is queued) the eigenvalue order has
+ *                     changed -- outputs not valid.  There is NO fallback solver behind this entry: the
  *                     caller checks the status (the SCF loops do, one cycle late, and redo the run
  *                     on nbx_eigh_warm_ex if it ever fails).
  * Nothing synchronises.  d_work: nbx_geig_refine_worksize() bytes.                              */

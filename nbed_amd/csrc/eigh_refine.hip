@@ -49,7 +49,8 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
                                                               const double* __restrict__ G, double* __restrict__ Ep,
                                                               double* __restrict__ lam_out, int* __restrict__ status,
                                                               double* __restrict__ norm_a, int iter, int max_iter,
-                                                              double* __restrict__ partial, int* __restrict__ counters) {
+                                                              double* __restrict__ partial, int* __restrict__ counters,
+                                                              int* __restrict__ final_status = nullptr) {
     extern __shared__ double sm[];
     double* lam = sm;
     double* red = sm + N;  // 3 * RF_THREADS/64 + 8 doubles
@@ -134,7 +135,14 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
         red[3 * NW + 1] = t1;
         red[3 * NW + 2] = t2;
     }
-    __syncthreads();
+    // `final_status`: this launch is the whole solve (one iteration queued, the caller takes the
+    // updated vectors in place and lam as the eigenvalues): accepted only if lam is already
+    // ascending -- refinement keeps column i with eigenvalue i, so the order changes only when
+    // two levels cross -- and the verdict goes to the caller's status word (1000 + 1 / <= 0)
+    int unsorted = 0;
+    if (final_status != nullptr)
+        for (int i = threadIdx.x + 1; i < N; i += RF_THREADS) unsorted |= lam[i - 1] > lam[i] ? 1 : 0;
+    unsorted = __syncthreads_or(unsorted);
     off2 = red[3 * NW + 0];
     r2 = red[3 * NW + 1];
     a2 = red[3 * NW + 2];
@@ -212,6 +220,10 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
             if (!(emax < RF_GIVE_UP)) st = -1;  // also NaN
             else if (emax < RF_TOL && cmax <= RF_CLUSTER_NOISE * na) st = iter + 1;
             else if (iter == max_iter - 1) st = -1;
+            if (final_status != nullptr) {
+                if (st > 0 && unsorted) st = -3;
+                final_status[b] = st > 0 ? 1000 + st : (st < 0 ? st : -2);
+            }
             status[b] = st;
             __hip_atomic_store(counter, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -414,9 +426,12 @@ extern "C" int nbx_geig_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const dou
     int* status = reinterpret_cast<int*>(base + L.status);
     const int64_t n2 = n * n;
     const bool pair = nbx_gemm_small_supported(n, n, n, 2 * batch);
+    // One iteration queued (the steady state of an SCF): the update GEMM writes the caller's d_c,
+    // the E kernel writes d_w and the verdict, and no sorting pass follows (4 launches).
+    const bool direct = max_iter == 1 && d_c != d_c0;
     for (int it = 0; it < max_iter; ++it) {
         const double* src = (it == 0) ? d_c0 : cb[it & 1];
-        double* dst = cb[(it + 1) & 1];
+        double* dst = direct ? d_c : cb[(it + 1) & 1];
         const int* gate = (it == 0) ? nullptr : status;
         int rc;
         if (pair) {
@@ -438,12 +453,13 @@ extern "C" int nbx_geig_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const dou
         }
         hipLaunchKernelGGL(refine_e_kernel, dim3(RF_WGS, (unsigned)batch), dim3(RF_THREADS),
                            (size_t)(n + 3 * (RF_THREADS / 64) + 8) * sizeof(double), ctx->stream, (int)n,
-                           static_cast<const double*>(nullptr), s, g, ep, lam, status, norm, it, max_iter, partial,
-                           ctx->d_counters);
+                           static_cast<const double*>(nullptr), s, g, ep, direct ? d_w : lam, status, norm, it, max_iter,
+                           partial, ctx->d_counters, direct ? d_status : static_cast<int*>(nullptr));
         NBX_LAUNCH_CHECK();
         rc = nbx_gemm_gated(ctx, 'N', 'N', n, n, n, 1.0, src, n, n2, ep, n, n2, 0.0, dst, n, n2, batch, status, 0, it + 1);
         if (rc != NBX_OK) return rc;
     }
+    if (direct) return NBX_OK;
     hipLaunchKernelGGL(refine_finish_kernel, dim3((unsigned)nbx_cdiv(n, RF_ROWS), (unsigned)batch), dim3(256),
                        (size_t)n * sizeof(double) + (size_t)n * sizeof(int), ctx->stream, (int)n, cb[0], cb[1], lam,
                        status, d_w, d_c, d_status);

@@ -584,6 +584,21 @@ def test_geig_refine_tracks_perturbed_pencil(be, n):
         np.testing.assert_allclose(w[x], we, rtol=0, atol=1e-11 * n)
         np.testing.assert_allclose(c[x].T @ s_h @ c[x], np.eye(n), rtol=0, atol=1e-12)
         np.testing.assert_allclose(f1[x] @ c[x], s_h @ c[x] * w[x], rtol=0, atol=1e-10 * n)
+    # one iteration queued: no sorting pass (the update GEMM writes the result, the E kernel the
+    # eigenvalues and the verdict); a tiny perturbation is accepted ...
+    f2 = f0 + 1e-9 * np.stack([symm(545, n), symm(546, n)])
+    w1, c1 = be.geig_refine(be.asarray(f2), s_b, be.asarray(c0), refine_iters=1)
+    assert np.all(be.to_host(be.last_eigh_status_d) == 1001)
+    w1, c1 = be.to_host(w1), be.to_host(c1)
+    for x in range(2):
+        np.testing.assert_allclose(w1[x], scipy.linalg.eigh(f2[x], s_h)[0], rtol=0, atol=1e-11 * n)
+        np.testing.assert_allclose(c1[x].T @ s_h @ c1[x], np.eye(n), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(f2[x] @ c1[x], s_h @ c1[x] * w1[x], rtol=0, atol=1e-10 * n)
+    # ... a start whose columns are not in ascending order of eigenvalue is refused (-3)
+    swapped = c0.copy()
+    swapped[:, :, [2, 3]] = swapped[:, :, [3, 2]]
+    be.geig_refine(be.asarray(f2), s_b, be.asarray(swapped), refine_iters=1)
+    assert np.all(be.to_host(be.last_eigh_status_d) == -3)
     # a start that is nowhere near: refused (status <= 0), never a silent wrong answer
     q = np.linalg.qr(rnd(544, n, n))[0]
     x_h = np.linalg.inv(scipy.linalg.sqrtm(s_h).real)
