@@ -172,12 +172,17 @@ def main():
     hist = []
     clock = {}
 
+    stamps = []
+
     def on_cycle(i):
+        if i > args.warmup:
+            stamps.append(time.perf_counter())
         if i == args.warmup:
             barrier()
             be.profile(True, slots=[_nbx.PROF_JK_DENSE])  # HIP events around the J/K kernel only
             be.profile_reset()
             clock["t0"] = time.perf_counter()
+            stamps.append(clock["t0"])
 
     huzinaga_scf(mf, pr["V_emb"], pr["D_env"], use_DIIS=True, history=hist, callback=on_cycle)
     barrier()
@@ -438,7 +443,13 @@ def main():
                 "launches": jk_cnt,
             },
             "cpu_baseline": cpu,
-            "breakdown_ms_per_cycle": {"jk_kernel": jk_avg_ms, "everything_else": dt / args.steps * 1e3 - jk_avg_ms},
+            "breakdown_ms_per_cycle": {
+                "jk_kernel": jk_avg_ms, "everything_else": dt / args.steps * 1e3 - jk_avg_ms,
+                # the pace at which the loop queued the timed cycles (it runs one cycle ahead of the GPU, so
+                # this is the GPU's pace): early cycles queue more eigensolver iterations than settled ones
+                "median_cycle": float(np.median(np.diff(stamps))) * 1e3 if len(stamps) > 2 else None,
+                "first_cycles": [round(float(x) * 1e3, 4) for x in np.diff(stamps)[:8]],
+            },
             "check": {"energy_last_cycle": e_last, "dm_change_last_cycle": dm_change_last},
             "transform": transform,
             "n2000_streamed": n2000,

@@ -48,6 +48,17 @@ class DIIS:
     def get_num_vec(self) -> int:
         return self._nd
 
+    def reserve(self, n: int) -> None:
+        """Allocate the ring for vectors of n elements now (and upload the empty Pulay matrix):
+        done lazily, the upload would make the first extrapolating cycle wait for the queue to drain."""
+        be = self.be
+        if self._xs is None:
+            self._xs = be.empty((self.space, n))
+            self._es = be.empty((self.space, n))
+        if hasattr(be, "diis_update") and self.min_space <= 1 and self._Hd is None:
+            self._Hd = be.asarray(self._H)
+            self._coef = be.zeros(self.space)
+
     def update(self, x):
         be = self.be
         flat = x.reshape(-1)
@@ -56,8 +67,7 @@ class DIIS:
             self._xprev = be.copy(flat)
             return x
         if self._xs is None:
-            self._xs = be.empty((self.space, flat.numel()))
-            self._es = be.empty((self.space, flat.numel()))
+            self.reserve(flat.numel())
         if self._head >= self.space:
             self._head = 0
         slot = self._head

@@ -208,6 +208,12 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
                  and hasattr(be, "density_occ"))
 
     can_track = lookahead and hasattr(be, "geig_refine")
+    # everything the loop will need from the host goes up now: an upload inside the loop waits for
+    # the cycles queued ahead of it and leaves the GPU idle while the host catches up
+    if can_track and allow_tracked:
+        s_b = be.asarray(np.stack([s_h] * nb))
+    if adiis is not None and hasattr(adiis, "reserve"):
+        adiis.reserve(nb * s_h.shape[0] * s_h.shape[1])
 
     def occupations(e_d, c_d):
         if lookahead:

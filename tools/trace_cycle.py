@@ -36,3 +36,16 @@ for r in rows[idx[19]:idx[20] + 1]:
     gap = (r[1] - prev) / 1e3 if prev else 0
     print(f"gap {gap:7.1f} us  dur {(r[2] - r[1]) / 1e3:7.1f} us  {short(r[0])}")
     prev = r[2]
+
+# where the idle time of every cycle sits (gap before the named kernel, > 3 us)
+for c in range(0, len(idx) - 1):
+    prev, tot, big = None, 0.0, []
+    for r in rows[idx[c]:idx[c + 1] + 1]:
+        if prev is not None:
+            gap = (r[1] - prev) / 1e3
+            tot += gap
+            if gap > 3.0:
+                big.append(f"{gap:.1f} before {short(r[0])[:24]}")
+        prev = r[2]
+    print(f"cycle {c}: period {(rows[idx[c + 1]][1] - rows[idx[c]][1]) / 1e3:7.1f} us  idle {tot:6.1f} us  "
+          f"kernels {idx[c + 1] - idx[c]}  " + "; ".join(big))
