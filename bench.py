@@ -449,6 +449,8 @@ def main():
                 # this is the GPU's pace): early cycles queue more eigensolver iterations than settled ones
                 "median_cycle": float(np.median(np.diff(stamps))) * 1e3 if len(stamps) > 2 else None,
                 "first_cycles": [round(float(x) * 1e3, 4) for x in np.diff(stamps)[:8]],
+                # from queueing the last cycle to the results on the host (C, eps, D, Hz downloaded)
+                "last_cycle_and_results": (dt - (stamps[-1] - stamps[0])) * 1e3 if world == 1 and stamps else None,
             },
             "check": {"energy_last_cycle": e_last, "dm_change_last_cycle": dm_change_last},
             "transform": transform,
