@@ -50,7 +50,9 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
                                                               double* __restrict__ lam_out, int* __restrict__ status,
                                                               double* __restrict__ norm_a, int iter, int max_iter,
                                                               double* __restrict__ partial, int* __restrict__ counters,
-                                                              int* __restrict__ final_status = nullptr) {
+                                                              int* __restrict__ final_status = nullptr,
+                                                              const double* __restrict__ norm_part = nullptr,
+                                                              int norm_tiles = 0) {
     extern __shared__ double sm[];
     double* lam = sm;
     double* red = sm + N;  // 3 * RF_THREADS/64 + 8 doubles
@@ -77,7 +79,19 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
     };
     // ---- phase 1: ||S - diag||_F^2, ||R||_F^2 (and ||A||_F^2 once)
     double off2 = 0.0, r2 = 0.0, a2 = 0.0;
-    for (int e0 = first; e0 < total; e0 += stride * RF_UNROLL) {
+    // `norm_part`: the GEMM that produced S and G left their squared norms tile by tile
+    // (gemm_small_kernel): every workgroup adds them up in the same fixed order -- no pass over the
+    // matrices and no waiting for the sibling workgroups
+    if (norm_part != nullptr) {
+        const double* ps = norm_part + (int64_t)b * 2 * norm_tiles * 2;
+        const double* pg = ps + (int64_t)norm_tiles * 2;
+        for (int w = threadIdx.x; w < norm_tiles; w += RF_THREADS) {
+            off2 += ps[2 * w];
+            a2 += ps[2 * w + 1];
+            r2 += pg[2 * w];
+        }
+    }
+    for (int e0 = first; e0 < total && norm_part == nullptr; e0 += stride * RF_UNROLL) {
         double sv[RF_UNROLL], gv[RF_UNROLL], av[RF_UNROLL];
 #pragma unroll
         for (int u = 0; u < RF_UNROLL; ++u) {
@@ -109,7 +123,18 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
         red[2 * NW + wave] = a2;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && norm_part != nullptr) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < NW; ++w) {
+            t0 += red[w];
+            t1 += red[NW + w];
+            t2 += red[2 * NW + w];
+        }
+        red[3 * NW + 3] = 0.0;
+        red[3 * NW + 0] = t0;
+        red[3 * NW + 1] = t1;
+        red[3 * NW + 2] = t2;
+    } else if (threadIdx.x == 0) {
         double t0 = 0.0, t1 = 0.0, t2 = 0.0;
         for (int w = 0; w < NW; ++w) {
             t0 += red[w];
@@ -211,7 +236,7 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
         publish(part + wg * 5 + 3, emax);
         publish(part + wg * 5 + 4, cmax);
         const int arrived = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == 2 * nwg - 1) {  // last workgroup of this matrix
+        if (arrived == (norm_part != nullptr ? 1 : 2) * nwg - 1) {  // last workgroup of this matrix
             for (int w = 0; w < nwg; ++w) {
                 emax = fmax(emax, peek(part + w * 5 + 3));
                 cmax = fmax(cmax, peek(part + w * 5 + 4));
@@ -375,7 +400,7 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
 // accepted (d_w, d_c written), <= 0 when not (outputs untouched): the caller must check it.
 namespace {
 struct GeigLayout {
-    size_t cb0, cb1, yt, zt, s, g, ep, lam, norm, partial, status, total;
+    size_t cb0, cb1, yt, zt, s, g, ep, lam, norm, partial, status, npart, total;
 };
 GeigLayout glayout(int64_t n, int64_t batch) {
     GeigLayout L;
@@ -392,6 +417,7 @@ GeigLayout glayout(int64_t n, int64_t batch) {
     L.norm = off; off += align256((size_t)batch * sizeof(double));
     L.partial = off; off += align256((size_t)(batch * RF_WGS * 5) * sizeof(double));
     L.status = off; off += align256((size_t)batch * sizeof(int));
+    L.npart = off; off += align256((size_t)nbx_gemm_small_norm_doubles(n, n, batch) * sizeof(double));
     L.total = off;
     return L;
 }
@@ -424,6 +450,8 @@ extern "C" int nbx_geig_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const dou
     double* norm = reinterpret_cast<double*>(base + L.norm);
     double* partial = reinterpret_cast<double*>(base + L.partial);
     int* status = reinterpret_cast<int*>(base + L.status);
+    double* npart = reinterpret_cast<double*>(base + L.npart);
+    const int norm_tiles = (int)(nbx_cdiv(n, 16) * nbx_cdiv(n, 16));
     const int64_t n2 = n * n;
     const bool pair = nbx_gemm_small_supported(n, n, n, 2 * batch);
     // One iteration queued (the steady state of an SCF): the update GEMM writes the caller's d_c,
@@ -438,8 +466,9 @@ extern "C" int nbx_geig_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const dou
             rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, d_f, n, n2, 0.0, yt, n, n2, batch, gate, 0,
                                       0, d_s, zt);
             if (rc != NBX_OK) return rc;
+            // ... and leaves the squared norms of S~ and I - G for the E kernel, tile by tile
             rc = nbx_gemm_small_gated(ctx, 'T', 'T', n, n, n, 1.0, src, n, n2, yt, n, n2, 0.0, s, n, n2, batch, gate, 0, 0,
-                                      zt, g);
+                                      zt, g, npart);
             if (rc != NBX_OK) return rc;
         } else {
             rc = nbx_gemm_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, d_f, n, n2, 0.0, yt, n, n2, batch, gate, 0, 0);
@@ -454,7 +483,8 @@ extern "C" int nbx_geig_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const dou
         hipLaunchKernelGGL(refine_e_kernel, dim3(RF_WGS, (unsigned)batch), dim3(RF_THREADS),
                            (size_t)(n + 3 * (RF_THREADS / 64) + 8) * sizeof(double), ctx->stream, (int)n,
                            static_cast<const double*>(nullptr), s, g, ep, direct ? d_w : lam, status, norm, it, max_iter,
-                           partial, ctx->d_counters, direct ? d_status : static_cast<int*>(nullptr));
+                           partial, ctx->d_counters, direct ? d_status : static_cast<int*>(nullptr),
+                           pair ? npart : static_cast<const double*>(nullptr), norm_tiles);
         NBX_LAUNCH_CHECK();
         rc = nbx_gemm_gated(ctx, 'N', 'N', n, n, n, 1.0, src, n, n2, ep, n, n2, 0.0, dst, n, n2, batch, status, 0, it + 1);
         if (rc != NBX_OK) return rc;

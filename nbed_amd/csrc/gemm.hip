@@ -289,10 +289,12 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(int M, int N, int K, dou
                                                         double beta, double* __restrict__ C, int64_t ldc,
                                                         int64_t stride_c, const int* __restrict__ gate, int gate_a,
                                                         int gate_b, const double* __restrict__ B2,
-                                                        double* __restrict__ C2, int split) {
+                                                        double* __restrict__ C2, int split,
+                                                        double* __restrict__ norm_part) {
     // z >= split: second product of a pair sharing op(A) (C2 = op(A) op(B2)), same batch entries
     int batch = blockIdx.z;
-    if (batch >= split) {
+    const bool second = batch >= split;
+    if (second) {
         batch -= split;
         B = B2;
         C = C2;
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(int M, int N, int K, dou
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], b[j], acc, 0, 0, 0);
     }
+    double q0 = 0.0, q1 = 0.0;
     if (b_ok) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -361,7 +364,26 @@ __global__ __launch_bounds__(64) void gemm_small_kernel(int M, int N, int K, dou
                 double* c = C + (int64_t)row * ldc + col_b;
                 const double v = alpha * acc[r];
                 *c = (beta == 0.0) ? v : fma(beta, *c, v);
+                if (second) {  // ||I - C2||_F^2
+                    const double d = (row == col_b) ? 1.0 - v : v;
+                    q0 = fma(d, d, q0);
+                } else {  // ||C - diag||_F^2 and ||C||_F^2
+                    if (row != col_b) q0 = fma(v, v, q0);
+                    q1 = fma(v, v, q1);
+                }
             }
+        }
+    }
+    // norm_part[((batch * 2 + second) * tiles + tile) * 2 + {0, 1}]: this tile's share of the three
+    // squared norms the refinement's E kernel needs of a pair (C = S~, C2 = G) -- see nbx_geig_refine
+    if (norm_part != nullptr) {
+        q0 = nbx_wave_sum(q0);
+        q1 = nbx_wave_sum(q1);
+        if (lane == 0) {
+            const int64_t tiles = (int64_t)gridDim.x * gridDim.y, tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+            double* np = norm_part + (((int64_t)batch * 2 + (second ? 1 : 0)) * tiles + tile) * 2;
+            np[0] = q0;
+            np[1] = q1;
         }
     }
 }
@@ -425,8 +447,10 @@ bool nbx_gemm_small_supported(int64_t m, int64_t n, int64_t k, int64_t batch) {
 int nbx_gemm_small_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t n, int64_t k, double alpha,
                          const double* d_a, int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb,
                          int64_t stride_b, double beta, double* d_c, int64_t ldc, int64_t stride_c, int64_t batch,
-                         const int* d_gate, int gate_a, int gate_b, const double* d_b2, double* d_c2) {
+                         const int* d_gate, int gate_a, int gate_b, const double* d_b2, double* d_c2,
+                         double* d_norm_part) {
     NBX_CHECK_ARG(ctx && d_a && d_b && d_c && m > 0 && n > 0 && k > 0 && batch > 0);
+    NBX_CHECK_ARG(d_norm_part == nullptr || (d_b2 != nullptr && beta == 0.0));
     NBX_CHECK_ARG(nbx_gemm_small_supported(m, n, k, batch));
     NBX_CHECK_ARG((d_b2 == nullptr) == (d_c2 == nullptr));
     const bool a_kc = !(trans_a == 'T' || trans_a == 't');
@@ -437,7 +461,7 @@ int nbx_gemm_small_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, in
 #define NBX_GEMM_SMALL(AK, BKC)                                                                               \
     hipLaunchKernelGGL((gemm_small_kernel<AK, BKC>), grid, dim3(64), 0, ctx->stream, (int)m, (int)n, (int)k, \
                        alpha, d_a, lda, stride_a, d_b, ldb, stride_b, beta, d_c, ldc, stride_c, d_gate, gate_a, gate_b, \
-                       d_b2, d_c2, split)
+                       d_b2, d_c2, split, d_norm_part)
     if (a_kc) {
         if (b_kc) NBX_GEMM_SMALL(true, true);
         else NBX_GEMM_SMALL(true, false);
@@ -541,7 +565,7 @@ int nbx_gemm_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t 
 #define NBX_GEMM_SMALL(AK, BKC)                                                                               \
     hipLaunchKernelGGL((gemm_small_kernel<AK, BKC>), grid, dim3(64), 0, ctx->stream, (int)m, (int)n, (int)k, \
                        alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c, d_gate, gate_a, gate_b, nullptr, \
-                       nullptr, 1 << 30)
+                       nullptr, 1 << 30, nullptr)
             if (a_kc) {
                 if (b_kc) NBX_GEMM_SMALL(true, true);
                 else NBX_GEMM_SMALL(true, false);

@@ -60,7 +60,11 @@ int nbx_gemm_small_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, in
                          const double* d_a, int64_t lda, int64_t stride_a, const double* d_b, int64_t ldb,
                          int64_t stride_b, double beta, double* d_c, int64_t ldc, int64_t stride_c, int64_t batch,
                          const int* d_gate, int gate_a, int gate_b, const double* d_b2 = nullptr,
-                         double* d_c2 = nullptr);
+                         double* d_c2 = nullptr, double* d_norm_part = nullptr);
+// doubles of d_norm_part for an (m x n) pair product over `batch` entries (16 x 16 tiles)
+inline int64_t nbx_gemm_small_norm_doubles(int64_t m, int64_t n, int64_t batch) {
+    return batch * 2 * ((m + 15) / 16) * ((n + 15) / 16) * 2;
+}
 
 // jk_sym.hip
 bool nbx_jk_sym_supported(int64_t nao);
