@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void refine_finish_kernel(int N, const double*
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RefineLayout {
-    size_t xb0, xb1, y, s, g, ep, lam, norm, partial, status, total;
+    size_t xb0, xb1, y, s, g, ep, lam, norm, partial, status, npart, total;
 };
 
 RefineLayout rlayout(int64_t n, int64_t batch) {
@@ -328,6 +328,7 @@ RefineLayout rlayout(int64_t n, int64_t batch) {
     L.norm = off; off += align256((size_t)batch * sizeof(double));
     L.partial = off; off += align256((size_t)(batch * RF_WGS * 5) * sizeof(double));
     L.status = off; off += align256((size_t)batch * sizeof(int));
+    L.npart = off; off += align256((size_t)nbx_gemm_small_norm_doubles(n, n, batch) * sizeof(double));
     L.total = off;
     return L;
 }
@@ -354,6 +355,8 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
     double* norm = reinterpret_cast<double*>(base + L.norm);
     double* partial = reinterpret_cast<double*>(base + L.partial);
     int* status = reinterpret_cast<int*>(base + L.status);
+    double* npart = reinterpret_cast<double*>(base + L.npart);
+    const int norm_tiles = (int)(nbx_cdiv(n, 16) * nbx_cdiv(n, 16));
     const int64_t n2 = n * n;
     const bool small = nbx_gemm_small_supported(n, n, n, batch);
     for (int it = 0; it < max_iter; ++it) {
@@ -365,9 +368,11 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
         int rc = nbx_gemm_gated(ctx, 'N', 'N', n, n, n, 1.0, d_a, n, n2, src, n, n2, 0.0, y, n, n2, batch, gate, 0, 0);
         if (rc != NBX_OK) return rc;
         if (small) {
-            // S = X^T Y and G = X^T X in one launch (they share op(A) = X^T)
+            // S = X^T Y and G = X^T X in one launch (they share op(A) = X^T), which also leaves the
+            // squared norms the E kernel needs (||S||_F then stands in for ||A||_F: X is orthonormal
+            // to rounding, it is the previous solve's result)
             rc = nbx_gemm_small_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, y, n, n2, 0.0, s, n, n2, batch, gate, 0, 0,
-                                      src, g);
+                                      src, g, npart);
             if (rc != NBX_OK) return rc;
         } else {
             rc = nbx_gemm_gated(ctx, 'T', 'N', n, n, n, 1.0, src, n, n2, y, n, n2, 0.0, s, n, n2, batch, gate, 0, 0);
@@ -377,7 +382,8 @@ int nbx_eigh_refine(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, c
         }
         hipLaunchKernelGGL(refine_e_kernel, dim3(RF_WGS, (unsigned)batch), dim3(RF_THREADS),
                            (size_t)(n + 3 * (RF_THREADS / 64) + 8) * sizeof(double), ctx->stream, (int)n, d_a, s, g, ep,
-                           lam, status, norm, it, max_iter, partial, ctx->d_counters);
+                           lam, status, norm, it, max_iter, partial, ctx->d_counters, static_cast<int*>(nullptr),
+                           small ? npart : static_cast<const double*>(nullptr), norm_tiles);
         NBX_LAUNCH_CHECK();
         rc = nbx_gemm_gated(ctx, 'N', 'N', n, n, n, 1.0, src, n, n2, ep, n, n2, 0.0, dst, n, n2, batch, status, 0, it + 1);
         if (rc != NBX_OK) return rc;
