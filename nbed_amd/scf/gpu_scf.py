@@ -21,7 +21,7 @@ import numpy as np
 
 from ..backend import get_backend
 from ..dist import Shards
-from .pyscf_compat import RHF, UHF
+from .pyscf_compat import RHF, UHF, UKS
 
 
 class Mole:
@@ -283,7 +283,7 @@ class GpuUHF(_GpuSCF, UHF):
 
         be = self.be
         patched = any(k in vars(self) for k in ("get_veff", "get_occ", "make_rdm1", "get_fock"))
-        if not patched and all(hasattr(be, a) for a in ("huz_cycle_scalars_async", "density_occ", "vo_sumsq",
+        if not patched and self._device_kernel_ok and all(hasattr(be, a) for a in ("huz_cycle_scalars_async", "density_occ", "vo_sumsq",
                                                        "async_to_host")):
             return self._kernel_device(dm0)
         h1e = np.asarray(self.get_hcore())  # possibly patched by the driver: evaluated once
@@ -293,10 +293,7 @@ class GpuUHF(_GpuSCF, UHF):
         dm_d = be.asarray(self.get_init_guess() if dm0 is None else np.asarray(dm0))
 
         def fock_and_energy(dm_dev):
-            jk = self.jk_device(dm_dev)
-            fock, vhf = be.fock_uhf(h_d, None, jk)
-            e1 = be.trace_prod(h_d, dm_dev).sum()
-            e2 = 0.5 * be.trace_prod(vhf, dm_dev).sum()
+            fock, e1, e2 = self._fock_energy_device(h_d, dm_dev)
             return fock, float(e1 + e2 + self.energy_nuc()), float(e1), float(e2)
 
         fock, e_tot, e1, e2 = fock_and_energy(dm_d)
@@ -330,6 +327,17 @@ class GpuUHF(_GpuSCF, UHF):
         self.e_tot = e_tot
         self.scf_summary["e1"], self.scf_summary["e2"] = e1, e2
         return e_tot
+
+    _device_kernel_ok = True  # the look-ahead loop below assumes veff = J - K[x] (Hartree-Fock)
+
+    def _fock_energy_device(self, h_d, dm_dev):
+        """(fock, e1, e2) of a two-spin density on the device: F = h + J - K[x], e1 = tr(h D),
+        e2 = 1/2 tr(vhf D) (PySCF uhf.energy_elec)."""
+        be = self.be
+        fock, vhf = be.fock_uhf(h_d, None, self.jk_device(dm_dev))
+        e1 = be.trace_prod(h_d, dm_dev).sum()
+        e2 = 0.5 * be.trace_prod(vhf, dm_dev).sum()
+        return fock, float(e1), float(e2)
 
     def _kernel_device(self, dm0=None):
         """The same control flow with nothing in a cycle waiting for the host (HIP backend): CDIIS,
@@ -429,6 +437,95 @@ class GpuUHF(_GpuSCF, UHF):
             g.append(fmo_h[x][~occ][:, occ].ravel())
         g = np.hstack(g)
         return float(np.linalg.norm(g) / np.sqrt(max(g.size, 1)))
+
+
+class TaggedVeff(np.ndarray):
+    """ndarray carrying ``.ecoul`` / ``.exc`` / ``.vj`` / ``.vk`` like the tagged array PySCF's
+    Kohn-Sham ``get_veff`` returns (read at nbed/scf/huzinaga_scf.py:55-56, nbed/driver.py:361-365)."""
+
+    ecoul = exc = vj = vk = None
+
+
+class GpuUKS(GpuUHF, UKS):
+    """Unrestricted Kohn-Sham object over dense S, hcore, (pq|rs): what the reference builds as
+    ``dft.UKS`` (nbed/driver.py:163,303) and hands to ``huzinaga_scf`` (KS branch,
+    nbed/scf/huzinaga_scf.py:36-62,176-180), ``_subsystem_dft`` (:315-431) and the embedding
+    potential (:845-852).  The Coulomb and exact-exchange parts are libnbx J/K builds,
+
+        veff[x] = J - hyb K[x] + v_xc[x],   ecoul = 1/2 tr(D_tot J),
+        exc     = E_xc[D] - hyb/2 sum_x tr(D[x] K[x]),
+
+    and the semi-local part (E_xc, v_xc) comes from ``xc_provider(dm (2,N,N)) -> (E_xc, v_xc (2,N,N))``
+    (``nbed_amd.xc``; None = no semi-local part, i.e. a pure exact-exchange hybrid: with hyb = 1
+    this object is Hartree-Fock with Kohn-Sham bookkeeping)."""
+
+    _device_kernel_ok = False
+
+    def __init__(self, mol, ovlp, hcore, eri=None, backend=None, shards=None, xc="hf", hyb=1.0, xc_provider=None):
+        super().__init__(mol, ovlp, hcore, eri, backend=backend, shards=shards)
+        self.xc = xc
+        self.hyb = float(hyb)
+        self.xc_provider = xc_provider
+
+    def _veff_parts_device(self, dm_d):
+        """(veff (2,N,N) device, ecoul, exc, jk (3,N,N) device) of a two-spin density."""
+        be = self.be
+        jk = self.jk_device(dm_d)
+        veff = be.copy(jk[1:])
+        for x in range(2):  # veff[x] = J - hyb K[x]
+            be.axpby(1.0, jk[0], -self.hyb, veff[x])
+        tr_j = be.trace_prod(jk[0], dm_d[0]) + be.trace_prod(jk[0], dm_d[1])
+        ecoul = 0.5 * float(tr_j)
+        exc = -0.5 * self.hyb * float(be.trace_prod(jk[1:], dm_d).sum())
+        if self.xc_provider is not None:
+            e_sl, v_sl = self.xc_provider(be.to_host(dm_d))
+            exc += float(e_sl)
+            be.axpby(1.0, be.asarray(np.asarray(v_sl)), 1.0, veff)
+        return veff, ecoul, exc, jk
+
+    def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
+        dm = self.make_rdm1() if dm is None else np.asarray(dm)
+        if dm.ndim == 2:
+            dm = np.array((dm * 0.5, dm * 0.5))
+        veff, ecoul, exc, jk = self._veff_parts_device(self.be.asarray(dm))
+        out = self.be.to_host(veff).view(TaggedVeff)
+        jk_h = self.be.to_host(jk)
+        out.ecoul, out.exc, out.vj, out.vk = ecoul, exc, jk_h[0], jk_h[1:]
+        return out
+
+    def get_veff_device(self, dm_d):
+        return self._veff_parts_device(dm_d)[0]
+
+    def fused_fock_available(self, hv_d) -> bool:
+        return False  # the fused build assembles the Hartree-Fock F = h + J - K[x]
+
+    def fock_device(self, dm_d, hv_d, dts_ready: bool = False):
+        veff = self.get_veff_device(dm_d)
+        fock = self.be.copy(hv_d)
+        self.be.axpby(1.0, veff, 1.0, fock)
+        return fock, veff
+
+    def _fock_energy_device(self, h_d, dm_dev):
+        be = self.be
+        veff, ecoul, exc, _ = self._veff_parts_device(dm_dev)
+        fock = be.copy(h_d)
+        be.axpby(1.0, veff, 1.0, fock)
+        return fock, float(be.trace_prod(h_d, dm_dev).sum()), ecoul + exc
+
+    def energy_elec(self, dm=None, h1e=None, vhf=None):
+        """PySCF ``uks.energy_elec``: e1 + ecoul + exc from the tagged veff."""
+        dm = self.make_rdm1() if dm is None else np.asarray(dm)
+        if dm.ndim == 2:
+            dm = np.array((dm * 0.5, dm * 0.5))
+        h1e = self.get_hcore() if h1e is None else np.asarray(h1e)
+        if h1e.ndim == 2:
+            h1e = np.array((h1e, h1e))
+        if vhf is None or getattr(vhf, "ecoul", None) is None:
+            vhf = self.get_veff(self.mol, dm)
+        e1 = float(self.be.trace_prod(self.be.asarray(h1e), self.be.asarray(dm)).sum())
+        e2 = float(vhf.ecoul + vhf.exc)
+        self.scf_summary.update(e1=e1, coul=float(vhf.ecoul), exc=float(vhf.exc), e2=e2)
+        return e1 + e2, e2
 
 
 class GpuRHF(_GpuSCF, RHF):

@@ -97,7 +97,7 @@ def calculate_ks_energy(scf_method, embedding_potential, density_matrix, huzinag
 
 def _is_fused(scf_method) -> bool:
     """GpuUHF with the class's own get_veff/get_hcore/get_occ (no instance monkey patches)."""
-    if not isinstance(scf_method, GpuUHF):
+    if not isinstance(scf_method, GpuUHF) or is_ks(scf_method):
         return False
     d = vars(scf_method)
     return not any(k in d for k in ("get_veff", "get_hcore", "get_occ", "make_rdm1"))

@@ -40,6 +40,17 @@ def get_huzinaga_operator(fock, dm_occ_s, dm_virt_s):
     return huz_occ + huz_virt
 
 
+def calculate_ks_energy(scf_method, embedding_potential, density_matrix, huzinaga_op_occ):
+    """nbed/scf/huzinaga_scf.py:36-62: E_coul + E_xc of the NEW density (a second get_veff) plus
+    tr[D (hcore + Hz + V_emb)] -- one value per spin for 3-D input."""
+    vhf_updated = scf_method.get_veff(dm=density_matrix)
+    energy = vhf_updated.ecoul + vhf_updated.exc
+    energy = energy + np.einsum(
+        "...ij,...ji->...", density_matrix, scf_method.get_hcore() + huzinaga_op_occ + embedding_potential
+    )
+    return energy
+
+
 def huzinaga_scf(
     scf_method,
     embedding_potential,
@@ -51,7 +62,7 @@ def huzinaga_scf(
     exact_power=False,
     history=None,
 ):
-    """nbed/scf/huzinaga_scf.py:93-206 (HF branch; ``:181-185``).
+    """nbed/scf/huzinaga_scf.py:93-206 (HF branch ``:181-185``; KS branch ``:176-180``).
 
     ``history`` (optional list) receives (energy, dm_diff) per cycle.
     ``exact_power`` switches S^-1/2 to scipy's fractional_matrix_power.
@@ -96,7 +107,9 @@ def huzinaga_scf(
         dm_mat_old = density_matrix
         density_matrix = scf_method.make_rdm1(mo_coeff=mo_coeff_std, mo_occ=mo_occ)
 
-        if isinstance(scf_method, (ToyRHF, ToyUHF)) or getattr(scf_method, "_is_hf", False):
+        if getattr(scf_method, "_is_ks", False):  # isinstance(..., (RKS, UKS)) is tested first (:176)
+            scf_energy = calculate_ks_energy(scf_method, embedding_potential, density_matrix, huzinaga_op)
+        elif isinstance(scf_method, (ToyRHF, ToyUHF)) or getattr(scf_method, "_is_hf", False):
             hamiltonian = scf_method.get_hcore() + embedding_potential + 0.5 * vhf + huzinaga_op
             scf_energy = np.einsum("...ij,...ji->...", hamiltonian, density_matrix)
         else:

@@ -355,6 +355,32 @@ class ToyUHF(_SCFBase):
         return np.hstack(gs)
 
 
+class TaggedArray(np.ndarray):
+    """ndarray carrying .ecoul / .exc like PySCF's tagged Kohn-Sham veff."""
+
+    ecoul = exc = None
+
+
+class ToyUKS(ToyUHF):
+    """Unrestricted Kohn-Sham object whose functional is a fraction ``hyb`` of exact exchange:
+    veff[x] = J - hyb K[x], ecoul = 1/2 tr(Dtot J), exc = -hyb/2 sum_x tr(D[x] K[x]) -- what
+    tests/golden/make_golden.py hands to the reference's KS branch
+    (nbed/scf/huzinaga_scf.py:36-62,176-180) in place of a B3LYP ``dft.UKS``."""
+
+    hyb = 0.2
+    _is_ks = True
+
+    def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0):
+        dm = self.make_rdm1() if dm is None else np.asarray(dm)
+        if dm.ndim == 2:
+            dm = np.array((dm * 0.5, dm * 0.5))
+        vj, vk = get_jk(self._eri, dm)
+        v = (vj[0] + vj[1] - self.hyb * vk).view(TaggedArray)
+        v.ecoul = 0.5 * float(np.einsum("ij,ji->", vj[0] + vj[1], dm[0] + dm[1]))
+        v.exc = -0.5 * self.hyb * float(np.einsum("xij,xji->", vk, dm))
+        return v
+
+
 class ToyRHF(_SCFBase):
     """Restricted SCF object (2-D arrays), for the 2-D branches of the path."""
 

@@ -130,6 +130,26 @@ class RefRHF(StubRHF, ToyRHF):
     pass
 
 
+class TaggedArray(np.ndarray):
+    """ndarray carrying .ecoul / .exc, as PySCF's tagged Kohn-Sham veff does."""
+
+
+class RefUKS(StubUKS, ToyUHF):
+    """Toy unrestricted Kohn-Sham object for the reference's KS branch (huzinaga_scf.py:36-62,
+    176-180): a hybrid whose only exchange-correlation is a fraction ``hyb`` of exact exchange,
+    veff[x] = J - hyb K[x], ecoul = 1/2 tr(Dtot J), exc = -hyb/2 sum_x tr(D[x] K[x])."""
+
+    hyb = 0.2
+
+    def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0):
+        dm = self.make_rdm1() if dm is None else np.asarray(dm)
+        vj, vk = self.get_jk(mol, dm)
+        v = (vj[0] + vj[1] - self.hyb * vk).view(TaggedArray)
+        v.ecoul = 0.5 * float(np.einsum("ij,ji->", vj[0] + vj[1], dm[0] + dm[1]))
+        v.exc = -0.5 * self.hyb * float(np.einsum("xij,xji->", vk, dm))
+        return v
+
+
 def canon_sign(c):
     """Flip each column so that its largest-|component| is positive (gauge fix)."""
     c = np.array(c, copy=True)
@@ -212,6 +232,24 @@ def main():
          nao=n, nelec=np.array(pr["nelec"]), max_cycle=60, conv_tol=1e-9, S=pr["S"], hcore=pr["hcore"],
          V_emb=pr["V_emb"][0], D_env=2 * pr["D_env"][0], mo_coeff_canon=canon_sign(c), mo_energy=e,
          dm=d, huz_op=hz, conv=conv)
+
+    # Kohn-Sham branch (:176-180 -> calculate_ks_energy :36-62: a second get_veff per cycle)
+    from nbed.scf.huzinaga_scf import calculate_ks_energy
+
+    for tag, n, nocc, n_env, diis, cyc in [("uks_n12_diis", 12, (4, 4), 1, True, 60),
+                                           ("uks_n24_nodiis_open", 24, (6, 5), 2, False, 80)]:
+        pr = synth.problem(n, nocc, n_env)
+        eri = synth.eri_dense(n)
+        ks = RefUKS(ToyMol(n, pr["nelec"], e_nuc=1.25), pr["S"], pr["hcore"], eri)
+        ks.max_cycle, ks.conv_tol = cyc, 1e-9
+        c, e, d, hz, conv = huzinaga_scf(ks, pr["V_emb"], pr["D_env"], use_DIIS=diis)
+        e_ks = calculate_ks_energy(ks, pr["V_emb"], d, hz)
+        save(f"huzinaga_scf_{tag}", "nbed/scf/huzinaga_scf.py:93-206 huzinaga_scf (UKS branch :176-180) + "
+             ":36-62 calculate_ks_energy; toy hybrid functional = 0.2 exact exchange",
+             ["pyscf.lib.diis.DIIS"] if diis else [],
+             nao=n, nelec=np.array(pr["nelec"]), n_env=n_env, max_cycle=cyc, conv_tol=1e-9, hyb=RefUKS.hyb,
+             use_DIIS=diis, S=pr["S"], hcore=pr["hcore"], V_emb=pr["V_emb"], D_env=pr["D_env"],
+             mo_coeff_canon=canon_sign(c), mo_energy=e, dm=d, huz_op=hz, conv=conv, e_ks=np.asarray(e_ks))
 
     # ------------------------------------------------------------------ 3. energy_elec
     mf, pr, eri = make_uhf(12, (4, 4), 1, 10, 1e-9)
@@ -397,7 +435,13 @@ def main():
          classical_energy=res["classical_energy"], hf_emb=res["hf_emb"], const=const,
          h1_abs=np.abs(b1), h2_abs=np.abs(b2))
 
-    (HERE / "MANIFEST.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
+    # entries written by other generators (make_water_integrals.py) are kept
+    mpath = HERE / "MANIFEST.json"
+    if mpath.exists():
+        for name, meta in json.loads(mpath.read_text()).items():
+            if name not in manifest and (HERE / f"{name}.npz").exists():
+                manifest[name] = meta
+    mpath.write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
     print("wrote", len(manifest), "fixtures to", HERE)
 
 

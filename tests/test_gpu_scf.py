@@ -57,6 +57,31 @@ def test_huzinaga_scf_restricted_golden(be):
     np.testing.assert_allclose(hz, g["huz_op"], rtol=0, atol=1e-8)
 
 
+@pytest.mark.parametrize("tag", ["uks_n12_diis", "uks_n24_nodiis_open"])
+def test_huzinaga_scf_kohn_sham_branch_golden(be, tag):
+    """KS branch (nbed/scf/huzinaga_scf.py:176-180 + calculate_ks_energy :36-62) on libnbx: GpuUKS
+    (J and the exact-exchange fraction from the HIP J/K kernels, tagged veff) against the reference's
+    own run of that branch on the same toy hybrid functional."""
+    from nbed_amd.scf import GpuUKS, Mole, calculate_ks_energy, huzinaga_scf
+
+    g = load_golden(f"huzinaga_scf_{tag}")
+    n = int(g["nao"])
+    ks = GpuUKS(Mole(n, tuple(g["nelec"])), g["S"], g["hcore"], be.synth_eri(n), backend=be, xc="toy-hybrid",
+                hyb=float(g["hyb"]))
+    ks.max_cycle, ks.conv_tol = int(g["max_cycle"]), float(g["conv_tol"])
+    hist = []
+    c, e, d, hz, conv = huzinaga_scf(ks, g["V_emb"], g["D_env"], use_DIIS=bool(g["use_DIIS"]), history=hist)
+    assert conv == bool(g["conv"])
+    tol = 1e-8 if bool(g["use_DIIS"]) else 1e-9
+    np.testing.assert_allclose(e, g["mo_energy"], rtol=0, atol=tol)
+    np.testing.assert_allclose(d, g["dm"], rtol=0, atol=tol)
+    np.testing.assert_allclose(hz, g["huz_op"], rtol=0, atol=tol)
+    np.testing.assert_allclose(canon_sign(c), g["mo_coeff_canon"], rtol=0, atol=1e-7)
+    assert hist[-1][0].shape == (2,)
+    e_ks = calculate_ks_energy(ks, g["V_emb"], g["dm"], g["huz_op"])
+    np.testing.assert_allclose(e_ks, g["e_ks"], rtol=0, atol=1e-10)
+
+
 @pytest.mark.parametrize("n,nocc,n_env", [(48, (10, 10), 4), (64, (12, 11), 5)])
 def test_huzinaga_scf_vs_oracle_converged(be, n, nocc, n_env):
     """Both sides converged tightly: embedded energy within 1e-8 Ha (north_star), projector

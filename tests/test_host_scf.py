@@ -8,11 +8,11 @@ import pytest
 
 from conftest import canon_sign, load_golden
 from oracle import synth
-from oracle.pyscf_like import ToyMol, ToyRHF, ToyUHF
+from oracle.pyscf_like import ToyMol, ToyRHF, ToyUHF, ToyUKS
 from oracle_backend import OracleBackend
 
-from nbed_amd.scf import GpuUHF, Mole, energy_elec, get_huzinaga_operator, huzinaga_scf
-from nbed_amd.scf.pyscf_compat import RHF, UHF
+from nbed_amd.scf import GpuUHF, GpuUKS, Mole, calculate_ks_energy, energy_elec, get_huzinaga_operator, huzinaga_scf
+from nbed_amd.scf.pyscf_compat import RHF, UHF, UKS
 
 
 class ForeignUHF(UHF, ToyUHF):
@@ -82,6 +82,66 @@ def test_huzinaga_scf_restricted_generic_path(be):
     np.testing.assert_allclose(e, g["mo_energy"], rtol=0, atol=1e-8)
     np.testing.assert_allclose(d, g["dm"], rtol=0, atol=1e-8)
     np.testing.assert_allclose(hz, g["huz_op"], rtol=0, atol=1e-8)
+
+
+class ForeignUKS(UKS, ToyUKS):
+    """A numpy Kohn-Sham object NOT from this package (tagged veff with .ecoul/.exc)."""
+
+
+@pytest.mark.parametrize("tag", ["uks_n12_diis", "uks_n24_nodiis_open"])
+@pytest.mark.parametrize("own", [True, False])
+def test_huzinaga_scf_kohn_sham_branch_matches_reference(be, tag, own):
+    """KS branch of the loop (nbed/scf/huzinaga_scf.py:176-180) and calculate_ks_energy (:36-62)
+    against the reference's run: the product's GpuUKS (J/K from the backend, hyb exact exchange)
+    and a foreign numpy KS object through the protocol path."""
+    g = load_golden(f"huzinaga_scf_{tag}")
+    n = int(g["nao"])
+    eri = synth.eri_dense(n)
+    if own:
+        ks = GpuUKS(Mole(n, tuple(g["nelec"])), g["S"], g["hcore"], eri, backend=be, xc="toy-hybrid", hyb=float(g["hyb"]))
+    else:
+        ks = ForeignUKS(ToyMol(n, tuple(g["nelec"])), g["S"], g["hcore"], eri)
+        ks.hyb = float(g["hyb"])
+    ks.max_cycle, ks.conv_tol = int(g["max_cycle"]), float(g["conv_tol"])
+    hist = []
+    c, e, d, hz, conv = huzinaga_scf(ks, g["V_emb"], g["D_env"], use_DIIS=bool(g["use_DIIS"]), backend=be, history=hist)
+    assert conv == bool(g["conv"])
+    tol = 1e-8 if bool(g["use_DIIS"]) else 1e-9
+    np.testing.assert_allclose(e, g["mo_energy"], rtol=0, atol=tol)
+    np.testing.assert_allclose(d, g["dm"], rtol=0, atol=tol)
+    np.testing.assert_allclose(hz, g["huz_op"], rtol=0, atol=tol)
+    np.testing.assert_allclose(canon_sign(c), g["mo_coeff_canon"], rtol=0, atol=1e-7)
+    assert hist[-1][0].shape == (2,)  # one KS energy per spin component, as the reference's einsum gives
+    e_ks = calculate_ks_energy(ks, g["V_emb"], g["dm"], g["huz_op"], backend=be)
+    np.testing.assert_allclose(e_ks, g["e_ks"], rtol=0, atol=1e-10)
+
+
+def test_gpu_uks_protocol(be):
+    """GpuUKS.get_veff tags (.ecoul/.exc/.vj/.vk), energy_elec and kernel() against the oracle's ToyUKS."""
+    n = 12
+    pr = synth.problem(n, (4, 3), 0)
+    eri = synth.eri_dense(n)
+    ks = GpuUKS(Mole(n, (4, 3), e_nuc=0.5), pr["S"], pr["hcore"], eri, backend=be, xc="toy-hybrid", hyb=0.2)
+    ref = ToyUKS(ToyMol(n, (4, 3), e_nuc=0.5), pr["S"], pr["hcore"], eri)
+    dm = ref.get_init_guess()
+    v, rv = ks.get_veff(dm=dm), ref.get_veff(dm=dm)
+    np.testing.assert_allclose(np.asarray(v), np.asarray(rv), rtol=0, atol=1e-12)
+    assert abs(v.ecoul - rv.ecoul) < 1e-11 and abs(v.exc - rv.exc) < 1e-11
+    assert v.vj.shape == (n, n) and v.vk.shape == (2, n, n)
+    e_el, e2 = ks.energy_elec(dm)
+    assert abs(e2 - (rv.ecoul + rv.exc)) < 1e-11
+    assert abs(e_el - (np.einsum("ij,xji->", pr["hcore"], dm) + rv.ecoul + rv.exc)) < 1e-10
+    ks.conv_tol = 1e-10
+    e_tot = ks.kernel()
+    assert ks.converged
+    d = ks.make_rdm1()
+    rv = ref.get_veff(dm=d)
+    assert abs(e_tot - (np.einsum("ij,xji->", pr["hcore"], d) + rv.ecoul + rv.exc + 0.5)) < 1e-8
+    # stationary: the converged density diagonalises its own Kohn-Sham matrix
+    f = pr["hcore"] + np.asarray(rv)
+    for x in range(2):
+        comm = f[x] @ d[x] @ pr["S"] - pr["S"] @ d[x] @ f[x]
+        assert np.max(np.abs(comm)) < 1e-5
 
 
 def test_huzinaga_scf_rejects_unknown_objects(be):

@@ -13,7 +13,7 @@ import pytest
 
 from conftest import GOLDEN, canon_sign, load_golden
 from oracle import embed, hamiltonian, huzinaga, localize, synth
-from oracle.pyscf_like import ToyMol, ToyRHF, ToyUHF
+from oracle.pyscf_like import ToyMol, ToyRHF, ToyUHF, ToyUKS
 
 TOL = dict(rtol=0, atol=1e-11)
 
@@ -73,6 +73,31 @@ def test_huzinaga_scf_rhf():
     np.testing.assert_allclose(e, g["mo_energy"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(d, g["dm"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(hz, g["huz_op"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["uks_n12_diis", "uks_n24_nodiis_open"])
+def test_huzinaga_scf_uks_branch(tag):
+    """The Kohn-Sham branch (huzinaga_scf.py:176-180, calculate_ks_energy :36-62) against the
+    reference's own run on a toy hybrid functional (tagged veff with .ecoul/.exc)."""
+    g = load_golden(f"huzinaga_scf_{tag}")
+    n = int(g["nao"])
+    ks = ToyUKS(ToyMol(n, tuple(g["nelec"])), g["S"], g["hcore"], synth.eri_dense(n))
+    ks.hyb = float(g["hyb"])
+    ks.max_cycle, ks.conv_tol = int(g["max_cycle"]), float(g["conv_tol"])
+    calls = []
+    orig = ks.get_veff
+    ks.get_veff = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    hist = []
+    c, e, d, hz, conv = huzinaga.huzinaga_scf(ks, g["V_emb"], g["D_env"], use_DIIS=bool(g["use_DIIS"]), history=hist)
+    assert conv == bool(g["conv"])
+    assert len(calls) == 2 * len(hist)  # the KS branch costs a second get_veff per cycle (:55)
+    tol = 1e-8 if bool(g["use_DIIS"]) else 1e-9
+    np.testing.assert_allclose(e, g["mo_energy"], rtol=0, atol=tol)
+    np.testing.assert_allclose(d, g["dm"], rtol=0, atol=tol)
+    np.testing.assert_allclose(hz, g["huz_op"], rtol=0, atol=tol)
+    e_ks = huzinaga.calculate_ks_energy(ks, g["V_emb"], g["dm"], g["huz_op"])
+    assert e_ks.shape == (2,)
+    np.testing.assert_allclose(e_ks, g["e_ks"], rtol=0, atol=1e-11)
 
 
 def test_energy_elec():
