@@ -73,6 +73,7 @@ class HipBackend:
     """libnbx on one MI355X."""
 
     name = "hip"
+    _PIN_SLOTS, _PIN_WIDTH = 256, 4 + 64  # 4 scalars + up to 64 status words (nbx_huz_cycle_scalars_dev)
 
     def __init__(self, device: int | None = None):
         import torch
@@ -91,6 +92,13 @@ class HipBackend:
         _nbx.check(self.lib, self.lib.nbx_ctx_create(self.device_index, ctypes.c_void_p(stream), 0, ctypes.byref(ctx)))
         self.ctx = ctx
         self._work: dict[str, object] = {}
+        # result slots for kernels that store straight into host memory (huz_cycle_scalars_async): a ring
+        # owned by the backend for its whole life, so that a handle dropped before its kernel ran
+        # (look-ahead cycles discarded after convergence) can never leave a queued kernel writing
+        # into memory the pinned allocator has handed to someone else.  A slot is reused after
+        # _PIN_SLOTS further calls; the SCF loops read a handle one call late.
+        self._pin_ring = torch.empty((self._PIN_SLOTS, self._PIN_WIDTH), dtype=torch.float64, pin_memory=True)
+        self._pin_next = 0
 
     def __del__(self):
         try:
@@ -143,6 +151,11 @@ class HipBackend:
         bufs = [torch.empty(chunk, dtype=torch.float64, pin_memory=True) for _ in range(nbuf)]
         events = [None] * nbuf
         stream = torch.cuda.Stream(device=self.device)
+        # ``out`` may be a block the caching allocator handed back while kernels queued on the compute
+        # stream still use it: the copy stream starts behind them, and the block is marked as in use
+        # on it
+        stream.wait_stream(torch.cuda.current_stream(self.device_index))
+        out.record_stream(stream)
         nchunks = (n + chunk - 1) // chunk
         with ThreadPoolExecutor(threads) as pool:
             for k in range(nchunks):
@@ -274,14 +287,18 @@ class HipBackend:
         out.narrow(axis, 0, a.shape[axis]).copy_(a)
         return out
 
-    def all_gather_stack(self, a, group=None):
-        """RCCL all-gather of equal-shaped pieces -> (world, *a.shape)."""
+    def all_gather_stack(self, a, group=None, out=None):
+        """RCCL all-gather of equal-shaped pieces -> (world, *a.shape).  ``out``: a contiguous tensor
+        of world * a.numel() elements to receive the pieces (no allocation in the caller's loop)."""
         import torch.distributed as dist
 
         world = dist.get_world_size(group)
         a = a.contiguous()
         # output in the concatenated form (world * n0, ...): the one every backend accepts
-        out = self.empty((world * a.shape[0],) + tuple(a.shape[1:]))
+        if out is None:
+            out = self.empty((world * a.shape[0],) + tuple(a.shape[1:]))
+        else:
+            out = out.view((world * a.shape[0],) + tuple(a.shape[1:]))
         dist.all_gather_into_tensor(out, a, group=group)
         return out.view((world,) + tuple(a.shape))
 
@@ -502,7 +519,10 @@ class HipBackend:
         ntail = 0 if extra is None else int(extra.numel())
         # the kernel's last workgroup stores the results straight into pinned host memory: no copy
         # (a device-to-host copy per cycle costs a launch and a cache flush in the middle of the chain)
-        h_out = self.torch.empty(4 + ntail, dtype=self.torch.float64, pin_memory=True)
+        if ntail > self._PIN_WIDTH - 4:
+            raise ValueError("huz_cycle_scalars_async: at most 64 status words")
+        h_out = self._pin_ring[self._pin_next][: 4 + ntail]
+        self._pin_next = (self._pin_next + 1) % self._PIN_SLOTS
         # ``dts``: a table from jk_dts_new() that the kernel fills with Dtot' of ``dm`` for the next
         # packed J/K build
         self._call("nbx_huz_cycle_scalars_dts", nao, self._p(hcore), hcore.dim(), self._p(vemb), self._p(vhf),
@@ -633,27 +653,32 @@ class HipBackend:
         return s, vt
 
     # ------------------------------------------------------------------ four-index transform
-    def ao2mo(self, eri, c1, c2, c3, c4, i0: int = 0, i1: int | None = None):
+    def ao2mo(self, eri, c1, c2, c3, c4, i0: int = 0, i1: int | None = None, out=None):
         """(i1-i0, n2, n3, n4) chemist-order MO integrals (nbx_ao2mo)."""
         nao = c1.shape[0]
         n1, n2, n3, n4 = c1.shape[1], c2.shape[1], c3.shape[1], c4.shape[1]
         i1 = n1 if i1 is None else i1
         nbytes = self.lib.nbx_ao2mo_worksize(nao, i1 - i0, n2, n3, n4)
         work = self._workspace("ao2mo", nbytes)
-        out = self.empty((i1 - i0, n2, n3, n4))
+        if out is None:
+            out = self.empty((i1 - i0, n2, n3, n4))
+        elif tuple(out.shape) != (i1 - i0, n2, n3, n4):
+            raise ValueError("ao2mo: output tensor has the wrong shape")
         self._call("nbx_ao2mo", nao, self._p(eri), self._p(c1), n1, i0, i1, self._p(c2), n2, self._p(c3), n3,
                    self._p(c4), n4, self._p(out), self._p(work), work.numel())
         return out
 
-    def ao2mo_pair(self, eri, c1, c2, c3, c4, c5, c6, i0: int = 0, i1: int | None = None):
+    def ao2mo_pair(self, eri, c1, c2, c3, c4, c5, c6, i0: int = 0, i1: int | None = None, out=None, out2=None):
         """((C1 C2|C3 C4), (C1 C2|C5 C6)) in one pass: quarters 1-2 shared (nbx_ao2mo_pair)."""
         nao = c1.shape[0]
         n1, n2, n3, n4, n5, n6 = (c.shape[1] for c in (c1, c2, c3, c4, c5, c6))
         i1 = n1 if i1 is None else i1
         nbytes = self.lib.nbx_ao2mo_pair_worksize(nao, i1 - i0, n2, n4, n6)
         work = self._workspace("ao2mo", nbytes)
-        out = self.empty((i1 - i0, n2, n3, n4))
-        out2 = self.empty((i1 - i0, n2, n5, n6))
+        out = self.empty((i1 - i0, n2, n3, n4)) if out is None else out
+        out2 = self.empty((i1 - i0, n2, n5, n6)) if out2 is None else out2
+        if tuple(out.shape) != (i1 - i0, n2, n3, n4) or tuple(out2.shape) != (i1 - i0, n2, n5, n6):
+            raise ValueError("ao2mo_pair: output tensor has the wrong shape")
         self._call("nbx_ao2mo_pair", nao, self._p(eri), self._p(c1), n1, i0, i1, self._p(c2), n2, self._p(c3), n3,
                    self._p(c4), n4, self._p(out), self._p(c5), n5, self._p(c6), n6, self._p(out2), self._p(work),
                    work.numel())
@@ -665,11 +690,12 @@ class HipBackend:
         self._call("nbx_eri_pack_rs", nao, self._p(eri), self._p(out))
         return out
 
-    def ao2mo_pair_sym(self, eri, c12, c3, c4, c5=None, c6=None, rs_packed: bool = False):
+    def ao2mo_pair_sym(self, eri, c12, c3, c4, c5=None, c6=None, rs_packed: bool = False, out=None, out2=None):
         """(C12 C12|C3 C4) [and (C12 C12|C5 C6)] over the whole outer range with (ij|kl) = (ji|kl):
         quarters 3-4 on the pairs j <= i only (nbx_ao2mo_pair_sym).  ``rs_packed``: ``eri`` comes from
         eri_pack_rs and quarters 1-2 use (pq|rs) = (pq|sr) as well.  Equal to ao2mo / ao2mo_pair up
-        to rounding; the outputs are exactly symmetric in (i, j)."""
+        to rounding; the outputs are exactly symmetric in (i, j).  ``out`` / ``out2``: result tensors to
+        reuse (a caller that builds repeatedly keeps the 8 n^4-byte allocations out of its loop)."""
         nao, n = c12.shape
         n3, n4 = c3.shape[1], c4.shape[1]
         pair = c5 is not None
@@ -677,8 +703,12 @@ class HipBackend:
         name = "nbx_ao2mo_pair_sym_rs" if rs_packed else "nbx_ao2mo_pair_sym"
         nbytes = getattr(self.lib, name + "_worksize")(nao, n, n4, n6)
         work = self._workspace("ao2mo", nbytes)
-        out = self.empty((n, n, n3, n4))
-        out2 = self.empty((n, n, n5, n6)) if pair else None
+        if out is None:
+            out = self.empty((n, n, n3, n4))
+        if pair and out2 is None:
+            out2 = self.empty((n, n, n5, n6))
+        if tuple(out.shape) != (n, n, n3, n4) or (pair and tuple(out2.shape) != (n, n, n5, n6)):
+            raise ValueError("ao2mo_pair_sym: output tensor has the wrong shape")
         self._call(name, nao, self._p(eri), self._p(c12), n, self._p(c3), n3, self._p(c4), n4,
                    self._p(out), self._p(c5), n5, self._p(c6), n6, self._p(out2), self._p(work), work.numel())
         return (out, out2) if pair else out

@@ -11,6 +11,14 @@ One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).
 * four-index transform: the outer MO index i of (ij|kl) is partitioned; each rank
   transforms its slab against the full ERI; one all-gather of n^4/G doubles.
 
+* streamed four-index transform (N_AO = 2000: the integrals are generated in registers and never
+  stored): the AO index r of (pq|rs) is partitioned instead -- rank g generates and half-transforms
+  only the pairs (r in R_g, s <= r), so the hash evaluations and quarters 1-2 (94 % of the work)
+  divide by G -- and the ranks' partial (ij|kl) tensors are summed by one all-reduce of n^4 doubles
+  (``streamed_transform``).  north_star's outer-MO-index shards + all-gather would make every rank
+  generate ALL N^4/2 integrals and leave the quarter-1 GEMM n/G = 16 rows tall; an all-reduce is
+  a reduce-scatter over the outer MO index followed by exactly that all-gather.
+
 Everything else in a cycle (Huzinaga products, DIIS, eigensolve) is N^3 and replicated:
 it is deterministic, so every rank holds identical matrices.
 """
@@ -72,13 +80,43 @@ class Shards:
             return partial
         return be.all_reduce_sum(partial, self.group)
 
-    def all_gather(self, be, slab, axis: int = 0):
+    def all_gather(self, be, slab, axis: int = 0, out=None):
         """Concatenate every rank's ``slab`` (its ``lo:hi`` piece along ``axis``) into the
-        full-length array.  ``slab`` may be shorter than ``chunk`` on the last ranks."""
+        full-length array.  ``slab`` may be shorter than ``chunk`` on the last ranks.  ``out``: a
+        full-length tensor to gather into -- used when the shards are even and ``axis`` is the
+        leading one, where the gathered pieces ARE the result (no padding, no reshuffling copy)."""
         if self.world == 1 and not self.force_collective:
             return slab
         if self._cuts is not None:
             raise ValueError("all_gather needs uniform shards")
+        if out is not None and axis == 0 and self.n == self.chunk * self.world:
+            try:
+                be.all_gather_stack(slab, self.group, out=out)
+                return out
+            except TypeError:  # a backend whose all_gather_stack takes no ``out``
+                pass
         padded = be.pad_axis(slab, axis, self.chunk)
         gathered = be.all_gather_stack(padded, self.group)  # (world, ...)
         return be.unstack_concat(gathered, axis, self.n)
+
+
+def streamed_transform(be, nao: int, ca, cb=None, shards: Shards | None = None, seed: int = 20250829):
+    """Spin blocks of the active-space two-electron tensor from GENERATED (pq|rs) (BASELINE
+    configs[3]; stands in for the ao2mo.kernel calls of nbed/ham_builder.py:127-133 when a dense
+    tensor cannot exist): ``(aa|aa)`` alone, or ``((aa|aa), (aa|bb), (bb|bb))`` when ``cb`` is given.
+
+    ``shards``: a ``Shards(nao, world, rank, balance="triangular")`` over the AO index r -- a range
+    costs ~sum (r + 1), so equal-work ranges are not equal-length.  Each rank transforms its range
+    (``nbx_ao2mo_synth[_pair]``), then one all-reduce per tensor sums the partial results; every
+    rank returns the full tensors (the same bits on every rank)."""
+    sh = shards if shards is not None else Shards(nao, balance="triangular")
+    if sh.n != nao:
+        raise ValueError(f"shards partition range({sh.n}), the AO index has {nao} values")
+    if cb is None:
+        parts = (be.ao2mo_synth(nao, ca, ca, ca, ca, r0=sh.lo, r1=sh.hi, seed=seed),)
+    else:
+        aa, ab = be.ao2mo_synth_pair(nao, ca, ca, ca, ca, cb, cb, r0=sh.lo, r1=sh.hi, seed=seed)
+        bb = be.ao2mo_synth(nao, cb, cb, cb, cb, r0=sh.lo, r1=sh.hi, seed=seed)
+        parts = (aa, ab, bb)
+    parts = tuple(sh.all_reduce(be, t) for t in parts)
+    return parts[0] if cb is None else parts

@@ -78,16 +78,36 @@ class PySCFProvider:
         ks.kernel()
         return ks
 
-    def local_hf(self, config: NbedConfig, embedded_mol, backend=None):
-        """GPU-backed UHF object over the embedded molecule's AO integrals."""
+    def local_hf(self, config: NbedConfig, embedded_mol, backend=None, run_qmmm: bool = False):
+        """GPU-backed UHF object over the embedded molecule's AO integrals.  With ``run_qmmm`` the
+        core Hamiltonian carries the point-charge potential and ``energy_nuc()`` the MM-nuclear term,
+        both taken from the ``qmmm.mm_charge``-wrapped PySCF object the reference builds
+        (nbed/driver.py:246-253)."""
+        from pyscf import qmmm
         from pyscf import scf as pyscf_scf
 
         from .scf import GpuUHF
 
         s = embedded_mol.intor("int1e_ovlp")
-        h = pyscf_scf.hf.get_hcore(embedded_mol)
         eri = embedded_mol.intor("int2e", aosym="s1")
-        return GpuUHF(embedded_mol, s, h, eri, backend=backend)
+        if run_qmmm:
+            wrapped = qmmm.mm_charge(pyscf_scf.UHF(embedded_mol), config.mm_coords, config.mm_charges,
+                                     config.mm_radii)
+            h, e_nuc = wrapped.get_hcore(), float(wrapped.energy_nuc())
+        else:
+            h, e_nuc = pyscf_scf.hf.get_hcore(embedded_mol), None
+        local = GpuUHF(embedded_mol, s, h, eri, backend=backend)
+        if e_nuc is not None:
+            local.energy_nuc = lambda *args: e_nuc  # nuclear repulsion + nuclei-MM charges
+        return local
+
+
+    def init_guess(self, config: NbedConfig, local_scf):
+        """Starting density of the mu-shift SCF: PySCF's default 'minao' guess for the embedded
+        molecule (electron count already overwritten), as scf.UHF.kernel() would take it."""
+        from pyscf import scf as pyscf_scf
+
+        return np.asarray(pyscf_scf.uhf.init_guess_by_minao(local_scf.mol))
 
 
 class _TaggedVeff(np.ndarray):
@@ -161,9 +181,11 @@ class BuiltinHFProvider:
         ks.kernel()
         return ks
 
-    def local_hf(self, config: NbedConfig, embedded_mol, backend=None):
+    def local_hf(self, config: NbedConfig, embedded_mol, backend=None, run_qmmm: bool = False):
         from .scf import GpuUHF
 
+        if run_qmmm:
+            raise NbedDriverError("BuiltinHFProvider has no QM/MM point-charge integrals")
         ints = self._integrals(config)
         return GpuUHF(embedded_mol, ints["S"], ints["hcore"], ints["eri"], backend=backend)
 
@@ -266,7 +288,20 @@ class NbedDriver:
         return mol
 
     def _init_local_hf(self):
-        local_hf = self.provider.local_hf(self.config, self._init_embedded_mol(), backend=self.be)
+        """Embedded HF object for the active subsystem (driver.py:230-260).  Under QM/MM the
+        provider must put the point-charge field into the local hcore and energy_nuc as well
+        (the reference wraps the local object in qmmm.mm_charge, :246-253): a provider that cannot
+        is refused, never silently run without the field."""
+        if self.run_qmmm:
+            import inspect
+
+            if "run_qmmm" not in inspect.signature(self.provider.local_hf).parameters:
+                raise NbedDriverError(
+                    "QM/MM was requested (mm_coords / mm_charges / mm_radii) but this provider's local_hf() "
+                    "cannot add the point-charge field to the embedded SCF object")
+            local_hf = self.provider.local_hf(self.config, self._init_embedded_mol(), backend=self.be, run_qmmm=True)
+        else:
+            local_hf = self.provider.local_hf(self.config, self._init_embedded_mol(), backend=self.be)
         local_hf.max_memory = self.config.max_ram_memory
         local_hf.conv_tol = self.config.convergence
         local_hf.max_cycle = self.config.max_hf_cycles
@@ -328,7 +363,14 @@ class NbedDriver:
             localized_scf.energy_elec = lambda *args: energy_elec(localized_scf, *args)
         hcore_std = localized_scf.get_hcore
         localized_scf.get_hcore = lambda *args: hcore_std(*args) + v_emb
-        localized_scf.kernel()
+        # PySCF's kernel() starts from the 'minao' guess (nbed/driver.py:533 -> scf.hf.kernel); a provider
+        # that can make one supplies it, otherwise the core-Hamiltonian guess of GpuUHF is used
+        dm0 = None
+        if hasattr(self.provider, "init_guess"):
+            dm0 = self.provider.init_guess(self.config, localized_scf)
+        localized_scf.kernel(dm0) if dm0 is not None else localized_scf.kernel()
+        if not localized_scf.converged:
+            logger.warning("mu-shift embedded SCF has NOT converged in %s cycles.", localized_scf.max_cycle)
         logger.info(f"Embedded scf energy MU_SHIFT: {localized_scf.e_tot}, converged: {localized_scf.converged}")
         return localized_scf, v_emb
 

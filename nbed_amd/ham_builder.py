@@ -101,7 +101,7 @@ class HamiltonianBuilder:
         # block uses (ij|kl) = (ji|kl) for quarters 3-4
         aaaa, aabb = self._transform_pair(eri, ca, ca, cb)
         bbbb = self._transform(eri, cb, cb, cb, cb)
-        self._eri_rs = None  # (the packed copy is 0.5 N^4 doubles: not kept beyond the build)
+        self._eri_rs = None  # (0.5 N^4 doubles: the builder keeps no reference beyond the build)
         n = n_a
         # (bb|aa)[i,j,k,l] = (aa|bb)[k,l,i,j]: a transpose of the (n^2 x n^2) matrix
         bbaa = be.transpose(aabb.reshape(n * n, n * n)).reshape(n, n, n, n)
@@ -121,7 +121,10 @@ class HamiltonianBuilder:
         if not hasattr(self.be, "eri_pack_rs"):
             return None
         if getattr(self, "_eri_rs", None) is None:
-            self._eri_rs = self.be.eri_pack_rs(eri, eri.shape[-1])
+            cached = getattr(self.scf_method, "eri_rs_device", None)  # kept by the SCF object per molecule
+            self._eri_rs = cached() if cached is not None else None
+            if self._eri_rs is None:
+                self._eri_rs = self.be.eri_pack_rs(eri, eri.shape[-1])
         return self._eri_rs
 
     def _transform(self, eri, c1, c2, c3, c4):

@@ -74,7 +74,10 @@ def _sign_fix(c: np.ndarray) -> np.ndarray:
 class _GpuSCF:
     """Shared machinery: device-resident S, hcore, (pq|rs) (possibly a row slab)."""
 
-    def __init__(self, mol: Mole, ovlp, hcore, eri=None, backend=None, shards: Shards | None = None):
+    def __init__(self, mol: Mole, ovlp, hcore, eri=None, backend=None, shards: Shards | None = None,
+                 eri_packed=None):
+        """``eri_packed``: the packed J/K copy of the same slab (``eri_packed_device()`` of another
+        object over the same integrals), so that objects sharing a molecule share it."""
         self.be = backend if backend is not None else get_backend()
         self.mol = mol
         self._s_h = np.asarray(ovlp, dtype=np.float64)
@@ -90,7 +93,7 @@ class _GpuSCF:
                     f"ERI slab has shape {tuple(eri.shape)}, expected {(self.shards.size, nao, nao, nao)}"
                 )
         self._eri_d = eri
-        self._eri_packed_d = None  # 4-fold packed copy of the slab for the J/K kernel, made on first use
+        self._eri_packed_d = eri_packed  # 4-fold packed copy of the slab for the J/K kernel, made on first use
         self._x_d = None  # S^-1/2, built on first use
         self.mo_coeff = None
         self.mo_occ = None
@@ -139,6 +142,23 @@ class _GpuSCF:
             if nao >= PACKED_JK_MIN_NAO and be.jk_packed_supported(nao):
                 self._eri_packed_d = be.eri_pack(self._eri_d, nao, self.shards.lo, self.shards.hi)
         return self._eri_packed_d
+
+    # the rs-packed copy is 4 N^4 bytes: kept with the object only while that is small beside HBM
+    ERI_RS_CACHE_MAX_BYTES = 32 << 30
+
+    def eri_rs_device(self):
+        """(pq|rs) with the pairs (r, s <= r) packed -- the input form of the four-index transform's
+        quarters 1-2 (nbx_eri_pack_rs; PySCF's ao2mo takes "s2kl" input the same way).  Made once per
+        molecule and kept: both Hamiltonian builds of a projector="both" run (nbed/driver.py:869,893)
+        reuse it.  None when it does not apply (row-slab object, backend without it, too large)."""
+        be = self.be
+        nao = self._s_h.shape[0]
+        if getattr(self, "_eri_rs_d", None) is None:
+            self._eri_rs_d = None
+            whole = self.shards.world == 1 and self._eri_d is not None
+            if whole and hasattr(be, "eri_pack_rs") and 4 * nao**4 <= self.ERI_RS_CACHE_MAX_BYTES:
+                self._eri_rs_d = be.eri_pack_rs(self._eri_d, nao)
+        return self._eri_rs_d
 
     def jk_device(self, dm_d):
         """(1+ndm, N, N) on device: J(sum dm), K(dm[x]).  The packed / symmetric kernels read only the

@@ -18,7 +18,7 @@ sys.path.insert(0, str(HERE.parent))
 from oracle import synth  # noqa: E402
 from oracle_backend import OracleBackend  # noqa: E402
 
-from nbed_amd.dist import Shards  # noqa: E402
+from nbed_amd.dist import Shards, streamed_transform  # noqa: E402
 from nbed_amd.ham_builder import HamiltonianBuilder  # noqa: E402
 from nbed_amd.scf import GpuUHF, Mole, huzinaga_scf  # noqa: E402
 
@@ -47,8 +47,12 @@ def main():
     full.mo_coeff, full.mo_occ = c[:, :, :nmo], mf.get_occ(e, c)[:, :nmo]
     ish = Shards.from_env(nmo)
     const, h1, h2 = HamiltonianBuilder(full, 0.25, backend=be, shards=ish).build()
+    # streamed (generated-integral) transform, the N_AO = 2000 path: r-sharded at equal work, all-reduce
+    rsh = Shards(n, world, rank, balance="triangular")
+    ca_d, cb_d = be.asarray(c[0][:, :nmo]), be.asarray(c[1][:, :nmo])
+    s_aa, s_ab, s_bb = (be.to_host(t) for t in streamed_transform(be, n, ca_d, cb_d, shards=rsh))
     np.savez(out_dir / f"rank{rank}.npz", c=c, e=e, d=d, hz=hz, conv=conv, h1=h1, h2=h2, lo=sh.lo, hi=sh.hi,
-             jk_calls=be.calls.get("jk", 0))
+             jk_calls=be.calls.get("jk", 0), s_aa=s_aa, s_ab=s_ab, s_bb=s_bb, r_lo=rsh.lo, r_hi=rsh.hi)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -232,6 +232,23 @@ class OracleBackend:
         return self.asarray(hamiltonian.ao2mo_full(self._np(eri), c1n[:, i0:i1], self._np(c2), self._np(c3),
                                                    self._np(c4)))
 
+    def ao2mo_synth(self, nao, c1, c2, c3, c4, r0=0, r1=None, seed=synth.SEED):
+        """Partial sum over r in [r0,r1) of the streamed transform (pairs s <= r and their mirrors),
+        layout of nbx_ao2mo_synth, by einsum on the dense synthetic tensor."""
+        self._count("ao2mo_synth")
+        r1 = nao if r1 is None else r1
+        eri = synth.eri_dense(nao, seed)
+        c1n, c2n, c3n, c4n = (self._np(c) for c in (c1, c2, c3, c4))
+        out = np.zeros((c1n.shape[1], c2n.shape[1], c3n.shape[1], c4n.shape[1]))
+        for r in range(r0, r1):
+            x = np.einsum("pi,qj,pqs->ijs", c1n, c2n, eri[:, :, r, : r + 1])  # half transform, s <= r
+            out += np.einsum("ijs,k,sl->ijkl", x, c3n[r], c4n[: r + 1])
+            out += np.einsum("ijs,sk,l->ijkl", x[:, :, :r], c3n[:r], c4n[r])
+        return self.asarray(out)
+
+    def ao2mo_synth_pair(self, nao, c1, c2, c3, c4, c5, c6, r0=0, r1=None, seed=synth.SEED):
+        return (self.ao2mo_synth(nao, c1, c2, c3, c4, r0, r1, seed), self.ao2mo_synth(nao, c1, c2, c5, c6, r0, r1, seed))
+
     def chem_to_phys(self, x):
         return self.asarray(self._np(x).transpose(0, 2, 3, 1))
 

@@ -84,6 +84,20 @@ def test_sharded_scf_and_transform_match_single_rank(tmp_path, world):
         for key in ("e", "d", "hz", "h1", "h2"):
             np.testing.assert_allclose(r[key], single[key], rtol=0, atol=1e-10, err_msg=key)
         assert int(r["jk_calls"]) == int(single["jk_calls"])  # same cycle count on every rank
+        # r-sharded streamed transform + all-reduce == the single-rank transform == the einsum oracle
+        for key in ("s_aa", "s_ab", "s_bb"):
+            np.testing.assert_allclose(r[key], single[key], rtol=0, atol=1e-12, err_msg=key)
+    from oracle import hamiltonian, synth
+
+    ca, cb = single["c"][0][:, :7], single["c"][1][:, :7]
+    eri = synth.eri_dense(n)
+    np.testing.assert_allclose(single["s_aa"], hamiltonian.ao2mo_full(eri, ca, ca, ca, ca), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(single["s_ab"], hamiltonian.ao2mo_full(eri, ca, ca, cb, cb), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(single["s_bb"], hamiltonian.ao2mo_full(eri, cb, cb, cb, cb), rtol=0, atol=1e-12)
+    r_bounds = sorted((int(r["r_lo"]), int(r["r_hi"])) for r in ranks)
+    assert r_bounds[0][0] == 0 and r_bounds[-1][1] == n and all(a[1] == b[0] for a, b in zip(r_bounds, r_bounds[1:]))
+    assert r_bounds[0][1] - r_bounds[0][0] > r_bounds[-1][1] - r_bounds[-1][0]  # equal work, not equal length
+    np.testing.assert_array_equal(ranks[0]["s_ab"], ranks[1]["s_ab"])  # all-reduce: same bits everywhere
     # replicated N^3 work is deterministic: all ranks hold identical results
     for key in ("e", "d", "h2"):
         np.testing.assert_array_equal(ranks[0][key], ranks[1][key])

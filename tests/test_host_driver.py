@@ -165,3 +165,54 @@ def test_driver_errors(be):
     except ImportError:
         with pytest.raises(NbedDriverError, match="PySCF"):
             NbedDriver(config(), backend=be).embed()
+
+
+def test_qmmm_field_reaches_the_embedded_scf_or_is_refused(be):
+    """QM/MM (nbed/driver.py:171-180, 246-253): the point-charge field must be in the embedded
+    object's hcore and energy_nuc, consistently with the global one; a provider whose local_hf()
+    cannot add it is refused instead of being run without the field."""
+    mm = dict(mm_coords=[[3.0, 0.0, 0.0]], mm_charges=[0.4], mm_radii=[1.0])
+    cfg = config(projector="huzinaga", virtual_localization="disable", **mm)
+
+    plain = SyntheticProvider(14, (5, 5), 5)
+    drv = NbedDriver(cfg, provider=plain, backend=be)
+    assert drv.run_qmmm
+    with pytest.raises((NbedDriverError, TypeError)):
+        drv.embed()
+
+    class FieldProvider(SyntheticProvider):
+        """Adds a fixed one-electron 'point-charge' potential and a constant MM-nuclear energy."""
+
+        v_mm = 0.01 * synth.sym_matrix(synth.STREAM_MISC + 20, 14)
+        e_mm = 0.37
+        seen = []
+
+        def global_ks(self, config, run_qmmm=False):
+            self.seen.append(("global", run_qmmm))
+            h0, e0 = self.h, self.e_nuc
+            if run_qmmm:
+                self.h, self.e_nuc = h0 + self.v_mm, e0 + self.e_mm
+            try:
+                return super().global_ks(config)
+            finally:
+                self.h, self.e_nuc = h0, e0
+
+        def local_hf(self, config, embedded_mol, backend=None, run_qmmm=False):
+            self.seen.append(("local", run_qmmm))
+            mf = GpuUHF(embedded_mol, self.S, self.h + (self.v_mm if run_qmmm else 0.0), self.eri, backend=backend)
+            if run_qmmm:
+                e_nuc = self.e_nuc + self.e_mm
+                mf.energy_nuc = lambda *a: e_nuc
+            return mf
+
+    prov = FieldProvider(14, (5, 5), 5)
+    drv = nbed(cfg, provider=prov, backend=be)
+    assert ("global", True) in prov.seen and ("local", True) in prov.seen
+    scf = drv.huzinaga["scf"]
+    np.testing.assert_allclose(np.asarray(scf._h_h), prov.h + prov.v_mm, rtol=0, atol=0)  # field in the local hcore
+    assert abs(scf.energy_nuc() - drv.e_nuc) < 1e-14  # ... and the same MM-nuclear term on both sides
+    # HF-in-HF with the field everywhere stays exact: embedded energy == global energy
+    assert abs(drv.huzinaga["e_rhf"] - drv._global_ks.e_tot) < 1e-7
+    drv0 = nbed(config(projector="huzinaga", virtual_localization="disable"), provider=FieldProvider(14, (5, 5), 5),
+                backend=be)
+    assert abs(drv0.huzinaga["e_rhf"] - drv.huzinaga["e_rhf"]) > 1e-4  # the field is not a no-op
