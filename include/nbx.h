@@ -124,7 +124,11 @@ int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const do
  * first the NB diagonal triangles (row-major, packed), then for r = 1..NB-1 the rectangles
  * (I, J = I ^ r), I > J, ordered by J, row-major with row stride s|1 (zero pad); each of the NB
  * chunks padded to an even number of doubles.
- *   nbx_jk_packed_supported : 1 for even N <= 256 with N % NB == 0, else 0 (use nbx_jk_dense_sym)
+ *   nbx_jk_packed_supported : 1 = a kernel instance serves N (even N <= 256 with N % NB == 0);
+ *            2 = N <= 256 is served as the next such size (at most 8 more) with the extra rows and
+ *            columns zero -- odd N, N = 102, 150, ...: the same entry points, the padding is internal
+ *            (tiles with p >= N are neither stored nor visited, D is padded on the way in, J/K cropped
+ *            on the way out); 0 = not covered (use nbx_jk_dense_sym)
  *   d_jk   : out, ((1+ndm), N, N): ADDITIVE over slabs exactly as nbx_jk_dense_sym
  *   d_work : nbx_jk_packed_worksize() bytes                                                  */
 int nbx_jk_packed_supported(int64_t nao);

@@ -41,15 +41,30 @@ __device__ __forceinline__ double2 s4_ldnt(const double* p) {
 }
 
 // dense slab rows [p0,p1) -> packed tiles T(p,q), q <= p (the buffer was zeroed: pads stay 0)
+// N: size of the source tensor; NP >= N: size whose tile geometry is used (entries a >= N stay zero)
 __global__ __launch_bounds__(256) void s4_pack_kernel(const double* __restrict__ eri, double* __restrict__ out, int N,
-                                                      int NB, int p0, int64_t t_begin) {
-    const S4Geom g = s4_geom(N, NB);
+                                                      int NP, int NB, int p0, int64_t t_begin) {
+    const S4Geom g = s4_geom(NP, NB);
     const int64_t T = t_begin + blockIdx.x;
     const int p = s4_tri_row(T), q = (int)(T - s4_tri(p));
     const double* src = eri + ((int64_t)(p - p0) * N + q) * (int64_t)N * N;
     double* dst = out + (int64_t)blockIdx.x * g.M;
     for (int a = 0; a < N; ++a)
         for (int b = threadIdx.x; b <= a; b += blockDim.x) dst[s4_flat(g, a, b)] = src[(int64_t)a * N + b];
+}
+
+// (nmat, N, N) -> (nmat, NP, NP) with zero rows/columns appended, and back
+__global__ void s4_pad_square_kernel(const double* __restrict__ src, double* __restrict__ dst, int N, int NP, int nmat) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nmat * NP * NP) return;
+    const int b = (int)(i % NP), a = (int)((i / NP) % NP), m = (int)(i / ((int64_t)NP * NP));
+    dst[i] = (a < N && b < N) ? src[((int64_t)m * N + a) * N + b] : 0.0;
+}
+__global__ void s4_crop_square_kernel(const double* __restrict__ src, double* __restrict__ dst, int N, int NP, int nmat) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nmat * N * N) return;
+    const int b = (int)(i % N), a = (int)((i / N) % N), m = (int)(i / ((int64_t)N * N));
+    dst[i] = src[((int64_t)m * NP + a) * NP + b];
 }
 
 // (a, b) of the entry at offset f of chunk ch; false for a pad
@@ -403,18 +418,23 @@ S4Plan s4_plan(int64_t N, int64_t p0, int64_t np, int64_t ndm) {
 
 }  // namespace
 
-extern "C" int nbx_jk_packed_supported(int64_t nao) { return s4_supported(nao) ? 1 : 0; }
+// 1: a kernel instance serves N; 2: served as the next covered size with zero rows/columns; 0: no
+extern "C" int nbx_jk_packed_supported(int64_t nao) {
+    return s4_supported(nao) ? 1 : (s4_padded(nao) > 0 ? 2 : 0);
+}
 
 extern "C" size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1) {
-    if (!s4_supported(nao) || p0 < 0 || p1 < p0 || p1 > nao) return 0;
-    const S4Geom g = s4_geom((int)nao, s4_nb(nao));
+    const int64_t NP = s4_padded(nao);
+    if (NP == 0 || p0 < 0 || p1 < p0 || p1 > nao) return 0;
+    const S4Geom g = s4_geom((int)NP, s4_nb(NP));
     return (size_t)((s4_tri(p1) - s4_tri(p0)) * g.M) * sizeof(double);
 }
 
 extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri, double* d_packed) {
     NBX_CHECK_ARG(ctx);
     NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
-    if (!s4_supported(nao)) {
+    const int64_t NP = s4_padded(nao);  // the tiles (p, q) with p < nao of the padded tensor: the others are zero
+    if (NP == 0) {
         nbx_set_error("nbx_eri_pack: N = %lld is not covered by the packed J/K kernel", (long long)nao);
         return NBX_E_UNSUPPORTED;
     }
@@ -424,22 +444,28 @@ extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
     int rc = nbx_memset(ctx, d_packed, 0, nbx_eri_packed_bytes(nao, p0, p1));
     if (rc != NBX_OK) return rc;
     hipLaunchKernelGGL(s4_pack_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, d_eri, d_packed, (int)nao,
-                       s4_nb(nao), (int)p0, s4_tri(p0));
+                       (int)NP, s4_nb(NP), (int)p0, s4_tri(p0));
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
 
 extern "C" size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm) {
-    if (!s4_supported(nao) || p0 < 0 || p1 < p0 || p1 > nao || ndm <= 0) return 0;
-    return s4_plan(nao, p0, p1 - p0, ndm).total;
+    const int64_t NP = s4_padded(nao);
+    if (NP == 0 || p0 < 0 || p1 < p0 || p1 > nao || ndm <= 0) return 0;
+    size_t total = s4_plan(NP, p0, p1 - p0, ndm).total;
+    if (NP != nao) total += s4_align256((size_t)((1 + 2 * ndm) * NP * NP) * sizeof(double));  // padded D and J/K
+    return total;
 }
 
 static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm,
                  int64_t ndm, double* d_jk, void* d_work, size_t work_bytes, const double* d_hv, double* d_fock,
                  double* d_vhf, const double* d_dts = nullptr);
+static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm,
+                        int64_t ndm, double* d_jk, void* d_work, size_t work_bytes, const double* d_hv,
+                        double* d_fock, double* d_vhf, const double* d_dts);
 
 extern "C" size_t nbx_jk_dts_bytes(int64_t nao) {
-    if (!s4_supported(nao)) return 0;
+    if (!s4_supported(nao)) return 0;  // (zero-padded sizes build their table themselves)
     const int NB = s4_nb(nao);
     return (size_t)(NB * NB * s4_lpt(nao) * 128) * sizeof(double);
 }
@@ -468,18 +494,48 @@ static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double
     NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
     NBX_CHECK_ARG(d_packed != nullptr || p0 == p1);
     NBX_CHECK_ARG(ndm == 1 || ndm == 2);
-    if (!s4_supported(nao)) {
-        nbx_set_error("nbx_jk_packed: N = %lld is not covered (even N <= 256, N %% 4 == 0 above 128)", (long long)nao);
+    const int64_t NPAD = s4_padded(nao);
+    if (NPAD == 0) {
+        nbx_set_error("nbx_jk_packed: N = %lld is not covered (N <= 256 within %d of an even size the kernel has an "
+                      "instance for)", (long long)nao, S4_MAX_PAD);
         return NBX_E_UNSUPPORTED;
     }
-    const int64_t np = p1 - p0, N = nao, n2 = N * N;
     const size_t need = nbx_jk_packed_worksize(nao, p0, p1, ndm);
     if (d_work == nullptr || work_bytes < need) {
         nbx_set_error("nbx_jk_packed: workspace %zu < %zu bytes", work_bytes, need);
         return NBX_E_NOMEM;
     }
     NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
-    if (np == 0) return nbx_memset(ctx, d_jk, 0, (size_t)((1 + ndm) * n2) * sizeof(double));
+    if (p1 == p0) return nbx_memset(ctx, d_jk, 0, (size_t)((1 + ndm) * nao * nao) * sizeof(double));
+    if (NPAD != nao) {
+        // Run as the NPAD x NPAD problem whose extra rows and columns are zero: the tiles (p, q) with
+        // p >= nao vanish (never stored, never visited); D is padded on the way in, J/K cropped on the
+        // way out.  The Fock assembly then is its own launch.
+        char* tail = static_cast<char*>(d_work) + s4_plan(NPAD, p0, p1 - p0, ndm).total;
+        double* dm_pad = reinterpret_cast<double*>(tail);
+        double* jk_pad = dm_pad + ndm * NPAD * NPAD;
+        const int64_t tin = ndm * NPAD * NPAD, tout = (1 + ndm) * nao * nao;
+        hipLaunchKernelGGL(s4_pad_square_kernel, dim3((unsigned)nbx_cdiv(tin, 256)), dim3(256), 0, ctx->stream, d_dm,
+                           dm_pad, (int)nao, (int)NPAD, (int)ndm);
+        NBX_LAUNCH_CHECK();
+        int rc = s4_jk_native(ctx, NPAD, p0, p1, d_packed, dm_pad, ndm, jk_pad, d_work, work_bytes, nullptr, nullptr,
+                              nullptr, nullptr);
+        if (rc != NBX_OK) return rc;
+        hipLaunchKernelGGL(s4_crop_square_kernel, dim3((unsigned)nbx_cdiv(tout, 256)), dim3(256), 0, ctx->stream,
+                           jk_pad, d_jk, (int)nao, (int)NPAD, (int)(1 + ndm));
+        NBX_LAUNCH_CHECK();
+        if (d_fock != nullptr) return nbx_fock_uhf(ctx, nao, d_hv, 3, nullptr, d_jk, d_fock, d_vhf);
+        return NBX_OK;
+    }
+    return s4_jk_native(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, work_bytes, d_hv, d_fock, d_vhf, d_dts);
+}
+
+// the kernel proper, for a size it has an instance for (arguments checked by s4_jk)
+static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm,
+                        int64_t ndm, double* d_jk, void* d_work, size_t work_bytes, const double* d_hv,
+                        double* d_fock, double* d_vhf, const double* d_dts) {
+    const int64_t np = p1 - p0, N = nao, n2 = N * N;
+    (void)work_bytes;
     const S4Plan pl = s4_plan(N, p0, np, ndm);
     char* base = static_cast<char*>(d_work);
     double* dtp = reinterpret_cast<double*>(base + pl.dtp_off);

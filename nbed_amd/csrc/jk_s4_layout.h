@@ -97,6 +97,17 @@ static inline bool s4_supported(int64_t N) {
 }
 
 
+// Sizes the kernel has no instance for (odd N, N = 102, 150, ...) run as the next covered size with
+// the extra rows and columns zero: at most S4_MAX_PAD of them, so that the padding stays a few per
+// cent of the tile (0: no covered size that close).
+constexpr int S4_MAX_PAD = 8;
+static inline int64_t s4_padded(int64_t N) {
+    if (N < 1) return 0;
+    for (int64_t M = N; M <= N + S4_MAX_PAD && M <= 256; ++M)
+        if (s4_supported(M)) return M;
+    return 0;
+}
+
 // loads per thread per chunk of the kernel instance that serves N (0: not covered)
 static inline int s4_lpt(int64_t N) {
     if (!s4_supported(N)) return 0;

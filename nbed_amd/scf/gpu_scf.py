@@ -60,8 +60,11 @@ class Mole:
 
 
 # Below this many basis functions the packed J/K kernel has no edge over the symmetric one (both
-# are launch bound) and the packed copy would only cost memory.
+# are launch bound) and the packed copy would only cost memory.  The symmetric kernel needs an even
+# N, though: odd sizes would drop to the plain dense kernel (4x the bytes), so they go packed
+# (zero-padded to the next size the kernel has an instance for) from PACKED_JK_MIN_NAO_ODD on.
 PACKED_JK_MIN_NAO = 100
+PACKED_JK_MIN_NAO_ODD = 48
 
 
 def _sign_fix(c: np.ndarray) -> np.ndarray:
@@ -139,7 +142,7 @@ class _GpuSCF:
         be = self.be
         nao = self._s_h.shape[0]
         if self._eri_packed_d is None and self._eri_d is not None and hasattr(be, "jk_packed"):
-            if nao >= PACKED_JK_MIN_NAO and be.jk_packed_supported(nao):
+            if nao >= (PACKED_JK_MIN_NAO_ODD if nao % 2 else PACKED_JK_MIN_NAO) and be.jk_packed_supported(nao):
                 self._eri_packed_d = be.eri_pack(self._eri_d, nao, self.shards.lo, self.shards.hi)
         return self._eri_packed_d
 
@@ -187,7 +190,10 @@ class _GpuSCF:
         if getattr(self, "_dts_d", None) is None:
             self._dts_d = None
             if self.eri_packed_device() is not None and hasattr(self.be, "jk_dts_new"):
-                self._dts_d = self.be.jk_dts_new(self._s_h.shape[0])
+                try:
+                    self._dts_d = self.be.jk_dts_new(self._s_h.shape[0])
+                except ValueError:  # a zero-padded size: the build prepares its own table
+                    self._dts_d = None
         return self._dts_d
 
     def fock_device(self, dm_d, hv_d, dts_ready: bool = False):

@@ -733,15 +733,73 @@ def test_jk_packed_fock_and_prepared_dtot_table(be, n):
 
 
 def test_jk_packed_unsupported_sizes(be):
-    """Sizes outside the packed kernel's coverage are refused loudly (the host then keeps the
-    symmetric kernel): odd N, blocks longer than a wave, tiny chunks."""
+    """Sizes outside the packed kernel's reach are refused loudly (the host then keeps the
+    symmetric / plain kernel): too small, above 256."""
     from nbed_amd._nbx import NbxError
 
-    for n in (7, 13, 16, 22, 102, 150, 258):
+    for n in (3, 7, 13, 258, 300):
         assert not be.jk_packed_supported(n)
-    eri = be.synth_eri(13)
+    eri = be.synth_eri(7)
     with pytest.raises((ValueError, NbxError)):
-        be.eri_pack(eri, 13)
+        be.eri_pack(eri, 7)
+
+
+@pytest.mark.parametrize("n", [17, 22, 49, 75, 102, 149, 150])
+def test_jk_packed_zero_padded_sizes_vs_oracle(be, n):
+    """Sizes the packed kernel has no instance for (odd N; N = 22, 102, 150: no fitting block
+    geometry) run as the next covered size with zero rows/columns (include/nbx.h): J and K against
+    the einsum / C oracle, slabs additive, Fock assembly, exact symmetry of J."""
+    from oracle import cref
+
+    assert be.lib.nbx_jk_packed_supported(n) == 2
+    eri_h = cref.synth_eri(n)
+    dm = np.stack([symm(536, n), symm(537, n)])
+    ref = cref.jk(eri_h, dm)
+    eri = be.asarray(eri_h)
+    packed = be.eri_pack(eri, n)
+    got = be.to_host(be.jk_packed(packed, be.asarray(dm)))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11)
+    np.testing.assert_array_equal(got[0], got[0].T)
+    cut = n // 3 + 1
+    parts = (be.to_host(be.jk_packed(be.eri_pack(eri[:cut], n, 0, cut), be.asarray(dm), 0, cut))
+             + be.to_host(be.jk_packed(be.eri_pack(eri[cut:], n, cut, n), be.asarray(dm), cut, n)))
+    np.testing.assert_allclose(parts, got, rtol=0, atol=1e-11)
+    hv = np.stack([symm(570, n), symm(571, n)])
+    fock, vhf = be.jk_packed_fock(packed, be.asarray(dm), be.asarray(hv))
+    np.testing.assert_allclose(be.to_host(vhf), ref[0] - ref[1:], rtol=0, atol=2e-11)
+    np.testing.assert_allclose(be.to_host(fock), hv + ref[0] - ref[1:], rtol=0, atol=2e-11)
+    one = be.to_host(be.jk_packed(packed, be.asarray(dm[:1])))
+    np.testing.assert_allclose(one, cref.jk(eri_h, dm[:1]), rtol=0, atol=1e-11)
+
+
+def test_fused_scf_on_a_zero_padded_size_vs_oracle(be):
+    """N = 149 (odd: padded to 152 inside libnbx) through the fused Huzinaga loop against the oracle."""
+    from oracle import cref
+    from oracle import huzinaga as oracle_huz
+    from oracle.pyscf_like import ToyMol, ToyUHF
+
+    from nbed_amd.scf import GpuUHF, Mole, huzinaga_scf
+
+    n, nocc, n_env = 149, (30, 29), 12
+    pr = synth.problem(n, nocc, n_env)
+    eri_h = cref.synth_eri(n)
+
+    class CUHF(ToyUHF):
+        def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0):
+            jk = cref.jk(self._eri, np.asarray(dm))
+            return jk[0] - jk[1:]
+
+    ref = CUHF(ToyMol(n, pr["nelec"]), pr["S"], pr["hcore"], eri_h)
+    mf = GpuUHF(Mole(n, pr["nelec"]), pr["S"], pr["hcore"], be.asarray(eri_h), backend=be)
+    assert mf.eri_packed_device() is not None
+    ref.max_cycle = mf.max_cycle = 60
+    ref.conv_tol = mf.conv_tol = 1e-10
+    rc, re, rd, rhz, rconv = oracle_huz.huzinaga_scf(ref, pr["V_emb"], pr["D_env"], dm_conv_tol=1e-8)
+    c, e, d, hz, conv = huzinaga_scf(mf, pr["V_emb"], pr["D_env"], dm_conv_tol=1e-8)
+    assert conv and rconv
+    np.testing.assert_allclose(e, re, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(d, rd, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(hz, rhz, rtol=0, atol=1e-8)
 
 
 def test_cdiis_device_and_orbital_gradient_norm(be):
