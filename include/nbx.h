@@ -407,6 +407,12 @@ int nbx_spinorb_scatter_h1(nbx_ctx* ctx, int64_t n, const double* d_one_body, do
 int nbx_spinorb_scatter_range(nbx_ctx* ctx, int64_t n, const double* d_two_body, double tol,
                               double h2_scale, int64_t idx0, int64_t count, double* d_h2_part);
 
+/* d_x[i] <- (|d_x[i]| < tol ? 0 : d_x[i]) * scale over n doubles: the 1e-8 truncation
+ * (nbed/ham_builder.py:213-214) and the 1/2 of build() (:254) applied to a SPATIAL block, for callers
+ * that keep the three unique spin blocks (aaaa, bbbb, aabb) instead of the 16x larger scattered
+ * spin-orbital tensor.                                                                          */
+int nbx_threshold_scale(nbx_ctx* ctx, int64_t n, double tol, double scale, double* d_x);
+
 #ifdef __cplusplus
 }
 #endif

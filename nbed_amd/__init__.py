@@ -10,9 +10,9 @@ Importing the package needs neither the library nor a GPU; computing does.
 from ._nbx import NbxError, NbxUnavailableError
 from .backend import HipBackend, get_backend, set_backend
 from .config import NbedConfig
-from .driver import NbedDriver
+from .driver import NbedDriver, dft_in_dft, run_emb_ccsd, run_emb_fci
 from .embed import nbed
-from .ham_builder import HamiltonianBuilder
+from .ham_builder import HamiltonianBuilder, SpatialHamiltonian
 
-__all__ = ["nbed", "NbedConfig", "NbedDriver", "HamiltonianBuilder", "HipBackend", "get_backend", "set_backend",
+__all__ = ["nbed", "NbedConfig", "NbedDriver", "HamiltonianBuilder", "SpatialHamiltonian", "run_emb_fci", "run_emb_ccsd", "dft_in_dft", "HipBackend", "get_backend", "set_backend",
            "NbxError", "NbxUnavailableError"]

@@ -126,6 +126,7 @@ SIGNATURES = {
     "nbx_spinorb_scatter_h1": (c_int, [_P, c_int64, _P, c_double, _P]),
     "nbx_spinorb_scatter_range": (c_int, [_P, c_int64, _P, c_double, c_double, c_int64, c_int64, _P]),
     "nbx_spinorb_scatter": (c_int, [_P, c_int64, _P, _P, c_double, c_double, _P, _P]),
+    "nbx_threshold_scale": (c_int, [_P, c_int64, c_double, c_double, _P]),
 }
 
 _lib = None

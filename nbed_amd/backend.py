@@ -812,6 +812,11 @@ class HipBackend:
         main.wait_stream(copy_stream)
         return self.to_host(h1), out.reshape((nq,) * 4)
 
+    def threshold_scale(self, x, tol: float, scale: float):
+        """x <- (|x| < tol ? 0 : x) * scale in place (nbx_threshold_scale)."""
+        self._call("nbx_threshold_scale", x.numel(), tol, scale, self._p(x))
+        return x
+
     def spinorb_scatter(self, one_body, two_body, tol: float, h2_scale: float):
         n = one_body.shape[-1]
         h1 = self.empty((2 * n, 2 * n))

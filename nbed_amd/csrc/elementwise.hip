@@ -760,6 +760,15 @@ __global__ void spinorb_h2_kernel(int n, const double* __restrict__ tb, double t
     }
 }
 
+// x <- (|x| < tol ? 0 : x) * scale: the truncation and the 1/2 of nbed/ham_builder.py:213-214,254 applied to
+// a spatial block (the "packed" Hamiltonian output keeps the blocks instead of the scattered tensor)
+__global__ void threshold_scale_kernel(int64_t n, double tol, double scale, double* __restrict__ x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = x[i];
+        x[i] = (fabs(v) < tol ? 0.0 : v) * scale;
+    }
+}
+
 __global__ void spinorb_h1_kernel(int n, const double* __restrict__ ob, double tol, double* __restrict__ h1) {
     const int nq = 2 * n;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1025,6 +1034,16 @@ int nbx_spinorb_scatter_range(nbx_ctx* ctx, int64_t n, const double* d_two_body,
     NBX_CHECK_ARG(d_h2_part != nullptr);
     hipLaunchKernelGGL(spinorb_h2_kernel, dim3(grid1d(count, 256, 8192)), dim3(256), 0, ctx->stream, (int)n,
                        d_two_body, tol, h2_scale, d_h2_part, idx0, count);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+
+int nbx_threshold_scale(nbx_ctx* ctx, int64_t n, double tol, double scale, double* d_x) {
+    NBX_CHECK_ARG(ctx && n >= 0);
+    if (n == 0) return NBX_OK;
+    NBX_CHECK_ARG(d_x != nullptr);
+    hipLaunchKernelGGL(threshold_scale_kernel, dim3(grid1d(n, 256, 8192)), dim3(256), 0, ctx->stream, n, tol, scale, d_x);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

@@ -102,6 +102,14 @@ class PySCFProvider:
         return local
 
 
+    def local_ks(self, config: NbedConfig, embedded_mol, xc_functional: str, backend=None):
+        """Embedded Kohn-Sham object (driver.py:289-313): PySCF's own ``dft.UKS`` -- the B3LYP
+        quadrature is PySCF's -- which ``huzinaga_scf`` / ``_mu_embed`` drive through the protocol path
+        (projector products, DIIS and eigensolves on the GPU; ``get_veff`` in PySCF)."""
+        from pyscf import dft
+
+        return dft.UKS(embedded_mol)
+
     def init_guess(self, config: NbedConfig, local_scf):
         """Starting density of the mu-shift SCF: PySCF's default 'minao' guess for the embedded
         molecule (electron count already overwritten), as scf.UHF.kernel() would take it."""
@@ -181,6 +189,15 @@ class BuiltinHFProvider:
         ks.kernel()
         return ks
 
+    def local_ks(self, config: NbedConfig, embedded_mol, xc_functional: str, backend=None):
+        """Embedded Kohn-Sham object of the 'hf' functional: ``GpuUKS`` with 100 % exact exchange."""
+        from .scf import GpuUKS
+
+        if str(xc_functional).lower() != "hf":
+            raise NbedDriverError("BuiltinHFProvider has no exchange-correlation quadrature: xc_functional='hf' only")
+        ints = self._integrals(config)
+        return GpuUKS(embedded_mol, ints["S"], ints["hcore"], ints["eri"], backend=backend, xc="hf", hyb=1.0)
+
     def local_hf(self, config: NbedConfig, embedded_mol, backend=None, run_qmmm: bool = False):
         from .scf import GpuUHF
 
@@ -193,7 +210,13 @@ class BuiltinHFProvider:
 class NbedDriver:
     """Run projection-based embedding and produce the embedded active-space Hamiltonian."""
 
-    def __init__(self, config: NbedConfig, provider=None, backend=None):
+    def __init__(self, config: NbedConfig, provider=None, backend=None, hamiltonian_format: str = "dense"):
+        """``hamiltonian_format``: "dense" -- ``result["second_quantised"]`` is the reference's
+        ``(constant, h1 (2n,2n), h2 (2n,2n,2n,2n))``; "spatial" -- a ``SpatialHamiltonian`` (three unique
+        spin blocks, 16/3 times smaller; ``.to_dense()`` gives the former)."""
+        if hamiltonian_format not in ("dense", "spatial"):
+            raise NbedDriverError(f"unknown hamiltonian_format {hamiltonian_format!r}")
+        self.hamiltonian_format = hamiltonian_format
         self.config = config
         self._provider = provider
         self._be = backend
@@ -309,7 +332,16 @@ class NbedDriver:
         return local_hf
 
     def _init_local_ks(self, xc_functional: str):
-        self._unsupported("An embedded Kohn-Sham object (DFT-in-DFT)")
+        """Embedded Kohn-Sham object for the active subsystem (driver.py:289-313): the provider's
+        ``local_ks(config, embedded_mol, xc, backend=)``."""
+        if not hasattr(self.provider, "local_ks"):
+            self._unsupported("An embedded Kohn-Sham object (DFT-in-DFT) with this provider")
+        local_ks = self.provider.local_ks(self.config, self._init_embedded_mol(), xc_functional, backend=self.be)
+        local_ks.max_memory = self.config.max_ram_memory
+        local_ks.conv_tol = self.config.convergence
+        local_ks.xc = xc_functional
+        local_ks.verbose = 1
+        return local_ks
 
     # ------------------------------------------------------------------ subsystem DFT (inputs)
     def _subsystem_dft(self, global_ks, localized_system):
@@ -447,13 +479,16 @@ class NbedDriver:
         return mo_coeff[:, keep], np.asarray(mo_energy)[keep], np.asarray(mo_occ)[keep]
 
     def _dft_in_dft(self, projection_method):
-        self._unsupported("DFT-in-DFT embedding")
+        """driver.py:793-806."""
+        return dft_in_dft(self, projection_method)
 
     def _run_emb_ccsd(self, emb_scf, frozen=None):
-        self._unsupported("Embedded CCSD")
+        """driver.py:451-474."""
+        return run_emb_ccsd(emb_scf, frozen, self.config.convergence, self.config.max_ram_memory)
 
     def _run_emb_fci(self, emb_scf, frozen=None):
-        self._unsupported("Embedded FCI")
+        """driver.py:476-498."""
+        return run_emb_fci(emb_scf, frozen, self.config.convergence, self.config.max_ram_memory)
 
     # ------------------------------------------------------------------ the embedding
     def embed(self, init_huzinaga_rhf_with_mu: bool = False,
@@ -539,12 +574,130 @@ class NbedDriver:
         result["classical_energy"] = self.e_env + self.two_e_cross + self.e_nuc - corr
 
         if cfg.run_ccsd_emb is True:
-            self._run_emb_ccsd(result["scf"])
+            ccsd_emb, _ = self._run_emb_ccsd(result["scf"])
+            result["e_ccsd"] = ccsd_emb.e_tot + self.e_env + self.two_e_cross - corr
+            result["ccsd_emb"] = ccsd_emb.e_tot - self.e_nuc
         if cfg.run_fci_emb is True:
-            self._run_emb_fci(result["scf"])
+            fci_emb = self._run_emb_fci(result["scf"])
+            result["e_fci"] = fci_emb.e_tot + self.e_env + self.two_e_cross - corr
+            result["fci_emb"] = fci_emb.e_tot - self.e_nuc
         result["hf_emb"] = result["scf"].e_tot - self.e_nuc
         if cfg.run_dft_in_dft is True:
-            self._dft_in_dft(projector)
+            result.update(self._dft_in_dft(projector))
 
-        result["second_quantised"] = HamiltonianBuilder(result["scf"], result["classical_energy"], backend=be).build()
+        builder = HamiltonianBuilder(result["scf"], result["classical_energy"], backend=be)
+        spatial = getattr(self, "hamiltonian_format", "dense") == "spatial"
+        result["second_quantised"] = builder.build_spatial() if spatial else builder.build()
         return result
+
+
+# ---------------------------------------------------------------------- consumers of the embedded SCF object
+def _as_pyscf_uhf(emb_scf):
+    """A PySCF ``scf.UHF`` carrying the embedded object's molecule, orbitals and patched hcore, for
+    the PySCF post-HF solvers (they index PySCF-internal attributes a GpuUHF does not have)."""
+    try:
+        from pyscf import scf as pyscf_scf
+    except ImportError as err:
+        raise NbedDriverError(
+            "embedded CCSD / FCI are PySCF's cc.CCSD / fci.FCI run on the embedded SCF object "
+            "(nbed/driver.py:1044-1135); PySCF is not installed. The active-space Hamiltonian in "
+            "result['second_quantised'] is what those solvers diagonalise.") from err
+    if isinstance(emb_scf, pyscf_scf.hf.SCF):
+        return emb_scf
+    mol = emb_scf.mol
+    if not hasattr(mol, "intor"):
+        raise NbedDriverError("embedded CCSD / FCI need an SCF object over a PySCF molecule (PySCFProvider)")
+    mf = pyscf_scf.UHF(mol)
+    hcore = np.asarray(emb_scf.get_hcore())
+    mf.get_hcore = lambda *args: hcore
+    mf.mo_coeff, mf.mo_occ, mf.mo_energy = emb_scf.mo_coeff, emb_scf.mo_occ, emb_scf.mo_energy
+    mf.e_tot, mf.converged = emb_scf.e_tot, emb_scf.converged
+    if "energy_nuc" in vars(emb_scf):
+        mf.energy_nuc = emb_scf.energy_nuc
+    return mf
+
+
+def run_emb_fci(emb_pyscf_scf_rhf, frozen: Optional[list] = None, convergence: Optional[float] = 1e-6,
+                max_ram_memory: Optional[int] = 4000):
+    """FCI on the embedded SCF object (nbed/driver.py:1044-1102): PySCF's ``fci.FCI`` (``mcscf.CASSCF``
+    with ``frozen``), with the one-electron part taken from the 3-D embedded hcore.  Outside the MI355X hot
+    path: delegated to a local PySCF, refused with ``NbedDriverError`` without one."""
+    mf = _as_pyscf_uhf(emb_pyscf_scf_rhf)
+    from pyscf import fci
+
+    if frozen is None:
+        fci_scf = fci.FCI(mf)
+    else:
+        from pyscf import mcscf
+
+        fci_scf = mcscf.CASSCF(mf, mf.mol.nelec, mf.mol.nao - len(frozen))
+        fci_scf.sort_mo([i + 1 for i in range(mf.mol.nao) if i not in frozen])
+    fci_scf.conv_tol = convergence
+    fci_scf.max_memory = max_ram_memory
+    fci_scf.verbose = 1
+    hcore = np.asarray(mf.get_hcore())
+    if hcore.ndim == 3:
+        mo = mf.mo_coeff
+        fci_scf.kernel(h1e=[mo[0].T @ hcore[0] @ mo[0], mo[1].T @ hcore[1] @ mo[1]])
+    else:
+        fci_scf.kernel()
+    logger.info(f"FCI embedding energy: {fci_scf.e_tot}")
+    return fci_scf
+
+
+def run_emb_ccsd(emb_pyscf_scf_rhf, frozen: Optional[list] = None, convergence: float = 1e-6,
+                 max_ram_memory: int = 4000):
+    """CCSD on the embedded SCF object (nbed/driver.py:1105-1135) -> ``(ccsd, e_ccsd_corr)``;
+    PySCF's ``cc.CCSD``, delegated like ``run_emb_fci``."""
+    mf = _as_pyscf_uhf(emb_pyscf_scf_rhf)
+    from pyscf import cc
+
+    ccsd = cc.CCSD(mf, frozen=frozen)
+    ccsd.conv_tol = convergence
+    ccsd.max_memory = max_ram_memory
+    ccsd.verbose = 2
+    e_ccsd_corr, _, _ = ccsd.kernel()
+    logger.info(f"Embedded CCSD energy: {e_ccsd_corr}")
+    return ccsd, e_ccsd_corr
+
+
+def dft_in_dft(driver: "NbedDriver", projection_method: ProjectorTypes) -> dict:
+    """Energy of DFT-in-DFT embedding (nbed/driver.py:1138-1231): the embedded SCF is repeated
+    with a Kohn-Sham object of the GLOBAL functional in place of Hartree-Fock; with an exact
+    embedding it reproduces the global Kohn-Sham energy (tests/test_driver.py:83-88).  Runs on the
+    GPU path: the provider's ``local_ks`` object (``GpuUKS``) goes through the same
+    ``_mu_embed`` / ``_huzinaga_embed`` (KS branch of ``huzinaga_scf``) as the Hartree-Fock one."""
+    be = driver.be
+    result = {}
+    e_nuc = driver._global_ks.energy_nuc()
+    local_ks = driver._init_local_ks(driver._global_ks.xc)
+    hcore_std = np.asarray(local_ks.get_hcore())
+    match projection_method:
+        case ProjectorTypes.MU:
+            result["scf_dft"], result["v_emb_dft"] = driver._mu_embed(local_ks, driver.embedding_potential)
+        case ProjectorTypes.HUZ:
+            result["scf_dft"], result["v_emb_dft"] = driver._huzinaga_embed(
+                local_ks, driver.embedding_potential, driver.localized_system)
+    result["scf_dft"] = driver._delete_environment(projection_method, result["scf_dft"], driver.localized_system,
+                                                   driver._env_projector)
+
+    def dot(a, b):  # einsum("ij,ij")
+        return float(be.dots(be.asarray(np.asarray(a)).reshape(-1), be.asarray(np.asarray(b)).reshape(1, -1))[0])
+
+    dm_active = driver.localized_system.dm_active
+    if dm_active.ndim == 2:
+        y_emb = result["scf_dft"].make_rdm1()
+        result["dft_correction"] = dot(result["v_emb_dft"], y_emb - dm_active)
+        result["dft_correction_beta"] = 0
+        veff = result["scf_dft"].get_veff(dm=y_emb)
+        rks_e_elec = veff.exc + veff.ecoul + dot(hcore_std, y_emb)
+    else:
+        y_a, y_b = result["scf_dft"].make_rdm1()
+        result["dft_correction"] = dot(result["v_emb_dft"][0], y_a - dm_active[0])
+        result["dft_correction_beta"] = dot(result["v_emb_dft"][1], y_b - dm_active[1])
+        veff = result["scf_dft"].get_veff(dm=np.array([y_a, y_b]))
+        rks_e_elec = veff.exc + veff.ecoul + dot(hcore_std, y_a) + dot(hcore_std, y_b)
+    result["e_dft_in_dft"] = (rks_e_elec + driver.e_env + driver.two_e_cross + result["dft_correction"]
+                              + result["dft_correction_beta"] + e_nuc)
+    result["emb_dft"] = rks_e_elec
+    return result

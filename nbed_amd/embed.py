@@ -10,9 +10,11 @@ from .config import NbedConfig, parse_config
 from .driver import NbedDriver
 
 
-def nbed(config: NbedConfig | str | Path | None = None, provider=None, backend=None, **config_kwargs) -> NbedDriver:
+def nbed(config: NbedConfig | str | Path | None = None, provider=None, backend=None,
+         hamiltonian_format: str = "dense", **config_kwargs) -> NbedDriver:
     """Validate the configuration, run ``NbedDriver.embed()`` and return the driver."""
-    driver = NbedDriver(parse_config(config, **config_kwargs), provider=provider, backend=backend)
+    driver = NbedDriver(parse_config(config, **config_kwargs), provider=provider, backend=backend,
+                        hamiltonian_format=hamiltonian_format)
     driver.embed()
     return driver
 

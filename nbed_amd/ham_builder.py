@@ -168,6 +168,19 @@ class HamiltonianBuilder:
                                     be.asarray(np.asarray(two_body_integrals)), EQ_TOLERANCE, 1.0)
         return be.to_host(h1), be.to_host(h2)
 
+    def build_spatial(self) -> "SpatialHamiltonian":
+        """The same Hamiltonian as ``build()`` kept in its three unique spatial spin blocks (not in the
+        reference: its (2n)^4 output is 60 GB per projector at n = 147, almost all of it zeros and
+        copies; this form is 6.4 GB and reaches the host 16/3 times sooner)."""
+        if self.n_frozen_virt != 0:
+            self.scf_method = reduce_virtuals(self.scf_method, self.n_frozen_virt)
+        be = self.be
+        one = be.asarray(self._one_body_integrals)
+        be.threshold_scale(one, EQ_TOLERANCE, 1.0)
+        two = self._two_body_device()[:3].contiguous()  # aaaa, bbbb, aabb (physicist order)
+        be.threshold_scale(two, EQ_TOLERANCE, 0.5)
+        return SpatialHamiltonian(self.constant_e_shift, be.to_host(one), be.to_host(two))
+
     def build(self) -> tuple[float, np.ndarray, np.ndarray]:
         """Second-quantised fermionic Hamiltonian: (constant, h1, 0.5 * h2)."""
         if self.n_frozen_virt != 0:
@@ -181,6 +194,62 @@ class HamiltonianBuilder:
             return self.constant_e_shift, h1_h, h2_h
         h1, h2 = be.spinorb_scatter(one, two, EQ_TOLERANCE, 0.5)
         return self.constant_e_shift, be.to_host(h1), be.to_host(h2)
+
+
+class SpatialHamiltonian:
+    """The second-quantised Hamiltonian in its three unique SPATIAL spin blocks -- what
+    ``HamiltonianBuilder.build()`` scatters into the (2n)^4 spin-orbital tensor (ham_builder.py:180-214),
+    16/3 times smaller and exactly equivalent:
+
+        constant                      float
+        one_body   (2, n, n)          C_x^T h_x C_x, |x| < 1e-8 zeroed
+        two_body   (3, n, n, n, n)    physicist-ordered aaaa, bbbb, aabb, |x| < 1e-8 zeroed, times 1/2;
+                                      bbaa[p,q,r,s] = aabb[q,p,s,r]
+
+    ``h1()`` / ``h2()`` / ``to_dense()`` expand to the reference's output (bit for bit what ``build()``
+    returns); ``h2_element(P, Q, R, S)`` reads one spin-orbital coefficient without expanding."""
+
+    def __init__(self, constant, one_body, two_body):
+        self.constant = constant
+        self.one_body = one_body
+        self.two_body = two_body
+        self.n = int(one_body.shape[-1])
+
+    def h1(self) -> np.ndarray:
+        nq = 2 * self.n
+        out = np.zeros((nq, nq))
+        out[0::2, 0::2] = self.one_body[0]
+        out[1::2, 1::2] = self.one_body[1]
+        return out
+
+    def h2(self) -> np.ndarray:
+        nq = 2 * self.n
+        out = np.zeros((nq,) * 4)
+        out[0::2, 0::2, 0::2, 0::2] = self.two_body[0]
+        out[1::2, 1::2, 1::2, 1::2] = self.two_body[1]
+        out[0::2, 1::2, 1::2, 0::2] = self.two_body[2]
+        out[1::2, 0::2, 0::2, 1::2] = self.two_body[2].transpose(1, 0, 3, 2)
+        return out
+
+    def h2_element(self, P: int, Q: int, R: int, S: int) -> float:
+        sp = (P & 1, Q & 1, R & 1, S & 1)
+        p, q, r, s = P >> 1, Q >> 1, R >> 1, S >> 1
+        if sp == (0, 0, 0, 0):
+            return float(self.two_body[0][p, q, r, s])
+        if sp == (1, 1, 1, 1):
+            return float(self.two_body[1][p, q, r, s])
+        if sp == (0, 1, 1, 0):
+            return float(self.two_body[2][p, q, r, s])
+        if sp == (1, 0, 0, 1):
+            return float(self.two_body[2][q, p, s, r])
+        return 0.0
+
+    def to_dense(self) -> tuple[float, np.ndarray, np.ndarray]:
+        return self.constant, self.h1(), self.h2()
+
+    @property
+    def nbytes(self) -> int:
+        return int(self.one_body.nbytes + self.two_body.nbytes)
 
 
 def reduce_virtuals(scf_method, n_frozen_virt: int):

@@ -1,5 +1,6 @@
 """Localizer classes (same exports as nbed/localizers/__init__.py:10-19)."""
 
+from .ace import ACELocalizer
 from .occupied.base import OccupiedLocalizer
 from .occupied.spade import SPADELocalizer
 from .occupied.unsupported import BOYSLocalizer, IBOLocalizer, PMLocalizer
@@ -9,6 +10,7 @@ from .virtual.concentric import ConcentricLocalizer
 from .virtual.unsupported import PAOLocalizer
 
 __all__ = [
+    "ACELocalizer",
     "BOYSLocalizer",
     "IBOLocalizer",
     "PMLocalizer",

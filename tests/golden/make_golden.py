@@ -435,6 +435,81 @@ def main():
          classical_energy=res["classical_energy"], hf_emb=res["hf_emb"], const=const,
          h1_abs=np.abs(b1), h2_abs=np.abs(b2))
 
+    # ------------------------------------------------------------------ 9. DFT-in-DFT (consumer of the path)
+    from nbed.driver import dft_in_dft
+
+    n, nocc, n_env = 12, (5, 5), 2
+    pr = synth.problem(n, nocc, n_env)
+    eri = synth.eri_dense(n)
+    _, cfull = synth.lowdin_orthonormal(pr["S"], pr["hcore"])
+    c_env = np.stack([pr["C_env"], pr["C_env"]])
+    c_act = np.stack([cfull[:, n_env:nocc[0]], cfull[:, n_env:nocc[1]]])
+    c_loc = np.stack([cfull[:, : nocc[0]], cfull[:, : nocc[1]]])
+    ls = LocalizedSystem(np.array([np.arange(3), np.arange(3)]),
+                         np.array([np.arange(3, 5), np.arange(3, 5)]), c_act, c_env, c_loc)
+    for tag, ptype in (("huzinaga", ProjectorTypes.HUZ), ("mu", ProjectorTypes.MU)):
+        drv = NbedDriver.__new__(NbedDriver)
+
+        class _GlobalKS:
+            xc = "toy-hybrid"
+
+            def get_ovlp(self_inner):
+                return pr["S"]
+
+            def energy_nuc(self_inner):
+                return 1.25
+
+        drv.__dict__["_global_ks"] = _GlobalKS()
+        drv.localized_system = ls
+        drv.config = types.SimpleNamespace(mu_level_shift=1e6)
+        drv.e_env, drv.two_e_cross, drv.e_nuc = -3.5, 0.75, 1.25
+        drv.embedding_potential = pr["V_emb"]
+
+        def _local_ks(xc, _pr=pr, _eri=eri):
+            ks = RefUKS(ToyMol(n, _pr["nelec"], e_nuc=1.25), _pr["S"], _pr["hcore"], _eri)
+            ks.max_cycle, ks.conv_tol, ks.xc = 80, 1e-10, xc
+            return ks
+
+        drv._init_local_ks = _local_ks
+        if ptype is ProjectorTypes.MU:
+            continue  # the mu path runs PySCF's kernel(): no executable reference here
+        res = dft_in_dft(drv, ptype)
+        save(f"dft_in_dft_{tag}_n12", "nbed/driver.py:1138-1231 dft_in_dft (Huzinaga projector; toy hybrid functional "
+             "= 0.2 exact exchange; local KS object through _huzinaga_embed's KS branch)", ["pyscf.lib.diis.DIIS"],
+             nao=n, nelec=np.array(pr["nelec"]), n_env=n_env, hyb=RefUKS.hyb, S=pr["S"], hcore=pr["hcore"],
+             V_emb=pr["V_emb"], c_active=c_act, c_enviro=c_env, c_loc_occ=c_loc, e_env=drv.e_env,
+             two_e_cross=drv.two_e_cross, e_nuc=drv.e_nuc, max_cycle=80, conv_tol=1e-10,
+             v_emb_dft=res["v_emb_dft"], dft_correction=res["dft_correction"],
+             dft_correction_beta=res["dft_correction_beta"], e_dft_in_dft=res["e_dft_in_dft"], emb_dft=res["emb_dft"],
+             mo_energy_post=res["scf_dft"].mo_energy, mo_occ_post=res["scf_dft"].mo_occ,
+             mo_coeff_post_canon=canon_sign(res["scf_dft"].mo_coeff), converged=res["scf_dft"].converged)
+
+    # ------------------------------------------------------------------ 10. ACE of SPADE
+    from nbed.localizers.ace import ACELocalizer
+
+    n, nocc, n_act_aos = 16, (6, 6), 6
+    path = []
+    coeffs, occs = [], []
+    for k in range(3):  # three "geometries": the same overlap, smoothly changing core Hamiltonians
+        pr_k = synth.problem(n, nocc, 0)
+        h_k = pr_k["hcore"] + 0.04 * k * synth.sym_matrix(synth.STREAM_MISC + 30, n)
+        _, ca = synth.lowdin_orthonormal(pr_k["S"], h_k)
+        _, cb = synth.lowdin_orthonormal(pr_k["S"], h_k + 0.002 * synth.sym_matrix(synth.STREAM_MISC + 7, n))
+        mo_occ = np.zeros((2, n))
+        mo_occ[:, : nocc[0]] = 1
+        mf = RefUHF(ToyMol(n, nocc, ao_slices=[[0, 1, 0, n_act_aos], [1, 2, n_act_aos, n]]), pr_k["S"], h_k, None)
+        mf.mo_coeff, mf.mo_occ = np.stack([ca, cb]), mo_occ
+        path.append(mf)
+        coeffs.append(mf.mo_coeff)
+        occs.append(mo_occ)
+    ace = ACELocalizer(path, 1)
+    n_ab = ace.localize_path()
+    sig_sets = [np.array([0.99, 0.97, 0.9, 0.35, 0.2, 0.05]), np.array([0.98, 0.95, 0.8, 0.4, 0.1, 0.02]),
+                np.array([0.99, 0.9, 0.85, 0.3, 0.25, 0.01])]
+    save("ace_of_spade_n16", "nbed/localizers/ace.py:54-131 ACELocalizer.localize_path / localize_spin", [],
+         nao=n, n_act_aos=n_act_aos, S=path[0].get_ovlp(), mo_coeff=np.stack(coeffs), mo_occ=np.stack(occs),
+         n_mo=np.array(n_ab), sigma_sets=np.stack(sig_sets), n_mo_from_sets=ACELocalizer.localize_spin(ace, sig_sets))
+
     # entries written by other generators (make_water_integrals.py) are kept
     mpath = HERE / "MANIFEST.json"
     if mpath.exists():

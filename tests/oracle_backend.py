@@ -252,6 +252,12 @@ class OracleBackend:
     def chem_to_phys(self, x):
         return self.asarray(self._np(x).transpose(0, 2, 3, 1))
 
+    def threshold_scale(self, x, tol, scale):
+        xn = self._np(x)
+        xn[np.abs(xn) < tol] = 0.0
+        xn *= scale
+        return x
+
     def spinorb_scatter(self, one_body, two_body, tol, h2_scale):
         h1, h2 = hamiltonian.spinorb_from_spatial(self._np(one_body), self._np(two_body), tol)
         return self.asarray(h1), self.asarray(h2 * h2_scale)

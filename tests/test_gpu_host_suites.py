@@ -15,12 +15,16 @@ from test_host_localizers_ham import (  # noqa: E402,F401
     test_spade_open_shell_raises_like_reference,
     test_spade_restricted_matches_reference,
     test_spinorb_and_build_match_reference,
+    test_ace_of_spade_matches_reference,
+    test_spatial_hamiltonian_equals_dense_build,
 )
 from test_host_driver import (  # noqa: E402,F401
     test_delete_environment_and_projector_match_reference,
     test_embed_matches_oracle_flow,
     test_post_embed_matches_reference_golden,
     test_projectors_agree,
+    test_dft_in_dft_matches_reference_golden,
+    test_qmmm_field_reaches_the_embedded_scf_or_is_refused,
 )
 from test_water_kat import (  # noqa: E402,F401
     test_hf_in_hf_embedding_of_water_is_exact,
@@ -33,6 +37,8 @@ from test_host_scf import (  # noqa: E402,F401
     test_huzinaga_operator_matches_reference,
     test_huzinaga_scf_restricted_generic_path,
     test_monkey_patched_get_veff_uses_generic_path,
+    test_huzinaga_scf_kohn_sham_branch_matches_reference,
+    test_gpu_uks_protocol,
 )
 
 

@@ -157,8 +157,14 @@ def test_driver_errors(be):
         NbedDriver(config(virtual_localization="pao"), provider=SyntheticProvider(14, (5, 5), 5), backend=be).embed()
     with pytest.raises(NotImplementedError):
         nbed(config(localization="pm"), provider=SyntheticProvider(14, (5, 5), 5), backend=be)
-    with pytest.raises(NotImplementedError):
-        nbed(config(run_ccsd_emb=True, virtual_localization="disable"), provider=SyntheticProvider(14, (5, 5), 5),
+    try:
+        import pyscf  # noqa: F401
+    except ImportError:  # CCSD is PySCF's solver: refused loudly without it
+        with pytest.raises(NbedDriverError, match="PySCF"):
+            nbed(config(run_ccsd_emb=True, virtual_localization="disable"), provider=SyntheticProvider(14, (5, 5), 5),
+                 backend=be)
+    with pytest.raises(NotImplementedError):  # a provider without local_ks cannot do DFT-in-DFT
+        nbed(config(run_dft_in_dft=True, virtual_localization="disable"), provider=SyntheticProvider(14, (5, 5), 5),
              backend=be)
     try:
         import pyscf  # noqa: F401
@@ -216,3 +222,66 @@ def test_qmmm_field_reaches_the_embedded_scf_or_is_refused(be):
     drv0 = nbed(config(projector="huzinaga", virtual_localization="disable"), provider=FieldProvider(14, (5, 5), 5),
                 backend=be)
     assert abs(drv0.huzinaga["e_rhf"] - drv.huzinaga["e_rhf"]) > 1e-4  # the field is not a no-op
+
+
+def test_dft_in_dft_matches_reference_golden(be):
+    """nbed/driver.py:1138-1231 dft_in_dft (Huzinaga projector): the product's function with a
+    GpuUKS local Kohn-Sham object (toy hybrid functional, exact-exchange fraction from the J/K
+    kernels) against the reference's own run."""
+    from nbed_amd.driver import dft_in_dft
+    from nbed_amd.scf import GpuUKS
+
+    g = load_golden("dft_in_dft_huzinaga_n12")
+    n = int(g["nao"])
+
+    class Provider:
+        def local_ks(self, cfg, mol, xc, backend=None):
+            ks = GpuUKS(Mole(n, tuple(g["nelec"]), e_nuc=float(g["e_nuc"])), g["S"], g["hcore"], synth.eri_dense(n),
+                        backend=backend, xc=xc, hyb=float(g["hyb"]))
+            ks.max_cycle = int(g["max_cycle"])
+            return ks
+
+        def build_mol(self, cfg):
+            return Mole(n, tuple(g["nelec"]), e_nuc=float(g["e_nuc"]))
+
+    drv = NbedDriver(config(projector="huzinaga", virtual_localization="disable", convergence=float(g["conv_tol"]),
+                            max_hf_cycles=int(g["max_cycle"])), provider=Provider(), backend=be)
+
+    class KS:
+        xc = "toy-hybrid"
+
+        def get_ovlp(self):
+            return g["S"]
+
+        def energy_nuc(self):
+            return float(g["e_nuc"])
+
+    drv.__dict__["_global_ks"] = KS()
+    drv.localized_system = LocalizedSystem(np.array([np.arange(3), np.arange(3)]),
+                                           np.array([np.arange(3, 5), np.arange(3, 5)]),
+                                           g["c_active"], g["c_enviro"], g["c_loc_occ"], backend=be)
+    drv.e_env, drv.two_e_cross, drv.e_nuc = float(g["e_env"]), float(g["two_e_cross"]), float(g["e_nuc"])
+    drv.embedding_potential = g["V_emb"]
+    res = dft_in_dft(drv, ProjectorTypes.HUZ)
+    assert bool(res["scf_dft"].converged) == bool(g["converged"])
+    np.testing.assert_allclose(res["v_emb_dft"], g["v_emb_dft"], rtol=0, atol=1e-8)
+    for k in ("dft_correction", "dft_correction_beta", "e_dft_in_dft", "emb_dft"):
+        np.testing.assert_allclose(res[k], g[k], rtol=0, atol=1e-8, err_msg=k)
+    np.testing.assert_allclose(res["scf_dft"].mo_energy, g["mo_energy_post"], rtol=0, atol=1e-8)
+    np.testing.assert_array_equal(res["scf_dft"].mo_occ, g["mo_occ_post"])
+    np.testing.assert_allclose(canon_sign(res["scf_dft"].mo_coeff), g["mo_coeff_post_canon"], rtol=0, atol=1e-6)
+
+
+def test_consumers_are_importable_and_fail_loudly_without_pyscf(be):
+    """run_emb_fci / run_emb_ccsd (nbed/driver.py:1044-1135) delegate to PySCF's solvers: importable from
+    the package root like the reference's, NbedDriverError (not a silent skip) without PySCF."""
+    import nbed_amd
+    from nbed_amd.driver import run_emb_ccsd, run_emb_fci
+
+    assert nbed_amd.run_emb_fci is run_emb_fci and nbed_amd.run_emb_ccsd is run_emb_ccsd
+    try:
+        import pyscf  # noqa: F401
+    except ImportError:
+        for fn in (run_emb_fci, run_emb_ccsd):
+            with pytest.raises(NbedDriverError):
+                fn(object())

@@ -184,3 +184,47 @@ def test_builder_errors_and_reduce_virtuals(be):
     const, h1, h2 = HamiltonianBuilder(rf, backend=be).build()
     assert h1.shape == (14, 14) and h2.shape == (14,) * 4
     np.testing.assert_allclose(h1[0::2, 0::2], h1[1::2, 1::2])
+
+
+def test_ace_of_spade_matches_reference(be):
+    """nbed/localizers/ace.py:54-131: MO count along a three-geometry path (SPADE on the backend at
+    every geometry, scalar Fermi-curve fits on the host) and localize_spin on explicit sigma sets."""
+    from nbed_amd.localizers import ACELocalizer
+
+    g = load_golden("ace_of_spade_n16")
+    n, n_act_aos = int(g["nao"]), int(g["n_act_aos"])
+    path = []
+    for c, occ in zip(g["mo_coeff"], g["mo_occ"]):
+        mol = Mole(n, (int(occ[0].sum()), int(occ[1].sum())), ao_slices=[[0, 1, 0, n_act_aos], [1, 2, n_act_aos, n]])
+        mf = GpuUHF(mol, g["S"], np.zeros((n, n)), None, backend=be)
+        mf.mo_coeff, mf.mo_occ = c, occ
+        path.append(mf)
+    ace = ACELocalizer(path, 1, backend=be)
+    assert tuple(ace.localize_path()) == tuple(int(x) for x in g["n_mo"])
+    assert ace.localize_spin(list(g["sigma_sets"])) == int(g["n_mo_from_sets"])
+    bad = GpuUHF(Mole(n - 1, (3, 3)), g["S"][:-1, :-1], np.zeros((n - 1, n - 1)), None, backend=be)
+    bad.mo_coeff = g["mo_coeff"][0][:, :-1, :-1]
+    with pytest.raises(ValueError):
+        ACELocalizer([path[0], bad], 1, backend=be)
+
+
+def test_spatial_hamiltonian_equals_dense_build(be):
+    """build_spatial() (three unique spin blocks) expands to exactly what build() returns, the reference's
+    output (golden ham_build_n10), element access included."""
+    g = load_golden("ham_build_n10")
+    n = int(g["nao"])
+    mf = GpuUHF(Mole(n, (4, 4)), np.eye(n), g["hcore3"][0], synth.eri_dense(n), backend=be)
+    mf.mo_coeff = g["mo_coeff"]
+    mf.mo_occ = np.zeros((2, g["mo_coeff"].shape[-1]))
+    mf.get_hcore = lambda *a: g["hcore3"]
+    const, h1, h2 = HamiltonianBuilder(mf, constant_e_shift=float(g["const"]), backend=be).build()
+    sp = HamiltonianBuilder(mf, constant_e_shift=float(g["const"]), backend=be).build_spatial()
+    c2, d1, d2 = sp.to_dense()
+    assert c2 == const
+    np.testing.assert_array_equal(d1, h1)
+    np.testing.assert_array_equal(d2, h2)
+    np.testing.assert_allclose(np.abs(d2), np.abs(g["h2"]), rtol=0, atol=1e-9)
+    nq = h1.shape[0]
+    for idx in [(0, 0, 0, 0), (1, 3, 5, 7), (0, 3, 5, 2), (3, 0, 2, 5), (1, 0, 1, 0), (2, 4, 6, 8), (nq - 1,) * 4]:
+        assert sp.h2_element(*idx) == h2[idx]
+    assert sp.nbytes < h2.nbytes / 4
