@@ -630,6 +630,73 @@ class HipBackend:
         self.last_eigh_status_d = status
         return w, c
 
+    def sym_pow_newton_schulz(self, s, p: float, s_host=None, max_iter: int = 28, check_every: int = 4):
+        """S^p for p in {-1/2, +1/2, -1} of a symmetric positive definite matrix by the coupled
+        Newton-Schulz iteration (Higham, Functions of Matrices, eq. 6.35): with A = S / c,
+            Y_0 = A, Z_0 = I;  T = (3 I - Z Y) / 2;  Y <- Y T -> A^1/2,  Z <- T Z -> A^-1/2,
+        three MFMA GEMMs per step and nothing else -- the Jacobi eigensolver behind ``sym_pow`` is one
+        workgroup per matrix and takes 2.9 ms at N = 148, this takes ~0.2 ms.  c = ||S||_inf bounds the
+        spectrum to (0, 1]; convergence (||I - Z Y||_F, quadratic at the end) is read back every
+        ``check_every`` steps.  Returns None when it does not converge (S not positive definite, or a
+        condition number beyond ~1e6, where the iteration would lose more than the eigen route does):
+        the caller then takes the eigendecomposition route.
+        Equal to scipy's fractional_matrix_power (nbed/scf/huzinaga_scf.py:128) to ~cond(S) * 1e-16."""
+        torch = self.torch
+        if p not in (-0.5, 0.5, -1.0) or s.dim() != 2:
+            return None
+        n = s.shape[-1]
+        if s_host is not None:
+            c = float(np.abs(np.asarray(s_host)).sum(axis=1).max())
+        else:
+            c = float(np.abs(self.to_host(s)).sum(axis=1).max())
+        if not np.isfinite(c) or c <= 0.0:
+            return None
+        eye = torch.eye(n, dtype=torch.float64, device=self.device)
+        eye3 = self.empty((n, n))
+        self.axpby(3.0, eye, 0.0, eye3)
+        y = self.empty((n, n))
+        self.axpby(1.0 / c, s, 0.0, y)  # y = S / c
+        z = self.copy(eye)
+        prev = None
+        done = False
+        for it in range(max_iter):
+            t = self.copy(eye3)
+            self.gemm(z, y, alpha=-1.0, beta=1.0, out=t)  # T' = 3 I - Z Y  (= 2 T)
+            if it % check_every == check_every - 1 or done:
+                r = self.copy(t)
+                self.axpby(-2.0, eye, 1.0, r)  # I - Z Y
+                res = float(np.sqrt(self.dots(r.reshape(-1), r.reshape(1, -1))[0]))
+                if not np.isfinite(res):
+                    return None
+                if done or res < 1e-14 * n:
+                    break
+                # quadratic phase reached: one more step takes the residual to rounding level
+                if res < 1e-6 or (prev is not None and res > 0.5 * prev and res < 1e-9):
+                    done = True
+                prev = res
+            y = self.gemm(y, t, alpha=0.5)
+            z = self.gemm(t, z, alpha=0.5)
+        else:
+            return None
+        if p == 0.5:
+            out, scale = y, float(np.sqrt(c))
+        elif p == -0.5:
+            out, scale = z, float(1.0 / np.sqrt(c))
+        else:
+            out, scale = self.gemm(z, z), 1.0 / c
+        # scale back and symmetrise (the iterates are symmetric up to rounding)
+        sym = self.transpose(out)
+        self.axpby(0.5 * scale, out, 0.5 * scale, sym)
+        return sym
+
+    def sym_pow_fast(self, s, p: float, s_host=None):
+        """S^p: Newton-Schulz (GEMMs) where it applies and converges, else the eigendecomposition."""
+        if s.shape[-1] >= 16:
+            out = self.sym_pow_newton_schulz(s, p, s_host)
+            if out is not None:
+                return out
+        return self.sym_pow(s, p)
+
     def sym_pow(self, s, p: float):
         n = s.shape[-1]
         nbytes = self.lib.nbx_sym_pow_worksize(n)

@@ -38,7 +38,9 @@ class SPADELocalizer(OccupiedLocalizer):
         n_act_aos = int(self._global_scf.mol.aoslice_by_atom()[self._n_active_atoms - 1][-1])
 
         if self._s_half is None:  # the reference recomputes S^1/2 per spin (:99); same matrix
-            self._s_half = be.sym_pow(be.asarray(self._global_scf.get_ovlp()), 0.5)
+            s_h = np.asarray(self._global_scf.get_ovlp())
+            fast = getattr(be, "sym_pow_fast", None)
+            self._s_half = fast(be.asarray(s_h), 0.5, s_h) if fast is not None else be.sym_pow(be.asarray(s_h), 0.5)
         occ_d = be.asarray(occupied_orbitals)
         rotated = be.gemm(self._s_half, occ_d)
         sigma_d, vt_d = be.svd_right(rotated[:n_act_aos, :].contiguous())

@@ -132,7 +132,9 @@ class _GpuSCF:
 
     def x_device(self):
         if self._x_d is None:
-            self._x_d = self.be.sym_pow(self._s_d, -0.5)
+            # S^-1/2 (nbed/scf/huzinaga_scf.py:128) by GEMMs where the backend has the iteration
+            fast = getattr(self.be, "sym_pow_fast", None)
+            self._x_d = fast(self._s_d, -0.5, self._s_h) if fast is not None else self.be.sym_pow(self._s_d, -0.5)
         return self._x_d
 
     def eri_packed_device(self):

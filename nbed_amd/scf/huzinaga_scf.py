@@ -161,7 +161,10 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
 
     s_h = np.asarray(scf_method.get_ovlp())
     s_d = scf_method._s_d if fused else be.asarray(s_h)
-    x_d = scf_method.x_device() if fused else be.sym_pow(s_d, -0.5)
+    if fused:
+        x_d = scf_method.x_device()
+    else:
+        x_d = be.sym_pow_fast(s_d, -0.5, s_h) if hasattr(be, "sym_pow_fast") else be.sym_pow(s_d, -0.5)
     adiis = DIIS(be) if use_DIIS else None
 
     ds_occ = be.gemm(_as3(be, dm_environment_occupied), s_d)

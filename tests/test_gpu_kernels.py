@@ -960,3 +960,35 @@ def test_c_abi_error_behaviour(be):
     jk = be.jk(eri, dm)
     eri_h = synth.eri_dense(n)
     np.testing.assert_allclose(be.to_host(jk)[0], np.einsum("pqrs,rs->pq", eri_h, be.to_host(dm).sum(0)), atol=1e-13)
+
+
+@pytest.mark.parametrize("n", [37, 148, 200])
+@pytest.mark.parametrize("p", [-0.5, 0.5, -1.0])
+def test_sym_pow_newton_schulz(be, n, p):
+    """S^p by coupled Newton-Schulz GEMM iterations (the SCF's S^-1/2, SPADE's S^1/2) against the
+    spectral definition and the eigensolver route; refusal (None) outside its domain."""
+    s = synth.overlap(n)
+    w, u = np.linalg.eigh(s)
+    ref = (u * w**p) @ u.T
+    got = be.sym_pow_newton_schulz(be.asarray(s), p, s)
+    assert got is not None
+    got = be.to_host(got)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13)
+    np.testing.assert_array_equal(got, got.T)
+    np.testing.assert_allclose(be.to_host(be.sym_pow_fast(be.asarray(s), p, s)), be.to_host(be.sym_pow(be.asarray(s), p)),
+                               rtol=0, atol=1e-12)
+    if n == 37:
+        # moderately ill-conditioned (1e4): still accurate to cond * eps
+        q, _ = np.linalg.qr(rnd(95, n, n))
+        wv = np.logspace(0, -4, n)
+        s2 = (q * wv) @ q.T
+        s2 = 0.5 * (s2 + s2.T)
+        got2 = be.sym_pow_newton_schulz(be.asarray(s2), p, s2)
+        ref2 = (q * wv**p) @ q.T
+        assert got2 is not None
+        np.testing.assert_allclose(be.to_host(got2), ref2, rtol=0, atol=1e-10 * np.max(np.abs(ref2)))
+        # indefinite / hopelessly conditioned input: refused, and sym_pow_fast falls back to the eigen route
+        assert be.sym_pow_newton_schulz(be.asarray(symm(96, n)), p) is None
+        s3 = (q * np.logspace(0, -9, n)) @ q.T
+        s3 = 0.5 * (s3 + s3.T)
+        assert be.sym_pow_newton_schulz(be.asarray(s3), p, s3) is None
