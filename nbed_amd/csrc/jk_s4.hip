@@ -31,6 +31,13 @@
 #include "nbx_common.h"
 #include "jk_s4_layout.h"
 
+// jk_s8.hip: the eight-wave, matrix-pipe form of the NB = 4 / six-loads instance
+bool nbx_jk_s8_covers(int64_t N);
+void nbx_jk_s8_plan(int64_t ntiles, int* wgs, int* L, int* S);
+int nbx_jk_s8_launch(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t np, int64_t ndm, const double* d_packed,
+                     const double* d_dm, const double* d_dts, double* d_j, double* k1, double* k2, int64_t t_begin,
+                     int64_t t_end, int wgs, int L, int S);
+
 namespace {
 
 constexpr int S4_CUS = 256;
@@ -543,7 +550,15 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
     if (tid == 0) store_j(par ^ 1, pj, qj);
 }
 
+bool s4_use_s8(int64_t N) {
+    // jk_s8.hip is EXPERIMENTAL: parity-tested, but measured 5-15 % slower than the four-wave VALU kernel
+    // below -- opt in with NBX_JK_S8=1
+    static const bool on = getenv("NBX_JK_S8") != nullptr;
+    return on && nbx_jk_s8_covers(N);
+}
+
 struct S4Plan {
+    bool s8;
     int NB, lpt, wgs, L, S, per_cu;
     size_t lds_bytes, dtp_off, k1_off, k2_off, total;
     S4Geom g;
@@ -576,6 +591,8 @@ S4Plan s4_plan(int64_t N, int64_t p0, int64_t np, int64_t ndm) {
     pl.L = (int)L;
     pl.wgs = (int)nbx_cdiv(ntiles, L);
     pl.S = (int)sqrt(2.0 * (double)L) + 3;
+    pl.s8 = s4_use_s8(N);
+    if (pl.s8) nbx_jk_s8_plan(ntiles, &pl.wgs, &pl.L, &pl.S);  // one eight-wave workgroup per CU
     size_t off = 0;
     pl.dtp_off = off; off += s4_align256((size_t)(pl.NB * pl.NB * pl.lpt * 128) * sizeof(double));
     pl.k1_off = off; off += s4_align256((size_t)((int64_t)pl.wgs * pl.S * ndm * N) * sizeof(double));
@@ -740,7 +757,11 @@ static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const
         if (ndm == 2) NBX_S4_GO(2, NB_, LPT_, PD_, DT_, WV_);                                                              \
         else NBX_S4_GO(1, NB_, LPT_, PD_, DT_, WV_);                                                                       \
     } while (0)
-        if (pl.NB == 2) {
+        if (pl.s8) {
+            const int rc8 = nbx_jk_s8_launch(ctx, N, p0, np, ndm, d_packed, d_dm, dtp, d_jk, k1, k2, t_begin, t_end,
+                                             pl.wgs, pl.L, pl.S);
+            if (rc8 != NBX_OK) return rc8;
+        } else if (pl.NB == 2) {
             if (pl.lpt == 2) NBX_S4_NDM(2, 2, 2, true, 2);
             else if (pl.lpt == 6) NBX_S4_NDM(2, 6, 2, true, 2);
             else NBX_S4_NDM(2, 10, 2, true, 1);

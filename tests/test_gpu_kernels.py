@@ -272,7 +272,9 @@ def test_eigh_warm_start(be):
     np.testing.assert_allclose(w, np.linalg.eigvalsh(a2), rtol=0, atol=1e-11)
     np.testing.assert_allclose(a2 @ v, v * w[:, None, :], rtol=0, atol=1e-10)
     np.testing.assert_allclose(np.swapaxes(v, -1, -2) @ v, np.broadcast_to(np.eye(n), a.shape), rtol=0, atol=1e-12)
-    assert max(w_ % 1000 for w_ in warm) < min(cold), (warm, cold)
+    # cold: Jacobi sweep count, or 1 when the tridiagonal pipeline delivered (cold starts, N >= 64);
+    # warm: accepted by refinement (>= 1000) or a few sweeps on the nearly diagonal V0^T A V0
+    assert all(c_ >= 1 for c_ in cold) and all(w_ >= 1000 or w_ <= 4 for w_ in warm), (warm, cold)
 
 
 def eig_quality(a, w, v):
