@@ -528,14 +528,14 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
         par ^= 1;
 #ifndef NBX_S4_MFMA_WALK
         if (q < p && live) {
-            double* k2 = kpart2 + (((int64_t)q * np + (p - p0)) * NDM) * N + trow;
+            double* k2 = kpart2 + ((T - t_begin) * NDM) * N + trow;  // tile order: sequential stores
 #pragma unroll
             for (int x = 0; x < NDM; ++x) k2[x * N] = kq[x];
         }
 #else
         // K_q columns: to the tile's row-q partial (q < p), dropped on the diagonal (q == p: the
         // K_p columns already carry the whole contribution)
-        flush_cols(kpart2 + (((int64_t)q * np + (p - p0)) * NDM) * N, true, q < p);
+        flush_cols(kpart2 + ((T - t_begin) * NDM) * N, true, q < p);
         xstore(xtab + ((T + 1) & 1) * (XW * N));
 #endif
         ++T;
@@ -596,7 +596,7 @@ S4Plan s4_plan(int64_t N, int64_t p0, int64_t np, int64_t ndm) {
     size_t off = 0;
     pl.dtp_off = off; off += s4_align256((size_t)(pl.NB * pl.NB * pl.lpt * 128) * sizeof(double));
     pl.k1_off = off; off += s4_align256((size_t)((int64_t)pl.wgs * pl.S * ndm * N) * sizeof(double));
-    pl.k2_off = off; off += s4_align256((size_t)(N * np * ndm * N) * sizeof(double));
+    pl.k2_off = off; off += s4_align256((size_t)(ntiles * ndm * N) * sizeof(double));  // one row-q partial per tile
     pl.total = off;
     return pl;
 }
@@ -775,5 +775,5 @@ static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const
 #undef NBX_S4_GO
     }
     NBX_LAUNCH_CHECK();
-    return nbx_jk_sym_reduce(ctx, k1, k2, d_jk + n2, N, p0, np, ndm, t_begin, pl.L, pl.S, d_jk, d_hv, d_fock, d_vhf);
+    return nbx_jk_sym_reduce(ctx, k1, k2, d_jk + n2, N, p0, np, ndm, t_begin, pl.L, pl.S, d_jk, d_hv, d_fock, d_vhf, 1);
 }

@@ -178,8 +178,17 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int r = 0; r < XR; ++r) {
             const int e = tid + S8_THREADS * r;
             const int c = min(e / XW, N - 1), n = e & (XW - 1);
-            xn[r] = dm[(int64_t)(n >> 1) * n2 + (int64_t)((n & 1) ? pp : qq) * N + c];
+            const double* src = dm + (int64_t)(n >> 1) * n2 + (int64_t)((n & 1) ? pp : qq) * N + c;
+            // Not a load the compiler knows about: it would guard the use (one tile later, with loops in
+            // between) with s_waitcnt vmcnt(0), i.e. with a wait for every streaming load in flight.  The
+            // wait is written by hand in xwait(): the counter is in order and S8_LOADS_PER_TILE vector loads
+            // are always issued between this one and its use.
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xn[r]) : "v"(src) : "memory");
         }
+    };
+    auto xwait = [&]() {
+        static_assert(XR == 2, "operand list below");
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xn[0]), "+v"(xn[1]) : "n"(NCH * LPT));
     };
     auto xstore = [&](double* dst) {
 #pragma unroll
@@ -189,6 +198,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     };
     xfetch(p, q);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn[0]), "+v"(xn[1]));
     xstore(xtab + (T & 1) * (XW * N));
     __syncthreads();  // dtab (and the first X table) complete before the first J sum
 
@@ -251,8 +261,11 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         qj = q;
         par ^= 1;
         // K_q columns: the tile's row-q partial (q < p); on the diagonal the K_p columns carry it all
-        if (!(dbg & 8)) flush_cols(kpart2 + (((int64_t)q * np + (p - p0)) * NDM) * N, true, q < p);
-        if (!(dbg & 4)) xstore(xtab + ((T + 1) & 1) * (XW * N));
+        if (!(dbg & 8)) flush_cols(kpart2 + ((T - t_begin) * NDM) * N, true, q < p);  // tile order
+        if (!(dbg & 4)) {
+            xwait();
+            xstore(xtab + ((T + 1) & 1) * (XW * N));
+        }
         ++T;
         tile += g.M;
         if (++q > p) {

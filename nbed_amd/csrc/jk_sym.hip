@@ -245,14 +245,34 @@ __global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __rest
                                                             const double* __restrict__ jfull = nullptr,
                                                             const double* __restrict__ hv = nullptr,
                                                             double* __restrict__ fock = nullptr,
-                                                            double* __restrict__ vhf = nullptr) {
+                                                            double* __restrict__ vhf = nullptr,
+                                                            int k2_tile_order = 0) {
     __shared__ double part[4][64];
     const int row = blockIdx.x, x = blockIdx.y;
     const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
     const int b = blockIdx.z * 64 + lane;
     const int pl_lo = max(0, row + 1 - p0);  // first local p with global p > row
     double t = 0.0;
-    if (b < N) {
+    if (b < N && k2_tile_order) {
+        // kpart2[T(p, row) - t_begin][x][b]: the row-q partials in the order the tiles are visited (a
+        // workgroup's stores are then sequential: with [q][p] every tile's 2.4 KB landed on a page of
+        // its own, 350 KB from the last, and the address translation misses stalled the stream behind)
+        const double* src = kpart2 + (int64_t)x * N + b;
+        const int64_t stride = (int64_t)ndm * N;
+        auto at = [&](int pl) {
+            const int64_t pg = p0 + pl;
+            return src[(pg * (pg + 1) / 2 + row - t_begin) * stride];
+        };
+        int pl = pl_lo + chunk;
+        for (; pl + 28 < np; pl += 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = at(pl + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; pl < np; pl += 4) t += at(pl);
+    } else if (b < N) {
         const double* src = kpart2 + (((int64_t)row * np) * ndm + x) * N + b;
         const int64_t stride = (int64_t)ndm * N;
         int pl = pl_lo + chunk;
@@ -474,10 +494,10 @@ bool nbx_jk_sym_supported(int64_t nao) { return nao >= 2 && nao % 2 == 0 && nao 
 // K[x][row][b] from the row-p / row-q partial buffers (shared with jk_s4.hip, same layouts)
 int nbx_jk_sym_reduce(nbx_ctx* ctx, const double* k1, const double* k2, double* d_k, int64_t N, int64_t p0, int64_t np,
                       int64_t ndm, int64_t t_begin, int L, int S, const double* d_j, const double* d_hv, double* d_fock,
-                      double* d_vhf) {
+                      double* d_vhf, int k2_tile_order) {
     hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
                        ctx->stream, k1, k2, d_k, (int)N, (int)p0, (int)np, (int)ndm, t_begin, L, S, 0, d_j, d_hv, d_fock,
-                       d_vhf);
+                       d_vhf, k2_tile_order);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
