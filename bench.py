@@ -525,6 +525,11 @@ def main():
                     "tiles q <= p of the dense (pq|rs) slab, read once: (pq|rs) = (qp|rs) halves "
                     "SURVEY 8d's 8 N^4; dense_equivalent_gbs prices the same launch at 8 N^4"),
                 "dense_equivalent_gbs": (8.0 * shards.size * N**3) / (jk_avg_ms * 1e-3) / 1e9 if jk_cnt else None,
+                # the floor of the contraction itself: the 8-fold unique integrals ((pq|rs) = (rs|pq) as well),
+                # which PySCF's in-core get_jk reads; this kernel does not use that last symmetry
+                "bytes_8fold_floor": float(4 * (N * (N + 1) // 2) * (N * (N + 1) // 2 + 1)) if world == 1 else None,
+                "frac_vs_8fold_floor": (4.0 * (N * (N + 1) // 2) * (N * (N + 1) // 2 + 1) / (jk_avg_ms * 1e-3) / 1e9
+                                        / HBM_PEAK_GBS) if (jk_cnt and world == 1) else None,
                 "avg_launch_ms": jk_avg_ms,
                 "launches": jk_cnt,
             },
