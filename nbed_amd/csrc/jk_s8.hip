@@ -45,19 +45,23 @@ __device__ __forceinline__ double2 s8_ldnt(const double* p) {
 // block; rows past the block and columns past s: addresses stay on the workgroup's LDS, the
 // products land in rows nobody stores / meet a zero in X.
 constexpr int S8_MAX_NK = 10;  // k-steps of four columns: s <= 39 in the instance this kernel replaces
-constexpr int S8_KG = 5;       // k-steps whose operands are requested together
 
-template <int KIND, int XW>
-__device__ __forceinline__ void s8_walk(const double* lb, int ls, int s, int r0, const double* xs, int fr, int fk,
-                                        double (&acc)[S8_NSTR]) {
+// TRI: packed triangle (lb = its start); otherwise a rectangle addressed as row * sa + column * sb of
+// THIS WAVE's matrix: (sa, sb) = (ls, 1) when its rows are the stored rows, (1, ls) when they are the
+// stored columns -- one code path for both sides.
+template <bool TRI, int XW, int S8_KG>
+__device__ __forceinline__ void s8_walk(const double* lb, int sa, int sb, int s, int r0, const double* xs, int fr,
+                                        int fk, double (&acc)[S8_NSTR]) {
     const int xcol = fr & (XW - 1);
     const int nk = (s + 3) >> 2;
-    int tt[S8_NSTR];
+    int tt[S8_NSTR], ta[S8_NSTR];
 #pragma unroll
-    for (int i = 0; i < S8_NSTR; ++i) tt[i] = min(r0 + 16 * i + fr, s - 1);
-    // the operands of S8_KG steps are requested before the first of their MFMAs: one workgroup owns
-    // the CU, so nobody else hides an LDS round trip per step (LDS returns in order: the MFMAs
-    // start as the first reads land)
+    for (int i = 0; i < S8_NSTR; ++i) {
+        tt[i] = min(r0 + 16 * i + fr, s - 1);
+        ta[i] = TRI ? (tt[i] * (tt[i] + 1)) >> 1 : tt[i] * sa;
+    }
+    // the operands of S8_KG steps are requested before the first of their MFMAs (LDS returns in
+    // order: the MFMAs start as the first reads land)
 #pragma unroll 1
     for (int j0 = 0; j0 < nk; j0 += S8_KG) {
         double a[S8_KG][S8_NSTR], b[S8_KG];
@@ -67,14 +71,8 @@ __device__ __forceinline__ void s8_walk(const double* lb, int ls, int s, int r0,
 #pragma unroll
             for (int i = 0; i < S8_NSTR; ++i) {
                 int off;
-                if (KIND == 0) {
-                    const int hi = max(tt[i], cc), lo = min(tt[i], cc);
-                    off = ((hi * (hi + 1)) >> 1) + lo;
-                } else if (KIND == 1) {
-                    off = tt[i] * ls + cc;
-                } else {
-                    off = cc * ls + tt[i];
-                }
+                if (TRI) off = tt[i] >= cc ? ta[i] + cc : ((cc * (cc + 1)) >> 1) + tt[i];
+                else off = ta[i] + cc * sb;
                 a[jj][i] = lb[off];
             }
             const double v = xs[cc * XW + xcol];
@@ -89,19 +87,24 @@ __device__ __forceinline__ void s8_walk(const double* lb, int ls, int s, int r0,
     }
 }
 
-template <int NDM>
-__global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void jk_s8_kernel(
+// DT_LDS: the Dtot' table lives in LDS (one workgroup per CU); otherwise each thread fetches the six
+// weights of its next chunk from the L2-resident table right before the tile loads of chunk + PD
+// (older than those in the in-order vector-memory queue, so consuming them waits for nothing the
+// chunk itself does not wait for) and two workgroups share a CU.
+template <int NDM, bool DT_LDS>
+__global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(DT_LDS ? 2 : 4, DT_LDS ? 2 : 4))) void jk_s8_kernel(
     const double* __restrict__ eri, const double* __restrict__ dm, const double* __restrict__ dts,
     double* __restrict__ jfull, double* __restrict__ kpart1, double* __restrict__ kpart2, int N, int p0, int np,
     int64_t t_begin, int64_t t_end, int L, int S, int dbg) {
     constexpr int NB = S8_NB, NCH = NB, LPT = S8_LPT, PD = S8_PD, BUFD = S8_BUFD, XW = 2 * NDM;
     constexpr int DTN = NCH * S8_WAVES * LPT * 128;  // doubles in the Dtot' table
+    constexpr int KG = DT_LDS ? 5 : 2;               // k-steps whose walk operands are requested together
     // buf[2][BUFD] | slack[128] | jred[2][8] | xtab[2][N][XW] | dtab[DTN]
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* slack = smem + 2 * BUFD;
     double* jred = slack + 128;
     double* xtab = jred + 2 * S8_WAVES;
-    double* dtab = xtab + ((2 * N * XW + 1) & ~1);
+    double* dtab = xtab + ((2 * N * XW + 1) & ~1);  // (DT_LDS only)
 
     int64_t T = t_begin + (int64_t)blockIdx.x * L;
     const int64_t T_end = min(t_end, T + L);
@@ -125,8 +128,15 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     auto chunk_len = [&](int ch) { return ch == 0 ? g.E0 : g.Er; };
 
     // the Dtot' table (the same for every tile): global -> LDS once
-    for (int i = tid; i < DTN / 2; i += S8_THREADS)
-        reinterpret_cast<double2*>(dtab)[i] = reinterpret_cast<const double2*>(dts)[i];
+    if (DT_LDS)
+        for (int i = tid; i < DTN / 2; i += S8_THREADS)
+            reinterpret_cast<double2*>(dtab)[i] = reinterpret_cast<const double2*>(dts)[i];
+    double2 wts[LPT];  // (!DT_LDS) weights of the chunk about to be consumed
+    auto issue_w = [&](int ch) {
+        const double* dd = dts + ((ch * S8_WAVES + W) * LPT) * 128 + 2 * lane;
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) wts[k] = *reinterpret_cast<const double2*>(dd + k * 128);
+    };
 
     double2 stage[PD][LPT];
     auto issue = [&](double2(&st)[LPT], const double* tp, int ch) {
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const double* tile = eri + (T - t_begin) * g.M;
 #pragma unroll
     for (int ch = 0; ch < PD; ++ch) issue(stage[ch], tile, ch);
+    if (!DT_LDS) issue_w(0);
 
     // accumulator fragments: column lane & 3 of the product, row 4 ((lane >> 2) & 3) + (lane >> 4) of a strip
     const int fr = lane & 15, fk = lane >> 4;
@@ -173,17 +184,26 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // X table: entries e = tid + 512 r < XW N; row c = e / XW, column n = e % XW
     constexpr int XR = 2;  // XW N <= 4 * 256
     double xn[XR];
+    // byte offset of entry r inside the density array without the row term, and whether its row is p
+    unsigned xoff[XR];
+    bool xisp[XR];
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+        const int e = tid + S8_THREADS * r;
+        const int c = min(e / XW, N - 1), n = e & (XW - 1);
+        xoff[r] = 8u * (unsigned)((n >> 1) * (int)n2 + c);
+        xisp[r] = (n & 1) != 0;
+    }
     auto xfetch = [&](int pp, int qq) {
 #pragma unroll
         for (int r = 0; r < XR; ++r) {
-            const int e = tid + S8_THREADS * r;
-            const int c = min(e / XW, N - 1), n = e & (XW - 1);
-            const double* src = dm + (int64_t)(n >> 1) * n2 + (int64_t)((n & 1) ? pp : qq) * N + c;
+            const unsigned off = xoff[r] + 8u * (unsigned)((xisp[r] ? pp : qq) * N);
             // Not a load the compiler knows about: it would guard the use (one tile later, with loops in
             // between) with s_waitcnt vmcnt(0), i.e. with a wait for every streaming load in flight.  The
-            // wait is written by hand in xwait(): the counter is in order and S8_LOADS_PER_TILE vector loads
-            // are always issued between this one and its use.
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xn[r]) : "v"(src) : "memory");
+            // wait is written by hand in xwait(): the counter is in order and NCH * LPT vector loads are
+            // always issued between this one and its use.  (Scalar base + 32-bit offset: no 64-bit
+            // address pairs to keep alive across the tile.)
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(xn[r]) : "v"(off), "s"(dm) : "memory");
         }
     };
     auto xwait = [&]() {
@@ -232,13 +252,14 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int k = 0; k < LPT; ++k) {
                 if (!(dbg & 2)) {
-                    const double2 d2 = *reinterpret_cast<const double2*>(dd + k * 128);
+                    const double2 d2 = DT_LDS ? *reinterpret_cast<const double2*>(dd + k * 128) : wts[k];
                     jacc = fma(st[k].x, d2.x, fma(st[k].y, d2.y, jacc));
                 }
                 const int ps = s4_slot_start(chunk_len(ch), LPT, W, k);
                 *reinterpret_cast<double2*>((ps < 0 ? slack : buf + 2 * ps) + 2 * lane) = st[k];
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (!DT_LDS) issue_w((ch + 1) % NCH);
             if (ch + PD < NCH) issue(st, tile, ch + PD);
             else issue(st, tile_next, ch + PD - NCH);
             __builtin_amdgcn_sched_barrier(0);
@@ -247,12 +268,12 @@ __global__ __launch_bounds__(S8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
             if (dbg & 1) {
             } else if (ch == 0) {
-                s8_walk<0, XW>(buf + w * g.tri, 0, s, r0, xt + w * s * XW, fr, fk, acc);
+                s8_walk<true, XW, KG>(buf + w * g.tri, 0, 0, s, r0, xt + w * s * XW, fr, fk, acc);
             } else {
                 const int u = w ^ ch;
                 const double* rect = buf + s4_slot(min(w, u), ch) * s * ls;
-                if (w > u) s8_walk<1, XW>(rect, ls, s, r0, xt + u * s * XW, fr, fk, acc);
-                else s8_walk<2, XW>(rect, ls, s, r0, xt + u * s * XW, fr, fk, acc);
+                const bool rows = w > u;  // this wave's rows are the rectangle's stored rows
+                s8_walk<false, XW, KG>(rect, rows ? ls : 1, rows ? 1 : ls, s, r0, xt + u * s * XW, fr, fk, acc);
             }
         }
         jacc = nbx_wave_sum(jacc);
@@ -290,7 +311,8 @@ bool nbx_jk_s8_covers(int64_t N) {
 
 // workgroups / tiles per workgroup / row slots of the partial buffers for the tile range of a slab
 void nbx_jk_s8_plan(int64_t ntiles, int* wgs, int* L, int* S) {
-    int64_t l = nbx_cdiv(ntiles, S8_CUS);
+    const int per_cu = getenv("NBX_S8_ONE_WG") == nullptr ? 2 : 1;
+    int64_t l = nbx_cdiv(ntiles, S8_CUS * per_cu);
     if (l < 1) l = 1;
     *L = (int)l;
     *wgs = (int)nbx_cdiv(ntiles, l);
@@ -301,23 +323,33 @@ int nbx_jk_s8_launch(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t np, int64_t nd
                      const double* d_dm, const double* d_dts, double* d_j, double* k1, double* k2, int64_t t_begin,
                      int64_t t_end, int wgs, int L, int S) {
     const int xw = 2 * (int)ndm;
+    static const bool two = getenv("NBX_S8_ONE_WG") == nullptr;  // default: two workgroups per CU, weights from L2
     const size_t lds = (size_t)(2 * S8_BUFD + 128 + 2 * S8_WAVES + ((2 * N * xw + 1) & ~1ll) +
-                                S8_NB * S8_WAVES * S8_LPT * 128) * sizeof(double);
+                                (two ? 0 : S8_NB * S8_WAVES * S8_LPT * 128)) * sizeof(double);
     static const int dbg = getenv("NBX_S8_DEBUG") ? atoi(getenv("NBX_S8_DEBUG")) : 0;  // timing ablations only
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jk_s8_kernel<1>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jk_s8_kernel<1, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jk_s8_kernel<2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jk_s8_kernel<2, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jk_s8_kernel<1, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jk_s8_kernel<2, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_set = true;
     }
-    if (ndm == 2)
-        hipLaunchKernelGGL((jk_s8_kernel<2>), dim3((unsigned)wgs), dim3(S8_THREADS), lds, ctx->stream, d_packed, d_dm,
-                           d_dts, d_j, k1, k2, (int)N, (int)p0, (int)np, t_begin, t_end, L, S, dbg);
-    else
-        hipLaunchKernelGGL((jk_s8_kernel<1>), dim3((unsigned)wgs), dim3(S8_THREADS), lds, ctx->stream, d_packed, d_dm,
-                           d_dts, d_j, k1, k2, (int)N, (int)p0, (int)np, t_begin, t_end, L, S, dbg);
+#define NBX_S8_GO(NDM_, DT_)                                                                                          \
+    hipLaunchKernelGGL((jk_s8_kernel<NDM_, DT_>), dim3((unsigned)wgs), dim3(S8_THREADS), lds, ctx->stream, d_packed,  \
+                       d_dm, d_dts, d_j, k1, k2, (int)N, (int)p0, (int)np, t_begin, t_end, L, S, dbg)
+    if (ndm == 2) {
+        if (two) NBX_S8_GO(2, false);
+        else NBX_S8_GO(2, true);
+    } else {
+        if (two) NBX_S8_GO(1, false);
+        else NBX_S8_GO(1, true);
+    }
+#undef NBX_S8_GO
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
