@@ -407,6 +407,52 @@ int nbx_spinorb_scatter_h1(nbx_ctx* ctx, int64_t n, const double* d_one_body, do
 int nbx_spinorb_scatter_range(nbx_ctx* ctx, int64_t n, const double* d_two_body, double tol,
                               double h2_scale, int64_t idx0, int64_t count, double* d_h2_part);
 
+/* ------------------------------------------------------------------ fused SCF cycle
+ * One Huzinaga-projected UHF cycle of nbed/scf/huzinaga_scf.py:154-201 queued by ONE call (the chain is
+ * 12-40 launches; issued one by one from the host language the first cycles of an SCF are host bound).
+ * The caller fills the state once per SCF -- every pointer a device pointer it owns -- and rotates the
+ * per-cycle result buffers itself; nothing here allocates or synchronises.  Same kernels, order and
+ * operands as the step-by-step entry points: bit-identical results.
+ *   mode 1 ("tracked"): nbx_geig_refine from d_c_in = the previous cycle's S-orthonormal C; status in
+ *          d_status_out.  mode 0 ("guarded"): X F X, nbx_eigh_warm_ex warm-started from d_c_in = the previous
+ *          cycle's orthonormal-basis vectors (NULL: cold), C = X V; d_v_out receives V.
+ *   diis_mode 0: no DIIS; 1: pyscf.lib.diis' first update (only remembers F); 2: nbx_diis_update with
+ *          (diis_slot, diis_nd) -- the ring bookkeeping stays with the caller.
+ *   dts_ready: st->d_dts holds the Dtot' table of d_dm_in (left by the previous call).
+ *   h_out: 6 doubles of pinned (device-mapped) host memory: E_alpha, E_beta, |dD_alpha|, |dD_beta|, and the
+ *          eigensolver's two status words; complete once the stream has passed this call.            */
+typedef struct nbx_huz_state {
+    int64_t nao, nocc_a, nocc_b;
+    const double* d_packed; /* nbx_eri_pack of the whole tensor */
+    const double* d_hv;     /* (2,N,N) hcore + V_emb */
+    const double* d_ds;     /* (2,N,N) D_env S */
+    const double* d_sb;     /* (2,N,N) the overlap, once per spin (tracked mode) */
+    const double* d_x;      /* (N,N) S^-1/2 (guarded mode) */
+    double* d_dts;          /* nbx_jk_dts_bytes() table or NULL */
+    double* d_jk;           /* (3,N,N) */
+    double* d_fock;         /* (2,N,N) h + V + vhf */
+    double* d_vhf;          /* (2,N,N) */
+    double* d_fock2;        /* (2,N,N) ... + Hz */
+    double* d_tmp;          /* (2,N,N) guarded mode */
+    double* d_fo;           /* (2,N,N) guarded mode */
+    void* d_jk_work;
+    size_t jk_work_bytes;   /* nbx_jk_packed_worksize(nao, 0, nao, 2) */
+    void* d_eig_work;
+    size_t eig_work_bytes;  /* nbx_eigh_worksize(nao, 2) */
+    void* d_geig_work;
+    size_t geig_work_bytes; /* nbx_geig_refine_worksize(nao, 2) */
+    int64_t diis_space;
+    double* d_diis_xs;      /* (space, 2 N^2) */
+    double* d_diis_es;
+    double* d_diis_h;       /* (space+1)^2, initialised by the caller (row/column 0 = 1) */
+    double* d_diis_coef;
+    double* d_diis_xprev;   /* 2 N^2 */
+} nbx_huz_state;
+int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, const double* d_c_in,
+                  double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out, double* d_hz_out, int mode,
+                  int refine_iters, int diis_mode, int diis_slot, int diis_nd, int dts_ready, double* h_out,
+                  int* d_status_out);
+
 /* d_x[i] <- (|d_x[i]| < tol ? 0 : d_x[i]) * scale over n doubles: the 1e-8 truncation
  * (nbed/ham_builder.py:213-214) and the 1/2 of build() (:254) applied to a SPATIAL block, for callers
  * that keep the three unique spin blocks (aaaa, bbbb, aabb) instead of the 16x larger scattered

@@ -37,6 +37,22 @@ class NbxUnavailableError(RuntimeError):
     """libnbx.so is not built or no MI355X is visible: the HIP path cannot run."""
 
 
+class HuzState(ctypes.Structure):
+    """``nbx_huz_state`` of include/nbx.h: the device pointers one SCF keeps for ``nbx_huz_cycle``."""
+
+    _fields_ = [
+        ("nao", c_int64), ("nocc_a", c_int64), ("nocc_b", c_int64),
+        ("d_packed", c_void_p), ("d_hv", c_void_p), ("d_ds", c_void_p), ("d_sb", c_void_p), ("d_x", c_void_p),
+        ("d_dts", c_void_p), ("d_jk", c_void_p), ("d_fock", c_void_p), ("d_vhf", c_void_p), ("d_fock2", c_void_p),
+        ("d_tmp", c_void_p), ("d_fo", c_void_p),
+        ("d_jk_work", c_void_p), ("jk_work_bytes", c_size_t),
+        ("d_eig_work", c_void_p), ("eig_work_bytes", c_size_t),
+        ("d_geig_work", c_void_p), ("geig_work_bytes", c_size_t),
+        ("diis_space", c_int64), ("d_diis_xs", c_void_p), ("d_diis_es", c_void_p), ("d_diis_h", c_void_p),
+        ("d_diis_coef", c_void_p), ("d_diis_xprev", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/nbx.h one to one
 _P = c_void_p
 SIGNATURES = {
@@ -127,6 +143,8 @@ SIGNATURES = {
     "nbx_spinorb_scatter_range": (c_int, [_P, c_int64, _P, c_double, c_double, c_int64, c_int64, _P]),
     "nbx_spinorb_scatter": (c_int, [_P, c_int64, _P, _P, c_double, c_double, _P, _P]),
     "nbx_threshold_scale": (c_int, [_P, c_int64, c_double, c_double, _P]),
+    "nbx_huz_cycle": (c_int, [_P, POINTER(HuzState), _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                              c_int, _P, _P]),
 }
 
 _lib = None

@@ -529,6 +529,61 @@ class HipBackend:
                    self._p(hz), self._p(dm), self._p(dm_old), self._p(h_out), self._p(extra), ntail, self._p(dts))
         return _PendingScalars(self.torch, None, ntail, host=h_out)
 
+    # ------------------------------------------------------------------ fused SCF cycle (one call per cycle)
+    def huz_cycle_state(self, nao, nelec, packed, hv, ds, s_b, x, dts, diis_space: int = 6):
+        """Everything one Huzinaga SCF keeps on the device for ``huz_cycle``: the state block of
+        ``nbx_huz_cycle`` (workspaces, scratch matrices, the DIIS ring with its Pulay matrix) and three
+        rotating sets of per-cycle results (the loop runs one cycle ahead and may hand back the cycle
+        before the last).  Returns a small holder object."""
+        torch, lib = self.torch, self.lib
+        n = int(nao)
+        nsq = 2 * n * n
+
+        class Holder:
+            pass
+
+        h = Holder()
+        h.n, h.nelec = n, (int(nelec[0]), int(nelec[1]))
+        h.keep = [packed, hv, ds, s_b, x, dts]
+        h.jk = self.empty((3, n, n))
+        h.fock, h.vhf, h.fock2, h.tmp, h.fo = (self.empty((2, n, n)) for _ in range(5))
+        h.jk_work = torch.empty(max(int(lib.nbx_jk_packed_worksize(n, 0, n, 2)), 256), dtype=torch.uint8, device=self.device)
+        h.eig_work = torch.empty(max(int(lib.nbx_eigh_worksize(n, 2)), 256), dtype=torch.uint8, device=self.device)
+        h.geig_work = torch.empty(max(int(lib.nbx_geig_refine_worksize(n, 2)), 256), dtype=torch.uint8, device=self.device)
+        h.diis_xs, h.diis_es = self.empty((diis_space, nsq)), self.empty((diis_space, nsq))
+        hm = np.zeros((diis_space + 1, diis_space + 1))
+        hm[0, 1:] = hm[1:, 0] = 1
+        h.diis_h = self.asarray(hm)
+        h.diis_coef = self.zeros(diis_space)
+        h.diis_xprev = self.empty(nsq)
+        h.sets = [{"c": self.empty((2, n, n)), "v": self.empty((2, n, n)), "w": self.empty((2, n)),
+                   "dm": self.empty((2, n, n)), "hz": self.empty((2, n, n)),
+                   "status": torch.empty(2, dtype=torch.int32, device=self.device)} for _ in range(3)]
+        st = _nbx.HuzState()
+        st.nao, st.nocc_a, st.nocc_b = n, h.nelec[0], h.nelec[1]
+        for name, t in (("d_packed", packed), ("d_hv", hv), ("d_ds", ds), ("d_sb", s_b), ("d_x", x), ("d_dts", dts),
+                        ("d_jk", h.jk), ("d_fock", h.fock), ("d_vhf", h.vhf), ("d_fock2", h.fock2), ("d_tmp", h.tmp),
+                        ("d_fo", h.fo), ("d_jk_work", h.jk_work), ("d_eig_work", h.eig_work),
+                        ("d_geig_work", h.geig_work), ("d_diis_xs", h.diis_xs), ("d_diis_es", h.diis_es),
+                        ("d_diis_h", h.diis_h), ("d_diis_coef", h.diis_coef), ("d_diis_xprev", h.diis_xprev)):
+            setattr(st, name, t.data_ptr() if t is not None else None)
+        st.jk_work_bytes, st.eig_work_bytes, st.geig_work_bytes = h.jk_work.numel(), h.eig_work.numel(), h.geig_work.numel()
+        st.diis_space = diis_space
+        h.st = st
+        return h
+
+    def huz_cycle(self, h, dm_in, c_in, out, tracked: bool, refine_iters: int, diis_mode: int, diis_slot: int,
+                  diis_nd: int, dts_ready: bool):
+        """Queue one SCF cycle (nbx_huz_cycle) writing into the result set ``out``; returns the handle of
+        its scalars + status words (read one cycle late, like ``huz_cycle_scalars_async``)."""
+        h_out = self._pin_ring[self._pin_next][:6]
+        self._pin_next = (self._pin_next + 1) % self._PIN_SLOTS
+        self._call("nbx_huz_cycle", ctypes.byref(h.st), self._p(dm_in), self._p(c_in), self._p(out["dm"]),
+                   self._p(out["c"]), self._p(out["v"]), self._p(out["w"]), self._p(out["hz"]), 1 if tracked else 0,
+                   int(refine_iters), int(diis_mode), int(diis_slot), int(diis_nd), 1 if dts_ready else 0,
+                   self._p(h_out), self._p(out["status"]))
+        return _PendingScalars(self.torch, None, 2, host=h_out)
+
     def async_to_host(self, d_vals):
         """Stream-ordered copy of a small device tensor to pinned memory; ``.get()`` waits for it only."""
         return _PendingScalars(self.torch, d_vals, 0, ncore=int(d_vals.numel()))

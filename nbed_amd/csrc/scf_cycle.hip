@@ -1,0 +1,93 @@
+// libnbx: one Huzinaga-projected UHF SCF cycle as ONE call (include/nbx.h "fused SCF cycle").
+//
+// The cycle of nbed/scf/huzinaga_scf.py:154-201 is a chain of 12 (settled) to 40 (first cycles, guarded
+// eigensolver) launches.  Issued from Python one by one -- a ctypes call with 10-17 marshalled arguments
+// and a handful of tensor allocations each -- the host needs 0.3-0.8 ms per early cycle, more than the
+// GPU does, and the GPU idles 100-300 us per cycle until the eigensolver settles
+// (tools/trace_cycle.py).  Here the chain is queued by one C call from a state block the host fills
+// once per SCF; all arithmetic stays in the kernels the step-by-step path uses (same entry points,
+// same order, same operands): results are bit-identical to that path.
+#include "nbx_common.h"
+
+extern "C" int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, const double* d_c_in,
+                             double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out, double* d_hz_out,
+                             int mode, int refine_iters, int diis_mode, int diis_slot, int diis_nd, int dts_ready,
+                             double* h_out, int* d_status_out) {
+    NBX_CHECK_ARG(ctx && st && d_dm_in && d_dm_out && d_c_out && d_w_out && d_hz_out && h_out);
+    NBX_CHECK_ARG(st->nao > 0 && st->d_packed && st->d_hv && st->d_ds && st->d_jk && st->d_fock && st->d_vhf &&
+                  st->d_fock2 && st->d_jk_work);
+    NBX_CHECK_ARG(mode == 0 || mode == 1);
+    NBX_CHECK_ARG(diis_mode >= 0 && diis_mode <= 2);
+    const int64_t N = st->nao, n2 = N * N;
+    int rc;
+
+    // ---- Fock build (:156-160): J/K on the packed integrals with the Fock assembly in its reduction
+    rc = nbx_jk_packed_fock(ctx, N, st->d_packed, d_dm_in, st->d_hv, st->d_jk, st->d_fock, st->d_vhf, st->d_jk_work,
+                            st->jk_work_bytes, (dts_ready && st->d_dts) ? st->d_dts : nullptr);
+    if (rc != NBX_OK) return rc;
+    // Huzinaga operator and F += Hz in one launch (:159-160); the operator of the pre-DIIS Fock matrix is
+    // what the loop returns (:206)
+    rc = nbx_huzinaga_fused(ctx, N, 2, st->d_fock, st->d_ds, 1.0, d_hz_out, st->d_fock2);
+    if (rc != NBX_OK) return rc;
+
+    // ---- DIIS (:162-164): pyscf.lib.diis.DIIS.update -- the first call only remembers F
+    const double* f_use = st->d_fock2;
+    if (diis_mode == 1) {
+        NBX_CHECK_ARG(st->d_diis_xprev);
+        rc = nbx_memcpy_d2d(ctx, st->d_diis_xprev, st->d_fock2, (size_t)(2 * n2) * sizeof(double));
+        if (rc != NBX_OK) return rc;
+    } else if (diis_mode == 2) {
+        NBX_CHECK_ARG(st->d_diis_xprev && st->d_diis_xs && st->d_diis_es && st->d_diis_h && st->d_diis_coef);
+        rc = nbx_diis_update(ctx, 2 * n2, st->diis_space, diis_slot, diis_nd, st->d_fock2, st->d_diis_xprev,
+                             st->d_diis_xs, st->d_diis_es, st->d_diis_h, st->d_diis_coef);
+        if (rc != NBX_OK) return rc;
+        f_use = st->d_diis_xprev;  // the extrapolated matrix
+    }
+
+    // ---- eigenproblem F C = S C eps (:166-169)
+    const int* d_status = nullptr;
+    if (mode == 1) {  // tracked: refine the previous cycle's (eps, C) on the pencil (F, S), no fallback queued
+        NBX_CHECK_ARG(d_c_in && st->d_sb && st->d_geig_work && d_status_out);
+        rc = nbx_geig_refine(ctx, N, 2, f_use, st->d_sb, d_c_in, d_w_out, d_c_out, d_status_out, st->d_geig_work,
+                             st->geig_work_bytes, refine_iters);
+        if (rc != NBX_OK) return rc;
+        d_status = d_status_out;
+    } else {  // guarded: Loewdin step, warm-started eigensolver (refinement, Jacobi behind it on the device)
+        NBX_CHECK_ARG(st->d_x && st->d_eig_work && st->d_tmp && st->d_fo && d_v_out);
+        rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_x, N, 0, f_use, N, n2, 0.0, st->d_tmp, N, n2, 2);
+        if (rc != NBX_OK) return rc;
+        rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_tmp, N, n2, st->d_x, N, 0, 0.0, st->d_fo, N, n2, 2);
+        if (rc != NBX_OK) return rc;
+        // d_c_in: the previous cycle's ORTHONORMAL-basis vectors (NULL: cold start)
+        rc = nbx_eigh_warm_ex(ctx, N, 2, st->d_fo, d_c_in, d_w_out, d_v_out, st->d_eig_work, st->eig_work_bytes,
+                              refine_iters);
+        if (rc != NBX_OK) return rc;
+        rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_x, N, 0, d_v_out, N, n2, 0.0, d_c_out, N, n2, 2);
+        if (rc != NBX_OK) return rc;
+        d_status = reinterpret_cast<const int*>(static_cast<const char*>(st->d_eig_work) +
+                                                nbx_eigh_status_offset(N, 2));
+    }
+
+    // ---- density of the aufbau occupation (:170-174): the solver returns ascending eigenvalues, so the
+    // occupied orbitals are the leading columns
+    if (st->nocc_a == st->nocc_b && st->nocc_a > 0) {
+        rc = nbx_gemm(ctx, 'N', 'T', N, N, st->nocc_a, 1.0, d_c_out, N, n2, d_c_out, N, n2, 0.0, d_dm_out, N, n2, 2);
+        if (rc != NBX_OK) return rc;
+    } else {
+        const int64_t nocc[2] = {st->nocc_a, st->nocc_b};
+        for (int x = 0; x < 2; ++x) {
+            if (nocc[x] > 0) {
+                rc = nbx_gemm(ctx, 'N', 'T', N, N, nocc[x], 1.0, d_c_out + x * n2, N, 0, d_c_out + x * n2, N, 0, 0.0,
+                              d_dm_out + x * n2, N, 0, 1);
+            } else {
+                rc = nbx_memset(ctx, d_dm_out + x * n2, 0, (size_t)n2 * sizeof(double));
+            }
+            if (rc != NBX_OK) return rc;
+        }
+    }
+
+    // ---- energy and convergence scalars (:181-194) + the eigensolver's status words, stored by the kernel
+    // into (pinned) host memory; it also leaves the Dtot' table of the new density for the next build
+    return nbx_huz_cycle_scalars_dts(ctx, N, st->d_hv, 3, nullptr, st->d_vhf, d_hz_out, d_dm_out, d_dm_in, h_out,
+                                     d_status, 2, st->d_dts);
+}

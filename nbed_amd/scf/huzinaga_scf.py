@@ -297,7 +297,53 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         scf_energy_prev = scf_energy
         return False
 
-    for i in range(scf_method.max_cycle):
+    # One C call per cycle (nbx_huz_cycle) instead of 12-40 marshalled launches: the first cycles of an
+    # SCF are host bound otherwise (the GPU idles 100-300 us per cycle until the eigensolver settles).
+    # Same kernels, order and operands as the step-by-step path below: bit-identical results.
+    use_cycle_call = (lookahead and ds_virt is None and dts_d is not None and hasattr(be, "huz_cycle")
+                      and os.environ.get("NBED_CYCLE_CALL", "1") != "0")
+    if use_cycle_call:
+        if s_b is None:
+            s_b = be.asarray(np.stack([s_h] * nb))
+        hstate = be.huz_cycle_state(s_h.shape[0], scf_method.mol.nelec, scf_method.eri_packed_device(), hv, ds_occ,
+                                    s_b, x_d, dts_d)
+        diis_state = {"first": True, "head": 0, "nd": 0, "space": 6}
+        for i in range(scf_method.max_cycle):
+            if callback is not None:
+                callback(i)
+            out = hstate.sets[i % 3]
+            tracked_now = bool(warm["tracked"] and warm["c"] is not None)
+            diis_mode = diis_slot = diis_nd = 0
+            if use_DIIS and i > 1:  # pyscf.lib.diis bookkeeping (scf/diis.py): first update only remembers F
+                if diis_state["first"]:
+                    diis_state["first"] = False
+                    diis_mode = 1
+                else:
+                    if diis_state["head"] >= diis_state["space"]:
+                        diis_state["head"] = 0
+                    diis_slot = diis_state["head"]
+                    diis_state["head"] += 1
+                    diis_state["nd"] = min(diis_state["nd"] + 1, diis_state["space"])
+                    diis_mode, diis_nd = 2, diis_state["nd"]
+            if tracked_now:
+                c_in = warm["c"]
+            else:
+                c_in = warm["v"]
+                if c_in is not None and c_in is out["v"]:  # stale vectors kept in the set about to be written
+                    c_in = warm["v"] = be.copy(c_in)
+            pending_now = be.huz_cycle(hstate, dm_d, c_in, out, tracked_now, warm["iters"], diis_mode, diis_slot,
+                                       diis_nd, dts_ready)
+            dts_ready = True
+            warm["c"] = out["c"]
+            if not tracked_now:
+                warm["v"] = out["v"]
+            dm_d, hz, c_d, mo_energy_h = out["dm"], out["hz"], out["c"], out["w"]
+            state_now = (i, pending_now, out["c"], out["w"], out["dm"], out["hz"], tracked_now)
+            if pending is not None and judge(pending):
+                break
+            pending = state_now
+
+    for i in range(0 if use_cycle_call else scf_method.max_cycle):
         if callback is not None:
             callback(i)
         # ---- Fock build (:156-160)

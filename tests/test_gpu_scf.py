@@ -128,13 +128,13 @@ def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch):
         return out, hist
 
     calls = {"n": 0}
-    orig = be.geig_refine
+    orig = be.huz_cycle  # the loop queues a whole cycle per call; `tracked` says which eigensolver it carries
 
-    def counting(*a, **k):
-        calls["n"] += 1
-        return orig(*a, **k)
+    def counting(h, dm_in, c_in, out, tracked, *a, **k):
+        calls["n"] += int(bool(tracked))
+        return orig(h, dm_in, c_in, out, tracked, *a, **k)
 
-    monkeypatch.setattr(be, "geig_refine", counting)
+    monkeypatch.setattr(be, "huz_cycle", counting)
     (c1, e1, d1, hz1, conv1), h1 = run()
     assert conv1 and calls["n"] > 3  # the tracked solver did most of the cycles
     monkeypatch.setenv("NBED_TRACKED_EIG", "0")
@@ -145,15 +145,31 @@ def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch):
     np.testing.assert_allclose(e1, e0, rtol=0, atol=1e-10)
     np.testing.assert_allclose(d1, d0, rtol=0, atol=1e-10)
     np.testing.assert_allclose(hz1, hz0, rtol=0, atol=1e-10)
+    # the step-by-step path (one launch per call from Python) gives the same bits as the one-call cycles
+    monkeypatch.setenv("NBED_CYCLE_CALL", "0")
+    (c3, e3, d3, hz3, conv3), h3 = run()
+    monkeypatch.setenv("NBED_CYCLE_CALL", "1")
+    assert conv3 and len(h3) == len(h0)
+    np.testing.assert_array_equal(d3, d0)
+    np.testing.assert_array_equal(e3, e0)
     # a tracked cycle that reports failure: the run is repeated with the guarded solver
     monkeypatch.setenv("NBED_TRACKED_EIG", "1")
 
-    def failing(fock, s_b, c0_, refine_iters=1):
-        w, c = orig(fock, s_b, c0_, refine_iters=refine_iters)
-        be.last_eigh_status_d = be.last_eigh_status_d * 0 - 1
-        return w, c
+    class Rejected:
+        def __init__(self, inner):
+            self.inner = inner
 
-    monkeypatch.setattr(be, "geig_refine", failing)
+        def get(self):
+            return self.inner.get()
+
+        def get_extra(self):
+            return self.inner.get_extra() * 0 - 1
+
+    def failing(h, dm_in, c_in, out, tracked, *a, **k):
+        pend = orig(h, dm_in, c_in, out, tracked, *a, **k)
+        return Rejected(pend) if tracked else pend
+
+    monkeypatch.setattr(be, "huz_cycle", failing)
     (c2, e2, d2, hz2, conv2), h2 = run()
     assert conv2 and len(h2) == len(h0)
     np.testing.assert_array_equal(d2, d0)
