@@ -111,13 +111,16 @@ def test_huzinaga_scf_vs_oracle_converged(be, n, nocc, n_env):
         np.testing.assert_allclose(d[x] @ s @ d[x], d[x], rtol=0, atol=1e-9)
 
 
-def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch):
+@pytest.mark.parametrize("n", [64, 104])
+def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch, n):
     """The unguarded refinement cycles (nbx_geig_refine, no fallback queued) give the run the guarded
     solver gives; a rejected tracked cycle makes the loop repeat the run guarded (same numbers)."""
     import nbed_amd.scf.huzinaga_scf as mod
     from nbed_amd.scf import GpuUHF, Mole, huzinaga_scf
 
-    n, nocc, n_env = 64, (12, 11), 5
+    # n = 64: the loop issues its launches one by one (be.geig_refine); n = 104 (packed J/K kernel):
+    # one nbx_huz_cycle call per cycle (be.huz_cycle with tracked=True)
+    nocc, n_env = (12, 11), 5
     pr = synth.problem(n, nocc, n_env)
 
     def run():
@@ -129,12 +132,18 @@ def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch):
 
     calls = {"n": 0}
     orig = be.huz_cycle  # the loop queues a whole cycle per call; `tracked` says which eigensolver it carries
+    orig_refine = be.geig_refine
 
     def counting(h, dm_in, c_in, out, tracked, *a, **k):
         calls["n"] += int(bool(tracked))
         return orig(h, dm_in, c_in, out, tracked, *a, **k)
 
+    def counting_refine(*a, **k):
+        calls["n"] += 1
+        return orig_refine(*a, **k)
+
     monkeypatch.setattr(be, "huz_cycle", counting)
+    monkeypatch.setattr(be, "geig_refine", counting_refine)
     (c1, e1, d1, hz1, conv1), h1 = run()
     assert conv1 and calls["n"] > 3  # the tracked solver did most of the cycles
     monkeypatch.setenv("NBED_TRACKED_EIG", "0")
@@ -169,7 +178,13 @@ def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch):
         pend = orig(h, dm_in, c_in, out, tracked, *a, **k)
         return Rejected(pend) if tracked else pend
 
+    def failing_refine(fock, s_b, c0_, refine_iters=1):
+        w, c = orig_refine(fock, s_b, c0_, refine_iters=refine_iters)
+        be.last_eigh_status_d = be.last_eigh_status_d * 0 - 1
+        return w, c
+
     monkeypatch.setattr(be, "huz_cycle", failing)
+    monkeypatch.setattr(be, "geig_refine", failing_refine)
     (c2, e2, d2, hz2, conv2), h2 = run()
     assert conv2 and len(h2) == len(h0)
     np.testing.assert_array_equal(d2, d0)
