@@ -123,11 +123,12 @@ class _TaggedVeff(np.ndarray):
 
 
 class BuiltinHFProvider:
-    """The out-of-path pieces without PySCF, for what ``nbed_amd.integrals`` covers: molecules of
-    s/p-shell elements in STO-3G with the "functional" ``xc_functional='hf'`` (exact exchange:
-    HF-in-HF embedding, the DFT-free analogue of the reference's workflow; PySCF's ``dft.UKS``
-    accepts the same string).  Integrals come from the host-side McMurchie-Davidson engine, the
-    global mean field is the product's own ``GpuUHF``."""
+    """The out-of-path pieces without PySCF, for what ``nbed_amd.integrals`` and ``nbed_amd.xc``
+    cover: molecules of s/p-shell elements in STO-3G with ``xc_functional`` = 'b3lyp' (the reference's
+    default workflow: global B3LYP Kohn-Sham, nbed/driver.py:155-191), 'lda' or 'hf' (exact exchange:
+    HF-in-HF embedding; PySCF's ``dft.UKS`` accepts the same strings).  Integrals come from the
+    host-side McMurchie-Davidson engine, exchange-correlation from the host-side quadrature
+    (``XCProvider``), Coulomb and exact exchange from libnbx (``GpuUKS`` / ``GpuUHF``)."""
 
     def __init__(self, backend=None):
         self._be = backend
@@ -137,8 +138,10 @@ class BuiltinHFProvider:
     def supports(config: NbedConfig) -> bool:
         from . import integrals
 
+        from . import xc as xcmod
+
         no_mm = None in [config.mm_charges, config.mm_coords, config.mm_radii]
-        return (str(config.xc_functional).lower() == "hf" and no_mm
+        return (str(config.xc_functional).lower().replace(" ", "") in xcmod.HYBRID_FRACTION and no_mm
                 and integrals.supports(config.geometry, str(config.basis)))
 
     def _integrals(self, config: NbedConfig):
@@ -161,11 +164,51 @@ class BuiltinHFProvider:
         return Mole(ints["nao"], nelec, ao_slices=ints["ao_slices"], e_nuc=ints["e_nuc"], atom=config.geometry,
                     basis=config.basis, charge=config.charge)
 
+    def global_hf(self, config: NbedConfig):
+        """Converged global UHF (nbed/driver.py:106-124), on libnbx."""
+        from .scf import GpuUHF
+
+        ints = self._integrals(config)
+        hf = GpuUHF(self.build_mol(config), ints["S"], ints["hcore"], ints["eri"], backend=self._be)
+        hf.conv_tol = config.convergence
+        hf.max_cycle = config.max_hf_cycles
+        hf.kernel()
+        return hf
+
+    def _xc_provider(self, config: NbedConfig, xc_functional: str):
+        """Quadrature of the semi-local part of ``xc_functional`` for this molecule (None for 'hf')."""
+        from . import integrals
+        from . import xc as xcmod
+
+        name = str(xc_functional).lower().replace(" ", "")
+        if name == "hf":
+            return None
+        key = ("xc", config.geometry, str(config.basis).lower(), str(config.unit), name)
+        if key not in self._cache:
+            atoms = integrals.parse_geometry(config.geometry, str(config.unit))
+            self._cache[key] = xcmod.XCProvider(atoms, integrals.Basis(atoms, str(config.basis)), name)
+        return self._cache[key]
+
+    def _uks(self, config: NbedConfig, mol, xc_functional: str, backend):
+        from . import xc as xcmod
+        from .scf import GpuUKS
+
+        ints = self._integrals(config)
+        return GpuUKS(mol, ints["S"], ints["hcore"], ints["eri"], backend=backend, xc=str(xc_functional),
+                      hyb=xcmod.hybrid_fraction(xc_functional), xc_provider=self._xc_provider(config, xc_functional))
+
     def global_ks(self, config: NbedConfig, run_qmmm: bool = False):
         from .scf import GpuUHF
 
         if run_qmmm or not self.supports(config):
-            raise NbedDriverError("BuiltinHFProvider covers xc_functional='hf', s/p elements in STO-3G, no QM/MM")
+            raise NbedDriverError("BuiltinHFProvider covers xc_functional in ('b3lyp', 'lda', 'hf'), s/p elements "
+                                  "in STO-3G, no QM/MM")
+        if str(config.xc_functional).lower() != "hf":
+            ks = self._uks(config, self.build_mol(config), config.xc_functional, self._be)
+            ks.conv_tol = config.convergence
+            ks.max_cycle = config.max_dft_cycles
+            ks.kernel()
+            return ks
         ints = self._integrals(config)
 
         class GlobalHF(GpuUHF):
@@ -190,13 +233,8 @@ class BuiltinHFProvider:
         return ks
 
     def local_ks(self, config: NbedConfig, embedded_mol, xc_functional: str, backend=None):
-        """Embedded Kohn-Sham object of the 'hf' functional: ``GpuUKS`` with 100 % exact exchange."""
-        from .scf import GpuUKS
-
-        if str(xc_functional).lower() != "hf":
-            raise NbedDriverError("BuiltinHFProvider has no exchange-correlation quadrature: xc_functional='hf' only")
-        ints = self._integrals(config)
-        return GpuUKS(embedded_mol, ints["S"], ints["hcore"], ints["eri"], backend=backend, xc="hf", hyb=1.0)
+        """Embedded Kohn-Sham object of ``xc_functional`` (DFT-in-DFT, nbed/driver.py:289-313)."""
+        return self._uks(config, embedded_mol, xc_functional, backend)
 
     def local_hf(self, config: NbedConfig, embedded_mol, backend=None, run_qmmm: bool = False):
         from .scf import GpuUHF
@@ -278,7 +316,18 @@ class NbedDriver:
 
     @cached_property
     def _global_fci(self):
-        self._unsupported("The global FCI reference calculation")
+        """Global FCI reference (nbed/driver.py:139-153): PySCF's solver on the global HF object, or for
+        small molecules the exact diagonalisation of its full-space Hamiltonian (``nbed_amd.fci``)."""
+        hf = self._global_hf
+        try:
+            return run_emb_fci(hf, None, self.config.convergence, self.config.max_ram_memory)
+        except NbedDriverError:
+            from . import fci
+
+            if 2 * np.asarray(hf.mo_coeff).shape[-1] > fci.MAX_SPIN_ORBITALS:
+                raise
+            const, h1, h2 = HamiltonianBuilder(hf, hf.energy_nuc(), backend=self.be).build()
+            return fci.ground_state(const, h1, h2, hf.mol.nelec)
 
     # ------------------------------------------------------------------ localisation
     def _localize(self) -> LocalizedSystem:
@@ -487,8 +536,20 @@ class NbedDriver:
         return run_emb_ccsd(emb_scf, frozen, self.config.convergence, self.config.max_ram_memory)
 
     def _run_emb_fci(self, emb_scf, frozen=None):
-        """driver.py:476-498."""
-        return run_emb_fci(emb_scf, frozen, self.config.convergence, self.config.max_ram_memory)
+        """driver.py:476-498.  Without PySCF, small active spaces are diagonalised exactly from the
+        active-space Hamiltonian of this same embedded object (``nbed_amd.fci``)."""
+        try:
+            return run_emb_fci(emb_scf, frozen, self.config.convergence, self.config.max_ram_memory)
+        except NbedDriverError:
+            from . import fci
+
+            n = np.asarray(emb_scf.mo_coeff).shape[-1]
+            if frozen is not None or 2 * n > fci.MAX_SPIN_ORBITALS:
+                raise
+            # Hamiltonian with the nuclear repulsion as its constant: its ground state is what PySCF's
+            # FCI object reports as e_tot (tests/test_builder.py:55-120)
+            const, h1, h2 = HamiltonianBuilder(emb_scf, emb_scf.energy_nuc(), backend=self.be).build()
+            return fci.ground_state(const, h1, h2, emb_scf.mol.nelec)
 
     # ------------------------------------------------------------------ the embedding
     def embed(self, init_huzinaga_rhf_with_mu: bool = False,

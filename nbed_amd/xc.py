@@ -1,0 +1,272 @@
+"""Exchange-correlation quadrature for the embedding-potential producer.
+
+The reference gets E_xc and v_xc from PySCF's ``dft.UKS.get_veff`` (numint + libxc) at
+nbed/driver.py:155-191 (global B3LYP Kohn-Sham), :315-431 (``_subsystem_dft``: E_xc of the active,
+environment and total densities), :845-852 (the embedding potential) and :1138-1231 (DFT-in-DFT).
+They are INPUTS of the embedded-SCF hot path -- produced a handful of times per molecule -- so this
+module is host code: atom-centred quadrature grids, AO values on them, and the functionals PySCF
+would hand to libxc.  The Coulomb and exact-exchange parts of the Kohn-Sham matrix stay on the GPU
+(``GpuUKS``: libnbx J/K); an ``XCProvider`` supplies the semi-local remainder
+``(E_xc, v_xc)`` through ``GpuUKS(xc_provider=...)``.
+
+Functionals (libxc definitions, spin-polarised):
+  * ``lda``    Slater exchange + VWN(RPA) correlation                      ("lda,vwn_rpa")
+  * ``b3lyp``  0.08 Slater + 0.72 B88 + 0.19 VWN(RPA) + 0.81 LYP + 0.20 HF  (libxc XC_HYB_GGA_XC_B3LYP,
+               what PySCF >= 2.3 means by "b3lyp": the warning captured in
+               docs/source/notebooks/localization.ipynb cell 13)
+  * ``hf``     no semi-local part, 100 % exact exchange
+Energy densities are written once, in torch float64; their derivatives with respect to
+(rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb) come from autograd, not from hand-derived formulas.
+
+Grid: Becke fuzzy cells (three smoothing iterations, Bragg-Slater size adjustment) over
+Gauss-Chebyshev radial shells (Becke's mapping r = R (1 + x) / (1 - x)) times a product angular rule
+(Gauss-Legendre in cos(theta) x uniform in phi, exact to degree 2 n_theta - 1).  It is NOT PySCF's
+grid (Treutler-Ahlrichs radial + pruned Lebedev angular): the two quadratures converge to the same
+integrals, so energies agree to the residual error of PySCF's default grid level 3 (~1e-6..1e-5 Ha),
+not bit for bit -- see DESIGN.md section 6.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import integrals
+
+#: Bragg-Slater radii (Angstrom) used for the radial scale and the cell-size adjustment (Becke 1988)
+BRAGG = {"H": 0.35, "C": 0.70, "N": 0.65, "O": 0.60, "F": 0.50}
+
+HYBRID_FRACTION = {"hf": 1.0, "b3lyp": 0.2, "lda": 0.0, "lda,vwn_rpa": 0.0, "slater": 0.0}
+
+
+def hybrid_fraction(xc: str) -> float:
+    key = str(xc).lower().replace(" ", "")
+    if key not in HYBRID_FRACTION:
+        raise ValueError(f"functional {xc!r} is not in nbed_amd.xc ({sorted(HYBRID_FRACTION)})")
+    return HYBRID_FRACTION[key]
+
+
+# ---------------------------------------------------------------------------------------------- grid
+def _angular_rule(n_theta: int):
+    """Unit vectors and weights (sum 4 pi) of the product rule: Gauss-Legendre in cos(theta), 2 n_theta
+    equidistant azimuths (half a step off the axes so that no point sits on a nucleus-nucleus line)."""
+    x, w = np.polynomial.legendre.leggauss(n_theta)
+    n_phi = 2 * n_theta
+    phi = (np.arange(n_phi) + 0.5) * (2.0 * math.pi / n_phi)
+    st = np.sqrt(1.0 - x * x)
+    pts = np.stack([np.outer(st, np.cos(phi)), np.outer(st, np.sin(phi)), np.outer(x, np.ones(n_phi))], axis=-1)
+    wts = np.outer(w, np.full(n_phi, 2.0 * math.pi / n_phi))
+    return pts.reshape(-1, 3), wts.reshape(-1)
+
+
+def _radial_rule(n_rad: int, scale: float):
+    """Gauss-Chebyshev (second kind) nodes mapped to (0, inf) by r = scale (1 + x) / (1 - x); weights
+    include r^2 dr."""
+    i = np.arange(1, n_rad + 1)
+    x = np.cos(i * math.pi / (n_rad + 1))
+    w = math.pi / (n_rad + 1) * np.sin(i * math.pi / (n_rad + 1)) ** 2 / np.sqrt(1.0 - x * x)
+    r = scale * (1.0 + x) / (1.0 - x)
+    dr = 2.0 * scale / (1.0 - x) ** 2
+    return r, w * dr * r * r
+
+
+def build_grid(atoms, n_rad: int = 96, n_theta: int = 28):
+    """(points (G, 3) in Bohr, weights (G,)) of the molecular grid."""
+    centres = np.array([pos for _, pos in atoms])
+    radii = np.array([BRAGG[sym] / integrals.BOHR for sym, _ in atoms])
+    ang_pts, ang_w = _angular_rule(n_theta)
+    natm = len(atoms)
+    dist = np.linalg.norm(centres[:, None, :] - centres[None, :, :], axis=-1)
+    # Becke's size adjustment a_ij from the ratio of the Bragg radii (|a| capped at 1/2)
+    chi = radii[:, None] / radii[None, :]
+    uab = (chi - 1.0) / (chi + 1.0)
+    aij = np.clip(uab / (uab * uab - 1.0), -0.5, 0.5)
+    pts_all, w_all = [], []
+    for ia, (sym, pos) in enumerate(atoms):
+        r, wr = _radial_rule(n_rad if sym != "H" else max(n_rad * 3 // 4, 24), radii[ia] if sym != "H" else 2 * radii[ia])
+        pts = pos[None, None, :] + r[:, None, None] * ang_pts[None, :, :]
+        w = wr[:, None] * ang_w[None, :]
+        pts = pts.reshape(-1, 3)
+        w = w.reshape(-1)
+        if natm > 1:
+            rg = np.linalg.norm(pts[:, None, :] - centres[None, :, :], axis=-1)  # (G, natm)
+            cell = np.ones((pts.shape[0], natm))
+            for i in range(natm):
+                for j in range(natm):
+                    if i == j:
+                        continue
+                    mu = (rg[:, i] - rg[:, j]) / dist[i, j]
+                    nu = mu + aij[i, j] * (1.0 - mu * mu)
+                    f = nu
+                    for _ in range(3):
+                        f = 1.5 * f - 0.5 * f**3
+                    cell[:, i] *= 0.5 * (1.0 - f)
+            w = w * cell[:, ia] / cell.sum(axis=1)
+        keep = w > 1e-22
+        pts_all.append(pts[keep])
+        w_all.append(w[keep])
+    return np.concatenate(pts_all), np.concatenate(w_all)
+
+
+# ---------------------------------------------------------------------------------------------- AOs on the grid
+def eval_ao(basis: "integrals.Basis", pts: np.ndarray, deriv: int = 1):
+    """AO values (G, nao) and, with ``deriv`` = 1, their gradients (3, G, nao) for contracted Cartesian
+    shells x^l y^m z^n sum_k c_k exp(-a_k r^2) in the AO order of ``integrals.Basis``."""
+    npts = pts.shape[0]
+    ao = np.zeros((npts, basis.nao))
+    dao = np.zeros((3, npts, basis.nao)) if deriv else None
+    for sh, ao0 in zip(basis.shells, basis.shell_ao0):
+        d = pts - sh.centre[None, :]
+        r2 = np.einsum("gx,gx->g", d, d)
+        ex = np.exp(-np.outer(r2, sh.exps))  # (G, nprim)
+        for ic, lmn in enumerate(sh.cart):
+            rad = ex @ sh.coefs[ic]                       # sum_k c_k e^{-a r^2}
+            drad = ex @ (sh.coefs[ic] * (-2.0 * sh.exps))  # d/d(r^2) * 2 -> multiplies x_i
+            poly = np.ones(npts)
+            for ax in range(3):
+                if lmn[ax]:
+                    poly = poly * d[:, ax] ** lmn[ax]
+            ao[:, ao0 + ic] = poly * rad
+            if deriv:
+                for ax in range(3):
+                    g = poly * drad * d[:, ax]
+                    if lmn[ax]:
+                        lower = np.ones(npts)
+                        for bx in range(3):
+                            e = lmn[bx] - (1 if bx == ax else 0)
+                            if e:
+                                lower = lower * d[:, bx] ** e
+                        g = g + lmn[ax] * lower * rad
+                    dao[ax, :, ao0 + ic] = g
+    return ao, dao
+
+
+# ---------------------------------------------------------------------------------------------- functionals
+def _torch():
+    import torch
+
+    return torch
+
+
+def _slater(t, ra, rb):
+    cx = 1.5 * (3.0 / (4.0 * math.pi)) ** (1.0 / 3.0)
+    return -cx * (ra ** (4.0 / 3.0) + rb ** (4.0 / 3.0))
+
+
+def _b88_correction(t, ra, rb, saa, sbb):
+    """Becke's 1988 gradient correction to the Slater exchange (beta = 0.0042)."""
+    beta = 0.0042
+    out = 0.0
+    for r, s in ((ra, saa), (rb, sbb)):
+        r43 = r ** (4.0 / 3.0)
+        x = t.sqrt(s) / r43
+        out = out - beta * r43 * x * x / (1.0 + 6.0 * beta * x * t.asinh(x))
+    return out
+
+
+def _vwn_rpa(t, ra, rb):
+    """Vosko-Wilk-Nusair correlation, the fit to the RPA data (libxc LDA_C_VWN_RPA; Gaussian's "VWN3")."""
+    rho = ra + rb
+    zeta = (ra - rb) / rho
+    x = ((3.0 / (4.0 * math.pi)) / rho) ** (1.0 / 6.0)  # sqrt(rs)
+
+    def ec(a, x0, b, c):
+        q = math.sqrt(4.0 * c - b * b)
+        xx = x * x + b * x + c
+        xx0 = x0 * x0 + b * x0 + c
+        at = t.atan(q / (2.0 * x + b))
+        return a * (t.log(x * x / xx) + 2.0 * b / q * at
+                    - b * x0 / xx0 * (t.log((x - x0) ** 2 / xx) + 2.0 * (b + 2.0 * x0) / q * at))
+
+    ec_p = ec(0.0310907, -0.409286, 13.0720, 42.7198)
+    ec_f = ec(0.01554535, -0.743294, 20.1231, 101.578)
+    fz = ((1.0 + zeta) ** (4.0 / 3.0) + (1.0 - zeta) ** (4.0 / 3.0) - 2.0) / (2.0 ** (4.0 / 3.0) - 2.0)
+    return rho * (ec_p + fz * (ec_f - ec_p))
+
+
+def _lyp(t, ra, rb, saa, sab, sbb):
+    """Lee-Yang-Parr correlation in the gradient-only form of Miehlich, Savin, Stoll and Preuss (1989)."""
+    a, b, c, d = 0.04918, 0.132, 0.2533, 0.349
+    rho = ra + rb
+    r13 = rho ** (-1.0 / 3.0)
+    denom = 1.0 + d * r13
+    omega = t.exp(-c * r13) / denom * rho ** (-11.0 / 3.0)
+    delta = c * r13 + d * r13 / denom
+    cf = 0.3 * (3.0 * math.pi**2) ** (2.0 / 3.0)
+    stot = saa + 2.0 * sab + sbb
+    t1 = -a * 4.0 / denom * ra * rb / rho
+    brace = (ra * rb * (2.0 ** (11.0 / 3.0) * cf * (ra ** (8.0 / 3.0) + rb ** (8.0 / 3.0))
+                        + (47.0 / 18.0 - 7.0 * delta / 18.0) * stot
+                        - (2.5 - delta / 18.0) * (saa + sbb)
+                        - (delta - 11.0) / 9.0 * (ra / rho * saa + rb / rho * sbb))
+             - 2.0 / 3.0 * rho * rho * stot
+             + (2.0 / 3.0 * rho * rho - ra * ra) * sbb
+             + (2.0 / 3.0 * rho * rho - rb * rb) * saa)
+    return t1 - a * b * omega * brace
+
+
+def energy_density(xc: str, ra, rb, saa, sab, sbb):
+    """Semi-local exchange-correlation energy per volume (torch tensors); None for ``hf``."""
+    t = _torch()
+    key = str(xc).lower().replace(" ", "")
+    if key == "hf":
+        return None
+    if key in ("lda", "lda,vwn_rpa"):
+        return _slater(t, ra, rb) + _vwn_rpa(t, ra, rb)
+    if key == "slater":
+        return _slater(t, ra, rb)
+    if key == "b3lyp":
+        return (0.8 * _slater(t, ra, rb) + 0.72 * _b88_correction(t, ra, rb, saa, sbb)
+                + 0.19 * _vwn_rpa(t, ra, rb) + 0.81 * _lyp(t, ra, rb, saa, sab, sbb))
+    raise ValueError(f"functional {xc!r} is not in nbed_amd.xc")
+
+
+class XCProvider:
+    """``(E_xc, v_xc (2,N,N))`` of a two-spin density matrix: the callable ``GpuUKS`` takes as
+    ``xc_provider``.  Built once per molecule (grid and AO values are kept)."""
+
+    RHO_FLOOR = 1e-14
+
+    def __init__(self, atoms, basis: "integrals.Basis", xc: str, n_rad: int = 96, n_theta: int = 28):
+        self.xc = str(xc).lower().replace(" ", "")
+        self.hyb = hybrid_fraction(self.xc)
+        self.points, self.weights = build_grid(atoms, n_rad, n_theta)
+        self.ao, self.dao = eval_ao(basis, self.points, deriv=1)
+        self.nelec_last = None
+
+    def __call__(self, dm):
+        t = _torch()
+        dm = np.asarray(dm, dtype=np.float64)
+        if self.xc == "hf":
+            return 0.0, np.zeros_like(dm)
+        ao, dao, w = self.ao, self.dao, self.weights
+        rho, grad = [], []
+        for x in range(2):
+            c = ao @ dm[x]                                   # (G, nao)
+            rho.append(np.einsum("gm,gm->g", c, ao))
+            grad.append(2.0 * np.einsum("xgm,gm->xg", dao, c))  # D symmetric
+        self.nelec_last = float(np.dot(w, rho[0] + rho[1]))
+        mask = (rho[0] + rho[1]) > self.RHO_FLOOR
+        ra = t.tensor(np.maximum(rho[0][mask], self.RHO_FLOOR * 0.5), dtype=t.float64, requires_grad=True)
+        rb = t.tensor(np.maximum(rho[1][mask], self.RHO_FLOOR * 0.5), dtype=t.float64, requires_grad=True)
+        ga, gb = grad[0][:, mask], grad[1][:, mask]
+        tiny = 1e-40
+        saa = t.tensor(np.einsum("xg,xg->g", ga, ga) + tiny, dtype=t.float64, requires_grad=True)
+        sab = t.tensor(np.einsum("xg,xg->g", ga, gb), dtype=t.float64, requires_grad=True)
+        sbb = t.tensor(np.einsum("xg,xg->g", gb, gb) + tiny, dtype=t.float64, requires_grad=True)
+        wm = t.tensor(w[mask], dtype=t.float64)
+        e = energy_density(self.xc, ra, rb, saa, sab, sbb)
+        exc = (wm * e).sum()
+        vra, vrb, vsaa, vsab, vsbb = (g.numpy() if g is not None else 0.0 for g in t.autograd.grad(
+            exc, (ra, rb, saa, sab, sbb), allow_unused=True))
+        # autograd differentiated sum_g w_g e_g: the derivatives already carry the weights
+        aom, daom = ao[mask], dao[:, mask]
+        vxc = np.zeros_like(dm)
+        for x, (vr, vs_same, gs, go) in enumerate(((vra, vsaa, ga, gb), (vrb, vsbb, gb, ga))):
+            # v = v_rho phi_m phi_n + (2 v_ss grad rho_s + v_ab grad rho_other) . grad(phi_m phi_n)
+            vec = 2.0 * vs_same * gs + vsab * go               # (3, G), weights included
+            half = 0.5 * vr[:, None] * aom + np.einsum("xg,xgm->gm", vec, daom)
+            m = aom.T @ half
+            vxc[x] = m + m.T
+        return float(exc.detach()), vxc

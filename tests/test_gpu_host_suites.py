@@ -31,6 +31,17 @@ from test_water_kat import (  # noqa: E402,F401
     test_product_scf_reproduces_reference_uhf_literals,
 )
 from test_host_integrals import test_driver_on_builtin_provider_hf_in_hf_water  # noqa: E402,F401
+from test_reference_kats import (  # noqa: E402,F401  (the reference's own KATs, libnbx doing the arithmetic)
+    drivers,
+    provider,
+    test_dft_in_dft_reproduces_global_ks,
+    test_embedded_fci_both_projectors,
+    test_global_hf_and_fci,
+    test_global_ks_b3lyp,
+    test_projectors_scf_match,
+    test_two_active_atoms_raw_xyz_and_subsystem_sum_rule,
+    test_usage_notebook_results,
+)
 from test_host_scf import (  # noqa: E402,F401
     test_energy_elec_matches_reference,
     test_gpu_uhf_protocol_matches_oracle_scf,

@@ -107,10 +107,60 @@ def test_driver_on_builtin_provider_hf_in_hf_water(be, projector):
 def test_builtin_provider_refuses_what_it_does_not_cover():
     from nbed_amd.exceptions import NbedDriverError
 
-    cfg = NbedConfig(geometry=WATER_XYZ, n_active_atoms=2, basis="STO-3G", xc_functional="b3lyp",
+    assert BuiltinHFProvider.supports(NbedConfig(geometry=WATER_XYZ, n_active_atoms=2, basis="STO-3G",
+                                                 xc_functional="b3lyp"))  # nbed_amd.xc has B3LYP
+    cfg = NbedConfig(geometry=WATER_XYZ, n_active_atoms=2, basis="STO-3G", xc_functional="pbe0",
                      projector="mu", convergence=1e-8)
     assert not BuiltinHFProvider.supports(cfg)
+    assert not BuiltinHFProvider.supports(NbedConfig(geometry=WATER_XYZ, n_active_atoms=2, basis="cc-pVDZ",
+                                                     xc_functional="b3lyp"))
     from nbed_amd.driver import NbedDriver
 
     with pytest.raises(NbedDriverError):
         NbedDriver(cfg, backend=OracleBackend()).provider
+
+
+def test_xc_quadrature_and_functional_derivatives():
+    """nbed_amd.xc: the grid integrates the density to the electron count and the AO overlap to S;
+    v_xc is the derivative of E_xc (finite differences along a random symmetric direction); LDA
+    exchange of the hydrogen 1s density (spin polarised) against its closed form."""
+    from nbed_amd import integrals, xc
+
+    geom = "3\n\nO   0.0000  0.000  0.115\nH   0.0000  0.754  -0.459\nH   0.0000  -0.754  -0.459"
+    atoms = integrals.parse_geometry(geom)
+    basis = integrals.Basis(atoms, "sto-3g")
+    ints = integrals.molecule_integrals(geom, "sto-3g", "angstrom")
+    prov = xc.XCProvider(atoms, basis, "b3lyp", n_rad=60, n_theta=18)
+    s_num = prov.ao.T @ (prov.ao * prov.weights[:, None])
+    np.testing.assert_allclose(s_num, ints["S"], rtol=0, atol=5e-7)
+    w, c = np.linalg.eigh(ints["S"])
+    x = (c / np.sqrt(w)) @ c.T
+    e, u = np.linalg.eigh(x @ ints["hcore"] @ x)
+    cmo = x @ u
+    dm = np.stack([cmo[:, :5] @ cmo[:, :5].T, cmo[:, :4] @ cmo[:, :4].T])  # open shell on purpose
+    exc, vxc = prov(dm)
+    assert abs(prov.nelec_last - 9.0) < 1e-5
+    np.testing.assert_allclose(vxc, vxc.transpose(0, 2, 1), rtol=0, atol=1e-12)
+    rng = np.random.default_rng(3)
+    d = rng.normal(size=(2, 7, 7)) * 1e-4
+    d = d + d.transpose(0, 2, 1)
+    fd = (prov(dm + d)[0] - prov(dm - d)[0]) / 2.0
+    assert abs(fd - np.einsum("xij,xji->", vxc, d)) < 1e-8
+    for name in ("lda", "hf"):
+        p2 = xc.XCProvider(atoms, basis, name, n_rad=40, n_theta=12)
+        e2, v2 = p2(dm)
+        assert (name == "hf") == (e2 == 0.0 and not np.any(v2))
+    assert xc.hybrid_fraction("b3lyp") == 0.2 and xc.hybrid_fraction("HF") == 1.0
+    with pytest.raises(ValueError):
+        xc.hybrid_fraction("pbe0")
+    # closed form: E_x^LDA of rho = e^{-2r}/pi, all spin up, is -(3/2)(3/4pi)^(1/3) int rho^(4/3)
+    #            = -(3/2)(3/(4 pi))^(1/3) pi^(-4/3) 4 pi 2 / (8/3)^3
+    h_atom = [("H", np.zeros(3))]
+    pts, wts = xc.build_grid(h_atom, n_rad=80, n_theta=8)
+    import torch
+
+    rho = torch.tensor(np.exp(-2.0 * np.linalg.norm(pts, axis=1)) / np.pi)
+    z = torch.zeros_like(rho)
+    ex = float((torch.tensor(wts) * xc.energy_density("slater", rho, z + 1e-30, z, z, z)).sum())
+    exact = -1.5 * (3.0 / (4.0 * np.pi)) ** (1.0 / 3.0) * np.pi ** (-4.0 / 3.0) * 8.0 * np.pi / (8.0 / 3.0) ** 3
+    assert abs(ex - exact) < 1e-6

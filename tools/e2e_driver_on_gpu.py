@@ -49,13 +49,15 @@ prov = Provider()
 t0 = time.perf_counter()
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
-drv = nbed(cfg, provider=prov, backend=be)
+FMT = os.environ.get("E2E_FORMAT", "dense")  # "spatial": three unique spin blocks instead of the (2n)^4 tensor
+drv = nbed(cfg, provider=prov, backend=be, hamiltonian_format=FMT)
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(int(os.environ.get("E2E_NSTATS", "28")))
 torch.cuda.synchronize()
 print(f"NbedDriver.embed() total: {time.perf_counter()-t0:.2f} s", flush=True)
 for name in ("mu", "huzinaga"):
     res = getattr(drv, name)
-    const, h1, h2 = res["second_quantised"]
-    print(name, "e_rhf", res["e_rhf"], "classical", res["classical_energy"], "h2 shape", h2.shape, "converged", bool(res["scf"].converged))
+    sq = res["second_quantised"]
+    shape = sq[2].shape if FMT == "dense" else ("spatial", sq.two_body.shape, f"{sq.nbytes / 1e9:.2f} GB")
+    print(name, "e_rhf", res["e_rhf"], "classical", res["classical_energy"], "h2", shape, "converged", bool(res["scf"].converged))
 print("global e_tot", drv._global_ks.e_tot)
