@@ -142,10 +142,10 @@ def test_xc_quadrature_and_functional_derivatives():
     assert abs(prov.nelec_last - 9.0) < 1e-5
     np.testing.assert_allclose(vxc, vxc.transpose(0, 2, 1), rtol=0, atol=1e-12)
     rng = np.random.default_rng(3)
-    d = rng.normal(size=(2, 7, 7)) * 1e-4
+    d = rng.normal(size=(2, 7, 7)) * 1e-5  # (the central difference's own error is cubic in the step)
     d = d + d.transpose(0, 2, 1)
     fd = (prov(dm + d)[0] - prov(dm - d)[0]) / 2.0
-    assert abs(fd - np.einsum("xij,xji->", vxc, d)) < 1e-8
+    assert abs(fd - np.einsum("xij,xji->", vxc, d)) < 2e-9
     for name in ("lda", "hf"):
         p2 = xc.XCProvider(atoms, basis, name, n_rad=40, n_theta=12)
         e2, v2 = p2(dm)
