@@ -44,10 +44,62 @@ BASIS_SETS = {
         "F": _sto3g_second_row((166.6791300, 30.3608120, 8.2168207), (6.4648032, 1.5022812, 0.4885885)),
     }
 }
+# 6-31G (Hehre, Ditchfield, Pople 1972): a six-primitive core s function and a 3 + 1 split valence with
+# shared s/p exponents; cc-pVDZ (Dunning 1989) with one spherical d (p for hydrogen) polarisation shell.
+_631G = {
+    "H": [(0, (18.7311370, 2.8253937, 0.6401217), (0.03349460, 0.23472695, 0.81375733)),
+          (0, (0.1612778,), (1.0,))],
+    "C": [(0, (3047.5249, 457.36951, 103.94869, 29.210155, 9.2866630, 3.1639270),
+           (0.0018347, 0.0140373, 0.0688426, 0.2321844, 0.4679413, 0.3623120)),
+          (0, (7.8682724, 1.8812885, 0.5442493), (-0.1193324, -0.1608542, 1.1434564)),
+          (1, (7.8682724, 1.8812885, 0.5442493), (0.0689991, 0.3164240, 0.7443083)),
+          (0, (0.1687144,), (1.0,)), (1, (0.1687144,), (1.0,))],
+    "N": [(0, (4173.5110, 627.45790, 142.90210, 40.234330, 12.820210, 4.3904370),
+           (0.0018348, 0.0139950, 0.0685870, 0.2322410, 0.4690700, 0.3604550)),
+          (0, (11.626358, 2.7162800, 0.7722180), (-0.1149610, -0.1691180, 1.1458520)),
+          (1, (11.626358, 2.7162800, 0.7722180), (0.0675800, 0.3239070, 0.7408950)),
+          (0, (0.2120313,), (1.0,)), (1, (0.2120313,), (1.0,))],
+    "O": [(0, (5484.6717, 825.23495, 188.04696, 52.964500, 16.897570, 5.7996353),
+           (0.0018311, 0.0139501, 0.0684451, 0.2327143, 0.4701930, 0.3585209)),
+          (0, (15.539616, 3.5999336, 1.0137618), (-0.1107775, -0.1480263, 1.1307670)),
+          (1, (15.539616, 3.5999336, 1.0137618), (0.0708743, 0.3397528, 0.7271586)),
+          (0, (0.2700058,), (1.0,)), (1, (0.2700058,), (1.0,))],
+}
+_CCPVDZ = {
+    "H": [(0, (13.01, 1.962, 0.4446, 0.1220), (0.019685, 0.137977, 0.478148, 0.501240)),
+          (0, (0.1220,), (1.0,)), (1, (0.727,), (1.0,))],
+    "C": [(0, (6665.0, 1000.0, 228.0, 64.71, 21.06, 7.495, 2.797, 0.5215, 0.1596),
+           (0.000692, 0.005329, 0.027077, 0.101718, 0.274740, 0.448564, 0.285074, 0.015204, -0.003191)),
+          (0, (6665.0, 1000.0, 228.0, 64.71, 21.06, 7.495, 2.797, 0.5215, 0.1596),
+           (-0.000146, -0.001154, -0.005725, -0.023312, -0.063955, -0.149981, -0.127262, 0.544529, 0.580496)),
+          (0, (0.1596,), (1.0,)),
+          (1, (9.439, 2.002, 0.5456, 0.1517), (0.038109, 0.209480, 0.508557, 0.468842)),
+          (1, (0.1517,), (1.0,)), (2, (0.550,), (1.0,))],
+    "O": [(0, (11720.0, 1759.0, 400.8, 113.7, 37.03, 13.27, 5.025, 1.013, 0.3023),
+           (0.000710, 0.005470, 0.027837, 0.104800, 0.283062, 0.448719, 0.270952, 0.015458, -0.002585)),
+          (0, (11720.0, 1759.0, 400.8, 113.7, 37.03, 13.27, 5.025, 1.013, 0.3023),
+           (-0.000160, -0.001263, -0.006267, -0.025716, -0.070924, -0.165411, -0.116955, 0.557368, 0.572759)),
+          (0, (0.3023,), (1.0,)),
+          (1, (17.70, 3.854, 1.046, 0.2753), (0.043018, 0.228913, 0.508728, 0.460531)),
+          (1, (0.2753,), (1.0,)), (2, (1.185,), (1.0,))],
+}
+# 6-31G*: one d shell (exponent 0.8) on the heavy atoms; PySCF evaluates it with five spherical components
+_631GS = {sym: (shells + [(2, (0.8,), (1.0,))] if sym != "H" else shells) for sym, shells in _631G.items()}
+BASIS_SETS["6-31g"] = _631G
+BASIS_SETS["6-31g*"] = _631GS
+BASIS_SETS["6-31g(d)"] = _631GS
+BASIS_SETS["cc-pvdz"] = _CCPVDZ
+BASIS_SETS["ccpvdz"] = _CCPVDZ
 NUCLEAR_CHARGE = {"H": 1, "C": 6, "N": 7, "O": 8, "F": 9}
 #: Slater exponents behind the table (1s, 2sp)
 STO3G_ZETA = {"H": (1.24, None), "C": (5.67, 1.72), "N": (6.67, 1.95), "O": (7.66, 2.25), "F": (8.65, 2.55)}
-_CART = {0: [(0, 0, 0)], 1: [(1, 0, 0), (0, 1, 0), (0, 0, 1)]}
+_CART = {0: [(0, 0, 0)], 1: [(1, 0, 0), (0, 1, 0), (0, 0, 1)],
+         2: [(2, 0, 0), (1, 1, 0), (1, 0, 1), (0, 2, 0), (0, 1, 1), (0, 0, 2)]}
+# real solid harmonics of l = 2 over (xx, xy, xz, yy, yz, zz), PySCF's order m = -2 .. 2:
+# xy, yz, (2 zz - xx - yy) / 2, xz, (xx - yy) sqrt(3) / 2  (the sqrt(3) of the xy-type ones is absorbed
+# by the numerical normalisation of each function)
+_SPH = {2: np.array([[0, 1, 0, 0, 0, 0], [0, 0, 0, 0, 1, 0], [-0.5, 0, 0, -0.5, 0, 1.0], [0, 0, 1, 0, 0, 0],
+                     [1.0, 0, 0, -1.0, 0, 0]], dtype=float)}
 
 
 def parse_geometry(xyz: str, unit: str = "angstrom"):
@@ -79,12 +131,22 @@ class Shell:
     """One contracted shell: centre, angular momentum, exponents and the coefficients of each of
     its Cartesian components including primitive and contracted normalisation."""
 
-    def __init__(self, centre, ang, exps, coefs):
+    def __init__(self, centre, ang, exps, coefs, cart: bool = False):
         self.centre = np.asarray(centre, dtype=float)
         self.ang = ang
         self.exps = np.asarray(exps, dtype=float)
         self.cart = _CART[ang]
-        self.coefs = np.array([self._normalised(lmn, np.asarray(coefs, dtype=float)) for lmn in self.cart])
+        if ang <= 1:  # Cartesian = spherical: every component normalised in closed form
+            self.coefs = np.array([self._normalised(lmn, np.asarray(coefs, dtype=float)) for lmn in self.cart])
+            self.sph = np.eye(len(self.cart))
+        else:
+            # the contraction coefficients refer to normalised primitives: relative weight a^((2l+3)/4); the
+            # spherical combinations are normalised numerically from the shell's own Cartesian overlap
+            c = np.asarray(coefs, dtype=float) * self.exps ** ((2 * ang + 3) / 4.0)
+            self.coefs = np.array([c for _ in self.cart])
+            self.sph = np.eye(len(self.cart)) if cart else _SPH[ang].copy()
+            ovl = _self_overlap(self)
+            self.sph = self.sph / np.sqrt(np.einsum("mi,ij,mj->m", self.sph, ovl, self.sph))[:, None]
 
     def _normalised(self, lmn, coefs):
         big_l = sum(lmn)
@@ -95,23 +157,60 @@ class Shell:
         return c / math.sqrt(math.pi ** 1.5 * dd / 2.0 ** big_l * pair.sum())
 
 
+def _self_overlap(sh):
+    """Overlap of the Cartesian components of one shell with themselves (its own normalisation)."""
+    a, b = np.meshgrid(sh.exps, sh.exps, indexing="ij")
+    a, b = a.ravel(), b.ravel()
+    p = a + b
+    e = _hermite_e(sh.ang, sh.ang, a, b, 0.0)
+    pref = (math.pi / p) ** 1.5
+    n = len(sh.cart)
+    out = np.zeros((n, n))
+    for i, la in enumerate(sh.cart):
+        for j, lb in enumerate(sh.cart):
+            w = (sh.coefs[i][:, None] * sh.coefs[j][None, :]).ravel()
+            out[i, j] = np.dot(w, e[(la[0], lb[0], 0)] * e[(la[1], lb[1], 0)] * e[(la[2], lb[2], 0)] * pref)
+    return out
+
+
 class Basis:
-    def __init__(self, atoms, basis: str = "sto-3g"):
+    """Shells of a molecule.  Integrals are evaluated over the CARTESIAN components (offsets
+    ``shell_ao0``, ``nao_cart`` of them) and brought to the AOs proper -- spherical d functions, as
+    PySCF's default -- by ``to_ao`` (the (nao, nao_cart) matrix ``cart2ao``; the identity for s/p bases)."""
+
+    def __init__(self, atoms, basis: str = "sto-3g", cart: bool = False):
         table = BASIS_SETS[basis.lower().replace("_", "-")]
         self.atoms = atoms
         self.shells: list[Shell] = []
         self.shell_ao0: list[int] = []
         self.ao_slices = []
-        nao = nsh = 0
+        nao = ncart = nsh = 0
+        blocks = []
         for iat, (sym, pos) in enumerate(atoms):
             ao0, sh0 = nao, nsh
             for ang, exps, coefs in table[sym]:
-                self.shells.append(Shell(pos, ang, exps, coefs))
-                self.shell_ao0.append(nao)
-                nao += len(_CART[ang])
+                sh = Shell(pos, ang, exps, coefs, cart)
+                self.shells.append(sh)
+                self.shell_ao0.append(ncart)
+                blocks.append((nao, ncart, sh.sph))
+                ncart += len(_CART[ang])
+                nao += sh.sph.shape[0]
                 nsh += 1
             self.ao_slices.append([sh0, nsh, ao0, nao])
-        self.nao = nao
+        self.nao, self.nao_cart = nao, ncart
+        self.cart2ao = np.zeros((nao, ncart))
+        for a0, c0, t in blocks:
+            self.cart2ao[a0:a0 + t.shape[0], c0:c0 + t.shape[1]] = t
+        self.pure_cartesian = nao == ncart and bool(np.array_equal(self.cart2ao, np.eye(nao)))
+
+    def to_ao(self, m: np.ndarray) -> np.ndarray:
+        """Cartesian-component tensor (every axis of length nao_cart) -> AO tensor."""
+        if self.pure_cartesian:
+            return m
+        u = self.cart2ao
+        for ax in range(m.ndim):
+            m = np.moveaxis(np.tensordot(u, m, axes=(1, ax)), 0, ax)
+        return m
 
 
 def _hermite_e(imax, jmax, a, b, q):
@@ -191,7 +290,7 @@ class _Pair:
 
 def one_electron(basis: Basis):
     """(S, T, V_nuc), each (nao, nao)."""
-    n = basis.nao
+    n = basis.nao_cart
     s_mat, t_mat, v_mat = np.zeros((n, n)), np.zeros((n, n)), np.zeros((n, n))
     for (ish, sa), (jsh, sb) in itertools.product(enumerate(basis.shells), repeat=2):
         pr = _Pair(sa, sb, extra=2)  # kinetic energy raises the ket by two
@@ -225,12 +324,27 @@ def one_electron(basis: Basis):
                 s_mat[i, j] = np.dot(w, s_val)
                 t_mat[i, j] = np.dot(w, t_val)
                 v_mat[i, j] = np.dot(w, v_val)
-    return s_mat, t_mat, v_mat
+    return basis.to_ao(s_mat), basis.to_ao(t_mat), basis.to_ao(v_mat)
+
+
+def overlap_cross(basis_a: Basis, basis_b: Basis) -> np.ndarray:
+    """<a_i | b_j> between the AOs of two basis sets (possibly of different molecules / kinds):
+    PySCF's ``gto.intor_cross('int1e_ovlp_sph', mol_a, mol_b)`` (nbed/localizers/virtual/concentric.py:83-88)."""
+    out = np.zeros((basis_a.nao_cart, basis_b.nao_cart))
+    for ish, sa in enumerate(basis_a.shells):
+        for jsh, sb in enumerate(basis_b.shells):
+            pr = _Pair(sa, sb)
+            pref = (math.pi / pr.p) ** 1.5
+            for ia, la in enumerate(sa.cart):
+                for ib, lb in enumerate(sb.cart):
+                    val = pr.e[0][(la[0], lb[0], 0)] * pr.e[1][(la[1], lb[1], 0)] * pr.e[2][(la[2], lb[2], 0)] * pref
+                    out[basis_a.shell_ao0[ish] + ia, basis_b.shell_ao0[jsh] + ib] = np.dot(pr.weights(ia, ib), val)
+    return basis_a.cart2ao @ out @ basis_b.cart2ao.T
 
 
 def two_electron(basis: Basis) -> np.ndarray:
     """(pq|rs), dense (nao,)*4 in chemist order; the 8-fold symmetry is used over shell quartets."""
-    n = basis.nao
+    n = basis.nao_cart
     eri = np.zeros((n, n, n, n))
     nsh = len(basis.shells)
     pairs = {(i, j): _Pair(basis.shells[i], basis.shells[j]) for i in range(nsh) for j in range(i + 1)}
@@ -262,7 +376,7 @@ def two_electron(basis: Basis) -> np.ndarray:
                     for (w, x), (y, z) in itertools.product(((a0, b0), (b0, a0)), ((c0, d0), (d0, c0))):
                         eri[w, x, y, z] = val
                         eri[y, z, w, x] = val
-    return eri
+    return basis.to_ao(eri)
 
 
 def nuclear_repulsion(atoms) -> float:
@@ -272,14 +386,40 @@ def nuclear_repulsion(atoms) -> float:
     return e
 
 
-def molecule_integrals(xyz: str, basis: str = "sto-3g", unit: str = "angstrom") -> dict:
+def two_electron_native(basis: Basis, nthreads: int = 0, cutoff: float = 1e-16) -> np.ndarray:
+    """(pq|rs) from libnbx's host engine (``nbx_host_eri``, csrc/ints_host.cpp: the same McMurchie-Davidson
+    scheme in C++ over a thread pool) -- what makes a 148-function molecule practical.  Raises if libnbx.so
+    is not built; ``two_electron`` above is the numpy engine it is tested against."""
+    import ctypes
+
+    from . import _nbx
+
+    lib = _nbx.load_library()
+    sh = basis.shells
+    ang = np.array([s.ang for s in sh], dtype=np.int32)
+    nprim = np.array([len(s.exps) for s in sh], dtype=np.int32)
+    nfunc = np.array([s.sph.shape[0] for s in sh], dtype=np.int32)
+    centres = np.ascontiguousarray([s.centre for s in sh], dtype=np.float64)
+    exps = np.concatenate([s.exps for s in sh]).astype(np.float64)
+    coefs = np.concatenate([s.coefs[0] for s in sh]).astype(np.float64)  # components of a shell share them
+    sph = np.concatenate([np.ascontiguousarray(s.sph, dtype=np.float64).ravel() for s in sh])
+    out = np.empty((basis.nao,) * 4)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    _nbx.check(lib, lib.nbx_host_eri(len(sh), ptr(ang), ptr(nprim), ptr(nfunc), ptr(centres), ptr(exps), ptr(coefs),
+                                     ptr(sph), float(cutoff), int(nthreads), ptr(out)))
+    return out
+
+
+def molecule_integrals(xyz: str, basis: str = "sto-3g", unit: str = "angstrom", cart: bool = False,
+                       engine: str = "native") -> dict:
     """Everything the embedding driver needs of a molecule: S, hcore = T + V, (pq|rs), e_nuc, the
     per-atom AO slices and the electron count of the neutral molecule."""
     atoms = parse_geometry(xyz, unit)
-    bs = Basis(atoms, basis)
+    bs = Basis(atoms, basis, cart)  # cart: six Cartesian d functions (PySCF's mol.cart), default five spherical
     s_mat, t_mat, v_mat = one_electron(bs)
     return {
-        "S": s_mat, "T": t_mat, "V": v_mat, "hcore": t_mat + v_mat, "eri": two_electron(bs),
+        "S": s_mat, "T": t_mat, "V": v_mat, "hcore": t_mat + v_mat,
+        "eri": two_electron_native(bs) if engine == "native" else two_electron(bs),
         "e_nuc": nuclear_repulsion(atoms), "ao_slices": bs.ao_slices, "nao": bs.nao,
         "nelectron": sum(NUCLEAR_CHARGE[s] for s, _ in atoms),
     }

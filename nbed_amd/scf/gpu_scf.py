@@ -158,11 +158,16 @@ class _GpuSCF:
         reuse it.  None when it does not apply (row-slab object, backend without it, too large)."""
         be = self.be
         nao = self._s_h.shape[0]
+        shared = getattr(self, "_eri_shared", None)  # set by a provider whose objects share one molecule
+        if getattr(self, "_eri_rs_d", None) is None and shared is not None:
+            self._eri_rs_d = shared.get("rs")
         if getattr(self, "_eri_rs_d", None) is None:
             self._eri_rs_d = None
             whole = self.shards.world == 1 and self._eri_d is not None
             if whole and hasattr(be, "eri_pack_rs") and 4 * nao**4 <= self.ERI_RS_CACHE_MAX_BYTES:
                 self._eri_rs_d = be.eri_pack_rs(self._eri_d, nao)
+                if shared is not None:
+                    shared["rs"] = self._eri_rs_d
         return self._eri_rs_d
 
     def jk_device(self, dm_d):
@@ -489,8 +494,9 @@ class GpuUKS(GpuUHF, UKS):
 
     _device_kernel_ok = False
 
-    def __init__(self, mol, ovlp, hcore, eri=None, backend=None, shards=None, xc="hf", hyb=1.0, xc_provider=None):
-        super().__init__(mol, ovlp, hcore, eri, backend=backend, shards=shards)
+    def __init__(self, mol, ovlp, hcore, eri=None, backend=None, shards=None, xc="hf", hyb=1.0, xc_provider=None,
+                 eri_packed=None):
+        super().__init__(mol, ovlp, hcore, eri, backend=backend, shards=shards, eri_packed=eri_packed)
         self.xc = xc
         self.hyb = float(hyb)
         self.xc_provider = xc_provider

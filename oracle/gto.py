@@ -1,4 +1,4 @@
-"""Oracle: a minimal Gaussian-integral engine (s and p shells) for real-molecule KATs.
+"""Oracle: a minimal Gaussian-integral engine (s, p and spherical d shells) for real-molecule KATs.
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  The reference obtains S, T, V_nuc and (pq|rs)
 from PySCF/libcint (``gto.Mole.intor``; nbed/driver.py:86-104 builds the molecule).  libcint is
@@ -10,6 +10,14 @@ STO-3G water, the system of the reference's DFT-free known-answer test
 Conventions follow PySCF so that the numbers are comparable: Bohr radius 0.52917721092 A
 (pyscf.data.nist.BOHR), AO order per atom = shells in basis order, p functions as (x, y, z),
 normalised contracted functions.
+
+``SphericalBasis`` (further down) adds d shells the way libcint defines them: real solid harmonics
+normalised on the sphere (m = -2 .. 2: xy, yz, z^2, xz, x^2 - y^2) times a radial contraction whose
+primitives are normalised in closed form (gamma functions), each AO a short list of weighted
+Cartesian monomials fed to the same primitive recursions.  The product (nbed_amd/integrals.py)
+normalises its spherical combinations NUMERICALLY from the shell's own overlap and evaluates
+shell pairs vectorised -- two routes to the same numbers.  The basis-set tables themselves are data
+(typed once); they are pinned by literature Hartree-Fock energies in tests/test_host_integrals.py.
 """
 
 from __future__ import annotations
@@ -247,3 +255,99 @@ def nuclear_repulsion(atoms) -> float:
         for j in range(i):
             e += CHARGE[atoms[i][0]] * CHARGE[atoms[j][0]] / np.linalg.norm(atoms[i][1] - atoms[j][1])
     return e
+
+
+# ------------------------------------------------------------------------------------------------
+# general angular momentum: AOs as weighted sums of Cartesian monomials over one radial contraction
+_SOLID = {
+    0: [[(1.0, (0, 0, 0))]],
+    1: [[(1.0, (1, 0, 0))], [(1.0, (0, 1, 0))], [(1.0, (0, 0, 1))]],
+    2: [  # r^2 Y_2m without the common sqrt(1/4pi) -- restored by _angular_norm
+        [(math.sqrt(15.0), (1, 1, 0))],
+        [(math.sqrt(15.0), (0, 1, 1))],
+        [(math.sqrt(5.0) / 2.0 * 2.0, (0, 0, 2)), (-math.sqrt(5.0) / 2.0, (2, 0, 0)), (-math.sqrt(5.0) / 2.0, (0, 2, 0))],
+        [(math.sqrt(15.0), (1, 0, 1))],
+        [(math.sqrt(15.0) / 2.0, (2, 0, 0)), (-math.sqrt(15.0) / 2.0, (0, 2, 0))],
+    ],
+}
+_ANG_COMMON = {0: 1.0, 1: math.sqrt(3.0), 2: 1.0}  # l = 1: sqrt(3/4pi) x;  l = 2 factors sit in _SOLID
+
+
+class SphericalBasis:
+    """AOs of a molecule from a table {symbol: [(l, exponents, coefficients), ...]}, l <= 2, real
+    spherical d functions.  ``aos`` holds (centre, [(weight, lmn), ...], exponents, coefficients)."""
+
+    def __init__(self, atoms, table):
+        self.atoms = atoms
+        self.aos = []
+        self.ao_slices = []
+        for iat, (sym, pos) in enumerate(atoms):
+            start = len(self.aos)
+            for ang, exps, coefs in table[sym]:
+                exps = np.asarray(exps, dtype=float)
+                c = np.asarray(coefs, dtype=float) * self._radial_norm(ang, exps)
+                ovl = 0.0  # radial self-overlap of the contraction: Gamma(l + 3/2) / (2 (a + b)^(l + 3/2))
+                for ci, ai in zip(c, exps):
+                    for cj, aj in zip(c, exps):
+                        ovl += ci * cj * math.gamma(ang + 1.5) / (2.0 * (ai + aj) ** (ang + 1.5))
+                c = c / math.sqrt(ovl)
+                ang_norm = _ANG_COMMON[ang] / math.sqrt(4.0 * math.pi)
+                for terms in _SOLID[ang]:
+                    self.aos.append((pos, [(w * ang_norm, lmn) for w, lmn in terms], exps, c))
+            self.ao_slices.append([iat, iat + 1, start, len(self.aos)])
+        self.nao = len(self.aos)
+
+    @staticmethod
+    def _radial_norm(ang, exps):
+        # int_0^inf r^(2l) e^(-2 a r^2) r^2 dr = Gamma(l + 3/2) / (2 (2a)^(l + 3/2))
+        return np.sqrt(2.0 * (2.0 * exps) ** (ang + 1.5) / math.gamma(ang + 1.5))
+
+
+def _ao_pair(f1, f2, prim, *extra):
+    A, t1, e1, c1 = f1
+    B, t2, e2, c2 = f2
+    s = 0.0
+    for w1, l1 in t1:
+        for w2, l2 in t2:
+            s += w1 * w2 * _contract((A, l1, e1, c1), (B, l2, e2, c2), prim, *extra)
+    return s
+
+
+def one_electron_general(basis: SphericalBasis):
+    n = basis.nao
+    S, T, V = np.zeros((n, n)), np.zeros((n, n)), np.zeros((n, n))
+    for i in range(n):
+        for j in range(i + 1):
+            fi, fj = basis.aos[i], basis.aos[j]
+            S[i, j] = S[j, i] = _ao_pair(fi, fj, _overlap_prim)
+            T[i, j] = T[j, i] = _ao_pair(fi, fj, _kinetic_prim)
+            v = 0.0
+            for sym, pos in basis.atoms:
+                v -= CHARGE_ALL[sym] * _ao_pair(fi, fj, _nuclear_prim, pos)
+            V[i, j] = V[j, i] = v
+    return S, T, V
+
+
+def overlap_cross_general(basis_a: SphericalBasis, basis_b: SphericalBasis):
+    return np.array([[_ao_pair(fa, fb, _overlap_prim) for fb in basis_b.aos] for fa in basis_a.aos])
+
+
+def eri_element_general(basis: SphericalBasis, p: int, q: int, r: int, s: int) -> float:
+    """One (pq|rs): every monomial and primitive combination summed."""
+    (A, t1, e1, c1), (B, t2, e2, c2), (C, t3, e3, c3), (D, t4, e4, c4) = (basis.aos[i] for i in (p, q, r, s))
+    val = 0.0
+    for w1, l1 in t1:
+        for w2, l2 in t2:
+            for w3, l3 in t3:
+                for w4, l4 in t4:
+                    acc = 0.0
+                    for a, ca in zip(e1, c1):
+                        for b, cb in zip(e2, c2):
+                            for c, cc in zip(e3, c3):
+                                for d, cd in zip(e4, c4):
+                                    acc += ca * cb * cc * cd * _eri_prim(a, l1, A, b, l2, B, c, l3, C, d, l4, D)
+                    val += w1 * w2 * w3 * w4 * acc
+    return val
+
+
+CHARGE_ALL = {"H": 1, "C": 6, "N": 7, "O": 8, "F": 9}

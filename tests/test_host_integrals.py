@@ -57,7 +57,9 @@ def test_integrals_match_the_oracle_engine(xyz):
 
 def test_supports():
     assert integrals.supports(WATER_XYZ, "STO-3G") and integrals.supports(H2_XYZ, "sto-3g")
-    assert not integrals.supports(WATER_XYZ, "cc-pVDZ")
+    assert integrals.supports(WATER_XYZ, "cc-pVDZ") and integrals.supports(H2O2_XYZ, "6-31G*")
+    assert not integrals.supports(WATER_XYZ, "def2-SVP")
+    assert not integrals.supports("2\n\nF 0 0 0\nH 0 0 0.9", "cc-pVDZ")  # no fluorine table in that set
     assert not integrals.supports("1\n\nS 0 0 0", "sto-3g")
 
 
@@ -77,6 +79,86 @@ def test_sto3g_table_is_zeta_scaled_universal_fit():
     assert m["nao"] == 8 and m["nelectron"] == 9
     np.testing.assert_allclose(np.diag(m["S"]), 1.0, atol=1e-12)
     assert np.all(np.linalg.eigvalsh(m["S"]) > 0)
+
+
+def test_d_shell_integrals_match_the_oracle_engine():
+    """Water / 6-31G* (18 AOs, five spherical d functions on oxygen): the product's vectorised
+    shell-pair code with numerically normalised spherical combinations against the oracle's scalar
+    recursions with libcint's closed-form normalisation; and the cross-basis overlap the concentric
+    localizer asks PySCF for (gto.intor_cross, nbed/localizers/virtual/concentric.py:83-88)."""
+    m = integrals.molecule_integrals(WATER_XYZ, "6-31G*")
+    atoms = oracle_gto.parse_xyz(WATER_XYZ)
+    ob = oracle_gto.SphericalBasis(atoms, integrals.BASIS_SETS["6-31g*"])
+    assert m["nao"] == ob.nao == 18 and [r[2:] for r in m["ao_slices"]] == [[0, 14], [14, 16], [16, 18]]
+    s, t, v = oracle_gto.one_electron_general(ob)
+    np.testing.assert_allclose(m["S"], s, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(m["T"], t, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(m["V"], v, rtol=0, atol=1e-11)
+    eri = m["eri"]
+    np.testing.assert_allclose(eri, eri.transpose(1, 0, 2, 3), rtol=0, atol=1e-14)
+    np.testing.assert_allclose(eri, eri.transpose(2, 3, 0, 1), rtol=0, atol=1e-14)
+    rng = np.random.default_rng(5)
+    picks = [(9, 9, 9, 9), (11, 11, 13, 13), (9, 15, 12, 17), (11, 3, 11, 0), (13, 13, 14, 16), (10, 5, 10, 5)]
+    picks += [tuple(int(x) for x in rng.integers(0, 18, 4)) for _ in range(40)]
+    nonzero = 0
+    for p, q, r, s_ in picks:
+        ref = oracle_gto.eri_element_general(ob, p, q, r, s_)
+        assert abs(ref - eri[p, q, r, s_]) < 1e-12
+        nonzero += abs(ref) > 1e-6
+    assert nonzero >= 15
+    atoms_p = integrals.parse_geometry(WATER_XYZ)
+    cross = integrals.overlap_cross(integrals.Basis(atoms_p, "6-31g"), integrals.Basis(atoms_p, "cc-pvdz"))
+    ref = oracle_gto.overlap_cross_general(oracle_gto.SphericalBasis(atoms, integrals.BASIS_SETS["6-31g"]),
+                                           oracle_gto.SphericalBasis(atoms, integrals.BASIS_SETS["cc-pvdz"]))
+    assert cross.shape == (13, 24)
+    np.testing.assert_allclose(cross, ref, rtol=0, atol=1e-13)
+    same = integrals.Basis(atoms_p, "cc-pvdz")
+    np.testing.assert_allclose(integrals.overlap_cross(same, same), integrals.one_electron(same)[0], rtol=0, atol=1e-14)
+
+
+def _rhf_energy(m, nocc):
+    s, h, eri = m["S"], m["hcore"], m["eri"]
+    w, c = np.linalg.eigh(s)
+    x = (c / np.sqrt(w)) @ c.T
+    cmo = x @ np.linalg.eigh(x @ h @ x)[1]
+    dm = 2 * cmo[:, :nocc] @ cmo[:, :nocc].T
+    for _ in range(300):
+        f = h + np.einsum("pqrs,rs->pq", eri, dm) - 0.5 * np.einsum("prqs,rs->pq", eri, dm)
+        e = 0.5 * np.einsum("pq,pq->", dm, h + f) + m["e_nuc"]
+        cmo = x @ np.linalg.eigh(x @ f @ x)[1]
+        new = 2 * cmo[:, :nocc] @ cmo[:, :nocc].T
+        if np.abs(new - dm).max() < 1e-9:
+            break
+        dm = 0.5 * (dm + new)
+    return e
+
+
+def _bent(sym, r, angle_deg):
+    th = np.radians(angle_deg / 2)
+    return f"3\n\n{sym} 0 0 0\nH 0 {r * np.sin(th)} {r * np.cos(th)}\nH 0 {-r * np.sin(th)} {r * np.cos(th)}"
+
+
+def test_basis_tables_reproduce_literature_hartree_fock_energies():
+    """Pins the 6-31G / 6-31G* / cc-pVDZ tables (and the d-shell code) to published closed-shell
+    Hartree-Fock energies (Hehre, Radom, Schleyer, Pople, *Ab Initio Molecular Orbital Theory*, 1986,
+    at the optimised geometries of the same level; cc-pVDZ water at the experimental geometry,
+    Dunning 1989 / CCCBDB): every digit printed there is reproduced."""
+    a = 1.082 / np.sqrt(3)
+    ch4 = f"5\n\nC 0 0 0\nH {a} {a} {a}\nH {-a} {-a} {a}\nH {-a} {a} {-a}\nH {a} {-a} {-a}"
+    r, al = 0.991, np.radians(116.1)
+    sb = 2 / np.sqrt(3) * np.sin(al / 2)
+    nh3 = "4\n\nN 0 0 0\n" + "\n".join(
+        f"H {r * sb * np.cos(p)} {r * sb * np.sin(p)} {-r * np.sqrt(1 - sb * sb)}" for p in (0, 2 * np.pi / 3, 4 * np.pi / 3))
+    cases = [
+        (_bent("O", 0.9496, 111.55), "6-31g", False, -75.98536),
+        (ch4, "6-31g", False, -40.18055),
+        (nh3, "6-31g", False, -56.16552),
+        (_bent("O", 0.9473, 105.5), "6-31g*", True, -76.01075),   # Pople's 6-31G* carries six Cartesian d functions
+        (_bent("O", 0.9572, 104.52), "cc-pvdz", False, -76.02680),
+    ]
+    for xyz, basis, cart, literature in cases:
+        m = integrals.molecule_integrals(xyz, basis, cart=cart)
+        assert abs(_rhf_energy(m, 5) - literature) < 6e-6, (basis, literature)
 
 
 @pytest.fixture()
@@ -112,7 +194,9 @@ def test_builtin_provider_refuses_what_it_does_not_cover():
     cfg = NbedConfig(geometry=WATER_XYZ, n_active_atoms=2, basis="STO-3G", xc_functional="pbe0",
                      projector="mu", convergence=1e-8)
     assert not BuiltinHFProvider.supports(cfg)
-    assert not BuiltinHFProvider.supports(NbedConfig(geometry=WATER_XYZ, n_active_atoms=2, basis="cc-pVDZ",
+    assert BuiltinHFProvider.supports(NbedConfig(geometry=WATER_XYZ, n_active_atoms=2, basis="cc-pVDZ",
+                                                 xc_functional="b3lyp"))
+    assert not BuiltinHFProvider.supports(NbedConfig(geometry=WATER_XYZ, n_active_atoms=2, basis="def2-SVP",
                                                      xc_functional="b3lyp"))
     from nbed_amd.driver import NbedDriver
 

@@ -138,3 +138,23 @@ def test_two_active_atoms_raw_xyz_and_subsystem_sum_rule(be):
     np.testing.assert_array_equal(drv.embedded_scf.mo_occ, np.array([[1, 1, 1, 1, 0, 0]] * 2))
     total = drv.e_act + drv.e_env + drv.two_e_cross + drv._global_ks.energy_nuc()
     assert abs(total - drv._global_ks.e_tot) < 1e-8
+
+
+def test_concentric_shell_numbers_water_631g(be, provider):
+    """tests/test_localizers.py:217-243 (fixtures :22-49): water / 6-31G, global B3LYP Kohn-Sham at
+    conv_tol 1e-6, SPADE with one active atom, then concentric localization of the virtuals:
+    ``shells == [12, 13]`` for either spin.  (Thirteen AOs; the eight virtuals overlap the nine oxygen
+    AOs with rank seven -- one b2 combination of the hydrogen functions is orthogonal to them by
+    symmetry, its singular value an exact zero that the 1e-15 threshold of concentric.py:170 drops.)"""
+    from nbed_amd.localizers import ConcentricLocalizer, SPADELocalizer
+
+    cfg = NbedConfig(**dict(NBED_ARGS, basis="6-31g"))
+    ks = provider.global_ks(cfg)
+    assert ks.converged
+    occ = SPADELocalizer(ks, n_active_atoms=1)
+    occ.localize()
+    virt = ConcentricLocalizer(occ._global_scf, n_active_atoms=1, backend=be)
+    virt.localize_virtual()
+    assert list(virt.shells[0]) == [12, 13] and list(virt.shells[1]) == [12, 13]
+    sv = virt.singular_values[0][0]
+    assert np.sum(sv > 1 - 1e-10) == 4 and sv[-1] < 1e-15  # four virtual directions lie entirely on oxygen
