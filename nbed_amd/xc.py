@@ -34,6 +34,12 @@ import numpy as np
 
 from . import integrals
 
+
+def _torch():
+    import torch
+
+    return torch
+
 #: Bragg-Slater radii (Angstrom) used for the radial scale and the cell-size adjustment (Becke 1988)
 BRAGG = {"H": 0.35, "C": 0.70, "N": 0.65, "O": 0.60, "F": 0.50}
 
@@ -71,8 +77,11 @@ def _radial_rule(n_rad: int, scale: float):
     return r, w * dr * r * r
 
 
-def build_grid(atoms, n_rad: int = 96, n_theta: int = 28):
-    """(points (G, 3) in Bohr, weights (G,)) of the molecular grid."""
+def build_grid(atoms, n_rad: int = 96, n_theta: int = 28, device="cpu"):
+    """(points (G, 3) in Bohr, weights (G,)) of the molecular grid.  The Becke cell functions -- a
+    (points x atoms x atoms) product -- are evaluated with torch on ``device`` in blocks of points."""
+    t = _torch()
+    dev = t.device(device)
     centres = np.array([pos for _, pos in atoms])
     radii = np.array([BRAGG[sym] / integrals.BOHR for sym, _ in atoms])
     ang_pts, ang_w = _angular_rule(n_theta)
@@ -82,6 +91,10 @@ def build_grid(atoms, n_rad: int = 96, n_theta: int = 28):
     chi = radii[:, None] / radii[None, :]
     uab = (chi - 1.0) / (chi + 1.0)
     aij = np.clip(uab / (uab * uab - 1.0), -0.5, 0.5)
+    centres_d = t.as_tensor(centres).to(dev)
+    aij_d = t.as_tensor(aij).to(dev)
+    inv_dist = t.as_tensor(1.0 / (dist + np.eye(natm))).to(dev)
+    off_diag = (1.0 - t.eye(natm, dtype=t.float64, device=dev))
     pts_all, w_all = [], []
     for ia, (sym, pos) in enumerate(atoms):
         r, wr = _radial_rule(n_rad if sym != "H" else max(n_rad * 3 // 4, 24), radii[ia] if sym != "H" else 2 * radii[ia])
@@ -90,19 +103,18 @@ def build_grid(atoms, n_rad: int = 96, n_theta: int = 28):
         pts = pts.reshape(-1, 3)
         w = w.reshape(-1)
         if natm > 1:
-            rg = np.linalg.norm(pts[:, None, :] - centres[None, :, :], axis=-1)  # (G, natm)
-            cell = np.ones((pts.shape[0], natm))
-            for i in range(natm):
-                for j in range(natm):
-                    if i == j:
-                        continue
-                    mu = (rg[:, i] - rg[:, j]) / dist[i, j]
-                    nu = mu + aij[i, j] * (1.0 - mu * mu)
-                    f = nu
-                    for _ in range(3):
-                        f = 1.5 * f - 0.5 * f**3
-                    cell[:, i] *= 0.5 * (1.0 - f)
-            w = w * cell[:, ia] / cell.sum(axis=1)
+            share = np.empty(pts.shape[0])
+            for g0 in range(0, pts.shape[0], 1 << 15):
+                p = t.as_tensor(pts[g0:g0 + (1 << 15)]).to(dev)
+                rg = (p[:, None, :] - centres_d[None, :, :]).norm(dim=-1)              # (g, natm)
+                mu = (rg[:, :, None] - rg[:, None, :]) * inv_dist[None]                # (g, i, j)
+                f = mu + aij_d[None] * (1.0 - mu * mu)
+                for _ in range(3):
+                    f = 1.5 * f - 0.5 * f**3
+                s = 0.5 * (1.0 - f) * off_diag[None] + (1.0 - off_diag)[None]          # j = i contributes 1
+                cell = s.prod(dim=2)                                                   # (g, natm)
+                share[g0:g0 + p.shape[0]] = (cell[:, ia] / cell.sum(dim=1)).cpu().numpy()
+            w = w * share
         keep = w > 1e-22
         pts_all.append(pts[keep])
         w_all.append(w[keep])
@@ -146,12 +158,49 @@ def eval_ao(basis: "integrals.Basis", pts: np.ndarray, deriv: int = 1):
     return ao, dao
 
 
+def eval_ao_torch(basis: "integrals.Basis", pts, deriv: int = 1):
+    """``eval_ao`` with torch tensors on the device of ``pts`` (G, 3): (ao (G, nao), dao (3, G, nao))."""
+    t = _torch()
+    npts = pts.shape[0]
+    kw = dict(dtype=t.float64, device=pts.device)
+    ao = t.zeros((npts, basis.nao_cart), **kw)
+    dao = t.zeros((3, npts, basis.nao_cart), **kw) if deriv else None
+    for sh, ao0 in zip(basis.shells, basis.shell_ao0):
+        d = pts - t.as_tensor(sh.centre, **kw)[None, :]
+        r2 = (d * d).sum(dim=1)
+        exps = t.as_tensor(sh.exps, **kw)
+        ex = t.exp(-r2[:, None] * exps[None, :])
+        for ic, lmn in enumerate(sh.cart):
+            coef = t.as_tensor(sh.coefs[ic], **kw)
+            rad = ex @ coef
+            drad = ex @ (coef * (-2.0 * exps))
+
+            def mono(e):
+                out = t.ones(npts, **kw)
+                for ax in range(3):
+                    if e[ax]:
+                        out = out * d[:, ax] ** e[ax]
+                return out
+
+            poly = mono(lmn)
+            ao[:, ao0 + ic] = poly * rad
+            if deriv:
+                for ax in range(3):
+                    g = poly * drad * d[:, ax]
+                    if lmn[ax]:
+                        low = list(lmn)
+                        low[ax] -= 1
+                        g = g + lmn[ax] * mono(low) * rad
+                    dao[ax, :, ao0 + ic] = g
+    if not basis.pure_cartesian:
+        u = t.as_tensor(basis.cart2ao, **kw)
+        ao = ao @ u.T
+        if deriv:
+            dao = dao @ u.T
+    return ao, dao
+
+
 # ---------------------------------------------------------------------------------------------- functionals
-def _torch():
-    import torch
-
-    return torch
-
 
 def _slater(t, ra, rb):
     cx = 1.5 * (3.0 / (4.0 * math.pi)) ** (1.0 / 3.0)
@@ -232,6 +281,7 @@ class XCProvider:
 
     RHO_FLOOR = 1e-14
     BLOCK = 1 << 16  # grid points per matmul block (bounds the temporaries, not the stored AO values)
+    SPLIT = 256      # rows per piece of the (nao x G) (G x nao) product: a batched GEMM summed over pieces
 
     def __init__(self, atoms, basis: "integrals.Basis", xc: str, n_rad: int = 96, n_theta: int = 28, device=None):
         """``device``: where the AO values live and the density / potential contractions run -- a torch
@@ -240,22 +290,27 @@ class XCProvider:
         t = _torch()
         self.xc = str(xc).lower().replace(" ", "")
         self.hyb = hybrid_fraction(self.xc)
-        self.points, self.weights = build_grid(atoms, n_rad, n_theta)
         if device is None:
             device = "cuda" if t.cuda.is_available() else "cpu"
         self.device = t.device(device)
+        self.points, self.weights = build_grid(atoms, n_rad, n_theta, device=self.device)
         self.nelec_last = None
         self._blocks = []  # (ao (g, nao), dao (3, g, nao)) per block of grid points
+        npts = self.points.shape[0]
+        pad = (-npts) % self.SPLIT  # zero rows: the long-K product of __call__ splits into equal pieces
         if self.xc != "hf":
-            for g0 in range(0, self.points.shape[0], self.BLOCK):
-                ao, dao = eval_ao(basis, self.points[g0:g0 + self.BLOCK], deriv=1)
-                self._blocks.append((t.as_tensor(ao).to(self.device), t.as_tensor(dao).to(self.device)))
-        self._w = t.as_tensor(self.weights).to(self.device)
+            for g0 in range(0, npts, self.BLOCK):
+                ao, dao = eval_ao_torch(basis, t.as_tensor(self.points[g0:g0 + self.BLOCK]).to(self.device))
+                if g0 + self.BLOCK >= npts and pad:
+                    ao = t.cat([ao, ao.new_zeros(pad, ao.shape[1])])
+                    dao = t.cat([dao, dao.new_zeros(3, pad, dao.shape[2])], dim=1)
+                self._blocks.append((ao.contiguous(), dao.contiguous()))
+        self._w = t.cat([t.as_tensor(self.weights), t.zeros(pad, dtype=t.float64)]).to(self.device)
 
     @property
     def ao(self) -> np.ndarray:
         """AO values on the whole grid (G, nao), on the host (tests integrate the overlap with them)."""
-        return np.concatenate([b[0].cpu().numpy() for b in self._blocks])
+        return np.concatenate([b[0].cpu().numpy() for b in self._blocks])[: self.points.shape[0]]
 
     def __call__(self, dm):
         t = _torch()
@@ -293,7 +348,8 @@ class XCProvider:
             for ao, dao in self._blocks:
                 g1 = g0 + ao.shape[0]
                 half = 0.5 * vr[g0:g1, None] * ao + (vec[:, g0:g1, None] * dao).sum(dim=0)
-                vxc[x] += ao.T @ half
+                n = ao.shape[1]  # K = grid points is long and M = N = nao short: split K, batch, sum
+                vxc[x] += (ao.view(-1, self.SPLIT, n).transpose(1, 2) @ half.view(-1, self.SPLIT, n)).sum(dim=0)
                 g0 = g1
         vxc = vxc + vxc.transpose(1, 2)
         return float(exc.detach()), vxc.cpu().numpy()

@@ -41,6 +41,7 @@ from test_reference_kats import (  # noqa: E402,F401  (the reference's own KATs,
     test_projectors_scf_match,
     test_two_active_atoms_raw_xyz_and_subsystem_sum_rule,
     test_usage_notebook_results,
+    test_concentric_shell_numbers_water_631g,
 )
 from test_host_scf import (  # noqa: E402,F401
     test_energy_elec_matches_reference,

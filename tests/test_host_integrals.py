@@ -116,6 +116,39 @@ def test_d_shell_integrals_match_the_oracle_engine():
     np.testing.assert_allclose(integrals.overlap_cross(same, same), integrals.one_electron(same)[0], rtol=0, atol=1e-14)
 
 
+@pytest.mark.parametrize("xyz,basis,cart", [(WATER_XYZ, "6-31g*", False), (WATER_XYZ, "6-31g*", True),
+                                            ("2\n\nH 0 0 0\nH 0 0 12.0", "cc-pvdz", False), (H2O2_XYZ, "sto-3g", False)])
+def test_native_eri_engine_matches_the_numpy_engine(xyz, basis, cart):
+    """libnbx's threaded host engine (nbx_host_eri, csrc/ints_host.cpp) against the shell-pair numpy code:
+    spherical and Cartesian d shells, and a pair of atoms 12 A apart whose Coulomb integrals sit in the
+    asymptotic branch of the Boys function (T ~ 1e3)."""
+    bs = integrals.Basis(integrals.parse_geometry(xyz), basis, cart)
+    ref = integrals.two_electron(bs)
+    for nthreads in (1, 0):
+        got = integrals.two_electron_native(bs, nthreads=nthreads)
+        assert got.shape == ref.shape == (bs.nao,) * 4
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-13)
+    np.testing.assert_array_equal(got, got.transpose(1, 0, 3, 2))
+    np.testing.assert_array_equal(got, got.transpose(2, 3, 0, 1))
+
+
+def test_native_eri_engine_rejects_bad_shells():
+    import ctypes
+
+    from nbed_amd import _nbx
+
+    lib = _nbx.load_library()
+    one = np.ones(1)
+    i32 = lambda *v: np.array(v, dtype=np.int32)  # noqa: E731
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    out = np.zeros(1)
+    args = lambda ang, nfunc: (1, ptr(i32(ang)), ptr(i32(1)), ptr(i32(nfunc)), ptr(np.zeros(3)), ptr(one), ptr(one),  # noqa: E731
+                               ptr(np.ones(36)), 1e-16, 1, ptr(out))
+    assert lib.nbx_host_eri(*args(3, 7)) == -1       # f shells are not covered
+    assert lib.nbx_host_eri(*args(2, 4)) == -1       # a d shell has five or six functions
+    assert lib.nbx_host_eri(*args(0, 1)) == 0 and out[0] > 0
+
+
 def _rhf_energy(m, nocc):
     s, h, eri = m["S"], m["hcore"], m["eri"]
     w, c = np.linalg.eigh(s)

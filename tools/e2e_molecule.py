@@ -43,8 +43,41 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"quadrature grid: {grid.points.shape[0]} points on {grid.device}, {t2 - t1:.2f} s", flush=True)
 fmt = os.environ.get("E2E_FORMAT", "spatial")
+import nbed_amd.driver as drv_mod  # noqa: E402
+
+_huz = drv_mod.huzinaga_scf
+_cyc = be.huz_cycle
+_count = {"cycles": 0}
+
+
+def _counted_cycle(*a, **k):
+    _count["cycles"] += 1
+    return _cyc(*a, **k)
+
+
+def _timed_huz(*a, **k):
+    be.huz_cycle = _counted_cycle
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    out = _huz(*a, **k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    n = _count["cycles"]
+    print(f"huzinaga_scf: {dt * 1e3:.1f} ms wall, {n} fused cycles queued" + (f" ({n / dt:.0f} cycles/s)" if n else ""), flush=True)
+    return out
+
+
+drv_mod.huzinaga_scf = _timed_huz
+import cProfile  # noqa: E402
+import pstats  # noqa: E402
+
+pr = cProfile.Profile()
+pr.enable()
 drv = nbed(cfg, provider=prov, backend=be, hamiltonian_format=fmt)
 torch.cuda.synchronize()
+pr.disable()
+if os.environ.get("E2E_PROFILE", "1") != "0":
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(int(os.environ.get("E2E_NSTATS", "45")))
 t3 = time.perf_counter()
 print(f"NbedDriver.embed(): {t3 - t2:.2f} s  (whole run {t3 - t0:.2f} s)", flush=True)
 ks = drv._global_ks
