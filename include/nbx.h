@@ -460,7 +460,7 @@ int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, 
 int nbx_threshold_scale(nbx_ctx* ctx, int64_t n, double tol, double scale, double* d_x);
 
 /* ------------------------------------------------------------------ AO integrals of a real molecule (HOST)
- * (pq|rs) over contracted Gaussian shells of angular momentum <= 2, dense (nao, nao, nao, nao) in HOST
+ * (pq|rs) over contracted Gaussian shells of angular momentum <= 3, dense (nao, nao, nao, nao) in HOST
  * memory: the producer the reference reaches through PySCF/libcint (gto.Mole.intor("int2e"), implied by
  * scf.UKS(mol).kernel() at nbed/driver.py:155-191 and ao2mo at nbed/ham_builder.py:139-170).  Input of
  * the hot path, produced once per molecule: host threads, no GPU, no context.
@@ -470,7 +470,8 @@ int nbx_threshold_scale(nbx_ctx* ctx, int64_t n, double tol, double scale, doubl
  *   exps, coefs                  primitives of all shells, concatenated; coefs carry the radial
  *                                normalisation (common to the components of a shell)
  *   sph                          per shell a (nfunc, ncart) matrix from the Cartesian components
- *                                (xx xy xz yy yz zz order) to its AOs, concatenated; only read for l >= 2
+ *                                (xx xy xz yy yz zz; xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz)
+ *                                to its AOs, concatenated; only read for l >= 2
  *   cutoff                       Schwarz bound below which a shell quartet is skipped (1e-16: below fp64
  *                                resolution of the O(1) integrals)
  *   nthreads                     <= 0: all hardware threads                                              */

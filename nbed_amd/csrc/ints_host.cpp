@@ -3,7 +3,7 @@
 // The reference gets (pq|rs) from PySCF/libcint (gto.Mole.intor("int2e"), reached through
 // scf.UKS(mol).kernel() and ao2mo at nbed/driver.py:86-191, nbed/ham_builder.py:139-170).  They are the
 // INPUT of the embedded-SCF hot path, produced once per molecule, so -- like libcint -- this is host code:
-// McMurchie-Davidson over contracted shells of angular momentum <= 2, the shell quartets of the
+// McMurchie-Davidson over contracted shells of angular momentum <= 3, the shell quartets of the
 // eight-fold unique set spread over a pool of threads.  The product's Python engine
 // (nbed_amd/integrals.py) evaluates the same scheme shell pair by shell pair in numpy; this one exists
 // because a 148-function molecule (octane / 6-31G*, the configuration BASELINE.json's metric is quoted
@@ -26,14 +26,14 @@
 
 namespace {
 
-constexpr int LMAX = 2;               // per shell
+constexpr int LMAX = 3;               // per shell (s, p, d, f)
 constexpr int LTOT = 4 * LMAX;        // highest Hermite order of a quartet
 constexpr int NCUBE = LTOT + 1;
 
 inline int ncart(int l) { return (l + 1) * (l + 2) / 2; }
 inline int nherm(int l) { return (l + 1) * (l + 2) * (l + 3) / 6; }
 
-// Cartesian components in the order of integrals.py's _CART: xx xy xz yy yz zz for d
+// Cartesian components in the order of integrals.py's _CART: xx xy xz yy yz zz for d, xxx xxy xxz xyy .. zzz for f
 void cart_list(int l, int (*out)[3]) {
     int k = 0;
     for (int lx = l; lx >= 0; --lx)
@@ -144,7 +144,7 @@ void build_pair(const Shell& sa, const Shell& sb, int ia, int ib, double prim_cu
     pr.lab = sa.l + sb.l;
     pr.nab = sa.ncart_ * sb.ncart_;
     pr.nh = nherm(pr.lab);
-    int ca[6][3], cb[6][3];
+    int ca[10][3], cb[10][3];
     cart_list(sa.l, ca);
     cart_list(sb.l, cb);
     const HermIndex& hi = hidx[pr.lab];
@@ -352,7 +352,7 @@ extern "C" int nbx_host_eri(int nshell, const int* ang, const int* nprim, const 
     {   // pair data and Schwarz bounds sqrt(max (ab|ab))
         std::atomic<int64_t> next{0};
         run_pool([&] {
-            std::vector<double> blk(36 * 36), w(36 * 35), rbuf(NCUBE * NCUBE * NCUBE), rtmp(NCUBE * NCUBE * NCUBE);
+            std::vector<double> blk(100 * 100), w(100 * 84), rbuf(NCUBE * NCUBE * NCUBE), rtmp(NCUBE * NCUBE * NCUBE);
             for (;;) {
                 const int64_t ij = next.fetch_add(1);
                 if (ij >= npair) break;
@@ -376,7 +376,7 @@ extern "C" int nbx_host_eri(int nshell, const int* ang, const int* nprim, const 
     std::memset(out, 0, sizeof(double) * n3 * n);
     std::atomic<int64_t> next{0};
     run_pool([&] {
-        std::vector<double> blk(1296), scr(1296), w(36 * 35), rbuf(NCUBE * NCUBE * NCUBE), rtmp(NCUBE * NCUBE * NCUBE);
+        std::vector<double> blk(10000), scr(10000), w(100 * 84), rbuf(NCUBE * NCUBE * NCUBE), rtmp(NCUBE * NCUBE * NCUBE);
         for (;;) {
             // heaviest bra pairs first would need a sort; descending index is a fair proxy (more kets)
             const int64_t ij = npair - 1 - next.fetch_add(1);

@@ -85,6 +85,46 @@ _CCPVDZ = {
 }
 # 6-31G*: one d shell (exponent 0.8) on the heavy atoms; PySCF evaluates it with five spherical components
 _631GS = {sym: (shells + [(2, (0.8,), (1.0,))] if sym != "H" else shells) for sym, shells in _631G.items()}
+# cc-pVTZ (Dunning 1989): [4s3p2d1f] for C, N, O and [3s2p1d] for H
+_CCPVTZ = {
+    "H": [(0, (33.87, 5.095, 1.159, 0.3258, 0.1027), (0.006068, 0.045308, 0.202822, 0.503903, 0.383421)),
+          (0, (0.3258,), (1.0,)), (0, (0.1027,), (1.0,)),
+          (1, (1.407,), (1.0,)), (1, (0.388,), (1.0,)), (2, (1.057,), (1.0,))],
+    "C": [(0, (8236.0, 1235.0, 280.8, 79.27, 25.59, 8.997, 3.319, 0.9059, 0.3643, 0.1285),
+           (0.000531, 0.004108, 0.021087, 0.081853, 0.234817, 0.434401, 0.346129, 0.039378, -0.008983, 0.002385)),
+          (0, (8236.0, 1235.0, 280.8, 79.27, 25.59, 8.997, 3.319, 0.9059, 0.3643, 0.1285),
+           (-0.000113, -0.000878, -0.004540, -0.018133, -0.055760, -0.126895, -0.170352, 0.140382, 0.598684, 0.395389)),
+          (0, (0.9059,), (1.0,)), (0, (0.1285,), (1.0,)),
+          (1, (18.71, 4.133, 1.200, 0.3827, 0.1209), (0.014031, 0.086866, 0.290216, 0.501008, 0.343406)),
+          (1, (0.3827,), (1.0,)), (1, (0.1209,), (1.0,)),
+          (2, (1.097,), (1.0,)), (2, (0.318,), (1.0,)), (3, (0.761,), (1.0,))],
+    "N": [(0, (11420.0, 1712.0, 389.3, 110.0, 35.57, 12.54, 4.644, 1.293, 0.5118, 0.1787),
+           (0.000523, 0.004045, 0.020775, 0.080727, 0.233074, 0.433501, 0.347472, 0.041262, -0.008508, 0.002384)),
+          (0, (11420.0, 1712.0, 389.3, 110.0, 35.57, 12.54, 4.644, 1.293, 0.5118, 0.1787),
+           (-0.000115, -0.000895, -0.004624, -0.018528, -0.057339, -0.132076, -0.172510, 0.151814, 0.599944, 0.387462)),
+          (0, (1.293,), (1.0,)), (0, (0.1787,), (1.0,)),
+          (1, (26.63, 5.948, 1.742, 0.5550, 0.1725), (0.014670, 0.091764, 0.298683, 0.498487, 0.337023)),
+          (1, (0.5550,), (1.0,)), (1, (0.1725,), (1.0,)),
+          (2, (1.654,), (1.0,)), (2, (0.469,), (1.0,)), (3, (1.093,), (1.0,))],
+    "O": [(0, (15330.0, 2299.0, 522.4, 147.3, 47.55, 16.76, 6.207, 1.752, 0.6882, 0.2384),
+           (0.000508, 0.003929, 0.020243, 0.079181, 0.230687, 0.433118, 0.350260, 0.042728, -0.008154, 0.002381)),
+          (0, (15330.0, 2299.0, 522.4, 147.3, 47.55, 16.76, 6.207, 1.752, 0.6882, 0.2384),
+           (-0.000115, -0.000895, -0.004636, -0.018724, -0.058463, -0.136463, -0.175740, 0.160934, 0.603418, 0.378765)),
+          (0, (1.752,), (1.0,)), (0, (0.2384,), (1.0,)),
+          (1, (34.46, 7.749, 2.280, 0.7156, 0.2140), (0.015928, 0.099740, 0.310492, 0.491026, 0.336337)),
+          (1, (0.7156,), (1.0,)), (1, (0.2140,), (1.0,)),
+          (2, (2.314,), (1.0,)), (2, (0.645,), (1.0,)), (3, (1.428,), (1.0,))],
+}
+_CCPVDZ["N"] = [
+    (0, (9046.0, 1357.0, 309.3, 87.73, 28.56, 10.21, 3.838, 0.7466, 0.2248),
+     (0.000700, 0.005389, 0.027406, 0.103207, 0.278723, 0.448540, 0.278238, 0.015440, -0.002864)),
+    (0, (9046.0, 1357.0, 309.3, 87.73, 28.56, 10.21, 3.838, 0.7466, 0.2248),
+     (-0.000153, -0.001208, -0.005992, -0.024544, -0.067459, -0.158078, -0.121831, 0.549003, 0.578815)),
+    (0, (0.2248,), (1.0,)),
+    (1, (13.55, 2.917, 0.7973, 0.2185), (0.039919, 0.217169, 0.510319, 0.462214)),
+    (1, (0.2185,), (1.0,)), (2, (0.817,), (1.0,))]
+BASIS_SETS["cc-pvtz"] = _CCPVTZ
+BASIS_SETS["ccpvtz"] = _CCPVTZ
 BASIS_SETS["6-31g"] = _631G
 BASIS_SETS["6-31g*"] = _631GS
 BASIS_SETS["6-31g(d)"] = _631GS
@@ -94,12 +134,22 @@ NUCLEAR_CHARGE = {"H": 1, "C": 6, "N": 7, "O": 8, "F": 9}
 #: Slater exponents behind the table (1s, 2sp)
 STO3G_ZETA = {"H": (1.24, None), "C": (5.67, 1.72), "N": (6.67, 1.95), "O": (7.66, 2.25), "F": (8.65, 2.55)}
 _CART = {0: [(0, 0, 0)], 1: [(1, 0, 0), (0, 1, 0), (0, 0, 1)],
-         2: [(2, 0, 0), (1, 1, 0), (1, 0, 1), (0, 2, 0), (0, 1, 1), (0, 0, 2)]}
+         2: [(2, 0, 0), (1, 1, 0), (1, 0, 1), (0, 2, 0), (0, 1, 1), (0, 0, 2)],
+         3: [(3, 0, 0), (2, 1, 0), (2, 0, 1), (1, 2, 0), (1, 1, 1), (1, 0, 2), (0, 3, 0), (0, 2, 1), (0, 1, 2), (0, 0, 3)]}
 # real solid harmonics of l = 2 over (xx, xy, xz, yy, yz, zz), PySCF's order m = -2 .. 2:
 # xy, yz, (2 zz - xx - yy) / 2, xz, (xx - yy) sqrt(3) / 2  (the sqrt(3) of the xy-type ones is absorbed
 # by the numerical normalisation of each function)
 _SPH = {2: np.array([[0, 1, 0, 0, 0, 0], [0, 0, 0, 0, 1, 0], [-0.5, 0, 0, -0.5, 0, 1.0], [0, 0, 1, 0, 0, 0],
-                     [1.0, 0, 0, -1.0, 0, 0]], dtype=float)}
+                     [1.0, 0, 0, -1.0, 0, 0]], dtype=float),
+        # l = 3 over (xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz), m = -3 .. 3:
+        # y(3xx - yy), xyz, y(4zz - xx - yy), z(2zz - 3xx - 3yy), x(4zz - xx - yy), z(xx - yy), x(xx - 3yy)
+        3: np.array([[0, 3, 0, 0, 0, 0, -1, 0, 0, 0],
+                     [0, 0, 0, 0, 1, 0, 0, 0, 0, 0],
+                     [0, -1, 0, 0, 0, 0, -1, 0, 4, 0],
+                     [0, 0, -3, 0, 0, 0, 0, -3, 0, 2],
+                     [-1, 0, 0, -1, 0, 4, 0, 0, 0, 0],
+                     [0, 0, 1, 0, 0, 0, 0, -1, 0, 0],
+                     [1, 0, 0, -3, 0, 0, 0, 0, 0, 0]], dtype=float)}
 
 
 def parse_geometry(xyz: str, unit: str = "angstrom"):
@@ -113,8 +163,8 @@ def parse_geometry(xyz: str, unit: str = "angstrom"):
     return atoms
 
 
-def supports(xyz: str, basis: str) -> bool:
-    table = BASIS_SETS.get(basis.lower().replace("_", "-"))
+def supports(xyz: str, basis) -> bool:
+    table = basis if isinstance(basis, dict) else BASIS_SETS.get(str(basis).lower().replace("_", "-"))
     if table is None:
         return False
     try:
@@ -178,8 +228,9 @@ class Basis:
     ``shell_ao0``, ``nao_cart`` of them) and brought to the AOs proper -- spherical d functions, as
     PySCF's default -- by ``to_ao`` (the (nao, nao_cart) matrix ``cart2ao``; the identity for s/p bases)."""
 
-    def __init__(self, atoms, basis: str = "sto-3g", cart: bool = False):
-        table = BASIS_SETS[basis.lower().replace("_", "-")]
+    def __init__(self, atoms, basis="sto-3g", cart: bool = False):
+        # a name of BASIS_SETS, or (as PySCF's mol.basis may be) a table {symbol: [(l, exponents, coefficients)]}
+        table = basis if isinstance(basis, dict) else BASIS_SETS[basis.lower().replace("_", "-")]
         self.atoms = atoms
         self.shells: list[Shell] = []
         self.shell_ao0: list[int] = []

@@ -1,4 +1,4 @@
-"""Oracle: a minimal Gaussian-integral engine (s, p and spherical d shells) for real-molecule KATs.
+"""Oracle: a minimal Gaussian-integral engine (s, p and spherical d, f shells) for real-molecule KATs.
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  The reference obtains S, T, V_nuc and (pq|rs)
 from PySCF/libcint (``gto.Mole.intor``; nbed/driver.py:86-104 builds the molecule).  libcint is
@@ -11,8 +11,8 @@ Conventions follow PySCF so that the numbers are comparable: Bohr radius 0.52917
 (pyscf.data.nist.BOHR), AO order per atom = shells in basis order, p functions as (x, y, z),
 normalised contracted functions.
 
-``SphericalBasis`` (further down) adds d shells the way libcint defines them: real solid harmonics
-normalised on the sphere (m = -2 .. 2: xy, yz, z^2, xz, x^2 - y^2) times a radial contraction whose
+``SphericalBasis`` (further down) adds d and f shells the way libcint defines them: real solid harmonics
+normalised on the sphere (m = -l .. l; d: xy, yz, z^2, xz, x^2 - y^2) times a radial contraction whose
 primitives are normalised in closed form (gamma functions), each AO a short list of weighted
 Cartesian monomials fed to the same primitive recursions.  The product (nbed_amd/integrals.py)
 normalises its spherical combinations NUMERICALLY from the shell's own overlap and evaluates
@@ -269,13 +269,22 @@ _SOLID = {
         [(math.sqrt(15.0), (1, 0, 1))],
         [(math.sqrt(15.0) / 2.0, (2, 0, 0)), (-math.sqrt(15.0) / 2.0, (0, 2, 0))],
     ],
+    3: [  # r^3 Y_3m sqrt(4 pi):  y(3xx-yy), xyz, y(4zz-xx-yy), z(2zz-3xx-3yy), x(4zz-xx-yy), z(xx-yy), x(xx-3yy)
+        [(3.0 * math.sqrt(35.0 / 8.0), (2, 1, 0)), (-math.sqrt(35.0 / 8.0), (0, 3, 0))],
+        [(math.sqrt(105.0), (1, 1, 1))],
+        [(4.0 * math.sqrt(21.0 / 8.0), (0, 1, 2)), (-math.sqrt(21.0 / 8.0), (2, 1, 0)), (-math.sqrt(21.0 / 8.0), (0, 3, 0))],
+        [(2.0 * math.sqrt(7.0 / 4.0), (0, 0, 3)), (-3.0 * math.sqrt(7.0 / 4.0), (2, 0, 1)), (-3.0 * math.sqrt(7.0 / 4.0), (0, 2, 1))],
+        [(4.0 * math.sqrt(21.0 / 8.0), (1, 0, 2)), (-math.sqrt(21.0 / 8.0), (3, 0, 0)), (-math.sqrt(21.0 / 8.0), (1, 2, 0))],
+        [(math.sqrt(105.0 / 4.0), (2, 0, 1)), (-math.sqrt(105.0 / 4.0), (0, 2, 1))],
+        [(math.sqrt(35.0 / 8.0), (3, 0, 0)), (-3.0 * math.sqrt(35.0 / 8.0), (1, 2, 0))],
+    ],
 }
-_ANG_COMMON = {0: 1.0, 1: math.sqrt(3.0), 2: 1.0}  # l = 1: sqrt(3/4pi) x;  l = 2 factors sit in _SOLID
+_ANG_COMMON = {0: 1.0, 1: math.sqrt(3.0), 2: 1.0, 3: 1.0}  # l = 1: sqrt(3/4pi) x;  l >= 2 factors sit in _SOLID
 
 
 class SphericalBasis:
-    """AOs of a molecule from a table {symbol: [(l, exponents, coefficients), ...]}, l <= 2, real
-    spherical d functions.  ``aos`` holds (centre, [(weight, lmn), ...], exponents, coefficients)."""
+    """AOs of a molecule from a table {symbol: [(l, exponents, coefficients), ...]}, l <= 3, real
+    spherical d and f functions.  ``aos`` holds (centre, [(weight, lmn), ...], exponents, coefficients)."""
 
     def __init__(self, atoms, table):
         self.atoms = atoms

@@ -91,3 +91,24 @@ def test_octane_631gs_embedding_end_to_end(be, octane):
     sq = drv.huzinaga["second_quantised"]
     n_mo = drv.huzinaga["scf"].mo_coeff.shape[-1]
     assert sq.two_body.shape[-1] == n_mo and 2 * n_mo < 2 * 148  # concentric shells truncated the virtuals
+
+
+def test_methyl_cation_ccpvtz_f_shells_end_to_end(be):
+    """cc-pVTZ ([4s3p2d1f] on carbon, d on hydrogen: 72 AOs) through the whole driver.  BASELINE configs[4]
+    names the methyl RADICAL: with SPADE its alpha and beta partitions differ in size and the driver raises,
+    exactly as the reference does (tests/test_host_localizers_ham.py::test_spade_open_shell_raises_like_
+    reference); the closed-shell cation, run unrestricted like everything here, exercises the same code.
+    Expected numbers: this very configuration on the CPU checker backend (tests/oracle_backend.py), 106 s."""
+    ch3 = "4\n\nC 0 0 0\nH 1.079 0 0\nH -0.5395 0.9344 0\nH -0.5395 -0.9344 0"
+    cfg = NbedConfig(geometry=ch3, n_active_atoms=2, basis="cc-pvtz", xc_functional="b3lyp", charge=1, convergence=1e-8,
+                     projector="both", max_hf_cycles=200, max_dft_cycles=200, virtual_localization="cl")
+    drv = nbed(cfg, provider=BuiltinHFProvider(be), backend=be, hamiltonian_format="spatial")
+    assert abs(drv._global_ks.e_tot - (-39.494909361743254)) < 1e-7
+    assert abs(drv.mu["e_rhf"] - (-39.383831492143045)) < 1e-6
+    assert abs(drv.huzinaga["e_rhf"] - (-39.38382736535953)) < 1e-6
+    assert abs(drv.huzinaga["classical_energy"] - (-7.401530920332425)) < 1e-7
+    assert drv.huzinaga["second_quantised"].two_body.shape == (3, 70, 70, 70, 70)
+    with pytest.raises(ValueError):  # the radical: ragged alpha / beta partitions, as in the reference
+        nbed(NbedConfig(geometry=ch3, n_active_atoms=2, basis="cc-pvdz", xc_functional="b3lyp", spin=1, convergence=1e-7,
+                        projector="huzinaga", max_hf_cycles=200, max_dft_cycles=200), provider=BuiltinHFProvider(be),
+             backend=be)

@@ -58,6 +58,7 @@ def test_integrals_match_the_oracle_engine(xyz):
 def test_supports():
     assert integrals.supports(WATER_XYZ, "STO-3G") and integrals.supports(H2_XYZ, "sto-3g")
     assert integrals.supports(WATER_XYZ, "cc-pVDZ") and integrals.supports(H2O2_XYZ, "6-31G*")
+    assert integrals.supports(WATER_XYZ, "cc-pVTZ")
     assert not integrals.supports(WATER_XYZ, "def2-SVP")
     assert not integrals.supports("2\n\nF 0 0 0\nH 0 0 0.9", "cc-pVDZ")  # no fluorine table in that set
     assert not integrals.supports("1\n\nS 0 0 0", "sto-3g")
@@ -143,10 +144,35 @@ def test_native_eri_engine_rejects_bad_shells():
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     out = np.zeros(1)
     args = lambda ang, nfunc: (1, ptr(i32(ang)), ptr(i32(1)), ptr(i32(nfunc)), ptr(np.zeros(3)), ptr(one), ptr(one),  # noqa: E731
-                               ptr(np.ones(36)), 1e-16, 1, ptr(out))
-    assert lib.nbx_host_eri(*args(3, 7)) == -1       # f shells are not covered
+                               ptr(np.ones(100)), 1e-16, 1, ptr(out))
+    assert lib.nbx_host_eri(*args(4, 9)) == -1       # g shells are not covered
     assert lib.nbx_host_eri(*args(2, 4)) == -1       # a d shell has five or six functions
     assert lib.nbx_host_eri(*args(0, 1)) == 0 and out[0] > 0
+
+
+def test_f_shell_integrals_match_the_oracle_engine():
+    """p, d and f shells mixed on two centres (a hand-made table, two primitives in the p shell): one-
+    electron matrices in full and sampled (pq|rs) of libnbx's engine against the oracle's closed-form
+    real solid harmonics; the numpy engine on the f-only part."""
+    table = {"C": [(1, (0.38, 0.9), (0.7, 0.4)), (2, (1.097,), (1.0,)), (3, (0.761,), (1.0,))],
+             "H": [(0, (0.3,), (1.0,)), (2, (1.057,), (1.0,)), (3, (0.9,), (1.0,))]}
+    xyz = "2\n\nC 0.1 -0.2 0.3\nH 0.9 0.5 -0.4"
+    bs = integrals.Basis(integrals.parse_geometry(xyz), table)
+    ob = oracle_gto.SphericalBasis(oracle_gto.parse_xyz(xyz), table)
+    assert bs.nao == ob.nao == 28 and bs.nao_cart == 36
+    for got, ref in zip(integrals.one_electron(bs), oracle_gto.one_electron_general(ob)):
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13)
+    eri = integrals.two_electron_native(bs)
+    rng = np.random.default_rng(1)
+    nonzero = 0
+    for _ in range(40):
+        p, q, r, s_ = (int(x) for x in rng.integers(0, bs.nao, 4))
+        ref = oracle_gto.eri_element_general(ob, p, q, r, s_)
+        assert abs(ref - eri[p, q, r, s_]) < 1e-13
+        nonzero += abs(ref) > 1e-6
+    assert nonzero >= 20
+    small = integrals.Basis(integrals.parse_geometry(xyz), {"C": [(3, (0.761,), (1.0,))], "H": [(0, (0.3,), (1.0,))]})
+    np.testing.assert_allclose(integrals.two_electron_native(small), integrals.two_electron(small), rtol=0, atol=1e-14)
 
 
 def _rhf_energy(m, nocc):
@@ -188,10 +214,18 @@ def test_basis_tables_reproduce_literature_hartree_fock_energies():
         (nh3, "6-31g", False, -56.16552),
         (_bent("O", 0.9473, 105.5), "6-31g*", True, -76.01075),   # Pople's 6-31G* carries six Cartesian d functions
         (_bent("O", 0.9572, 104.52), "cc-pvdz", False, -76.02680),
+        (_bent("O", 0.9572, 104.52), "cc-pvtz", False, -76.05717),  # [4s3p2d1f | 3s2p1d], 58 functions
     ]
     for xyz, basis, cart, literature in cases:
         m = integrals.molecule_integrals(xyz, basis, cart=cart)
         assert abs(_rhf_energy(m, 5) - literature) < 6e-6, (basis, literature)
+    # the hydrogen atom in Dunning's sets (one electron: the lowest eigenvalue of hcore), N2 for nitrogen
+    for basis, literature in (("cc-pvdz", -0.499278), ("cc-pvtz", -0.499810)):
+        m = integrals.molecule_integrals("1\n\nH 0 0 0", basis)
+        w, c = np.linalg.eigh(m["S"])
+        x = (c / np.sqrt(w)) @ c.T
+        assert abs(np.linalg.eigvalsh(x @ m["hcore"] @ x)[0] - literature) < 1e-6
+    assert abs(_rhf_energy(integrals.molecule_integrals("2\n\nN 0 0 0\nN 0 0 1.0977", "cc-pvdz"), 7) - (-108.9541)) < 5e-5
 
 
 @pytest.fixture()
