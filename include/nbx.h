@@ -122,8 +122,10 @@ int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const do
  * 8 N^4 (p1-p0)/N.  Storage: the tiles T(p,q) = p(p+1)/2 + q, q <= p, in sequence; a tile is the
  * lower triangle of its (r,s) matrix cut into NB = 2 (N <= 128) or 4 blocks of s = N/NB rows:
  * first the NB diagonal triangles (row-major, packed), then for r = 1..NB-1 the rectangles
- * (I, J = I ^ r), I > J, ordered by J, row-major with row stride s|1 (zero pad); each of the NB
- * chunks padded to an even number of doubles.
+ * (I, J = I ^ r), I > J, ordered by the row block I, row-major with row stride s|1 (zero pad); each
+ * of the NB chunks padded to an even number of doubles.  (With NBX_JK_P8=1 in the environment whole
+ * tensors of N = 100..156, N % 4 == 0 are stored 8-fold instead -- of every tile only the entries
+ * (r,s) <= (p,q), csrc/jk_p8.hip; same entry points and results, experimental: DESIGN.md section 9.)
  *   nbx_jk_packed_supported : 1 = a kernel instance serves N (even N <= 256 with N % NB == 0);
  *            2 = N <= 256 is served as the next such size (at most 8 more) with the extra rows and
  *            columns zero -- odd N, N = 102, 150, ...: the same entry points, the padding is internal

@@ -30,6 +30,15 @@
 
 #include "nbx_common.h"
 #include "jk_s4_layout.h"
+#include "jk_s4_device.h"
+
+// jk_p8.hip: the 8-fold form (truncated tiles) that serves whole tensors of the NB = 4 / six-loads sizes
+bool nbx_jk_p8_covers(int64_t N, int64_t p0, int64_t p1);
+size_t nbx_jk_p8_packed_bytes(int64_t N);
+size_t nbx_jk_p8_worksize(int64_t N, int64_t ndm);
+int nbx_jk_p8_pack(nbx_ctx* ctx, int64_t N, const double* d_eri, double* d_packed);
+int nbx_jk_p8(nbx_ctx* ctx, int64_t N, const double* d_packed, const double* d_dm, int64_t ndm, double* d_jk, void* d_work,
+              const double* d_hv, double* d_fock, double* d_vhf, const double* d_dts_in);
 
 // jk_s8.hip: the eight-wave, matrix-pipe form of the NB = 4 / six-loads instance
 bool nbx_jk_s8_covers(int64_t N);
@@ -42,12 +51,6 @@ namespace {
 
 constexpr int S4_CUS = 256;
 constexpr size_t S4_LDS_PER_CU = 160 * 1024;
-
-__device__ __forceinline__ double2 s4_ldnt(const double* p) {
-    typedef double nbx_d2 __attribute__((ext_vector_type(2)));
-    const nbx_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nbx_d2*>(p));
-    return make_double2(t.x, t.y);
-}
 
 // dense slab rows [p0,p1) -> packed tiles T(p,q), q <= p (the buffer was zeroed: pads stay 0)
 // N: size of the source tensor; NP >= N: size whose tile geometry is used (entries a >= N stay zero)
@@ -74,25 +77,6 @@ __global__ void s4_crop_square_kernel(const double* __restrict__ src, double* __
     if (i >= (int64_t)nmat * N * N) return;
     const int b = (int)(i % N), a = (int)((i / N) % N), m = (int)(i / ((int64_t)N * N));
     dst[i] = src[((int64_t)m * NP + a) * NP + b];
-}
-
-// (a, b) of the entry at offset f of chunk ch; false for a pad
-__device__ __forceinline__ bool s4_unflat(const S4Geom& g, int ch, int f, int& a, int& b) {
-    if (ch == 0) {
-        if (f >= g.NB * g.tri) return false;
-        const int I = f / g.tri, rem = f - I * g.tri, ai = s4_tri_row(rem);
-        a = I * g.s + ai;
-        b = I * g.s + rem - (int)s4_tri(ai);
-        return true;
-    }
-    const int slot = f / (g.s * g.ls), rem = f - slot * g.s * g.ls, ai = rem / g.ls, bi = rem - ai * g.ls;
-    if (slot >= g.NB / 2 || bi >= g.s) return false;
-    int hb = 0;
-    while ((ch >> (hb + 1)) != 0) ++hb;
-    const int lo = ((slot >> hb) << (hb + 1)) | (slot & ((1 << hb) - 1));  // inverse of s4_slot
-    a = (lo ^ ch) * g.s + ai;
-    b = lo * g.s + bi;
-    return true;
 }
 
 // Dtot' in the order the staging slots hold the tile: dts[ch][w][k][lane] = the pair of
@@ -124,113 +108,6 @@ __global__ __launch_bounds__(256) void s4_dtot_kernel(const double* __restrict__
         }
     }
     *reinterpret_cast<double2*>(dts + 2 * (int64_t)i) = make_double2(out[0], out[1]);
-}
-
-// The walk of one chunk: s steps, thread-private element tv = Lsym[trow][u*s + c] from LDS and the
-// wave-uniform density values D_q[u*s + c], D_p[u*s + c] through scalar loads.  A wavefront issues
-// at most one instruction every four cycles, whatever its kind, so the walk costs what its
-// instruction count costs: the scalar loads are written as s_load_dwordx8 with one running SGPR
-// offset (no pointer arithmetic per load), rows of the row side are read with immediate offsets.
-// LDS and scalar loads share one counter and scalar loads return out of order, so a wait for
-// either is a wait for everything: the loop is software pipelined by hand in groups of four steps
-// -- wait, issue the next group's loads, then do this group's FMAs -- with two register sets.
-// (The compiler does not track the inline-asm loads: every use below follows an explicit wait.)
-// The last group starts at s - 4 and masks the steps an earlier group has done.
-// KIND 0: diagonal triangle (per-lane row / column select), 1: rectangle, row side (consecutive
-// doubles), 2: rectangle, column side (stride `step` doubles).
-typedef double s4_v4d __attribute__((ext_vector_type(4)));
-
-template <int NDM, int KIND>
-__device__ __forceinline__ void s4_walk(const double* lb, int step, int il, int tri_il, const double* xq,
-                                        const double* xp, int64_t n2, int s, double (&kp)[NDM], double (&kq)[NDM]) {
-    const int ng = (s + 3) >> 2;
-    const double* xqs[NDM];
-    const double* xps[NDM];
-#pragma unroll
-    for (int x = 0; x < NDM; ++x) {
-        xqs[x] = xq + x * n2;
-        xps[x] = xp + x * n2;
-    }
-    const char* lbc = reinterpret_cast<const char*>(lb);
-    // diagonal triangle: LDS byte addresses of the lane's row (L[il][0]) and of its column's head
-    // (L[0][il] if the rows above il were full); opaque, so that the uniform parts of the per-step
-    // addresses stay in scalar registers
-    typedef __attribute__((address_space(3))) const char* s4_lds_cp;
-    typedef __attribute__((address_space(3))) const double* s4_lds_dp;
-    int row_a = (int)(size_t)(s4_lds_cp)lbc + tri_il * 8, col_a = (int)(size_t)(s4_lds_cp)lbc + il * 8;
-    if (KIND == 0) {
-        asm volatile("" : "+v"(row_a));
-        asm volatile("" : "+v"(col_a));
-    }
-    auto load = [&](int g, s4_v4d(&a)[NDM], s4_v4d(&b)[NDM], double(&t)[4]) {
-        const int c0 = min(4 * g, s - 4);
-        const int off = c0 * 8;
-#pragma unroll
-        for (int x = 0; x < NDM; ++x) {
-            asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(a[x]) : "s"(xqs[x]), "s"(off));
-            asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(b[x]) : "s"(xps[x]), "s"(off));
-        }
-        if (KIND == 0) {
-            // row part (c <= il): L[il][c] at tri(il) + c; column part: L[c][il] at tri(c) + il
-            const int rb = row_a + off;
-            int tric = (int)(((unsigned)c0 * (unsigned)(c0 + 1)) >> 1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int sj = (tric - j) * 8;  // minus j: the read below adds 8 j to both forms
-                const int ab = (il >= c0 + j) ? rb : col_a + sj;
-                t[j] = *(s4_lds_dp)(size_t)(ab + 8 * j);
-                tric += c0 + j + 1;
-            }
-        } else if (KIND == 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const double*>(lbc + off + 8 * j);
-        } else {
-            const int sb = step * 8;
-            int ab = c0 * sb;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t[j] = *reinterpret_cast<const double*>(lbc + ab);
-                ab += sb;
-            }
-        }
-    };
-    auto fmas = [&](const s4_v4d(&a)[NDM], const s4_v4d(&b)[NDM], const double(&t)[4], int skip) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double tj = j >= skip ? t[j] : 0.0;
-#pragma unroll
-            for (int x = 0; x < NDM; ++x) {
-                kp[x] = fma(tj, a[x][j], kp[x]);
-                kq[x] = fma(tj, b[x][j], kq[x]);
-            }
-        }
-    };
-#define S4_WAIT_THEN(LOADS)                  \
-    __builtin_amdgcn_s_waitcnt(0xC07F);      \
-    __builtin_amdgcn_sched_barrier(0);       \
-    LOADS;                                   \
-    __builtin_amdgcn_sched_barrier(0)
-    s4_v4d a0[NDM], b0[NDM], a1[NDM], b1[NDM];
-    double t0[4], t1[4];
-    load(0, a0, b0, t0);
-    int g = 0;
-    for (; g + 2 < ng; g += 2) {
-        S4_WAIT_THEN(load(g + 1, a1, b1, t1));
-        fmas(a0, b0, t0, 0);
-        S4_WAIT_THEN(load(g + 2, a0, b0, t0));
-        fmas(a1, b1, t1, 0);
-    }
-    const int skip = 4 * ng - s;  // steps of the last group that belong to the one before it
-    if (g + 1 < ng) {  // two groups left: set 0 holds a full one
-        S4_WAIT_THEN(load(g + 1, a1, b1, t1));
-        fmas(a0, b0, t0, 0);
-        S4_WAIT_THEN((void)0);
-        fmas(a1, b1, t1, skip);
-    } else {
-        S4_WAIT_THEN((void)0);
-        fmas(a0, b0, t0, skip);
-    }
-#undef S4_WAIT_THEN
 }
 
 // EXPERIMENTAL (compiled with -DNBX_S4_MFMA_WALK only; measured slower):
@@ -550,6 +427,19 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
     if (tid == 0) store_j(par ^ 1, pj, qj);
 }
 
+}  // namespace
+
+// the Dtot' table of a density (shared with jk_p8.hip, which keeps the table's format)
+int nbx_jk_s4_dtot(nbx_ctx* ctx, int64_t N, const double* d_dm, int64_t ndm, double* d_dts) {
+    const int NB = s4_nb(N), lpt = s4_lpt(N);
+    hipLaunchKernelGGL(s4_dtot_kernel, dim3((unsigned)nbx_cdiv(NB * NB * lpt * 64, 256)), dim3(256), 0, ctx->stream, d_dm,
+                       d_dts, (int)N, NB, lpt, (int)ndm);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+namespace {
+
 bool s4_use_s8(int64_t N) {
     // jk_s8.hip is EXPERIMENTAL: parity-tested, but measured 5-15 % slower than the four-wave VALU kernel
     // below -- opt in with NBX_JK_S8=1
@@ -611,6 +501,7 @@ extern "C" int nbx_jk_packed_supported(int64_t nao) {
 extern "C" size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1) {
     const int64_t NP = s4_padded(nao);
     if (NP == 0 || p0 < 0 || p1 < p0 || p1 > nao) return 0;
+    if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_packed_bytes(nao);
     const S4Geom g = s4_geom((int)NP, s4_nb(NP));
     return (size_t)((s4_tri(p1) - s4_tri(p0)) * g.M) * sizeof(double);
 }
@@ -625,6 +516,7 @@ extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
     }
     if (p0 == p1) return NBX_OK;
     NBX_CHECK_ARG(d_eri && d_packed);
+    if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_pack(ctx, nao, d_eri, d_packed);
     const int64_t ntiles = s4_tri(p1) - s4_tri(p0);
     int rc = nbx_memset(ctx, d_packed, 0, nbx_eri_packed_bytes(nao, p0, p1));
     if (rc != NBX_OK) return rc;
@@ -637,6 +529,7 @@ extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
 extern "C" size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm) {
     const int64_t NP = s4_padded(nao);
     if (NP == 0 || p0 < 0 || p1 < p0 || p1 > nao || ndm <= 0) return 0;
+    if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_worksize(nao, ndm);
     size_t total = s4_plan(NP, p0, p1 - p0, ndm).total;
     if (NP != nao) total += s4_align256((size_t)((1 + 2 * ndm) * NP * NP) * sizeof(double));  // padded D and J/K
     return total;
@@ -692,6 +585,7 @@ static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double
     }
     NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
     if (p1 == p0) return nbx_memset(ctx, d_jk, 0, (size_t)((1 + ndm) * nao * nao) * sizeof(double));
+    if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8(ctx, nao, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
     if (NPAD != nao) {
         // Run as the NPAD x NPAD problem whose extra rows and columns are zero: the tiles (p, q) with
         // p >= nao vanish (never stored, never visited); D is padded on the way in, J/K cropped on the
@@ -767,7 +661,11 @@ static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const
             else NBX_S4_NDM(2, 10, 2, true, 1);
         } else {
             if (pl.lpt == 2) NBX_S4_NDM(4, 2, 4, true, 2);
-            else if (pl.lpt == 6) NBX_S4_NDM(4, 6, 2, true, 2);
+            else if (pl.lpt == 6) {
+                static const bool dt_stream = getenv("NBX_S4_DT_STREAM") != nullptr;  // probe: Dtot' re-read per chunk
+                if (dt_stream) NBX_S4_NDM(4, 6, 2, false, 2);
+                else NBX_S4_NDM(4, 6, 2, true, 2);
+            }
             else if (pl.lpt == 10) NBX_S4_NDM(4, 10, 2, true, 1);   // one workgroup per CU (LDS): 512 registers
             else NBX_S4_NDM(4, 17, 1, false, 1);
         }

@@ -34,8 +34,11 @@ __host__ __device__ __forceinline__ static S4Geom s4_geom(int N, int NB) {
     return g;
 }
 
-// position of the rectangle (lo, lo ^ r), lo < lo ^ r, among the NB/2 rectangles of round r
+// position of the rectangle (lo, lo ^ r), lo < lo ^ r, among the NB/2 rectangles of round r: in
+// ascending order of the row block lo ^ r, so that the rows a <= p of a chunk are a PREFIX of it (the
+// 8-fold form stores and reads only that prefix, jk_p8.hip)
 __host__ __device__ __forceinline__ static int s4_slot(int lo, int r) {
+    if (r == 3) return 1 - lo;  // NB = 4: (2,1) before (3,0)
     int hb = 0;
     while ((r >> (hb + 1)) != 0) ++hb;  // highest set bit of r: clear in lo
     return ((lo >> (hb + 1)) << hb) | (lo & ((1 << hb) - 1));

@@ -225,3 +225,17 @@ def test_fused_huzinaga_scf_bench_inputs_vs_oracle(be, eri148):
     for x in range(2):
         assert abs(np.trace(d[x] @ s) - pr["nelec"][x]) < 1e-9
         assert abs(np.trace(d[x] @ s @ pr["D_env"][x] @ s)) < 1e-9
+
+
+def test_jk_eightfold_experimental_vs_c_oracle():
+    """csrc/jk_p8.hip (8-fold tiles; opt-in, NBX_JK_P8=1 is read once per process: a child process) at
+    N = 148 and 104 against oracle/c/jk_ref.c, the Fock epilogue included."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    env = dict(os.environ, NBX_JK_P8="1")
+    out = subprocess.run([sys.executable, str(Path(__file__).with_name("_p8_worker.py"))], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "P8 OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -652,6 +652,8 @@ def s4_layout(n):
                 r = i ^ j
                 hb = r.bit_length() - 1
                 slot = ((j >> (hb + 1)) << hb) | (j & ((1 << hb) - 1))
+                if r == 3:  # ordered by row block: (2, 1) before (3, 0)
+                    slot = 1 - j
                 off[a, b] = e0 + (r - 1) * er + slot * s * ls + ai * ls + bi
     return off, e0 + (nb - 1) * er
 
