@@ -480,6 +480,12 @@ int nbx_threshold_scale(nbx_ctx* ctx, int64_t n, double tol, double scale, doubl
 int nbx_host_eri(int nshell, const int* ang, const int* nprim, const int* nfunc, const double* centres,
                  const double* exps, const double* coefs, const double* sph, double cutoff, int nthreads,
                  double* out);
+/* Overlap, kinetic-energy and nuclear-attraction matrices (nao, nao) of the same shells, HOST memory:
+ * intor("int1e_ovlp"), ("int1e_kin"), ("int1e_nuc") behind get_ovlp() / get_hcore() (nbed/driver.py:155-191).
+ *   charges (natm), atom_xyz (natm, 3): the point charges of V (nuclei; Bohr)                      */
+int nbx_host_1e(int nshell, const int* ang, const int* nprim, const int* nfunc, const double* centres,
+                const double* exps, const double* coefs, const double* sph, int natm, const double* charges,
+                const double* atom_xyz, int nthreads, double* s_out, double* t_out, double* v_out);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,8 @@
 //                    recursion), contracted first with the ket's densities, then with the bra's
 //   per quartet      Cartesian -> spherical with the matrices the caller passes (they carry the
 //                    normalisation), scattered to the eight images in the dense (nao)^4 tensor
+#include <sys/mman.h>
+
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -373,7 +375,25 @@ extern "C" int nbx_host_eri(int nshell, const int* ang, const int* nprim, const 
 
     const int n = eng.nao;
     const size_t n2 = size_t(n) * n, n3 = n2 * n;
-    std::memset(out, 0, sizeof(double) * n3 * n);
+    {   // first touch of the output (3.8 GB at 148 functions) is page faults, not arithmetic: huge pages where the
+        // kernel grants them, and every thread clears a contiguous slice
+        const size_t bytes = sizeof(double) * n3 * n;
+#ifdef MADV_HUGEPAGE
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(out) + 4095) & ~uintptr_t(4095);
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(out) + bytes) & ~uintptr_t(4095);
+        if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
+#endif
+        std::atomic<int> slice{0};
+        const int nsl = nthreads * 8;
+        run_pool([&] {
+            for (;;) {
+                const int k = slice.fetch_add(1);
+                if (k >= nsl) break;
+                const size_t a = bytes / nsl * k, b = k + 1 == nsl ? bytes : bytes / nsl * (k + 1);
+                std::memset(reinterpret_cast<char*>(out) + a, 0, b - a);
+            }
+        });
+    }
     std::atomic<int64_t> next{0};
     run_pool([&] {
         std::vector<double> blk(10000), scr(10000), w(100 * 84), rbuf(NCUBE * NCUBE * NCUBE), rtmp(NCUBE * NCUBE * NCUBE);
@@ -409,5 +429,169 @@ extern "C" int nbx_host_eri(int nshell, const int* ang, const int* nprim, const 
             }
         }
     });
+    return NBX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// One-electron matrices: overlap, kinetic energy, nuclear attraction (gto.Mole.intor("int1e_ovlp" / "int1e_kin"
+// / "int1e_nuc"), reached through scf.UKS(mol).get_ovlp() / get_hcore(), nbed/driver.py:155-191).  Shell pairs
+// over the thread pool; the same Hermite coefficients and R_tuv as above.
+namespace {
+
+constexpr int LB2 = LMAX + 2;  // the kinetic energy raises the ket by two
+
+// E[i][j][t], i <= la, j <= lb, for one direction
+void hermite_e_wide(int la, int lb, double a, double b, double xab, double e[LMAX + 1][LB2 + 1][LMAX + LB2 + 1]) {
+    const double p = a + b, mu = a * b / p;
+    const double xpa = -b / p * xab, xpb = a / p * xab, half = 0.5 / p;
+    for (int i = 0; i <= LMAX; ++i)
+        for (int j = 0; j <= LB2; ++j)
+            for (int t = 0; t <= LMAX + LB2; ++t) e[i][j][t] = 0.0;
+    e[0][0][0] = std::exp(-mu * xab * xab);
+    for (int i = 0; i < la; ++i)
+        for (int t = 0; t <= i + 1; ++t) {
+            double v = xpa * e[i][0][t];
+            if (t > 0) v += half * e[i][0][t - 1];
+            if (t + 1 <= i) v += (t + 1) * e[i][0][t + 1];
+            e[i + 1][0][t] = v;
+        }
+    for (int i = 0; i <= la; ++i)
+        for (int j = 0; j < lb; ++j)
+            for (int t = 0; t <= i + j + 1; ++t) {
+                double v = xpb * e[i][j][t];
+                if (t > 0) v += half * e[i][j][t - 1];
+                if (t + 1 <= i + j) v += (t + 1) * e[i][j][t + 1];
+                e[i][j + 1][t] = v;
+            }
+}
+
+// (na x nb) Cartesian block -> (fa x fb) AO block
+void block_to_ao(const Shell& sa, const Shell& sb, const double* blk, double* out) {
+    double tmp[10 * 10];
+    const int na = sa.ncart_, nb = sb.ncart_, fa = sa.nsph, fb = sb.nsph;
+    for (int m = 0; m < fa; ++m)
+        for (int y = 0; y < nb; ++y) {
+            double acc = 0.0;
+            if (sa.l < 2) acc = blk[m * nb + y];
+            else
+                for (int x = 0; x < na; ++x) acc += sa.sph[m * na + x] * blk[x * nb + y];
+            tmp[m * nb + y] = acc;
+        }
+    for (int m = 0; m < fa; ++m)
+        for (int n = 0; n < fb; ++n) {
+            double acc = 0.0;
+            if (sb.l < 2) acc = tmp[m * nb + n];
+            else
+                for (int y = 0; y < nb; ++y) acc += sb.sph[n * nb + y] * tmp[m * nb + y];
+            out[m * fb + n] = acc;
+        }
+}
+
+}  // namespace
+
+extern "C" int nbx_host_1e(int nshell, const int* ang, const int* nprim, const int* nfunc, const double* centres,
+                           const double* exps, const double* coefs, const double* sph, int natm, const double* charges,
+                           const double* atom_xyz, int nthreads, double* s_out, double* t_out, double* v_out) {
+    if (nshell <= 0 || !ang || !nprim || !nfunc || !centres || !exps || !coefs || !sph || natm < 0 || !s_out || !t_out ||
+        !v_out || (natm > 0 && (!charges || !atom_xyz)))
+        return NBX_E_INVALID;
+    std::vector<Shell> shells(nshell);
+    int poff = 0, soff = 0, ao = 0;
+    for (int s = 0; s < nshell; ++s) {
+        if (ang[s] < 0 || ang[s] > LMAX || nprim[s] <= 0) return NBX_E_INVALID;
+        Shell& sh = shells[s];
+        sh.l = ang[s];
+        sh.nprim = nprim[s];
+        sh.ncart_ = ncart(sh.l);
+        sh.nsph = nfunc[s];
+        if (sh.nsph != 2 * sh.l + 1 && sh.nsph != sh.ncart_) return NBX_E_INVALID;
+        sh.exps = exps + poff;
+        sh.coefs = coefs + poff;
+        sh.sph = sph + soff;
+        sh.ao0 = ao;
+        for (int d = 0; d < 3; ++d) sh.c[d] = centres[3 * s + d];
+        poff += sh.nprim;
+        soff += sh.nsph * sh.ncart_;
+        ao += sh.nsph;
+    }
+    const int n = ao;
+    const BoysTable boys;
+    const int64_t npair = int64_t(nshell) * (nshell + 1) / 2;
+    if (nthreads <= 0) nthreads = int(std::thread::hardware_concurrency());
+    if (nthreads <= 0) nthreads = 1;
+    std::atomic<int64_t> next{0};
+    auto body = [&] {
+        std::vector<double> rbuf(NCUBE * NCUBE * NCUBE), rtmp(NCUBE * NCUBE * NCUBE);
+        double bs[100], bt[100], bv[100], os[100], ot[100], ov[100];
+        for (;;) {
+            const int64_t ij = next.fetch_add(1);
+            if (ij >= npair) break;
+            int ia = int((std::sqrt(8.0 * double(ij) + 1.0) - 1.0) / 2.0);
+            while (int64_t(ia) * (ia + 1) / 2 > ij) --ia;
+            while (int64_t(ia + 1) * (ia + 2) / 2 <= ij) ++ia;
+            const int ib = int(ij - int64_t(ia) * (ia + 1) / 2);
+            const Shell &sa = shells[ia], &sb = shells[ib];
+            int ca[10][3], cb[10][3];
+            cart_list(sa.l, ca);
+            cart_list(sb.l, cb);
+            const int na = sa.ncart_, nb = sb.ncart_, lab = sa.l + sb.l;
+            for (int k = 0; k < na * nb; ++k) bs[k] = bt[k] = bv[k] = 0.0;
+            double ab[3];
+            for (int d = 0; d < 3; ++d) ab[d] = sa.c[d] - sb.c[d];
+            for (int i = 0; i < sa.nprim; ++i)
+                for (int j = 0; j < sb.nprim; ++j) {
+                    const double a = sa.exps[i], b = sb.exps[j], p = a + b, w = sa.coefs[i] * sb.coefs[j];
+                    double e[3][LMAX + 1][LB2 + 1][LMAX + LB2 + 1];
+                    for (int d = 0; d < 3; ++d) hermite_e_wide(sa.l, sb.l + 2, a, b, ab[d], e[d]);
+                    const double pref = std::pow(M_PI / p, 1.5) * w;
+                    const double pc[3] = {(a * sa.c[0] + b * sb.c[0]) / p, (a * sa.c[1] + b * sb.c[1]) / p,
+                                          (a * sa.c[2] + b * sb.c[2]) / p};
+                    // one-dimensional kinetic factors  t(i, j) = -2 b^2 s(i, j+2) + b (2j+1) s(i, j) - j(j-1)/2 s(i, j-2)
+                    auto s1 = [&](int d, int ii, int jj) { return jj < 0 ? 0.0 : e[d][ii][jj][0]; };
+                    auto t1 = [&](int d, int ii, int jj) {
+                        return -2.0 * b * b * s1(d, ii, jj + 2) + b * (2 * jj + 1) * s1(d, ii, jj) -
+                               0.5 * jj * (jj - 1) * s1(d, ii, jj - 2);
+                    };
+                    for (int x = 0; x < na; ++x)
+                        for (int y = 0; y < nb; ++y) {
+                            const double sx = s1(0, ca[x][0], cb[y][0]), sy = s1(1, ca[x][1], cb[y][1]),
+                                         sz = s1(2, ca[x][2], cb[y][2]);
+                            bs[x * nb + y] += pref * sx * sy * sz;
+                            bt[x * nb + y] += pref * (t1(0, ca[x][0], cb[y][0]) * sy * sz + sx * t1(1, ca[x][1], cb[y][1]) * sz +
+                                                      sx * sy * t1(2, ca[x][2], cb[y][2]));
+                        }
+                    const double vpref = 2.0 * M_PI / p * w;
+                    for (int c = 0; c < natm; ++c) {
+                        hermite_r(lab, p, pc[0] - atom_xyz[3 * c], pc[1] - atom_xyz[3 * c + 1], pc[2] - atom_xyz[3 * c + 2], boys,
+                                  rbuf.data(), rtmp.data());
+                        const double z = -charges[c] * vpref;
+                        for (int x = 0; x < na; ++x)
+                            for (int y = 0; y < nb; ++y) {
+                                double acc = 0.0;
+                                for (int t = 0; t <= ca[x][0] + cb[y][0]; ++t)
+                                    for (int u = 0; u <= ca[x][1] + cb[y][1]; ++u)
+                                        for (int v = 0; v <= ca[x][2] + cb[y][2]; ++v)
+                                            acc += e[0][ca[x][0]][cb[y][0]][t] * e[1][ca[x][1]][cb[y][1]][u] *
+                                                   e[2][ca[x][2]][cb[y][2]][v] * rbuf[(t * NCUBE + u) * NCUBE + v];
+                                bv[x * nb + y] += z * acc;
+                            }
+                    }
+                }
+            block_to_ao(sa, sb, bs, os);
+            block_to_ao(sa, sb, bt, ot);
+            block_to_ao(sa, sb, bv, ov);
+            for (int m = 0; m < sa.nsph; ++m)
+                for (int k = 0; k < sb.nsph; ++k) {
+                    const size_t r = size_t(sa.ao0 + m), c = size_t(sb.ao0 + k);
+                    s_out[r * n + c] = s_out[c * n + r] = os[m * sb.nsph + k];
+                    t_out[r * n + c] = t_out[c * n + r] = ot[m * sb.nsph + k];
+                    v_out[r * n + c] = v_out[c * n + r] = ov[m * sb.nsph + k];
+                }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(body);
+    body();
+    for (auto& th : pool) th.join();
     return NBX_OK;
 }

@@ -437,6 +437,33 @@ def nuclear_repulsion(atoms) -> float:
     return e
 
 
+def _shell_arrays(basis: Basis):
+    sh = basis.shells
+    return (np.array([s.ang for s in sh], dtype=np.int32), np.array([len(s.exps) for s in sh], dtype=np.int32),
+            np.array([s.sph.shape[0] for s in sh], dtype=np.int32),
+            np.ascontiguousarray([s.centre for s in sh], dtype=np.float64),
+            np.concatenate([s.exps for s in sh]).astype(np.float64),
+            np.concatenate([s.coefs[0] for s in sh]).astype(np.float64),  # components of a shell share them
+            np.concatenate([np.ascontiguousarray(s.sph, dtype=np.float64).ravel() for s in sh]))
+
+
+def one_electron_native(basis: Basis, nthreads: int = 0):
+    """(S, T, V_nuc) from libnbx's host engine (``nbx_host_1e``): ``one_electron`` in threaded C++."""
+    import ctypes
+
+    from . import _nbx
+
+    lib = _nbx.load_library()
+    ang, nprim, nfunc, centres, exps, coefs, sph = _shell_arrays(basis)
+    charges = np.array([NUCLEAR_CHARGE[s] for s, _ in basis.atoms], dtype=np.float64)
+    xyz = np.ascontiguousarray([p for _, p in basis.atoms], dtype=np.float64)
+    out = [np.empty((basis.nao, basis.nao)) for _ in range(3)]
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    _nbx.check(lib, lib.nbx_host_1e(len(basis.shells), ptr(ang), ptr(nprim), ptr(nfunc), ptr(centres), ptr(exps), ptr(coefs),
+                                    ptr(sph), len(charges), ptr(charges), ptr(xyz), int(nthreads), *(ptr(o) for o in out)))
+    return tuple(out)
+
+
 def two_electron_native(basis: Basis, nthreads: int = 0, cutoff: float = 1e-16) -> np.ndarray:
     """(pq|rs) from libnbx's host engine (``nbx_host_eri``, csrc/ints_host.cpp: the same McMurchie-Davidson
     scheme in C++ over a thread pool) -- what makes a 148-function molecule practical.  Raises if libnbx.so
@@ -467,7 +494,7 @@ def molecule_integrals(xyz: str, basis: str = "sto-3g", unit: str = "angstrom", 
     per-atom AO slices and the electron count of the neutral molecule."""
     atoms = parse_geometry(xyz, unit)
     bs = Basis(atoms, basis, cart)  # cart: six Cartesian d functions (PySCF's mol.cart), default five spherical
-    s_mat, t_mat, v_mat = one_electron(bs)
+    s_mat, t_mat, v_mat = one_electron_native(bs) if engine == "native" else one_electron(bs)
     return {
         "S": s_mat, "T": t_mat, "V": v_mat, "hcore": t_mat + v_mat,
         "eri": two_electron_native(bs) if engine == "native" else two_electron(bs),

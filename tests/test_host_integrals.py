@@ -131,6 +131,10 @@ def test_native_eri_engine_matches_the_numpy_engine(xyz, basis, cart):
         np.testing.assert_allclose(got, ref, rtol=0, atol=2e-13)
     np.testing.assert_array_equal(got, got.transpose(1, 0, 3, 2))
     np.testing.assert_array_equal(got, got.transpose(2, 3, 0, 1))
+    # one-electron matrices of the same shells: nbx_host_1e against the numpy engine
+    for a, b in zip(integrals.one_electron_native(bs, nthreads=2), integrals.one_electron(bs)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=5e-13)
+        np.testing.assert_array_equal(a, a.T)
 
 
 def test_native_eri_engine_rejects_bad_shells():
