@@ -341,9 +341,26 @@ class NbedDriver:
             return self.provider.global_hf(self.config)
         self._unsupported("The global Hartree-Fock reference calculation")
 
+    def _ccsd_of(self, scf_obj, frozen=None):
+        """CCSD of an SCF object: PySCF's solver where there is one, else -- for small orbital spaces -- the
+        spin-orbital equations over the Hamiltonian ``HamiltonianBuilder`` makes of it (``nbed_amd.ccsd``)."""
+        try:
+            return run_emb_ccsd(scf_obj, frozen, self.config.convergence, self.config.max_ram_memory)[0]
+        except NbedDriverError:
+            from . import ccsd
+
+            n = np.asarray(scf_obj.mo_coeff).shape[-1]
+            if frozen is not None or 2 * n > ccsd.MAX_SPIN_ORBITALS:
+                raise
+            const, h1, h2 = HamiltonianBuilder(scf_obj, scf_obj.energy_nuc(), backend=self.be).build()
+            na, nb = scf_obj.mol.nelec
+            occupied = [2 * i for i in range(na)] + [2 * i + 1 for i in range(nb)]  # aufbau, alpha on the even indices
+            return ccsd.solve(const, h1, h2, occupied, conv_tol=min(self.config.convergence, 1e-8))
+
     @cached_property
     def _global_ccsd(self):
-        self._unsupported("The global CCSD reference calculation")
+        """Global CCSD reference (nbed/driver.py:122-136)."""
+        return self._ccsd_of(self._global_hf)
 
     @cached_property
     def _global_fci(self):
@@ -563,8 +580,10 @@ class NbedDriver:
         return dft_in_dft(self, projection_method)
 
     def _run_emb_ccsd(self, emb_scf, frozen=None):
-        """driver.py:451-474."""
-        return run_emb_ccsd(emb_scf, frozen, self.config.convergence, self.config.max_ram_memory)
+        """driver.py:451-474 -> ``(ccsd, e_corr)``.  Without PySCF, small active spaces go through
+        ``nbed_amd.ccsd`` on the active-space Hamiltonian of this same embedded object."""
+        cc = self._ccsd_of(emb_scf, frozen)
+        return cc, cc.e_corr
 
     def _run_emb_fci(self, emb_scf, frozen=None):
         """driver.py:476-498.  Without PySCF, small active spaces are diagonalised exactly from the

@@ -42,6 +42,8 @@ from test_reference_kats import (  # noqa: E402,F401  (the reference's own KATs,
     test_two_active_atoms_raw_xyz_and_subsystem_sum_rule,
     test_usage_notebook_results,
     test_concentric_shell_numbers_water_631g,
+    test_global_and_embedded_ccsd,
+    test_ccsd_is_exact_for_two_electrons,
 )
 from test_host_scf import (  # noqa: E402,F401
     test_energy_elec_matches_reference,

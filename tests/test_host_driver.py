@@ -159,9 +159,15 @@ def test_driver_errors(be):
         nbed(config(localization="pm"), provider=SyntheticProvider(14, (5, 5), 5), backend=be)
     try:
         import pyscf  # noqa: F401
-    except ImportError:  # CCSD is PySCF's solver: refused loudly without it
+    except ImportError:
+        # CCSD without PySCF: small active spaces go through nbed_amd.ccsd (the correlation energy lowers the
+        # embedded energy), larger ones are refused loudly
+        drv = nbed(config(run_ccsd_emb=True, virtual_localization="disable"), provider=SyntheticProvider(14, (5, 5), 5),
+                   backend=be)
+        res = drv.mu if drv.mu is not None else drv.huzinaga
+        assert res["e_ccsd"] < res["e_rhf"] and res["e_rhf"] - res["e_ccsd"] < 1.0
         with pytest.raises(NbedDriverError, match="PySCF"):
-            nbed(config(run_ccsd_emb=True, virtual_localization="disable"), provider=SyntheticProvider(14, (5, 5), 5),
+            nbed(config(run_ccsd_emb=True, virtual_localization="disable"), provider=SyntheticProvider(24, (5, 5), 5),
                  backend=be)
     with pytest.raises(NotImplementedError):  # a provider without local_ks cannot do DFT-in-DFT
         nbed(config(run_dft_in_dft=True, virtual_localization="disable"), provider=SyntheticProvider(14, (5, 5), 5),

@@ -140,6 +140,53 @@ def test_two_active_atoms_raw_xyz_and_subsystem_sum_rule(be):
     assert abs(total - drv._global_ks.e_tot) < 1e-8
 
 
+def test_global_and_embedded_ccsd(drivers):
+    """tests/test_driver.py:64-69 (global CCSD e_tot / e_corr) and :98-108 (embedded CCSD, either projector),
+    through ``nbed_amd.ccsd``: the spin-orbital CCSD equations over the Hamiltonian HamiltonianBuilder makes of
+    the SCF object (no PySCF).  The reference stops its amplitude iterations at 1e-6: its literals sit 7e-8
+    from the converged numbers."""
+    drv = drivers["mu"]
+    cc = drv._global_ccsd
+    assert cc.converged
+    assert abs(cc.e_tot - (-75.0090124134578)) < 3e-7
+    assert abs(cc.e_corr - (-0.04801281045273269)) < 3e-7
+    assert cc.e_tot > drv._global_fci.e_tot  # CCSD is not variational, but here it lies above FCI by 1.1e-4
+    for proj in ("mu", "huzinaga"):
+        d = drivers[proj]
+        res = getattr(d, proj)
+        emb_cc, ecorr = d._run_emb_ccsd(d.embedded_scf)
+        e_emb = emb_cc.e_tot + d.e_env + d.two_e_cross - res["correction"] - res["beta_correction"]
+        # the same 1.5e-5 as the embedded FCI number (the reference's loosely converged, spin-contaminated
+        # B3LYP inputs: module docstring); CCSD and FCI of this active space agree to 1.5e-7 here, to 5.8e-7 there
+        assert abs(e_emb - (-75.1285849238916)) < 3e-5
+        assert abs(ecorr - (-0.00477765364464925)) < 2e-5
+        fci_e = d._run_emb_fci(d.embedded_scf).e_tot
+        assert abs(fci_e - emb_cc.e_tot) < 1e-6
+
+
+def test_ccsd_is_exact_for_two_electrons(be, provider):
+    """CCSD = FCI for two electrons: H2 in three basis sets (d shells included), equilibrium and stretched."""
+    from nbed_amd import ccsd, fci
+    from nbed_amd.ham_builder import HamiltonianBuilder
+
+    for r, basis in ((0.74, "sto-3g"), (0.74, "6-31g"), (1.6, "6-31g"), (0.74, "cc-pvdz")):
+        cfg = NbedConfig(geometry=f"2\n\nH 0 0 0\nH 0 0 {r}", n_active_atoms=1, basis=basis, xc_functional="hf",
+                         convergence=1e-11)
+        hf = provider.global_hf(cfg)
+        const, h1, h2 = HamiltonianBuilder(hf, hf.energy_nuc(), backend=be).build()
+        cc = ccsd.solve(const, h1, h2, [0, 1], conv_tol=1e-12)
+        assert cc.converged and abs(cc.e_hf - hf.e_tot) < 1e-10
+        if h1.shape[0] <= fci.MAX_SPIN_ORBITALS:
+            assert abs(cc.e_tot - fci.ground_state(const, h1, h2, (1, 1)).e_tot) < 1e-10
+        else:  # two electrons: the singlet ground state from the (n x n) two-particle matrix in the MO basis
+            n = h1.shape[0] // 2
+            ha = h1[0::2, 0::2]
+            v = 2.0 * h2[0::2, 1::2, 1::2, 0::2]        # <p_a q_b| r_a s_b> as build() stores it: a+_pa a+_qb a_sb... 
+            ham = (np.einsum("pr,qs->pqrs", ha, np.eye(n)) + np.einsum("qs,pr->pqrs", ha, np.eye(n))
+                   + v.transpose(0, 1, 3, 2)).reshape(n * n, n * n)
+            assert abs(cc.e_tot - (np.linalg.eigvalsh(0.5 * (ham + ham.T))[0] + const)) < 1e-9
+
+
 def test_concentric_shell_numbers_water_631g(be, provider):
     """tests/test_localizers.py:217-243 (fixtures :22-49): water / 6-31G, global B3LYP Kohn-Sham at
     conv_tol 1e-6, SPADE with one active atom, then concentric localization of the virtuals:
