@@ -1,7 +1,7 @@
 """Embedded SCF methods (mirror of nbed/scf/__init__.py:3-6)."""
 
 from .embedded_hcore_funcs import energy_elec
-from .gpu_scf import GpuRHF, GpuUHF, GpuUKS, Mole
+from .gpu_scf import GpuRHF, GpuRKS, GpuUHF, GpuUKS, Mole
 from .huzinaga_scf import calculate_hf_energy, calculate_ks_energy, get_huzinaga_operator, huzinaga_scf
 
 __all__ = [
@@ -12,6 +12,7 @@ __all__ = [
     "calculate_ks_energy",
     "GpuUHF",
     "GpuRHF",
+    "GpuRKS",
     "GpuUKS",
     "Mole",
 ]

@@ -21,7 +21,7 @@ import numpy as np
 
 from ..backend import get_backend
 from ..dist import Shards
-from .pyscf_compat import RHF, UHF, UKS
+from .pyscf_compat import RHF, RKS, UHF, UKS
 
 
 class Mole:
@@ -557,6 +557,53 @@ class GpuUKS(GpuUHF, UKS):
         if vhf is None or getattr(vhf, "ecoul", None) is None:
             vhf = self.get_veff(self.mol, dm)
         e1 = float(self.be.trace_prod(self.be.asarray(h1e), self.be.asarray(dm)).sum())
+        e2 = float(vhf.ecoul + vhf.exc)
+        self.scf_summary.update(e1=e1, coul=float(vhf.ecoul), exc=float(vhf.exc), e2=e2)
+        return e1 + e2, e2
+
+
+class GpuRKS(_GpuSCF, RKS):
+    """Restricted Kohn-Sham object (2-D arrays; the density carries the factor 2): ``dft.RKS`` as the
+    reference's tests hand it to ``huzinaga_scf`` (tests/test_scf.py:19-40).  J and the exact-exchange
+    fraction are libnbx builds; the semi-local part comes from ``xc_provider`` (``nbed_amd.xc``), called
+    with the two equal spin halves of the density."""
+
+    def __init__(self, mol, ovlp, hcore, eri=None, backend=None, xc="lda,vwn", hyb=0.0, xc_provider=None):
+        super().__init__(mol, ovlp, hcore, eri, backend=backend)
+        self.xc, self.hyb, self.xc_provider = xc, float(hyb), xc_provider
+
+    def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
+        be = self.be
+        dm = self.make_rdm1() if dm is None else np.asarray(dm)
+        jk = be.to_host(self.jk_device(be.asarray(dm[None])))
+        veff = jk[0] - 0.5 * self.hyb * jk[1]
+        ecoul = 0.5 * float(np.einsum("ij,ji->", jk[0], dm))
+        exc = -0.25 * self.hyb * float(np.einsum("ij,ji->", jk[1], dm))
+        if self.xc_provider is not None:
+            e_sl, v_sl = self.xc_provider(np.array((0.5 * dm, 0.5 * dm)))
+            exc += float(e_sl)
+            veff = veff + 0.5 * (np.asarray(v_sl)[0] + np.asarray(v_sl)[1])
+        out = np.asarray(veff).view(TaggedVeff)
+        out.ecoul, out.exc, out.vj, out.vk = ecoul, exc, jk[0], jk[1]
+        return out
+
+    def get_occ(self, mo_energy=None, mo_coeff=None):
+        mo_energy = self.mo_energy if mo_energy is None else np.asarray(mo_energy)
+        mo_occ = np.zeros_like(mo_energy)
+        mo_occ[np.argsort(mo_energy)[: self.mol.nelectron // 2]] = 2
+        return mo_occ
+
+    def make_rdm1(self, mo_coeff=None, mo_occ=None):
+        mo_coeff = np.asarray(self.mo_coeff if mo_coeff is None else mo_coeff)
+        mo_occ = np.asarray(self.mo_occ if mo_occ is None else mo_occ)
+        return (mo_coeff * mo_occ) @ mo_coeff.T
+
+    def energy_elec(self, dm=None, h1e=None, vhf=None):
+        dm = self.make_rdm1() if dm is None else np.asarray(dm)
+        h1e = self.get_hcore() if h1e is None else np.asarray(h1e)
+        if vhf is None or getattr(vhf, "ecoul", None) is None:
+            vhf = self.get_veff(self.mol, dm)
+        e1 = float(np.einsum("ij,ji->", h1e, dm))
         e2 = float(vhf.ecoul + vhf.exc)
         self.scf_summary.update(e1=e1, coul=float(vhf.ecoul), exc=float(vhf.exc), e2=e2)
         return e1 + e2, e2

@@ -11,6 +11,7 @@ would hand to libxc.  The Coulomb and exact-exchange parts of the Kohn-Sham matr
 
 Functionals (libxc definitions, spin-polarised):
   * ``lda``    Slater exchange + VWN(RPA) correlation                      ("lda,vwn_rpa")
+  * ``lda,vwn`` Slater exchange + VWN5 correlation (libxc LDA_C_VWN: PySCF's default functional)
   * ``b3lyp``  0.08 Slater + 0.72 B88 + 0.19 VWN(RPA) + 0.81 LYP + 0.20 HF  (libxc XC_HYB_GGA_XC_B3LYP,
                what PySCF >= 2.3 means by "b3lyp": the warning captured in
                docs/source/notebooks/localization.ipynb cell 13)
@@ -43,7 +44,8 @@ def _torch():
 #: Bragg-Slater radii (Angstrom) used for the radial scale and the cell-size adjustment (Becke 1988)
 BRAGG = {"H": 0.35, "C": 0.70, "N": 0.65, "O": 0.60, "F": 0.50}
 
-HYBRID_FRACTION = {"hf": 1.0, "b3lyp": 0.2, "lda": 0.0, "lda,vwn_rpa": 0.0, "slater": 0.0}
+HYBRID_FRACTION = {"hf": 1.0, "b3lyp": 0.2, "lda": 0.0, "lda,vwn_rpa": 0.0, "lda,vwn": 0.0, "lda,vwn5": 0.0, "svwn": 0.0,
+                   "slater": 0.0}
 
 
 def hybrid_fraction(xc: str) -> float:
@@ -238,6 +240,30 @@ def _vwn_rpa(t, ra, rb):
     return rho * (ec_p + fz * (ec_f - ec_p))
 
 
+def _vwn5(t, ra, rb):
+    """Vosko-Wilk-Nusair correlation, the fit to the Ceperley-Alder data with the spin interpolation of the
+    paper (libxc LDA_C_VWN, what PySCF means by "vwn" -- its default functional is "lda,vwn")."""
+    rho = ra + rb
+    zeta = (ra - rb) / rho
+    x = ((3.0 / (4.0 * math.pi)) / rho) ** (1.0 / 6.0)  # sqrt(rs)
+
+    def ec(a, x0, b, c):
+        q = math.sqrt(4.0 * c - b * b)
+        xx = x * x + b * x + c
+        xx0 = x0 * x0 + b * x0 + c
+        at = t.atan(q / (2.0 * x + b))
+        return a * (t.log(x * x / xx) + 2.0 * b / q * at
+                    - b * x0 / xx0 * (t.log((x - x0) ** 2 / xx) + 2.0 * (b + 2.0 * x0) / q * at))
+
+    ec_p = ec(0.0310907, -0.10498, 3.72744, 12.9352)
+    ec_f = ec(0.01554535, -0.32500, 7.06042, 18.0578)
+    alpha = ec(-1.0 / (6.0 * math.pi**2), -0.0047584, 1.13107, 13.0045)  # spin stiffness
+    fz = ((1.0 + zeta) ** (4.0 / 3.0) + (1.0 - zeta) ** (4.0 / 3.0) - 2.0) / (2.0 ** (4.0 / 3.0) - 2.0)
+    fpp0 = 4.0 / (9.0 * (2.0 ** (1.0 / 3.0) - 1.0))
+    z4 = zeta**4
+    return rho * (ec_p + alpha * fz / fpp0 * (1.0 - z4) + (ec_f - ec_p) * fz * z4)
+
+
 def _lyp(t, ra, rb, saa, sab, sbb):
     """Lee-Yang-Parr correlation in the gradient-only form of Miehlich, Savin, Stoll and Preuss (1989)."""
     a, b, c, d = 0.04918, 0.132, 0.2533, 0.349
@@ -267,6 +293,8 @@ def energy_density(xc: str, ra, rb, saa, sab, sbb):
         return None
     if key in ("lda", "lda,vwn_rpa"):
         return _slater(t, ra, rb) + _vwn_rpa(t, ra, rb)
+    if key in ("lda,vwn", "lda,vwn5", "svwn"):
+        return _slater(t, ra, rb) + _vwn5(t, ra, rb)
     if key == "slater":
         return _slater(t, ra, rb)
     if key == "b3lyp":

@@ -44,6 +44,7 @@ from test_reference_kats import (  # noqa: E402,F401  (the reference's own KATs,
     test_concentric_shell_numbers_water_631g,
     test_global_and_embedded_ccsd,
     test_ccsd_is_exact_for_two_electrons,
+    test_huzinaga_scf_outputs_of_test_scf,
 )
 from test_host_scf import (  # noqa: E402,F401
     test_energy_elec_matches_reference,

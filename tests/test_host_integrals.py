@@ -305,7 +305,16 @@ def test_xc_quadrature_and_functional_derivatives():
         p2 = xc.XCProvider(atoms, basis, name, n_rad=40, n_theta=12)
         e2, v2 = p2(dm)
         assert (name == "hf") == (e2 == 0.0 and not np.any(v2))
-    assert xc.hybrid_fraction("b3lyp") == 0.2 and xc.hybrid_fraction("HF") == 1.0
+    import torch
+
+    # VWN5 (PySCF's "vwn") reproduces the Ceperley-Alder energies it was fitted to (Hartree per electron):
+    # paramagnetic rs = 1, 2, 5: -0.0600, -0.0448, -0.0282; ferromagnetic rs = 1, 2: -0.0316, -0.0239
+    for rs, zeta, ca in ((1, 0, -0.0600), (2, 0, -0.0448), (5, 0, -0.0282), (1, 1, -0.0316), (2, 1, -0.0239)):
+        rho = 3.0 / (4.0 * np.pi * rs**3)
+        ra = torch.tensor([rho * (1 + zeta) / 2 + 1e-300], dtype=torch.float64)
+        rb = torch.tensor([rho * (1 - zeta) / 2 + 1e-300], dtype=torch.float64)
+        assert abs(float(xc._vwn5(torch, ra, rb)) / rho - ca) < 1.2e-4
+    assert xc.hybrid_fraction("b3lyp") == 0.2 and xc.hybrid_fraction("HF") == 1.0 and xc.hybrid_fraction("lda,vwn") == 0.0
     with pytest.raises(ValueError):
         xc.hybrid_fraction("pbe0")
     # closed form: E_x^LDA of rho = e^{-2r}/pi, all spin up, is -(3/2)(3/4pi)^(1/3) int rho^(4/3)

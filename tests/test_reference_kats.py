@@ -187,6 +187,58 @@ def test_ccsd_is_exact_for_two_electrons(be, provider):
             assert abs(cc.e_tot - (np.linalg.eigvalsh(0.5 * (ham + ham.T))[0] + const)) < 1e-9
 
 
+def test_huzinaga_scf_outputs_of_test_scf(be, provider):
+    """tests/test_scf.py:19-134 (RKS, UKS with PySCF's default functional "lda,vwn" = Slater + VWN5; RHF, UHF):
+    ``huzinaga_scf`` on a Hartree-Fock object of the WHOLE water molecule (tests/molecules/water.xyz) with the
+    embedding potential and environment density of the two-active-atom run on the H,O,H geometry
+    (conftest.py:104-125) -- an unphysical but fully determined combination.  The loop never reads the object's
+    own orbitals, so no ``kernel()`` is needed.  Occupied levels, the density and the operator agree to the
+    1e-5 the reference's inputs are good to; the level the projector pushes to +3.6 / +2.4 Ha is the most
+    sensitive to them (the reference's own alpha and beta differ by 6e-5 there) and agrees to 1.3e-3."""
+    from nbed_amd import integrals, xc
+    from nbed_amd.scf import GpuRHF, GpuRKS, GpuUHF, GpuUKS, huzinaga_scf
+
+    raw = "3\n \nH\t0.2774\t0.8929\t0.2544\nO\t0\t0\t0\nH\t0.6068\t-0.2383\t-0.7169"
+    drv = nbed(NbedConfig(**dict(NBED_ARGS, geometry=raw, n_active_atoms=2, run_fci_emb=False)), provider=provider,
+               backend=be)
+    vemb, denv = np.asarray(drv.embedding_potential), np.asarray(drv.localized_system.dm_enviro)
+    wcfg = NbedConfig(geometry=WATER, n_active_atoms=1, basis="STO-3G", xc_functional="hf")
+    m, mol = provider._integrals(wcfg), provider.build_mol(wcfg)
+    c, e, d, hz, conv = huzinaga_scf(GpuRHF(mol, m["S"], m["hcore"], m["eri"], backend=be), embedding_potential=vemb[0],
+                                     dm_environment_occupied=denv[0], backend=be)
+    ref = np.array([-19.346243, -0.59741322, 0.12747464, 0.6132579, 0.79561917, 3.56833278, 4.1655741])
+    assert conv and c.shape == d.shape == hz.shape == (7, 7)
+    np.testing.assert_allclose(e[[0, 1, 2, 4, 6]], ref[[0, 1, 2, 4, 6]], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(e, ref, rtol=0, atol=1.5e-3)
+    assert abs(np.mean(d) - 0.17985591319811933) < 5e-6 and abs(np.mean(hz) - (-0.01224642921175508)) < 1e-5
+    c, e, d, hz, conv = huzinaga_scf(GpuUHF(mol, m["S"], m["hcore"], m["eri"], backend=be), embedding_potential=vemb,
+                                     dm_environment_occupied=denv, backend=be)
+    ref = np.array([[-19.18005207, -0.618383, 0.07366692, 0.39496279, 0.72192366, 2.44806433, 4.12874389],
+                    [-19.17991953, -0.6183819, 0.07366408, 0.39491023, 0.72191934, 2.44812268, 4.12874047]])
+    assert conv and c.shape == d.shape == hz.shape == (2, 7, 7)
+    np.testing.assert_allclose(e[:, [1, 2, 4, 6]], ref[:, [1, 2, 4, 6]], rtol=0, atol=6e-5)
+    np.testing.assert_allclose(e, ref, rtol=0, atol=1e-3)
+    np.testing.assert_allclose(e[0], e[1], rtol=0, atol=1e-9)  # closed shell: no spin contamination here
+    assert abs(np.mean(d) - 0.0920247346776863) < 5e-6 and abs(np.mean(hz) - (-0.024315876434944768)) < 1e-5
+    # Kohn-Sham objects of PySCF's default functional
+    atoms = integrals.parse_geometry(WATER)
+    lda = xc.XCProvider(atoms, integrals.Basis(atoms, "sto-3g"), "lda,vwn")
+    rks = GpuRKS(mol, m["S"], m["hcore"], m["eri"], backend=be, xc="lda,vwn", hyb=0.0, xc_provider=lda)
+    c, e, d, hz, conv = huzinaga_scf(rks, embedding_potential=vemb[0], dm_environment_occupied=denv[0], backend=be)
+    ref = np.array([-17.44629099, -0.27614116, 0.37893061, 0.89022282, 1.12092664, 3.32762378, 3.86532114])
+    assert conv
+    np.testing.assert_allclose(e[[0, 1, 2, 4, 6]], ref[[0, 1, 2, 4, 6]], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(e, ref, rtol=0, atol=1.5e-3)
+    assert abs(np.mean(d) - 0.1822057642580939) < 5e-6 and abs(np.mean(hz) - (-0.011214890666261626)) < 1e-5
+    uks = GpuUKS(mol, m["S"], m["hcore"], m["eri"], backend=be, xc="lda,vwn", hyb=0.0, xc_provider=lda)
+    c, e, d, hz, conv = huzinaga_scf(uks, embedding_potential=vemb, dm_environment_occupied=denv, backend=be)
+    ref = np.array([-17.29060406, -0.28451256, 0.31504139, 0.60348835, 1.0520797, 2.22020625, 3.8346852])
+    assert conv
+    np.testing.assert_allclose(e[0][[0, 1, 2, 4, 6]], ref[[0, 1, 2, 4, 6]], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(e[0], ref, rtol=0, atol=1e-3)
+    assert abs(np.mean(d) - 0.09276688041715254) < 5e-6 and abs(np.mean(hz) - (-0.02251188710459783)) < 1e-5
+
+
 def test_concentric_shell_numbers_water_631g(be, provider):
     """tests/test_localizers.py:217-243 (fixtures :22-49): water / 6-31G, global B3LYP Kohn-Sham at
     conv_tol 1e-6, SPADE with one active atom, then concentric localization of the virtuals:
