@@ -291,3 +291,44 @@ def test_consumers_are_importable_and_fail_loudly_without_pyscf(be):
         for fn in (run_emb_fci, run_emb_ccsd):
             with pytest.raises(NbedDriverError):
                 fn(object())
+
+
+def test_nbed_config_input_forms(be, tmp_path):
+    """tests/test_embed.py:10-41 -- the forms ``nbed()`` accepts: a config object, keyword overrides on
+    top of it, a path to a .json file, bare keyword arguments, ``config=None``, an object that is not a config
+    (ignored in favour of the keywords), and a pydantic ValidationError when a required field is missing."""
+    import json
+
+    from pydantic import ValidationError
+
+    from nbed_amd.config import parse_config
+
+    base = config(virtual_localization="disable")
+    prov = SyntheticProvider(14, (5, 5), 5)
+    assert isinstance(nbed(base, provider=prov, backend=be), NbedDriver)
+    assert nbed(base, provider=prov, backend=be, n_active_atoms=1).config.n_active_atoms == 1
+    args = base.model_dump()
+    path = tmp_path / "config.json"
+    path.write_text(json.dumps(base.model_dump(mode="json")))
+    assert parse_config(str(path)) == base and parse_config(path) == base
+    assert isinstance(nbed(str(path), provider=prov, backend=be), NbedDriver)
+    assert isinstance(nbed(provider=prov, backend=be, **args), NbedDriver)
+    assert parse_config(None, **args) == base
+    assert parse_config(["a", "list"], **args) == base
+    args.pop("geometry")
+    with pytest.raises(ValidationError):
+        parse_config(None, **args)
+
+
+def test_geometry_helpers(tmp_path):
+    """tests/test_utils.py:32-58: active atoms first, tab separated, the file under molecular_structures/."""
+    from nbed_amd.utils import build_ordered_xyz_string, save_ordered_xyz_file
+
+    water = {0: ("O", (0, 0, 0)), 1: ("H", (0.2774, 0.8929, 0.2544)), 2: ("H", (0.6068, -0.2383, -0.7169))}
+    o_first = "3\n \nO\t0\t0\t0\nH\t0.2774\t0.8929\t0.2544\nH\t0.6068\t-0.2383\t-0.7169\n"
+    assert build_ordered_xyz_string(water, [0]) == o_first
+    assert build_ordered_xyz_string(water, [1, 2]) == "3\n \nH\t0.2774\t0.8929\t0.2544\nH\t0.6068\t-0.2383\t-0.7169\nO\t0\t0\t0\n"
+    path = save_ordered_xyz_file("water_test", water, [0], save_location=tmp_path)
+    assert path.read_text() == o_first and path.parent.name == "molecular_structures"
+    with pytest.raises(ValueError):
+        build_ordered_xyz_string(water, [5])
