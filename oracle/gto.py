@@ -23,7 +23,6 @@ shell pairs vectorised -- two routes to the same numbers.  The basis-set tables 
 from __future__ import annotations
 
 import math
-from functools import lru_cache
 
 import numpy as np
 from scipy.special import hyp1f1

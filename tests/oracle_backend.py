@@ -14,7 +14,6 @@ import numpy as np
 import torch
 
 from oracle import hamiltonian
-from oracle.pyscf_like import get_jk
 from oracle import synth
 
 

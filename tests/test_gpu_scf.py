@@ -115,7 +115,6 @@ def test_huzinaga_scf_vs_oracle_converged(be, n, nocc, n_env):
 def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch, n):
     """The unguarded refinement cycles (nbx_geig_refine, no fallback queued) give the run the guarded
     solver gives; a rejected tracked cycle makes the loop repeat the run guarded (same numbers)."""
-    import nbed_amd.scf.huzinaga_scf as mod
     from nbed_amd.scf import GpuUHF, Mole, huzinaga_scf
 
     # n = 64: the loop issues its launches one by one (be.geig_refine); n = 104 (packed J/K kernel):
