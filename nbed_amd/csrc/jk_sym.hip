@@ -29,9 +29,6 @@ constexpr int JS_THREADS = 256;
 // (N = 148: 0.389 vs 0.403 ms), QB = 4 for long ones (N = 256: 2.89 vs 3.07 ms).
 constexpr int js_waves(int qb) { return qb <= 2 ? 4 : 3; }
 constexpr int JS_CUS = 256;
-// row-chunks (waves) per workgroup of the reduction kernel: the longest row sums N - 1 partials, a chain of
-// dependent-latency batches when only four waves share it
-constexpr int JS_RED_CHUNKS = 16;
 constexpr size_t JS_LDS_PER_CU = 160 * 1024;
 
 __device__ __forceinline__ void fma2(double2& acc, double s, double2 v) {
@@ -241,8 +238,7 @@ void jk_sym_kernel(const double* __restrict__ eri, const double* __restrict__ dm
 //                                     + sum over slab rows p > row of kpart2[row][p - p0][x][b]
 // grid (N, NDM, ceil(N/64)); 256 threads = 4 row-chunks x 64 column lanes, 8 independent loads in
 // flight per thread; fixed summation order.
-template <int NCHK>
-__global__ __launch_bounds__(64 * NCHK) void jk_sym_reduce_kernel(const double* __restrict__ kpart1,
+__global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __restrict__ kpart1,
                                                             const double* __restrict__ kpart2,
                                                             double* __restrict__ kout, int N, int p0, int np, int ndm,
                                                             int64_t t_begin, int L, int S, int accumulate,
@@ -251,7 +247,7 @@ __global__ __launch_bounds__(64 * NCHK) void jk_sym_reduce_kernel(const double* 
                                                             double* __restrict__ fock = nullptr,
                                                             double* __restrict__ vhf = nullptr,
                                                             int k2_tile_order = 0) {
-    __shared__ double part[NCHK][64];
+    __shared__ double part[4][64];
     const int row = blockIdx.x, x = blockIdx.y;
     const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
     const int b = blockIdx.z * 64 + lane;
@@ -268,33 +264,31 @@ __global__ __launch_bounds__(64 * NCHK) void jk_sym_reduce_kernel(const double* 
             return src[(pg * (pg + 1) / 2 + row - t_begin) * stride];
         };
         int pl = pl_lo + chunk;
-        for (; pl + 7 * NCHK < np; pl += 8 * NCHK) {
+        for (; pl + 28 < np; pl += 32) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = at(pl + NCHK * u);
+            for (int u = 0; u < 8; ++u) v[u] = at(pl + 4 * u);
 #pragma unroll
             for (int u = 0; u < 8; ++u) t += v[u];
         }
-        for (; pl < np; pl += NCHK) t += at(pl);
+        for (; pl < np; pl += 4) t += at(pl);
     } else if (b < N) {
         const double* src = kpart2 + (((int64_t)row * np) * ndm + x) * N + b;
         const int64_t stride = (int64_t)ndm * N;
         int pl = pl_lo + chunk;
-        for (; pl + 7 * NCHK < np; pl += 8 * NCHK) {
+        for (; pl + 28 < np; pl += 32) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(pl + NCHK * u) * stride];
+            for (int u = 0; u < 8; ++u) v[u] = src[(pl + 4 * u) * stride];
 #pragma unroll
             for (int u = 0; u < 8; ++u) t += v[u];
         }
-        for (; pl < np; pl += NCHK) t += src[pl * stride];
+        for (; pl < np; pl += 4) t += src[pl * stride];
     }
     part[chunk][lane] = t;
     __syncthreads();
     if (chunk == 0 && b < N) {
-        double tot = 0.0;
-#pragma unroll
-        for (int c = 0; c < NCHK; ++c) tot += part[c][lane];
+        double tot = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
         if (row >= p0 && row < p0 + np) {
             const int64_t w_lo = (tri_index(row, 0) - t_begin) / L, w_hi = (tri_index(row, row) - t_begin) / L;
             for (int64_t w = w_lo; w <= w_hi; ++w) {
@@ -501,7 +495,7 @@ bool nbx_jk_sym_supported(int64_t nao) { return nao >= 2 && nao % 2 == 0 && nao 
 int nbx_jk_sym_reduce(nbx_ctx* ctx, const double* k1, const double* k2, double* d_k, int64_t N, int64_t p0, int64_t np,
                       int64_t ndm, int64_t t_begin, int L, int S, const double* d_j, const double* d_hv, double* d_fock,
                       double* d_vhf, int k2_tile_order) {
-    hipLaunchKernelGGL(jk_sym_reduce_kernel<JS_RED_CHUNKS>, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(64 * JS_RED_CHUNKS), 0,
+    hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
                        ctx->stream, k1, k2, d_k, (int)N, (int)p0, (int)np, (int)ndm, t_begin, L, S, 0, d_j, d_hv, d_fock,
                        d_vhf, k2_tile_order);
     NBX_LAUNCH_CHECK();
@@ -592,7 +586,7 @@ extern "C" int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p
 #undef NBX_JS_GO
     }
     NBX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jk_sym_reduce_kernel<JS_RED_CHUNKS>, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(64 * JS_RED_CHUNKS), 0,
+    hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
                        ctx->stream, k1, k2,
                        d_jk + n2, (int)N, (int)p0, (int)np, (int)ndm, t_begin, pl.L, pl.S, 0);
     NBX_LAUNCH_CHECK();
@@ -687,7 +681,7 @@ extern "C" int nbx_jk_synth_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p
 #undef NBX_GS_GO
         }
         NBX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(jk_sym_reduce_kernel<JS_RED_CHUNKS>, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(64 * JS_RED_CHUNKS), 0,
+        hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
                            ctx->stream, k1, k2, d_jk + n2, (int)N, (int)c0, (int)np, (int)ndm, t_begin, pl.L, pl.S, 1);
         NBX_LAUNCH_CHECK();
     }
