@@ -195,9 +195,10 @@ def real_molecule_leg(be, args) -> dict:
         "ms_per_cycle_settled": float(np.median(np.diff(stamps)[-8:])) * 1e3,
         "queue_pace_ms_first_cycles": [round(float(x) * 1e3, 3) for x in np.diff(stamps)[:12]],
         "protocol": f"as value: {args.steps} cycles after {args.warmup} warm-up cycles of one huzinaga_scf run, DIIS on, stopping rule off; "
-                    "the first ~8 cycles of a real molecule fall back to the Jacobi eigensolver (levels 4e-4 Ha apart "
-                    "in the virtual space defeat the refinement while the Fock matrix still moves), the settled cycles "
-                    "run at the pace of the synthetic workload",
+                    "the first cycles of a real molecule defeat the warm-started eigensolvers (levels 4e-4 Ha apart in the "
+                    "virtual space, a Fock matrix that still moves): cycles 0-1 pay a Jacobi solve, the next ones take their "
+                    "density from purification (nbx_purify), one cold eigensolve follows when the density has settled, "
+                    "then the refinement runs at the pace of the synthetic workload",
     }
 
 

@@ -418,6 +418,10 @@ int nbx_spinorb_scatter_range(nbx_ctx* ctx, int64_t n, const double* d_two_body,
  *   mode 1 ("tracked"): nbx_geig_refine from d_c_in = the previous cycle's S-orthonormal C; status in
  *          d_status_out.  mode 0 ("guarded"): X F X, nbx_eigh_warm_ex warm-started from d_c_in = the previous
  *          cycle's orthonormal-basis vectors (NULL: cold), C = X V; d_v_out receives V.
+ *          mode 2 ("purified"): no eigenvectors at all -- D = X P X with P the projector on the occupied
+ *          levels of X F X from nbx_purify (refine_iters caps its steps, <= 0: the limit); d_c_out, d_v_out
+ *          and d_w_out are NOT written, the status words are nbx_purify's.  For the first cycles of a run,
+ *          whose Fock matrix moves too much for a warm-started eigensolver.
  *   diis_mode 0: no DIIS; 1: pyscf.lib.diis' first update (only remembers F); 2: nbx_diis_update with
  *          (diis_slot, diis_nd) -- the ring bookkeeping stays with the caller.
  *   dts_ready: st->d_dts holds the Dtot' table of d_dm_in (left by the previous call).
@@ -454,6 +458,20 @@ int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, 
                   double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out, double* d_hz_out, int mode,
                   int refine_iters, int diis_mode, int diis_slot, int diis_nd, int dts_ready, double* h_out,
                   int* d_status_out);
+
+/* ------------------------------------------------------------------ density by purification
+ * The projector P on the nocc LOWEST eigenvectors of each symmetric matrix d_f (batch, n, n; an orthonormal
+ * basis), i.e. C_occ C_occ^T of `eigh` + aufbau occupation (nbed/scf/huzinaga_scf.py:166-174) without the
+ * eigenvectors: trace-correcting purification (SP2), one (n x n) product per step, everything decided on
+ * the device.  For SCF cycles whose Fock matrix still moves too much for a warm-started eigensolver.
+ *   nocc_a, nocc_b : occupied levels of matrix 0 and of the others (batch = 2: alpha, beta)
+ *   d_p            : out (batch, n, n)
+ *   d_work         : nbx_purify_worksize() bytes;  max_iter <= 0: the limit (72 steps)
+ *   d_status[b]    : > 0 steps taken; < 0 no gap between levels nocc and nocc + 1 was resolved (or the
+ *                    matrix is not finite): d_p is then meaningless                                      */
+size_t nbx_purify_worksize(int64_t n, int64_t batch);
+int nbx_purify(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_f, int64_t nocc_a, int64_t nocc_b, double* d_p,
+               void* d_work, size_t work_bytes, int max_iter, int* d_status);
 
 /* d_x[i] <- (|d_x[i]| < tol ? 0 : d_x[i]) * scale over n doubles: the 1e-8 truncation
  * (nbed/ham_builder.py:213-214) and the 1/2 of build() (:254) applied to a SPATIAL block, for callers

@@ -575,11 +575,13 @@ class HipBackend:
     def huz_cycle(self, h, dm_in, c_in, out, tracked: bool, refine_iters: int, diis_mode: int, diis_slot: int,
                   diis_nd: int, dts_ready: bool):
         """Queue one SCF cycle (nbx_huz_cycle) writing into the result set ``out``; returns the handle of
-        its scalars + status words (read one cycle late, like ``huz_cycle_scalars_async``)."""
+        its scalars + status words (read one cycle late, like ``huz_cycle_scalars_async``).  ``tracked``:
+        False / 0 guarded eigensolve, True / 1 tracked refinement, 2 density by purification (``refine_iters``
+        then caps its steps; no orbitals are written)."""
         h_out = self._pin_ring[self._pin_next][:6]
         self._pin_next = (self._pin_next + 1) % self._PIN_SLOTS
         self._call("nbx_huz_cycle", ctypes.byref(h.st), self._p(dm_in), self._p(c_in), self._p(out["dm"]),
-                   self._p(out["c"]), self._p(out["v"]), self._p(out["w"]), self._p(out["hz"]), 1 if tracked else 0,
+                   self._p(out["c"]), self._p(out["v"]), self._p(out["w"]), self._p(out["hz"]), int(tracked),
                    int(refine_iters), int(diis_mode), int(diis_slot), int(diis_nd), 1 if dts_ready else 0,
                    self._p(h_out), self._p(out["status"]))
         return _PendingScalars(self.torch, None, 2, host=h_out)
@@ -684,6 +686,21 @@ class HipBackend:
                    self._p(status), self._p(work), work.numel(), int(refine_iters))
         self.last_eigh_status_d = status
         return w, c
+
+    def purify(self, f, nocc, max_iter: int = 0):
+        """Projector on the ``nocc[b]`` lowest eigenvectors of each symmetric matrix of ``f`` (batch, n, n) by
+        trace-correcting purification (nbx_purify) -> ``(p, status)`` device tensors; status[b] > 0 = steps."""
+        torch = self.torch
+        f = f if f.dim() == 3 else f.reshape(1, *f.shape)
+        batch, n = int(f.shape[0]), int(f.shape[-1])
+        nocc = [int(nocc)] * 2 if np.isscalar(nocc) else [int(x) for x in nocc]
+        p = torch.empty_like(f)
+        status = torch.zeros(batch, dtype=torch.int32, device=self.device)
+        nbytes = int(self.lib.nbx_purify_worksize(n, batch))
+        work = self._workspace("purify", nbytes)
+        self._call("nbx_purify", n, batch, self._p(f), nocc[0], nocc[-1], self._p(p), self._p(work), nbytes, int(max_iter),
+                   self._p(status))
+        return p, status
 
     def sym_pow_newton_schulz(self, s, p: float, s_host=None, max_iter: int = 28, check_every: int = 4):
         """S^p for p in {-1/2, +1/2, -1} of a symmetric positive definite matrix by the coupled

@@ -16,7 +16,7 @@ extern "C" int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double
     NBX_CHECK_ARG(ctx && st && d_dm_in && d_dm_out && d_c_out && d_w_out && d_hz_out && h_out);
     NBX_CHECK_ARG(st->nao > 0 && st->d_packed && st->d_hv && st->d_ds && st->d_jk && st->d_fock && st->d_vhf &&
                   st->d_fock2 && st->d_jk_work);
-    NBX_CHECK_ARG(mode == 0 || mode == 1);
+    NBX_CHECK_ARG(mode == 0 || mode == 1 || mode == 2);
     NBX_CHECK_ARG(diis_mode >= 0 && diis_mode <= 2);
     const int64_t N = st->nao, n2 = N * N;
     int rc;
@@ -46,6 +46,26 @@ extern "C" int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double
 
     // ---- eigenproblem F C = S C eps (:166-169)
     const int* d_status = nullptr;
+    if (mode == 2) {
+        // density without eigenvectors: the projector on the nocc lowest levels of X F X by purification
+        // (purify.hip), D = X P X.  For cycles whose Fock matrix still moves too much for a warm start to help;
+        // d_c_out / d_w_out are NOT written (the caller must not use this cycle's orbitals).
+        NBX_CHECK_ARG(st->d_x && st->d_eig_work && st->d_tmp && st->d_fo && d_status_out);
+        NBX_CHECK_ARG(st->eig_work_bytes >= nbx_purify_worksize(N, 2));
+        rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_x, N, 0, f_use, N, n2, 0.0, st->d_tmp, N, n2, 2);
+        if (rc != NBX_OK) return rc;
+        rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_tmp, N, n2, st->d_x, N, 0, 0.0, st->d_fo, N, n2, 2);
+        if (rc != NBX_OK) return rc;
+        rc = nbx_purify(ctx, N, 2, st->d_fo, st->nocc_a, st->nocc_b, st->d_tmp, st->d_eig_work, st->eig_work_bytes,
+                        refine_iters, d_status_out);
+        if (rc != NBX_OK) return rc;
+        rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_x, N, 0, st->d_tmp, N, n2, 0.0, st->d_fo, N, n2, 2);
+        if (rc != NBX_OK) return rc;
+        rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_fo, N, n2, st->d_x, N, 0, 0.0, d_dm_out, N, n2, 2);
+        if (rc != NBX_OK) return rc;
+        return nbx_huz_cycle_scalars_dts(ctx, N, st->d_hv, 3, nullptr, st->d_vhf, d_hz_out, d_dm_out, d_dm_in, h_out,
+                                         d_status_out, 2, st->d_dts);
+    }
     if (mode == 1) {  // tracked: refine the previous cycle's (eps, C) on the pencil (F, S), no fallback queued
         NBX_CHECK_ARG(d_c_in && st->d_sb && st->d_geig_work && d_status_out);
         rc = nbx_geig_refine(ctx, N, 2, f_use, st->d_sb, d_c_in, d_w_out, d_c_out, d_status_out, st->d_geig_work,

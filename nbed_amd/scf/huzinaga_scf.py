@@ -106,6 +106,17 @@ def _is_fused(scf_method) -> bool:
 MAX_REFINE_ITERS = 6  # the library's limit (nbx_eigh_warm_ex / nbx_geig_refine)
 
 
+class _PurificationFailed(Exception):
+    """A cycle whose density came from purification did not resolve a gap (or the run ended on such a cycle,
+    whose orbitals do not exist): the run is repeated with an eigensolver in every cycle."""
+
+
+# purification cycles (nbx_huz_cycle mode 2): entered when a guarded cycle needed at least this many Jacobi
+# sweeps while the density still moved by more than PURIFY_DM_CHANGE, left when it moves less
+PURIFY_MIN_SWEEPS = 6
+PURIFY_DM_CHANGE = 0.03
+
+
 class _TrackedEigensolveFailed(Exception):
     """A cycle solved by unguarded refinement (nbx_geig_refine) was not accepted."""
 
@@ -137,17 +148,26 @@ def huzinaga_scf(
     """
     args = (scf_method, embedding_potential, dm_environment_occupied, dm_environment_virtual, dm_conv_tol,
             dm_initial_guess, use_DIIS, backend, history, callback)
-    try:
-        return _huzinaga_scf(*args, allow_tracked=os.environ.get("NBED_TRACKED_EIG", "1") != "0")
-    except _TrackedEigensolveFailed:
-        logger.warning("tracked eigensolve rejected a cycle: repeating the SCF with the guarded solver")
+    tracked = os.environ.get("NBED_TRACKED_EIG", "1") != "0"
+    purify = os.environ.get("NBED_PURIFY", "1")
+    # NBED_PURIFY: "1" densities by purification once a guarded cycle shows that warm starts do not help (default);
+    # "0" never; "force" from the first cycle on, until the density settles (tests)
+    for _ in range(3):
+        try:
+            return _huzinaga_scf(*args, allow_tracked=tracked, allow_purify=purify)
+        except _TrackedEigensolveFailed:
+            logger.warning("tracked eigensolve rejected a cycle: repeating the SCF with the guarded solver")
+            tracked = False
+        except _PurificationFailed as exc:
+            logger.warning("purification cycle unusable (%s): repeating the SCF with an eigensolver in every cycle", exc)
+            purify = "0"
         if history is not None:
             del history[:]
-        return _huzinaga_scf(*args, allow_tracked=False)
+    return _huzinaga_scf(*args, allow_tracked=False, allow_purify="0")
 
 
 def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_environment_virtual, dm_conv_tol,
-                  dm_initial_guess, use_DIIS, backend, history, callback, allow_tracked):
+                  dm_initial_guess, use_DIIS, backend, history, callback, allow_tracked, allow_purify="0"):
     if not (is_ks(scf_method) or is_hf(scf_method)):
         raise TypeError("Cannot run Huzinaga SCF with type %s" % type(scf_method))
     be = backend if backend is not None else (getattr(scf_method, "be", None) or get_backend())
@@ -181,7 +201,8 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         be.axpby(1.0, hcore_d if hcore_d.dim() == 2 else hcore_d[x], 1.0, hv[x])
         be.axpby(1.0, vemb_d if vemb_d.dim() == 2 else vemb_d[x], 1.0, hv[x])
 
-    warm = {"v": None, "iters": MAX_REFINE_ITERS, "tracked": False, "c": None}
+    warm = {"v": None, "iters": MAX_REFINE_ITERS, "tracked": False, "c": None,
+            "purify": allow_purify == "force", "pur_iters": 0}
     s_b = None  # the overlap once per spin, for the tracked solver
 
     def diagonalise(fock3):
@@ -268,16 +289,27 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         # matrices were all accepted after ONE refinement iteration, queue only one from now on
         # (anything it does not finish falls through to Jacobi on the device); otherwise three
         st = handle.get_extra()
-        if st is not None:
+        purified = len(state) > 7 and state[7]
+        if st is not None and purified:
+            logger.debug("cycle %s purification steps %s", cycle, st.tolist())
+            if np.any(st <= 0):
+                raise _PurificationFailed(f"cycle {cycle}: status {st.tolist()}")
+            warm["pur_iters"] = int(np.max(st)) + 8
+            if float(np.max(sc[2:])) < PURIFY_DM_CHANGE:
+                warm["purify"] = False  # the next cycle queued solves the eigenproblem again (cold: no vectors)
+        elif st is not None:
             logger.debug("cycle %s eigensolver status %s tracked=%s", cycle, st.tolist(), state[6])
             if state[6] and np.any(st <= 0):
                 raise _TrackedEigensolveFailed(f"cycle {cycle}: status {st.tolist()}")
+            if (allow_purify == "1" and not state[6] and np.all(st > 0) and np.all(st < 1000)
+                    and int(np.max(st)) >= PURIFY_MIN_SWEEPS and float(np.max(sc[2:])) > PURIFY_DM_CHANGE):
+                warm["purify"] = True  # warm starts are not helping: densities by purification until they would
             # every matrix accepted by refinement within two iterations: from the next cycle queued
             # on, refine without the guard -- with one iteration in reserve while the density still
             # moves; anything else (re-)arms the guarded solver
             accepted = bool(np.all(st >= 1001))
             needed = int(np.max(st)) - 1000 if accepted else 99
-            warm["tracked"] = bool(allow_tracked and can_track and needed <= 2)
+            warm["tracked"] = bool(allow_tracked and can_track and needed <= 2 and not warm["purify"])
             if warm["tracked"]:
                 warm["iters"] = needed + (1 if float(np.max(sc[2:])) > 1e-8 else 0)
             else:  # guarded: refinement converges quadratically from max|E| < 0.25, so up to six
@@ -313,6 +345,7 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
                 callback(i)
             out = hstate.sets[i % 3]
             tracked_now = bool(warm["tracked"] and warm["c"] is not None)
+            purify_now = bool(warm["purify"] and not tracked_now and allow_purify != "0")
             diis_mode = diis_slot = diis_nd = 0
             if use_DIIS and i > 1:  # pyscf.lib.diis bookkeeping (scf/diis.py): first update only remembers F
                 if diis_state["first"]:
@@ -331,14 +364,19 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
                 c_in = warm["v"]
                 if c_in is not None and c_in is out["v"]:  # stale vectors kept in the set about to be written
                     c_in = warm["v"] = be.copy(c_in)
-            pending_now = be.huz_cycle(hstate, dm_d, c_in, out, tracked_now, warm["iters"], diis_mode, diis_slot,
-                                       diis_nd, dts_ready)
+            if purify_now:  # density by purification: this cycle has no orbitals, the next eigensolve starts cold
+                pending_now = be.huz_cycle(hstate, dm_d, None, out, 2, warm["pur_iters"], diis_mode, diis_slot, diis_nd,
+                                           dts_ready)
+                warm["c"] = warm["v"] = None
+            else:
+                pending_now = be.huz_cycle(hstate, dm_d, c_in, out, tracked_now, warm["iters"], diis_mode, diis_slot,
+                                           diis_nd, dts_ready)
+                warm["c"] = out["c"]
+                if not tracked_now:
+                    warm["v"] = out["v"]
             dts_ready = True
-            warm["c"] = out["c"]
-            if not tracked_now:
-                warm["v"] = out["v"]
             dm_d, hz, c_d, mo_energy_h = out["dm"], out["hz"], out["c"], out["w"]
-            state_now = (i, pending_now, out["c"], out["w"], out["dm"], out["hz"], tracked_now)
+            state_now = (i, pending_now, out["c"], out["w"], out["dm"], out["hz"], tracked_now, purify_now)
             if pending is not None and judge(pending):
                 break
             pending = state_now
@@ -419,7 +457,9 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         if not conv_flag and pending is not None:
             judge(pending)  # the last cycle queued
         if result["state"] is not None:
-            _, _, c_d, mo_energy_d, dm_d, hz, _ = result["state"]
+            if len(result["state"]) > 7 and result["state"][7]:
+                raise _PurificationFailed("the run ended on a cycle without orbitals")
+            _, _, c_d, mo_energy_d, dm_d, hz = result["state"][:6]
             mo_energy_h = be.to_host(mo_energy_d)
 
     if conv_flag is False:

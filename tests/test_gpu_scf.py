@@ -263,3 +263,42 @@ def test_driver_end_to_end_on_device_hf_in_hf_exact(be):
         nq = h1.shape[0]
         assert h1.shape == (nq, nq) and h2.shape == (nq,) * 4 and nq % 2 == 0
         assert np.isfinite(const) and np.all(np.isfinite(h1))
+
+
+@pytest.mark.parametrize("n", [104, 148])
+def test_huzinaga_scf_purified_early_cycles_equal_eigensolver_cycles(be, monkeypatch, n):
+    """Densities of the first cycles from purification (nbx_huz_cycle mode 2: no eigenvectors until the density
+    has settled, then one cold eigensolve, then the refinement) give the run an eigensolver in every cycle gives:
+    same number of cycles, same orbitals, energies and operator to 1e-11."""
+    from nbed_amd.scf import GpuUHF, Mole, huzinaga_scf
+
+    nocc, n_env = ((12, 11), 5) if n == 104 else ((33, 33), 20)
+    pr = synth.problem(n, nocc, n_env)
+    eri = be.synth_eri(n)
+
+    def run(mode):
+        monkeypatch.setenv("NBED_PURIFY", mode)
+        mf = GpuUHF(Mole(n, pr["nelec"]), pr["S"], pr["hcore"], eri, backend=be)
+        mf.max_cycle, mf.conv_tol = 100, 1e-10
+        hist = []
+        calls = []
+        orig = be.huz_cycle
+
+        def spy(h, dm_in, c_in, out, tracked, *a, **k):
+            calls.append(int(tracked))
+            return orig(h, dm_in, c_in, out, tracked, *a, **k)
+
+        monkeypatch.setattr(be, "huz_cycle", spy)
+        out = huzinaga_scf(mf, pr["V_emb"], pr["D_env"], dm_conv_tol=1e-9, history=hist)
+        monkeypatch.setattr(be, "huz_cycle", orig)
+        return out, hist, calls
+
+    (c0, e0, d0, hz0, conv0), h0, calls0 = run("0")
+    (c1, e1, d1, hz1, conv1), h1, calls1 = run("force")
+    assert conv0 and conv1 and 2 not in calls0
+    assert calls1[0] == 2 and calls1.count(2) >= 2 and calls1[-1] != 2  # purified first, orbitals at the end
+    assert len(h0) == len(h1)
+    np.testing.assert_allclose(e1, e0, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(d1, d0, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(hz1, hz0, rtol=0, atol=1e-11)
+    np.testing.assert_allclose([x[0] for x in h1], [x[0] for x in h0], rtol=0, atol=1e-9)  # the same trajectory
