@@ -111,10 +111,12 @@ class _PurificationFailed(Exception):
     whose orbitals do not exist): the run is repeated with an eigensolver in every cycle."""
 
 
-# purification cycles (nbx_huz_cycle mode 2): entered when a guarded cycle needed at least this many Jacobi
-# sweeps while the density still moved by more than PURIFY_DM_CHANGE, left when it moves less
+# purification cycles (nbx_huz_cycle mode 2): from the first cycle on, left once a cycle's density moved by less
+# than PURIFY_DM_CHANGE (judged one cycle late, so the eigensolve that follows sees a change ~10x smaller and
+# the cycles after it are settled by refinement); entered again when a guarded cycle needed at least
+# PURIFY_MIN_SWEEPS Jacobi sweeps while the density still moved by more than that
 PURIFY_MIN_SWEEPS = 6
-PURIFY_DM_CHANGE = 0.03
+PURIFY_DM_CHANGE = 0.2
 
 
 class _TrackedEigensolveFailed(Exception):
@@ -150,8 +152,8 @@ def huzinaga_scf(
             dm_initial_guess, use_DIIS, backend, history, callback)
     tracked = os.environ.get("NBED_TRACKED_EIG", "1") != "0"
     purify = os.environ.get("NBED_PURIFY", "1")
-    # NBED_PURIFY: "1" densities by purification once a guarded cycle shows that warm starts do not help (default);
-    # "0" never; "force" from the first cycle on, until the density settles (tests)
+    # NBED_PURIFY: "1" (default) densities by purification from the first cycle on, until the density has settled
+    # (and again whenever a guarded cycle shows that warm starts do not help); "0" never
     for _ in range(3):
         try:
             return _huzinaga_scf(*args, allow_tracked=tracked, allow_purify=purify)
@@ -202,7 +204,7 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         be.axpby(1.0, vemb_d if vemb_d.dim() == 2 else vemb_d[x], 1.0, hv[x])
 
     warm = {"v": None, "iters": MAX_REFINE_ITERS, "tracked": False, "c": None,
-            "purify": allow_purify == "force", "pur_iters": 0}
+            "purify": allow_purify != "0", "pur_iters": 0}
     s_b = None  # the overlap once per spin, for the tracked solver
 
     def diagonalise(fock3):
@@ -301,7 +303,7 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
             logger.debug("cycle %s eigensolver status %s tracked=%s", cycle, st.tolist(), state[6])
             if state[6] and np.any(st <= 0):
                 raise _TrackedEigensolveFailed(f"cycle {cycle}: status {st.tolist()}")
-            if (allow_purify == "1" and not state[6] and np.all(st > 0) and np.all(st < 1000)
+            if (allow_purify != "0" and not state[6] and np.all(st > 0) and np.all(st < 1000)
                     and int(np.max(st)) >= PURIFY_MIN_SWEEPS and float(np.max(sc[2:])) > PURIFY_DM_CHANGE):
                 warm["purify"] = True  # warm starts are not helping: densities by purification until they would
             # every matrix accepted by refinement within two iterations: from the next cycle queued
@@ -334,6 +336,8 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
     # Same kernels, order and operands as the step-by-step path below: bit-identical results.
     use_cycle_call = (lookahead and ds_virt is None and dts_d is not None and hasattr(be, "huz_cycle")
                       and os.environ.get("NBED_CYCLE_CALL", "1") != "0")
+    if not use_cycle_call:
+        warm["purify"] = False  # (nbx_huz_cycle mode 2 only: the step-by-step path always solves the eigenproblem)
     if use_cycle_call:
         if s_b is None:
             s_b = be.asarray(np.stack([s_h] * nb))
@@ -364,10 +368,13 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
                 c_in = warm["v"]
                 if c_in is not None and c_in is out["v"]:  # stale vectors kept in the set about to be written
                     c_in = warm["v"] = be.copy(c_in)
-            if purify_now:  # density by purification: this cycle has no orbitals, the next eigensolve starts cold
+            if purify_now:  # density by purification: this cycle has no orbitals; the next eigensolve starts from
+                # the last vectors there were (stale, but a better start for the Jacobi solver than none)
                 pending_now = be.huz_cycle(hstate, dm_d, None, out, 2, warm["pur_iters"], diis_mode, diis_slot, diis_nd,
                                            dts_ready)
-                warm["c"] = warm["v"] = None
+                warm["c"] = None
+                if warm["v"] is not None and any(warm["v"] is st_["v"] for st_ in hstate.sets):
+                    warm["v"] = be.copy(warm["v"])  # (the result sets rotate: keep the vectors out of their way)
             else:
                 pending_now = be.huz_cycle(hstate, dm_d, c_in, out, tracked_now, warm["iters"], diis_mode, diis_slot,
                                            diis_nd, dts_ready)

@@ -134,7 +134,7 @@ def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch, n):
     orig_refine = be.geig_refine
 
     def counting(h, dm_in, c_in, out, tracked, *a, **k):
-        calls["n"] += int(bool(tracked))
+        calls["n"] += int(tracked is True or tracked == 1)  # (2: a purification cycle, no eigensolver at all)
         return orig(h, dm_in, c_in, out, tracked, *a, **k)
 
     def counting_refine(*a, **k):
@@ -156,12 +156,17 @@ def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch, n):
     np.testing.assert_allclose(d1, d0, rtol=0, atol=1e-10)
     np.testing.assert_allclose(hz1, hz0, rtol=0, atol=1e-10)
     # the step-by-step path (one launch per call from Python) gives the same bits as the one-call cycles
+    # (with an eigensolver in every cycle: purification cycles exist in nbx_huz_cycle only)
+    monkeypatch.setenv("NBED_PURIFY", "0")
+    (c2, e2, d2, hz2, conv2), h2 = run()
     monkeypatch.setenv("NBED_CYCLE_CALL", "0")
     (c3, e3, d3, hz3, conv3), h3 = run()
     monkeypatch.setenv("NBED_CYCLE_CALL", "1")
-    assert conv3 and len(h3) == len(h0)
-    np.testing.assert_array_equal(d3, d0)
-    np.testing.assert_array_equal(e3, e0)
+    monkeypatch.delenv("NBED_PURIFY")
+    assert conv2 and conv3 and len(h3) == len(h2)
+    np.testing.assert_array_equal(d3, d2)
+    np.testing.assert_array_equal(e3, e2)
+    np.testing.assert_allclose(d2, d0, rtol=0, atol=1e-10)
     # a tracked cycle that reports failure: the run is repeated with the guarded solver
     monkeypatch.setenv("NBED_TRACKED_EIG", "1")
 
@@ -177,7 +182,7 @@ def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch, n):
 
     def failing(h, dm_in, c_in, out, tracked, *a, **k):
         pend = orig(h, dm_in, c_in, out, tracked, *a, **k)
-        return Rejected(pend) if tracked else pend
+        return Rejected(pend) if (tracked is True or tracked == 1) else pend
 
     def failing_refine(fock, s_b, c0_, refine_iters=1):
         w, c = orig_refine(fock, s_b, c0_, refine_iters=refine_iters)
@@ -294,7 +299,7 @@ def test_huzinaga_scf_purified_early_cycles_equal_eigensolver_cycles(be, monkeyp
         return out, hist, calls
 
     (c0, e0, d0, hz0, conv0), h0, calls0 = run("0")
-    (c1, e1, d1, hz1, conv1), h1, calls1 = run("force")
+    (c1, e1, d1, hz1, conv1), h1, calls1 = run("1")
     assert conv0 and conv1 and 2 not in calls0
     assert calls1[0] == 2 and calls1.count(2) >= 2 and calls1[-1] != 2  # purified first, orbitals at the end
     assert len(h0) == len(h1)
