@@ -197,7 +197,7 @@ def real_molecule_leg(be, args) -> dict:
         "protocol": f"as value: {args.steps} cycles after {args.warmup} warm-up cycles of one huzinaga_scf run, DIIS on, stopping rule off; "
                     "the first cycles of a real molecule defeat the warm-started eigensolvers (levels 4e-4 Ha apart in the "
                     "virtual space, a Fock matrix that still moves), so the first cycles take their density from purification "
-                    "(nbx_purify, no eigenvectors), one Jacobi eigensolve follows when the density has settled (cycle 8 here), "
+                    "(nbx_purify, no eigenvectors), one cold eigensolve follows when the density has settled (cycle 7 here), "
                     "then the refinement runs at the pace of the synthetic workload",
     }
 

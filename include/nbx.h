@@ -290,6 +290,16 @@ size_t nbx_eigh_status_offset(int64_t n, int64_t batch);
  * h_sweeps[b] > 0 = sweeps used (1000 + k: accepted by the warm-start refinement after k
  * iterations, no sweeps); returns NBX_E_NOCONV if any matrix hit the sweep limit.          */
 int nbx_eigh_status(nbx_ctx* ctx, int64_t n, int64_t batch, const void* d_work, int* h_sweeps);
+/* Eigenpairs to inverse-iteration accuracy with nothing read back: Householder reduction, multisection,
+ * inverse iteration, back-transformation and one Newton-Schulz orthonormalisation step, all queued (the cold
+ * route of nbx_eigh without its two host decisions).  A START for nbx_eigh_warm_ex / nbx_huz_cycle mode 0 on
+ * the same or a nearby matrix -- e.g. solved on a second stream beside SCF cycles that do not need orbitals
+ * (nbx_huz_cycle mode 2) -- not a result: d_status[b] = 1 the vectors are orthonormal to ~1e-12 (their
+ * residual is whatever inverse iteration left, typically 1e-10 ||A||); -1 clustered levels left nearly
+ * dependent vectors (or NaN): do not use them.  n <= 2048.                                          */
+size_t nbx_eigh_approx_worksize(int64_t n, int64_t batch);
+int nbx_eigh_approx(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
+                    void* d_work, size_t work_bytes, int* d_status);
 /* out = S^p for symmetric positive definite S (N,N): U diag(w^p) U^T.
  * scipy.linalg.fractional_matrix_power(S, -0.5 / +0.5) at nbed/scf/huzinaga_scf.py:128,
  * nbed/localizers/occupied/spade.py:99; np.linalg.inv(S_AA) at
@@ -419,9 +429,11 @@ int nbx_spinorb_scatter_range(nbx_ctx* ctx, int64_t n, const double* d_two_body,
  *          d_status_out.  mode 0 ("guarded"): X F X, nbx_eigh_warm_ex warm-started from d_c_in = the previous
  *          cycle's orthonormal-basis vectors (NULL: cold), C = X V; d_v_out receives V.
  *          mode 2 ("purified"): no eigenvectors at all -- D = X P X with P the projector on the occupied
- *          levels of X F X from nbx_purify (refine_iters caps its steps, <= 0: the limit); d_c_out, d_v_out
- *          and d_w_out are NOT written, the status words are nbx_purify's.  For the first cycles of a run,
- *          whose Fock matrix moves too much for a warm-started eigensolver.
+ *          levels of X F X from nbx_purify (refine_iters caps its steps, <= 0: the limit); d_c_out and
+ *          d_w_out are NOT written, d_v_out (if given) receives X F X -- the matrix an eigensolver would
+ *          have been given, so that the cycle's orbitals can be had later or beside the next cycles on
+ *          another stream; the status words are nbx_purify's.  For the first cycles of a run, whose
+ *          Fock matrix moves too much for a warm-started eigensolver.
  *   diis_mode 0: no DIIS; 1: pyscf.lib.diis' first update (only remembers F); 2: nbx_diis_update with
  *          (diis_slot, diis_nd) -- the ring bookkeeping stays with the caller.
  *   dts_ready: st->d_dts holds the Dtot' table of d_dm_in (left by the previous call).

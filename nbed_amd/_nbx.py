@@ -112,6 +112,8 @@ SIGNATURES = {
     "nbx_geig_refine": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int]),
     "nbx_eigh_warm_ex": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, c_size_t, c_int]),
     "nbx_eigh_status_offset": (c_size_t, [c_int64, c_int64]),
+    "nbx_eigh_approx_worksize": (c_size_t, [c_int64, c_int64]),
+    "nbx_eigh_approx": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "nbx_eigh_status": (c_int, [_P, c_int64, c_int64, _P, POINTER(c_int)]),
     "nbx_sym_pow_worksize": (c_size_t, [c_int64]),
     "nbx_sym_pow": (c_int, [_P, c_int64, _P, c_double, _P, _P, c_size_t]),

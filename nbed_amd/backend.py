@@ -119,6 +119,31 @@ class HipBackend:
     def synchronize(self):
         self._call("nbx_sync")
 
+    def side(self):
+        """A second context of this device on a stream of its own (``.stream``), for work that runs BESIDE what
+        this backend queues -- e.g. the two-workgroup Jacobi eigensolve of a purified SCF cycle while the next
+        cycles use the other 254 CUs.  Order the two with events: ``fork_to(side)`` / ``join_from(side)``."""
+        if getattr(self, "_side", None) is None:
+            torch = self.torch
+            stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(stream):
+                other = type(self)(self.device_index)
+            other.stream = stream
+            self._side = other
+        return self._side
+
+    def fork_to(self, other):
+        """Everything queued here so far happens before what ``other`` (a ``side()`` backend) queues next."""
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device_index))
+        other.stream.wait_event(ev)
+
+    def join_from(self, other):
+        """Everything ``other`` has queued so far happens before what this backend queues next."""
+        ev = self.torch.cuda.Event()
+        ev.record(other.stream)
+        self.torch.cuda.current_stream(self.device_index).wait_event(ev)
+
     def empty(self, *shape):
         return self.torch.empty(*shape, dtype=self.torch.float64, device=self.device)
 
@@ -669,6 +694,20 @@ class HipBackend:
             self._call("nbx_eigh_status", n, batch, self._p(work), sweeps)
             self.last_eigh_sweeps = list(sweeps)
         return w, v
+
+    def eigh_approx(self, a):
+        """Approximate eigenpairs of symmetric ``a`` with nothing read back (nbx_eigh_approx): ``(w, v, status)``
+        device tensors, status[b] = 1 usable as warm-start vectors, -1 not.  Safe to queue on a ``side()`` stream."""
+        torch = self.torch
+        a3 = a if a.dim() == 3 else a.reshape(1, *a.shape)
+        batch, n = int(a3.shape[0]), int(a3.shape[-1])
+        nbytes = int(self.lib.nbx_eigh_approx_worksize(n, batch))
+        work = self._workspace("eigh_approx", nbytes)
+        w = self.empty(a.shape[:-1])
+        v = torch.empty_like(a)
+        status = torch.empty(batch, dtype=torch.int32, device=self.device)
+        self._call("nbx_eigh_approx", n, batch, self._p(a), self._p(w), self._p(v), self._p(work), nbytes, self._p(status))
+        return w, v, status
 
     def geig_refine(self, fock, ovlp_b, c0, refine_iters: int = 1):
         """Eigenpairs of the pencil (fock[b], S) refined from the previous cycle's S-orthonormal

@@ -419,7 +419,8 @@ __global__ void ns_factor_kernel(double* __restrict__ G, int N, int64_t total) {
     G[idx] = (i == j ? 1.5 : 0.0) - 0.5 * G[idx];
 }
 
-// max_{i != j} |G_ij| and max_i |G_ii - 1| -> out[b*2 + {0,1}]
+// max_{i != j} |G_ij| and max_i |G_ii - 1| -> out[b*2 + {0,1}]; a NaN anywhere in G comes out as NaN
+__device__ __forceinline__ double td_nanmax(double a, double b) { return (a != a || b != b) ? a + b : fmax(a, b); }
 __global__ __launch_bounds__(256) void gram_defect_kernel(const double* __restrict__ G, int N, double* __restrict__ out) {
     __shared__ double red_o[4], red_d[4];
     const int b = blockIdx.x;
@@ -427,13 +428,13 @@ __global__ __launch_bounds__(256) void gram_defect_kernel(const double* __restri
     double mo = 0.0, md = 0.0;
     for (int64_t idx = threadIdx.x; idx < (int64_t)N * N; idx += 256) {
         const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
-        if (i == j) md = fmax(md, fabs(r[idx] - 1.0));
-        else mo = fmax(mo, fabs(r[idx]));
+        if (i == j) md = td_nanmax(md, fabs(r[idx] - 1.0));
+        else mo = td_nanmax(mo, fabs(r[idx]));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        mo = fmax(mo, __shfl_xor(mo, off, 64));
-        md = fmax(md, __shfl_xor(md, off, 64));
+        mo = td_nanmax(mo, __shfl_xor(mo, off, 64));
+        md = td_nanmax(md, __shfl_xor(md, off, 64));
     }
     if ((threadIdx.x & 63) == 0) {
         red_o[threadIdx.x >> 6] = mo;
@@ -441,8 +442,8 @@ __global__ __launch_bounds__(256) void gram_defect_kernel(const double* __restri
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[2 * b] = fmax(fmax(red_o[0], red_o[1]), fmax(red_o[2], red_o[3]));
-        out[2 * b + 1] = fmax(fmax(red_d[0], red_d[1]), fmax(red_d[2], red_d[3]));
+        out[2 * b] = td_nanmax(td_nanmax(red_o[0], red_o[1]), td_nanmax(red_o[2], red_o[3]));
+        out[2 * b + 1] = td_nanmax(td_nanmax(red_d[0], red_d[1]), td_nanmax(red_d[2], red_d[3]));
     }
 }
 
@@ -498,30 +499,19 @@ TdLayout layout(int64_t n, int64_t batch) {
 
 size_t nbx_eigh_tridiag_worksize(int64_t n, int64_t batch) { return layout(n, batch).total; }
 
-// Approximate eigenpairs by the tridiagonal route: d_w (batch,N) ascending, d_v (batch,N,N) with
-// orthonormal columns.  h_quality[b] = max off-diagonal of V^T A V divided by max |diagonal|.
-int nbx_eigh_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
-                     void* d_work, size_t work_bytes, double* h_quality) {
-    const TdLayout L = layout(n, batch);
-    if (d_work == nullptr || work_bytes < L.total) {
-        nbx_set_error("nbx_eigh(tridiagonal): workspace %zu < %zu bytes", work_bytes, L.total);
-        return NBX_E_NOMEM;
-    }
-    if (n > TD_MAXSEG * TD_THREADS) {
-        nbx_set_error("nbx_eigh(tridiagonal): N=%lld > %d unsupported", (long long)n, TD_MAXSEG * TD_THREADS);
-        return NBX_E_UNSUPPORTED;
-    }
-    char* base = static_cast<char*>(d_work);
+// Householder reduction, eigenvalues, inverse iteration, back-transformation, and the Gram matrix W = Z^T Z of
+// the vectors with its defect (max |off-diagonal|, max |diagonal - 1| per matrix) in ctx->d_scratch: everything
+// of the tridiagonal route that needs no decision.
+static int td_pipeline(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, const TdLayout& L,
+                       char* base) {
     double* W = reinterpret_cast<double*>(base + L.w_off);
     double* d = reinterpret_cast<double*>(base + L.d_off);
     double* e = reinterpret_cast<double*>(base + L.e_off);
     double* tau = reinterpret_cast<double*>(base + L.tau_off);
     double* Vh = reinterpret_cast<double*>(base + L.vh_off);
     double* Z = reinterpret_cast<double*>(base + L.z_off);
-    double* Zt = reinterpret_cast<double*>(base + L.zt_off);
     double* scr = reinterpret_cast<double*>(base + L.scr_off);
     const int N = (int)n;
-    nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
     hipLaunchKernelGGL(tridiag_kernel, dim3((unsigned)batch), dim3(TD_THREADS),
                        (size_t)(3 * N + TD_THREADS + 20) * sizeof(double), ctx->stream, d_a, N, W, d, e, tau, Vh);
     NBX_LAUNCH_CHECK();
@@ -534,21 +524,86 @@ int nbx_eigh_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, 
     hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)nbx_cdiv(N, BT_COLS), (unsigned)batch), dim3(BT_THREADS),
                        (size_t)(N + BT_GROUPS * BT_COLS) * sizeof(double), ctx->stream, Vh, tau, N, Z);
     NBX_LAUNCH_CHECK();
-    // Orthonormalise the columns of Z.  Inverse-iteration vectors of well separated eigenvalues
-    // are orthogonal to ~1e-10 already: one Newton-Schulz step V <- V (3I - V^T V)/2 on the MFMA
-    // GEMM squares that defect.  Only when clusters left nearly dependent vectors (defect > 1e-6)
-    // does the sequential Gram-Schmidt kernel run.
     int rc = nbx_gemm(ctx, 'T', 'N', n, n, n, 1.0, Z, n, n * n, Z, n, n * n, 0.0, W, n, n * n, batch);
     if (rc != NBX_OK) return rc;
     NBX_CHECK_ARG(2 * batch <= NBX_SCRATCH_DOUBLES);
     hipLaunchKernelGGL(gram_defect_kernel, dim3((unsigned)batch), dim3(256), 0, ctx->stream, W, N, ctx->d_scratch);
     NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+static int td_check(int64_t n, int64_t batch, const void* d_work, size_t work_bytes, const TdLayout& L) {
+    if (d_work == nullptr || work_bytes < L.total) {
+        nbx_set_error("nbx_eigh(tridiagonal): workspace %zu < %zu bytes", work_bytes, L.total);
+        return NBX_E_NOMEM;
+    }
+    if (n > TD_MAXSEG * TD_THREADS) {
+        nbx_set_error("nbx_eigh(tridiagonal): N=%lld > %d unsupported", (long long)n, TD_MAXSEG * TD_THREADS);
+        return NBX_E_UNSUPPORTED;
+    }
+    (void)batch;
+    return NBX_OK;
+}
+
+__global__ void approx_status_kernel(const double* __restrict__ defect, int batch, int* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) status[b] = (defect[2 * b] <= 1.0e-6 && defect[2 * b + 1] <= 1.0e-6) ? 1 : -1;  // NaN: -1
+}
+
+// include/nbx.h: eigenpairs to inverse-iteration accuracy with NOTHING read back -- a start for a warm solver
+extern "C" size_t nbx_eigh_approx_worksize(int64_t n, int64_t batch) {
+    return (n <= 0 || batch <= 0) ? 0 : layout(n, batch).total;
+}
+
+extern "C" int nbx_eigh_approx(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
+                               void* d_work, size_t work_bytes, int* d_status) {
+    NBX_CHECK_ARG(ctx && d_a && d_w && d_v && d_status && n > 0 && batch > 0 && batch <= 1024);
+    const TdLayout L = layout(n, batch);
+    int rc = td_check(n, batch, d_work, work_bytes, L);
+    if (rc != NBX_OK) return rc;
+    NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
+    char* base = static_cast<char*>(d_work);
+    double* W = reinterpret_cast<double*>(base + L.w_off);
+    double* Z = reinterpret_cast<double*>(base + L.z_off);
+    nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
+    rc = td_pipeline(ctx, n, batch, d_a, d_w, L, base);
+    if (rc != NBX_OK) return rc;
+    hipLaunchKernelGGL(approx_status_kernel, dim3((unsigned)nbx_cdiv(batch, 64)), dim3(64), 0, ctx->stream,
+                       ctx->d_scratch, (int)batch, d_status);
+    NBX_LAUNCH_CHECK();
+    // one Newton-Schulz step V = Z (3I - Z^T Z)/2: squares a defect below 1e-6 (status 1); vectors that
+    // clusters left nearly dependent stay so, and status says it (-1)
+    const int64_t total = batch * n * n;
+    hipLaunchKernelGGL(ns_factor_kernel, dim3((unsigned)nbx_cdiv(total, 256)), dim3(256), 0, ctx->stream, W, (int)n, total);
+    NBX_LAUNCH_CHECK();
+    return nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, Z, n, n * n, W, n, n * n, 0.0, d_v, n, n * n, batch);
+}
+
+// Approximate eigenpairs by the tridiagonal route: d_w (batch,N) ascending, d_v (batch,N,N) with
+// orthonormal columns.  h_quality[b] = max off-diagonal of V^T A V divided by max |diagonal|.
+int nbx_eigh_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
+                     void* d_work, size_t work_bytes, double* h_quality) {
+    const TdLayout L = layout(n, batch);
+    int rc = td_check(n, batch, d_work, work_bytes, L);
+    if (rc != NBX_OK) return rc;
+    char* base = static_cast<char*>(d_work);
+    double* W = reinterpret_cast<double*>(base + L.w_off);
+    double* Z = reinterpret_cast<double*>(base + L.z_off);
+    double* Zt = reinterpret_cast<double*>(base + L.zt_off);
+    const int N = (int)n;
+    nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
+    // Orthonormalise the columns of Z.  Inverse-iteration vectors of well separated eigenvalues
+    // are orthogonal to ~1e-10 already: one Newton-Schulz step V <- V (3I - V^T V)/2 on the MFMA
+    // GEMM squares that defect.  Only when clusters left nearly dependent vectors (defect > 1e-6)
+    // does the sequential Gram-Schmidt kernel run.
+    rc = td_pipeline(ctx, n, batch, d_a, d_w, L, base);
+    if (rc != NBX_OK) return rc;
     NBX_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch, (size_t)(2 * batch) * sizeof(double), hipMemcpyDeviceToHost,
                            ctx->stream));
     NBX_HIP(hipStreamSynchronize(ctx->stream));
-    double defect = 0.0;
-    for (int64_t bb = 0; bb < 2 * batch; ++bb) defect = ctx->h_pinned[bb] > defect ? ctx->h_pinned[bb] : defect;
-    if (defect <= 1.0e-6) {
+    bool nearly_orthonormal = true;
+    for (int64_t bb = 0; bb < 2 * batch; ++bb) nearly_orthonormal = nearly_orthonormal && (ctx->h_pinned[bb] <= 1.0e-6);
+    if (nearly_orthonormal) {
         const int64_t total = batch * n * n;
         hipLaunchKernelGGL(ns_factor_kernel, dim3((unsigned)nbx_cdiv(total, 256)), dim3(256), 0, ctx->stream, W, N, total);
         NBX_LAUNCH_CHECK();

@@ -49,14 +49,17 @@ extern "C" int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double
     if (mode == 2) {
         // density without eigenvectors: the projector on the nocc lowest levels of X F X by purification
         // (purify.hip), D = X P X.  For cycles whose Fock matrix still moves too much for a warm start to help;
-        // d_c_out / d_w_out are NOT written (the caller must not use this cycle's orbitals).
+        // d_c_out / d_w_out are NOT written (this cycle has no orbitals).
         NBX_CHECK_ARG(st->d_x && st->d_eig_work && st->d_tmp && st->d_fo && d_status_out);
         NBX_CHECK_ARG(st->eig_work_bytes >= nbx_purify_worksize(N, 2));
+        // d_v_out given: X F X is left there (an eigensolve of this cycle's matrix can then be run later, or
+        // beside the following cycles on another stream: the orbitals of a purified cycle on demand)
+        double* fo = d_v_out ? d_v_out : st->d_fo;
         rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_x, N, 0, f_use, N, n2, 0.0, st->d_tmp, N, n2, 2);
         if (rc != NBX_OK) return rc;
-        rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_tmp, N, n2, st->d_x, N, 0, 0.0, st->d_fo, N, n2, 2);
+        rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_tmp, N, n2, st->d_x, N, 0, 0.0, fo, N, n2, 2);
         if (rc != NBX_OK) return rc;
-        rc = nbx_purify(ctx, N, 2, st->d_fo, st->nocc_a, st->nocc_b, st->d_tmp, st->d_eig_work, st->eig_work_bytes,
+        rc = nbx_purify(ctx, N, 2, fo, st->nocc_a, st->nocc_b, st->d_tmp, st->d_eig_work, st->eig_work_bytes,
                         refine_iters, d_status_out);
         if (rc != NBX_OK) return rc;
         rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_x, N, 0, st->d_tmp, N, n2, 0.0, st->d_fo, N, n2, 2);

@@ -107,14 +107,14 @@ MAX_REFINE_ITERS = 6  # the library's limit (nbx_eigh_warm_ex / nbx_geig_refine)
 
 
 class _PurificationFailed(Exception):
-    """A cycle whose density came from purification did not resolve a gap (or the run ended on such a cycle,
-    whose orbitals do not exist): the run is repeated with an eigensolver in every cycle."""
+    """A density taken from purification (initial guess or cycle) did not resolve a gap: the run is repeated
+    with an eigensolver in every cycle."""
 
 
-# purification cycles (nbx_huz_cycle mode 2): from the first cycle on, left once a cycle's density moved by less
-# than PURIFY_DM_CHANGE (judged one cycle late, so the eigensolve that follows sees a change ~10x smaller and
-# the cycles after it are settled by refinement); entered again when a guarded cycle needed at least
-# PURIFY_MIN_SWEEPS Jacobi sweeps while the density still moved by more than that
+# purification (nbx_purify; nbx_huz_cycle mode 2): the density of the initial guess and of the cycles up to the
+# first one whose density moved by less than PURIFY_DM_CHANGE (judged one cycle late, so the cold eigensolve that
+# follows sees a change ~10x smaller and the cycles after it are settled by refinement); entered again when a
+# guarded cycle needed at least PURIFY_MIN_SWEEPS Jacobi sweeps while the density still moved by more than that
 PURIFY_MIN_SWEEPS = 6
 PURIFY_DM_CHANGE = 0.2
 
@@ -261,19 +261,35 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
     def unbatch(a_h):
         return a_h[0] if restricted else a_h
 
-    # ---- initial guess from the projected core Hamiltonian (:139-148)
-    if dm_initial_guess is None:
-        fock = be.copy(hv)
-        _huzinaga_device(be, fock, ds_occ, ds_virt, kappa, fock_io=fock)
-        e_d, c_d = diagonalise(fock)
-        _, occ_h = occupations(e_d, c_d)
-        dm_d = density(c_d, occ_h)
-    else:
-        dm_d = _as3(be, dm_initial_guess)
-
     dts_d, dts_ready = None, False
     if lookahead and hasattr(scf_method, "dts_device") and scf_method.fused_fock_available(hv):
         dts_d = scf_method.dts_device()
+    # One C call per cycle (nbx_huz_cycle) instead of 12-40 marshalled launches: the first cycles of an
+    # SCF are host bound otherwise (the GPU idles 100-300 us per cycle until the eigensolver settles).
+    # Same kernels, order and operands as the step-by-step path below: bit-identical results.
+    use_cycle_call = (lookahead and ds_virt is None and dts_d is not None and hasattr(be, "huz_cycle")
+                      and os.environ.get("NBED_CYCLE_CALL", "1") != "0")
+    if not use_cycle_call:
+        warm["purify"] = False  # (nbx_huz_cycle mode 2 only: the step-by-step path always solves the eigenproblem)
+
+    # ---- initial guess from the projected core Hamiltonian (:139-148)
+    guess_status = None
+    if dm_initial_guess is None:
+        fock = be.copy(hv)
+        _huzinaga_device(be, fock, ds_occ, ds_virt, kappa, fock_io=fock)
+        if warm["purify"]:
+            # only the density of the guess is used (:148): the projector on its occupied levels by purification
+            # (0.4 ms) instead of a cold Jacobi eigensolve (3 ms at N = 148); verdict read with cycle 0's
+            p_d, pst = be.purify(be.gemm(be.gemm(x_d, fock), x_d), scf_method.mol.nelec)
+            dm_d = be.gemm(be.gemm(x_d, p_d), x_d)
+            guess_status = be.async_to_host(pst)
+        else:
+            e_d, c_d = diagonalise(fock)
+            _, occ_h = occupations(e_d, c_d)
+            dm_d = density(c_d, occ_h)
+    else:
+        dm_d = _as3(be, dm_initial_guess)
+
     conv_flag = False
     scf_energy_prev = 0
     mo_energy_h = None
@@ -285,8 +301,13 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
     def judge(state):
         """Convergence test of a queued cycle (:186-194); records it as the current result."""
         nonlocal conv_flag, scf_energy_prev
+        nonlocal guess_status
         cycle, handle = state[0], state[1]
         sc = handle.get()
+        if guess_status is not None:
+            gst, guess_status = guess_status.get(), None
+            if np.any(gst <= 0):
+                raise _PurificationFailed(f"initial guess: status {gst.tolist()}")
         # launch-count policy for the eigensolver (results do not depend on it): once a cycle's
         # matrices were all accepted after ONE refinement iteration, queue only one from now on
         # (anything it does not finish falls through to Jacobi on the device); otherwise three
@@ -298,7 +319,7 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
                 raise _PurificationFailed(f"cycle {cycle}: status {st.tolist()}")
             warm["pur_iters"] = int(np.max(st)) + 8
             if float(np.max(sc[2:])) < PURIFY_DM_CHANGE:
-                warm["purify"] = False  # the next cycle queued solves the eigenproblem again (cold: no vectors)
+                warm["purify"] = False  # the next cycle queued solves the eigenproblem (cold: there are no vectors)
         elif st is not None:
             logger.debug("cycle %s eigensolver status %s tracked=%s", cycle, st.tolist(), state[6])
             if state[6] and np.any(st <= 0):
@@ -331,13 +352,6 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         scf_energy_prev = scf_energy
         return False
 
-    # One C call per cycle (nbx_huz_cycle) instead of 12-40 marshalled launches: the first cycles of an
-    # SCF are host bound otherwise (the GPU idles 100-300 us per cycle until the eigensolver settles).
-    # Same kernels, order and operands as the step-by-step path below: bit-identical results.
-    use_cycle_call = (lookahead and ds_virt is None and dts_d is not None and hasattr(be, "huz_cycle")
-                      and os.environ.get("NBED_CYCLE_CALL", "1") != "0")
-    if not use_cycle_call:
-        warm["purify"] = False  # (nbx_huz_cycle mode 2 only: the step-by-step path always solves the eigenproblem)
     if use_cycle_call:
         if s_b is None:
             s_b = be.asarray(np.stack([s_h] * nb))
@@ -362,20 +376,12 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
                     diis_state["head"] += 1
                     diis_state["nd"] = min(diis_state["nd"] + 1, diis_state["space"])
                     diis_mode, diis_nd = 2, diis_state["nd"]
-            if tracked_now:
-                c_in = warm["c"]
-            else:
-                c_in = warm["v"]
-                if c_in is not None and c_in is out["v"]:  # stale vectors kept in the set about to be written
-                    c_in = warm["v"] = be.copy(c_in)
-            if purify_now:  # density by purification: this cycle has no orbitals; the next eigensolve starts from
-                # the last vectors there were (stale, but a better start for the Jacobi solver than none)
+            if purify_now:  # density by purification: this cycle has no orbitals, X F X is left in out["v"]
                 pending_now = be.huz_cycle(hstate, dm_d, None, out, 2, warm["pur_iters"], diis_mode, diis_slot, diis_nd,
                                            dts_ready)
-                warm["c"] = None
-                if warm["v"] is not None and any(warm["v"] is st_["v"] for st_ in hstate.sets):
-                    warm["v"] = be.copy(warm["v"])  # (the result sets rotate: keep the vectors out of their way)
+                warm["c"] = warm["v"] = None
             else:
+                c_in = warm["c"] if tracked_now else warm["v"]
                 pending_now = be.huz_cycle(hstate, dm_d, c_in, out, tracked_now, warm["iters"], diis_mode, diis_slot,
                                            diis_nd, dts_ready)
                 warm["c"] = out["c"]
@@ -383,7 +389,7 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
                     warm["v"] = out["v"]
             dts_ready = True
             dm_d, hz, c_d, mo_energy_h = out["dm"], out["hz"], out["c"], out["w"]
-            state_now = (i, pending_now, out["c"], out["w"], out["dm"], out["hz"], tracked_now, purify_now)
+            state_now = (i, pending_now, out["c"], out["w"], out["dm"], out["hz"], tracked_now, purify_now, out["v"])
             if pending is not None and judge(pending):
                 break
             pending = state_now
@@ -464,9 +470,11 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         if not conv_flag and pending is not None:
             judge(pending)  # the last cycle queued
         if result["state"] is not None:
-            if len(result["state"]) > 7 and result["state"][7]:
-                raise _PurificationFailed("the run ended on a cycle without orbitals")
             _, _, c_d, mo_energy_d, dm_d, hz = result["state"][:6]
+            if len(result["state"]) > 7 and result["state"][7]:
+                # the run ended on a purified cycle: its orbitals now, from the X F X it left behind (:166-169)
+                mo_energy_d, v_d = be.eigh(result["state"][8])
+                c_d = be.gemm(x_d, v_d)
             mo_energy_h = be.to_host(mo_energy_d)
 
     if conv_flag is False:

@@ -1035,3 +1035,63 @@ def test_purify_reports_a_missing_gap(be):
     f = (q * lam) @ q.T
     _, st = be.purify(be.asarray(np.stack([0.5 * (f + f.T)] * 2)), (k, k))
     assert np.all(st.cpu().numpy() < 0)
+
+
+@pytest.mark.parametrize("n", [37, 104, 148, 260])
+def test_eigh_approx_seeds_the_warm_solver_from_another_stream(be, n):
+    """nbx_eigh_approx (the tridiagonal route with nothing read back) on a side stream: eigenvalues as numpy's,
+    vectors orthonormal with small residuals, and nbx_eigh_warm_ex started from them gives nbx_eigh's result."""
+    import torch
+
+    rng = np.random.default_rng(n)
+    mats = []
+    for x in range(2):
+        q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+        lam = np.sort(rng.uniform(-11, 4, size=n))
+        f = (q * lam) @ q.T
+        mats.append(0.5 * (f + f.T))
+    a_h = np.stack(mats)
+    a = be.asarray(a_h)
+    side = be.side()
+    assert side is be.side() and side.ctx.value != be.ctx.value
+    be.fork_to(side)
+    with torch.cuda.stream(side.stream):
+        w, v, st = side.eigh_approx(a)
+        st_h = side.async_to_host(st)
+    assert np.all(st_h.get() == 1)
+    be.join_from(side)
+    w_h, v_h = be.to_host(w), be.to_host(v)
+    for x in range(2):
+        np.testing.assert_allclose(w_h[x], np.linalg.eigvalsh(a_h[x]), rtol=0, atol=1e-11)
+        np.testing.assert_allclose(v_h[x].T @ v_h[x], np.eye(n), rtol=0, atol=1e-11)
+        assert np.abs(a_h[x] @ v_h[x] - v_h[x] * w_h[x]).max() < 1e-7
+    w_cold, v_cold = be.eigh(a)
+    w_warm, v_warm = be.eigh(a, v0=v, refine_iters=6)
+    np.testing.assert_allclose(be.to_host(w_warm), be.to_host(w_cold), rtol=0, atol=1e-12)
+    vw = be.to_host(v_warm)
+    for x in range(2):
+        assert np.abs(a_h[x] @ vw[x] - vw[x] * be.to_host(w_warm)[x]).max() < 1e-11
+    # same bits again (the SCF loop relies on the side solve being reproducible)
+    with torch.cuda.stream(side.stream):
+        w2, v2, _ = side.eigh_approx(a)
+    be.join_from(side)
+    np.testing.assert_array_equal(be.to_host(v2), v_h)
+
+
+def test_eigh_approx_flags_vectors_it_could_not_separate(be):
+    """A spectrum with an exactly degenerate cluster: inverse iteration cannot separate it, status -1 (or, if the
+    vectors happen to come out independent, they are orthonormal): never a silent non-orthonormal start."""
+    n = 96
+    rng = np.random.default_rng(5)
+    q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    lam = np.sort(rng.uniform(-3, 3, size=n))
+    lam[40:52] = lam[40]
+    f = (q * lam) @ q.T
+    a = be.asarray(np.stack([0.5 * (f + f.T)] * 2))
+    w, v, st = be.eigh_approx(a)
+    st, v_h = st.cpu().numpy(), be.to_host(v)
+    for x in range(2):
+        if st[x] > 0:
+            np.testing.assert_allclose(v_h[x].T @ v_h[x], np.eye(n), rtol=0, atol=1e-10)
+        else:
+            assert st[x] == -1
