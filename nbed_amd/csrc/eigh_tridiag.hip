@@ -168,6 +168,200 @@ __global__ __launch_bounds__(TD_THREADS) void tridiag_kernel(const double* __res
     }
 }
 
+// ---------------------------------------------------------------- K1 for N <= 198: the matrix in registers
+// The same reduction with the whole (full, symmetric) matrix held in the registers of one 512-thread workgroup
+// (eight waves: 256 registers each and a cheap barrier).  Thread (gr, gc) of a GR x GC grid keeps the TR x TC
+// elements A[gr + r GR][gc + s GC] -- interleaved in both directions, so the shrinking trailing block stays
+// spread over all threads, and 2-D, so that a step reads TR + TC LDS values per TR TC elements, not 2 per element.
+// A step touches no memory but LDS vectors and is arranged for THREE barriers (tridiag_kernel: twelve, and two
+// passes over the trailing block in L2 -- 7.4 us per step at N = 148):
+//   1  row k (= column k: the raw reflector x) and row k+1 go to LDS from the registers that hold them
+//   2  partial sums of q = A22 x over each thread's rows, and of |x|^2, to LDS.  With v = (x - beta e1)/(alpha -
+//      beta) the product A22 v = (q - beta A22[:,1]) / (alpha - beta) needs no second pass once beta is known
+//   3  everyone adds up |x|^2 -> beta, tau; the first N threads finish p = tau A22 v, publish v, p and the partial
+//      sums of p^T v;  then every thread forms w = p - (tau/2)(p^T v) v for its rows and columns and updates its
+//      registers:  A22 -= v w^T + w v^T.
+// GR, GC, TR, TC are compile-time: the LDS address of "my row r" is one register plus an immediate (with run-time
+// strides the compiler keeps an address register per row and per vector alive across the k loop and spills).
+// Sums run in a fixed order: bit-reproducible.  Outputs as tridiag_kernel (d, e, tau, Vh); W is not written.
+constexpr int TDR_THREADS = 512;
+constexpr int TDR_LD = 224;  // length of the LDS vectors (>= GR TR, GC TC of every instance)
+
+template <int TR, int TC, int GR, int GC>
+__global__ __launch_bounds__(TDR_THREADS) void tridiag_reg_kernel(const double* __restrict__ a_in, int N,
+                                                                 double* __restrict__ db, double* __restrict__ eb,
+                                                                 double* __restrict__ taub, double* __restrict__ Vhb) {
+    static_assert(GR * GC <= TDR_THREADS && GR * TR <= TDR_LD && GC * TC <= TDR_LD, "instance geometry");
+    __shared__ __attribute__((aligned(16))) double xs[TDR_LD];         // raw reflector: row k (index = column)
+    __shared__ __attribute__((aligned(16))) double a1[TDR_LD];         // row k+1 (= column k+1 of the trailing block)
+    __shared__ __attribute__((aligned(16))) double vs[TDR_LD];         // v
+    __shared__ __attribute__((aligned(16))) double ps[TDR_LD];         // p
+    __shared__ __attribute__((aligned(16))) double part[GR * TDR_LD];  // partial q per row group
+    __shared__ double ssp[TDR_THREADS / 64], dotp[TDR_THREADS / 64];   // per-wave |x|^2, p^T v
+    const int b = blockIdx.x;
+    const int64_t n2 = (int64_t)N * N;
+    a_in += b * n2;
+    double* d = db + (int64_t)b * N;
+    double* e = eb + (int64_t)b * N;
+    double* tau = taub + (int64_t)b * N;
+    double* Vh = Vhb + b * n2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gr = tid / GC, gc = tid - gr * GC;
+    const bool active = gr < GR;
+
+    double a[TR][TC];
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+        for (int sc = 0; sc < TC; ++sc) {
+            const int i = gr + r * GR, c = gc + sc * GC;
+            a[r][sc] = (active && i < N && c < N) ? ((i >= c) ? a_in[(int64_t)i * N + c] : a_in[(int64_t)c * N + i])
+                                                   : 0.0;  // UPLO = 'L'
+        }
+
+    for (int k = 0; k < N - 1; ++k) {
+        // ---- 1: rows k and k+1 out of the registers
+        {
+            const int g0 = k % GR, r0 = k / GR, g1 = (k + 1) % GR, r1 = (k + 1) / GR;
+            if (active && (gr == g0 || gr == g1)) {
+#pragma unroll
+                for (int sc = 0; sc < TC; ++sc) {
+                    const int c = gc + sc * GC;
+                    double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+                    for (int r = 0; r < TR; ++r) {
+                        x0 = (r == r0) ? a[r][sc] : x0;
+                        x1 = (r == r1) ? a[r][sc] : x1;
+                    }
+                    if (gr == g0) {
+                        if (c > k && c < N) xs[c] = x0;
+                        if (c == k) d[k] = x0;
+                    }
+                    if (gr == g1 && c > k && c < N) a1[c] = x1;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 2: partial q_c = sum_{i > k, i in my rows} A[i][c] x_i ; |x|^2 without its first element
+        {
+            if (active) {
+                double q[TC];
+#pragma unroll
+                for (int sc = 0; sc < TC; ++sc) q[sc] = 0.0;
+#pragma unroll
+                for (int r = 0; r < TR; ++r) {
+                    const int i = gr + r * GR;
+                    const double xi = (i > k && i < N) ? xs[i] : 0.0;
+#pragma unroll
+                    for (int sc = 0; sc < TC; ++sc) q[sc] = fma(a[r][sc], xi, q[sc]);
+                }
+#pragma unroll
+                for (int sc = 0; sc < TC; ++sc) part[gr * TDR_LD + gc + sc * GC] = q[sc];
+            }
+            double ss = 0.0;
+            if (tid < N && tid > k + 1) ss = xs[tid] * xs[tid];
+            ss = nbx_wave_sum(ss);
+            if (lane == 0) ssp[wave] = ss;
+        }
+        __syncthreads();
+        // ---- 3: beta, tau; p, v, p^T v
+        double ss = 0.0;
+#pragma unroll
+        for (int w = 0; w < TDR_THREADS / 64; ++w) ss += ssp[w];
+        const double alpha = xs[k + 1];
+        double beta, tk, scale;
+        if (ss == 0.0) {
+            beta = alpha;
+            tk = 0.0;
+            scale = 0.0;
+        } else {
+            beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
+            tk = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        {
+            double pv = 0.0;
+            if (tid < N && tid > k) {
+                double q = 0.0;
+#pragma unroll
+                for (int gg = 0; gg < GR; ++gg) q += part[gg * TDR_LD + tid];
+                const double vc = (tid == k + 1) ? 1.0 : xs[tid] * scale;
+                const double pc = tk * scale * fma(-beta, a1[tid], q);
+                vs[tid] = vc;
+                ps[tid] = pc;
+                Vh[(int64_t)k * N + (tid - k - 1)] = vc;
+                pv = pc * vc;
+            }
+            pv = nbx_wave_sum(pv);
+            if (lane == 0) dotp[wave] = pv;
+            if (tid == 0) {
+                e[k] = beta;
+                tau[k] = tk;
+            }
+        }
+        __syncthreads();
+        if (tk == 0.0) continue;  // uniform: H = I
+        double dot = 0.0;
+#pragma unroll
+        for (int w = 0; w < TDR_THREADS / 64; ++w) dot += dotp[w];
+        const double alpha2 = -0.5 * tk * dot;
+        if (active) {
+            // rows and columns at or before k get v = w = 0: their elements (already final) stay as they are
+            double vcol[TC], wcol[TC];
+#pragma unroll
+            for (int sc = 0; sc < TC; ++sc) {
+                const int c = gc + sc * GC;
+                const bool in = c > k && c < N;
+                vcol[sc] = in ? vs[c] : 0.0;
+                wcol[sc] = in ? fma(alpha2, vcol[sc], ps[c]) : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                const int i = gr + r * GR;
+                const bool in = i > k && i < N;
+                const double vi = in ? vs[i] : 0.0;
+                const double wi = in ? fma(alpha2, vi, ps[i]) : 0.0;
+#pragma unroll
+                for (int sc = 0; sc < TC; ++sc) a[r][sc] -= fma(vi, wcol[sc], wi * vcol[sc]);
+            }
+        }
+        // (the next step's phase 1 writes xs / a1 only, which nobody reads after barrier 3)
+    }
+    // the last diagonal element
+    {
+        const int g0 = (N - 1) % GR, r0 = (N - 1) / GR;
+        if (active && gr == g0) {
+#pragma unroll
+            for (int sc = 0; sc < TC; ++sc) {
+                double x0 = 0.0;
+#pragma unroll
+                for (int r = 0; r < TR; ++r) x0 = (r == r0) ? a[r][sc] : x0;
+                if (gc + sc * GC == N - 1) {
+                    d[N - 1] = x0;
+                    e[N - 1] = 0.0;
+                    tau[N - 1] = 0.0;
+                }
+            }
+        }
+    }
+}
+
+static bool tridiag_reg_launch(nbx_ctx* ctx, int N, int64_t batch, const double* d_a, double* d, double* e, double* tau,
+                               double* Vh) {
+#define NBX_TDR_GO(TR_, TC_, GR_, GC_)                                                                              \
+    hipLaunchKernelGGL((tridiag_reg_kernel<TR_, TC_, GR_, GC_>), dim3((unsigned)batch), dim3(TDR_THREADS), 0,       \
+                       ctx->stream, d_a, N, d, e, tau, Vh)
+    if (N < 2) return false;
+    if (N <= 64) NBX_TDR_GO(4, 2, 16, 32);
+    else if (N <= 128) NBX_TDR_GO(8, 4, 16, 32);
+    else if (N <= 150) NBX_TDR_GO(8, 6, 19, 25);
+    else if (N <= 176) NBX_TDR_GO(8, 8, 22, 23);
+    else if (N <= 198) NBX_TDR_GO(9, 9, 22, 23);
+    else return false;  // (a 10 x 10 tile spills: slower than the in-memory kernel)
+#undef NBX_TDR_GO
+    return true;
+}
+
 // ---------------------------------------------------------------- K2: eigenvalues of T (Sturm multisection)
 __device__ __forceinline__ int sturm_count(const double* __restrict__ d, const double* __restrict__ e2, int N,
                                            double x, double pivmin) {
@@ -230,34 +424,25 @@ __global__ __launch_bounds__(64) void bisect_kernel(const double* __restrict__ d
 }
 
 // ---------------------------------------------------------------- K3: eigenvectors of T (inverse iteration)
-// one thread per eigenvalue; per-thread work arrays with stride NT (threads) for coalescing
-__global__ __launch_bounds__(256) void invit_kernel(const double* __restrict__ db, const double* __restrict__ eb,
-                                                    const double* __restrict__ wb, int N, double* __restrict__ scratch,
-                                                    double* __restrict__ Zb) {
-    const int b = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    const double* d = db + (int64_t)b * N;
-    const double* e = eb + (int64_t)b * N;
-    const double lam = wb[(int64_t)b * N + j];
-    const int64_t NT = N;  // stride between consecutive rows of one thread's arrays
-    double* base = scratch + (int64_t)b * 6 * N * NT;
-    double* ua = base + j;              // U diagonal
-    double* ub = ua + (int64_t)N * NT;  // U first superdiagonal
-    double* uc = ub + (int64_t)N * NT;  // U second superdiagonal
-    double* lm = uc + (int64_t)N * NT;  // multipliers
-    double* sw = lm + (int64_t)N * NT;  // 1.0 if rows i, i+1 were swapped
-    double* x = sw + (int64_t)N * NT;   // solution / rhs
-
+// One thread per eigenvalue: LU of T - lambda I with partial pivoting, three solves from a hash start vector.  The
+// chain of N dependent steps per sweep is latency bound, so what matters is where the thread's six work arrays
+// live: `row stride NT` elements apart in global memory (invit_kernel: 256 threads per workgroup, any N -- each
+// step then waits for L2), or in LDS (invit_lds_kernel: 16 threads per workgroup, 6 N 16 doubles <= 160 KB, i.e.
+// N <= 208 -- N/16 workgroups on as many CUs, three times faster at N = 148).
+template <typename WorkPtr>
+__device__ __forceinline__ void invit_solve(const double* __restrict__ d, const double* __restrict__ e, double lam, int N,
+                                            int64_t NT, WorkPtr ua, WorkPtr ub, WorkPtr uc, WorkPtr lm, WorkPtr sw,
+                                            WorkPtr x, int j, int b, double* __restrict__ zcol) {
     double tnorm = 0.0;
     for (int i = 0; i < N; ++i)
         tnorm = fmax(tnorm, fabs(d[i]) + (i > 0 ? fabs(e[i - 1]) : 0.0) + (i < N - 1 ? fabs(e[i]) : 0.0));
     const double eps = 2.220446049250313e-16;
     const double pivtol = fmax(eps * tnorm, 1.0e-300);
 
-    // LU with partial pivoting of T - lam I  (LAPACK dlagtf restated)
+    // LU with partial pivoting of T - lam I  (LAPACK dlagtf restated); the pivots are kept as reciprocals
     double ai = d[0] - lam;
     double bi = N > 1 ? e[0] : 0.0;  // super-diagonal entry of the current row
+#pragma unroll 4
     for (int i = 0; i < N - 1; ++i) {
         const double ci = e[i];                        // sub-diagonal entry (row i+1, col i)
         double anext = d[i + 1] - lam;                 // diagonal of row i+1
@@ -265,8 +450,9 @@ __global__ __launch_bounds__(256) void invit_kernel(const double* __restrict__ d
         if (fabs(ai) >= fabs(ci) || fabs(ci) < pivtol) {
             double piv = ai;
             if (fabs(piv) < pivtol) piv = copysign(pivtol, piv == 0.0 ? 1.0 : piv);
-            const double mult = ci / piv;
-            ua[(int64_t)i * NT] = piv;
+            const double rp = 1.0 / piv;
+            const double mult = ci * rp;
+            ua[(int64_t)i * NT] = rp;
             ub[(int64_t)i * NT] = bi;
             uc[(int64_t)i * NT] = 0.0;
             lm[(int64_t)i * NT] = mult;
@@ -274,8 +460,9 @@ __global__ __launch_bounds__(256) void invit_kernel(const double* __restrict__ d
             ai = anext - mult * bi;
             bi = bnext;
         } else {
-            const double mult = ai / ci;
-            ua[(int64_t)i * NT] = ci;
+            const double rp = 1.0 / ci;
+            const double mult = ai * rp;
+            ua[(int64_t)i * NT] = rp;
             ub[(int64_t)i * NT] = anext;
             uc[(int64_t)i * NT] = bnext;
             lm[(int64_t)i * NT] = mult;
@@ -285,7 +472,7 @@ __global__ __launch_bounds__(256) void invit_kernel(const double* __restrict__ d
         }
     }
     if (fabs(ai) < pivtol) ai = copysign(pivtol, ai == 0.0 ? 1.0 : ai);
-    ua[(int64_t)(N - 1) * NT] = ai;
+    ua[(int64_t)(N - 1) * NT] = 1.0 / ai;
     ub[(int64_t)(N - 1) * NT] = 0.0;
     uc[(int64_t)(N - 1) * NT] = 0.0;
 
@@ -294,8 +481,10 @@ __global__ __launch_bounds__(256) void invit_kernel(const double* __restrict__ d
 
     for (int it = 0; it < 3; ++it) {
         // forward: apply the row operations of the factorisation to the right-hand side
+        double yi = x[0];
+#pragma unroll 4
         for (int i = 0; i < N - 1; ++i) {
-            double yi = x[(int64_t)i * NT], yn = x[(int64_t)(i + 1) * NT];
+            double yn = x[(int64_t)(i + 1) * NT];
             if (sw[(int64_t)i * NT] != 0.0) {
                 const double t = yi;
                 yi = yn;
@@ -303,13 +492,15 @@ __global__ __launch_bounds__(256) void invit_kernel(const double* __restrict__ d
             }
             yn -= lm[(int64_t)i * NT] * yi;
             x[(int64_t)i * NT] = yi;
-            x[(int64_t)(i + 1) * NT] = yn;
+            yi = yn;
         }
+        x[(int64_t)(N - 1) * NT] = yi;
         // backward substitution with the three diagonals of U
         double x1 = 0.0, x2 = 0.0, amax = 0.0;
+#pragma unroll 4
         for (int i = N - 1; i >= 0; --i) {
             const double t = x[(int64_t)i * NT] - ub[(int64_t)i * NT] * x1 - uc[(int64_t)i * NT] * x2;
-            const double xi = t / ua[(int64_t)i * NT];
+            const double xi = t * ua[(int64_t)i * NT];
             x[(int64_t)i * NT] = xi;
             x2 = x1;
             x1 = xi;
@@ -321,8 +512,69 @@ __global__ __launch_bounds__(256) void invit_kernel(const double* __restrict__ d
     double nrm = 0.0;
     for (int i = 0; i < N; ++i) nrm = fma(x[(int64_t)i * NT], x[(int64_t)i * NT], nrm);
     const double s = nrm > 0.0 ? 1.0 / sqrt(nrm) : 1.0;
-    double* Z = Zb + (int64_t)b * N * N;
-    for (int i = 0; i < N; ++i) Z[(int64_t)i * N + j] = x[(int64_t)i * NT] * s;
+    for (int i = 0; i < N; ++i) zcol[(int64_t)i * N] = x[(int64_t)i * NT] * s;
+}
+
+__global__ __launch_bounds__(256) void invit_kernel(const double* __restrict__ db, const double* __restrict__ eb,
+                                                    const double* __restrict__ wb, int N, double* __restrict__ scratch,
+                                                    double* __restrict__ Zb) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const int64_t NT = N;  // stride between consecutive rows of one thread's arrays
+    double* base = scratch + (int64_t)b * 6 * N * NT;
+    // (restrict: the arrays do not overlap, so the loads of the next rows can be issued ahead of the recurrence)
+    double* __restrict__ ua = base + j;              // 1 / (U diagonal)
+    double* __restrict__ ub = ua + (int64_t)N * NT;  // U first superdiagonal
+    double* __restrict__ uc = ub + (int64_t)N * NT;  // U second superdiagonal
+    double* __restrict__ lm = uc + (int64_t)N * NT;  // multipliers
+    double* __restrict__ sw = lm + (int64_t)N * NT;  // 1.0 if rows i, i+1 were swapped
+    double* __restrict__ x = sw + (int64_t)N * NT;   // solution / rhs
+    invit_solve(db + (int64_t)b * N, eb + (int64_t)b * N, wb[(int64_t)b * N + j], N, NT, ua, ub, uc, lm, sw, x, j, b,
+                Zb + (int64_t)b * N * N + j);
+}
+
+constexpr int IVL_TPB = 16;
+constexpr int IVL_MAX_N = 208;  // 6 N 16 doubles + d, e within 160 KB
+
+__global__ __launch_bounds__(IVL_TPB) void invit_lds_kernel(const double* __restrict__ db, const double* __restrict__ eb,
+                                                            const double* __restrict__ wb, int N, double* __restrict__ Zb) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.y;
+    const int t = threadIdx.x;
+    const int j = blockIdx.x * IVL_TPB + t;
+    double* ds = smem;          // [N] diagonal
+    double* es = ds + N;        // [N] off-diagonal
+    double* work = es + N;      // six arrays [N][IVL_TPB]
+    for (int i = t; i < N; i += IVL_TPB) {
+        ds[i] = db[(int64_t)b * N + i];
+        es[i] = eb[(int64_t)b * N + i];
+    }
+    __syncthreads();
+    if (j >= N) return;
+    const int64_t NT = IVL_TPB;
+    double* ua = work + t;
+    double* ub = ua + (int64_t)N * NT;
+    double* uc = ub + (int64_t)N * NT;
+    double* lm = uc + (int64_t)N * NT;
+    double* sw = lm + (int64_t)N * NT;
+    double* x = sw + (int64_t)N * NT;
+    invit_solve(ds, es, wb[(int64_t)b * N + j], N, NT, ua, ub, uc, lm, sw, x, j, b, Zb + (int64_t)b * N * N + j);
+}
+
+static bool invit_lds_launch(nbx_ctx* ctx, int N, int64_t batch, const double* d, const double* e, const double* w,
+                             double* Z) {
+    if (N > IVL_MAX_N) return false;
+    const size_t lds = (size_t)(2 * N + 6 * N * IVL_TPB) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&invit_lds_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(invit_lds_kernel, dim3((unsigned)nbx_cdiv(N, IVL_TPB), (unsigned)batch), dim3(IVL_TPB), lds,
+                       ctx->stream, d, e, w, N, Z);
+    return true;
 }
 
 // ---------------------------------------------------------------- K4: V = Q Z (apply the reflectors)
@@ -363,6 +615,82 @@ __global__ __launch_bounds__(BT_THREADS) void backtransform_kernel(const double*
             for (int t = tg; t < L; t += BT_GROUPS) Z[(int64_t)(k + 1 + t) * N + col] -= tot * vk[t];
         __syncthreads();
     }
+}
+
+// K4 for N <= 208: the same tile of Z in registers -- thread (tg, j) keeps the rows tg + 16 r of its column -- so that
+// a reflector costs two barriers and LDS traffic only (backtransform_kernel: three barriers and a read-modify-write of
+// the tile in L2, 2 us per reflector); the next reflector is fetched while the current one is applied.
+template <int RB>
+__global__ __launch_bounds__(BT_THREADS) void backtransform_reg_kernel(const double* __restrict__ Vhb,
+                                                                       const double* __restrict__ taub, int N,
+                                                                       double* __restrict__ Zb) {
+    constexpr int LD = RB * BT_GROUPS;
+    __shared__ __attribute__((aligned(16))) double vk[2][LD];              // reflector, indexed by the row it acts on
+    __shared__ __attribute__((aligned(16))) double partial[BT_GROUPS * BT_COLS];
+    const int b = blockIdx.y;
+    const int j = threadIdx.x % BT_COLS, tg = threadIdx.x / BT_COLS;
+    const int col = blockIdx.x * BT_COLS + j;
+    const double* Vh = Vhb + (int64_t)b * N * N;
+    const double* tau = taub + (int64_t)b * N;
+    double* Z = Zb + (int64_t)b * N * N;
+    const bool live = col < N;
+    double z[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int i = tg + r * BT_GROUPS;
+        z[r] = (live && i < N) ? Z[(int64_t)i * N + col] : 0.0;
+    }
+    // this thread's element of a reflector: row threadIdx.x (LD <= 256 = BT_THREADS)
+    const int row = threadIdx.x;
+    auto fetch = [&](int k) -> double {  // v_k at row `row` (0 outside rows k+1 .. N-1)
+        return (k >= 0 && row > k && row < N) ? Vh[(int64_t)k * N + (row - k - 1)] : 0.0;
+    };
+    int cur = 0;
+    if (row < LD) vk[0][row] = fetch(N - 2);
+    double tk_next = N > 1 ? tau[N - 2] : 0.0;
+    __syncthreads();
+    for (int k = N - 2; k >= 0; --k) {
+        const double tk = tk_next;
+        const double nxt = fetch(k - 1);  // (both loads are consumed only after this reflector's arithmetic)
+        tk_next = k > 0 ? tau[k - 1] : 0.0;
+        if (tk != 0.0) {  // uniform
+            double dot = 0.0;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) dot = fma(vk[cur][tg + r * BT_GROUPS], z[r], dot);  // (zero outside the rows)
+            partial[tg * BT_COLS + j] = dot;
+        }
+        if (row < LD) vk[cur ^ 1][row] = nxt;
+        __syncthreads();
+        if (tk != 0.0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int gg = 0; gg < BT_GROUPS; ++gg) tot += partial[gg * BT_COLS + j];
+            tot *= tk;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) z[r] = fma(-tot, vk[cur][tg + r * BT_GROUPS], z[r]);
+        }
+        __syncthreads();  // partial[] and vk[cur] are rewritten by the next two steps
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int i = tg + r * BT_GROUPS;
+        if (live && i < N) Z[(int64_t)i * N + col] = z[r];
+    }
+}
+
+static bool backtransform_reg_launch(nbx_ctx* ctx, int N, int64_t batch, const double* Vh, const double* tau,
+                                     double* Z) {
+    const dim3 grid((unsigned)nbx_cdiv(N, BT_COLS), (unsigned)batch);
+#define NBX_BTR_GO(RB_) \
+    hipLaunchKernelGGL(backtransform_reg_kernel<RB_>, grid, dim3(BT_THREADS), 0, ctx->stream, Vh, tau, N, Z)
+    if (N <= 64) NBX_BTR_GO(4);
+    else if (N <= 128) NBX_BTR_GO(8);
+    else if (N <= 160) NBX_BTR_GO(10);
+    else if (N <= 208) NBX_BTR_GO(13);
+    else return false;
+#undef NBX_BTR_GO
+    return true;
 }
 
 // ---------------------------------------------------------------- K5: CGS2 orthonormalisation, vectors = rows of Vt
@@ -419,59 +747,48 @@ __global__ void ns_factor_kernel(double* __restrict__ G, int N, int64_t total) {
     G[idx] = (i == j ? 1.5 : 0.0) - 0.5 * G[idx];
 }
 
-// max_{i != j} |G_ij| and max_i |G_ii - 1| -> out[b*2 + {0,1}]; a NaN anywhere in G comes out as NaN
+// NaN-propagating max (fmax drops a NaN operand)
 __device__ __forceinline__ double td_nanmax(double a, double b) { return (a != a || b != b) ? a + b : fmax(a, b); }
-__global__ __launch_bounds__(256) void gram_defect_kernel(const double* __restrict__ G, int N, double* __restrict__ out) {
-    __shared__ double red_o[4], red_d[4];
+
+// Per (N,N) matrix: max_{i != j} |M_ij| and max_i |M_ii - DIAG_SHIFT| -> out[b*2 + {0,1}]; a NaN anywhere comes out
+// as NaN.  One 1024-thread workgroup per matrix, a wave per row (no index division, 30 independent loads per
+// thread at N = 148: 6 us where the element-per-thread loop of 256 threads took 33).
+//   DIAG_SHIFT = 1: the defect of a Gram matrix;  0: the off-diagonal weight of R = V^T A V against its diagonal
+template <int DIAG_SHIFT>
+__global__ __launch_bounds__(1024) void offdiag_diag_max_kernel(const double* __restrict__ M, int N,
+                                                                double* __restrict__ out) {
+    __shared__ double red_o[16], red_d[16];
     const int b = blockIdx.x;
-    const double* r = G + (int64_t)b * N * N;
+    const double* m = M + (int64_t)b * N * N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double mo = 0.0, md = 0.0;
-    for (int64_t idx = threadIdx.x; idx < (int64_t)N * N; idx += 256) {
-        const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
-        if (i == j) md = td_nanmax(md, fabs(r[idx] - 1.0));
-        else mo = td_nanmax(mo, fabs(r[idx]));
+    for (int i = wave; i < N; i += 16) {
+        const double* row = m + (int64_t)i * N;
+        for (int j = lane; j < N; j += 64) {
+            const double x = row[j];
+            if (i == j) md = td_nanmax(md, fabs(x - (double)DIAG_SHIFT));
+            else mo = td_nanmax(mo, fabs(x));
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         mo = td_nanmax(mo, __shfl_xor(mo, off, 64));
         md = td_nanmax(md, __shfl_xor(md, off, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
-        red_o[threadIdx.x >> 6] = mo;
-        red_d[threadIdx.x >> 6] = md;
+    if (lane == 0) {
+        red_o[wave] = mo;
+        red_d[wave] = md;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[2 * b] = td_nanmax(td_nanmax(red_o[0], red_o[1]), td_nanmax(red_o[2], red_o[3]));
-        out[2 * b + 1] = td_nanmax(td_nanmax(red_d[0], red_d[1]), td_nanmax(red_d[2], red_d[3]));
-    }
-}
-
-// max_{i != j} |R_ij| and max_i |R_ii| of each (N,N) matrix -> out[b*2 + {0,1}]
-__global__ __launch_bounds__(256) void offdiag_max_kernel(const double* __restrict__ R, int N, double* __restrict__ out) {
-    __shared__ double red_o[4], red_d[4];
-    const int b = blockIdx.x;
-    const double* r = R + (int64_t)b * N * N;
-    double mo = 0.0, md = 0.0;
-    for (int64_t idx = threadIdx.x; idx < (int64_t)N * N; idx += 256) {
-        const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
-        const double a = fabs(r[idx]);
-        if (i == j) md = fmax(md, a);
-        else mo = fmax(mo, a);
-    }
+        double o = red_o[0], d = red_d[0];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mo = fmax(mo, __shfl_xor(mo, off, 64));
-        md = fmax(md, __shfl_xor(md, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        red_o[threadIdx.x >> 6] = mo;
-        red_d[threadIdx.x >> 6] = md;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        out[2 * b] = fmax(fmax(red_o[0], red_o[1]), fmax(red_o[2], red_o[3]));
-        out[2 * b + 1] = fmax(fmax(red_d[0], red_d[1]), fmax(red_d[2], red_d[3]));
+        for (int w = 1; w < 16; ++w) {
+            o = td_nanmax(o, red_o[w]);
+            d = td_nanmax(d, red_d[w]);
+        }
+        out[2 * b] = o;
+        out[2 * b + 1] = d;
     }
 }
 
@@ -512,22 +829,26 @@ static int td_pipeline(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a
     double* Z = reinterpret_cast<double*>(base + L.z_off);
     double* scr = reinterpret_cast<double*>(base + L.scr_off);
     const int N = (int)n;
-    hipLaunchKernelGGL(tridiag_kernel, dim3((unsigned)batch), dim3(TD_THREADS),
-                       (size_t)(3 * N + TD_THREADS + 20) * sizeof(double), ctx->stream, d_a, N, W, d, e, tau, Vh);
+    static const bool in_memory = getenv("NBX_TRIDIAG_IN_MEMORY") != nullptr;  // A/B switch
+    if (in_memory || !tridiag_reg_launch(ctx, N, batch, d_a, d, e, tau, Vh))
+        hipLaunchKernelGGL(tridiag_kernel, dim3((unsigned)batch), dim3(TD_THREADS),
+                           (size_t)(3 * N + TD_THREADS + 20) * sizeof(double), ctx->stream, d_a, N, W, d, e, tau, Vh);
     NBX_LAUNCH_CHECK();
     hipLaunchKernelGGL(bisect_kernel, dim3((unsigned)N, (unsigned)batch), dim3(64), (size_t)(2 * N) * sizeof(double),
                        ctx->stream, d, e, N, d_w);
     NBX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(invit_kernel, dim3((unsigned)nbx_cdiv(N, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d, e,
-                       d_w, N, scr, Z);
+    if (in_memory || !invit_lds_launch(ctx, N, batch, d, e, d_w, Z))
+        hipLaunchKernelGGL(invit_kernel, dim3((unsigned)nbx_cdiv(N, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d,
+                           e, d_w, N, scr, Z);
     NBX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)nbx_cdiv(N, BT_COLS), (unsigned)batch), dim3(BT_THREADS),
-                       (size_t)(N + BT_GROUPS * BT_COLS) * sizeof(double), ctx->stream, Vh, tau, N, Z);
+    if (in_memory || !backtransform_reg_launch(ctx, N, batch, Vh, tau, Z))
+        hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)nbx_cdiv(N, BT_COLS), (unsigned)batch), dim3(BT_THREADS),
+                           (size_t)(N + BT_GROUPS * BT_COLS) * sizeof(double), ctx->stream, Vh, tau, N, Z);
     NBX_LAUNCH_CHECK();
     int rc = nbx_gemm(ctx, 'T', 'N', n, n, n, 1.0, Z, n, n * n, Z, n, n * n, 0.0, W, n, n * n, batch);
     if (rc != NBX_OK) return rc;
     NBX_CHECK_ARG(2 * batch <= NBX_SCRATCH_DOUBLES);
-    hipLaunchKernelGGL(gram_defect_kernel, dim3((unsigned)batch), dim3(256), 0, ctx->stream, W, N, ctx->d_scratch);
+    hipLaunchKernelGGL(offdiag_diag_max_kernel<1>, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, W, N, ctx->d_scratch);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
@@ -624,7 +945,7 @@ int nbx_eigh_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, 
     rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, W, n, n * n, d_v, n, n * n, 0.0, Z, n, n * n, batch);
     if (rc != NBX_OK) return rc;
     NBX_CHECK_ARG(2 * batch <= NBX_SCRATCH_DOUBLES);
-    hipLaunchKernelGGL(offdiag_max_kernel, dim3((unsigned)batch), dim3(256), 0, ctx->stream, Z, N, ctx->d_scratch);
+    hipLaunchKernelGGL(offdiag_diag_max_kernel<0>, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, Z, N, ctx->d_scratch);
     NBX_LAUNCH_CHECK();
     NBX_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch, (size_t)(2 * batch) * sizeof(double), hipMemcpyDeviceToHost,
                            ctx->stream));
