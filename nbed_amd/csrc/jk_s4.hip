@@ -47,6 +47,14 @@ int nbx_jk_s8_launch(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t np, int64_t nd
                      const double* d_dm, const double* d_dts, double* d_j, double* k1, double* k2, int64_t t_begin,
                      int64_t t_end, int wgs, int L, int S);
 
+// jk_s4d.hip: the NB = 4 / six-loads instance with the tiles streamed straight into LDS
+bool nbx_jk_s4d_covers(int NB, int lpt);
+size_t nbx_jk_s4d_lds_bytes(int NB, int lpt, int variant);
+int nbx_jk_s4d_per_cu(int variant);
+int nbx_jk_s4d_launch(nbx_ctx* ctx, int variant, int64_t N, int64_t p0, int64_t np, int64_t ndm, int lpt,
+                      const double* d_packed, const double* d_dm, const double* d_dts, double* d_j, double* k1, double* k2,
+                      int64_t t_begin, int64_t t_end, int wgs, int L, int S);
+
 namespace {
 
 constexpr int S4_CUS = 256;
@@ -447,8 +455,14 @@ bool s4_use_s8(int64_t N) {
     return on && nbx_jk_s8_covers(N);
 }
 
+int s4_use_dma(int NB, int lpt) {  // 0: off; 1-3: the variants of jk_s4d.hip (A/B switch while they are measured)
+    static const int v = getenv("NBX_JK_DMA") ? atoi(getenv("NBX_JK_DMA")) : 0;
+    return (v >= 1 && v <= 3 && nbx_jk_s4d_covers(NB, lpt)) ? v : 0;
+}
+
 struct S4Plan {
     bool s8;
+    int dma;
     int NB, lpt, wgs, L, S, per_cu;
     size_t lds_bytes, dtp_off, k1_off, k2_off, total;
     S4Geom g;
@@ -468,9 +482,11 @@ S4Plan s4_plan(int64_t N, int64_t p0, int64_t np, int64_t ndm) {
 #else
     pl.lds_bytes = (size_t)(2 * pl.lpt * nt * 2 + 128 + 2 * pl.NB) * sizeof(double);
 #endif
+    pl.dma = s4_use_dma(pl.NB, pl.lpt);
+    if (pl.dma) pl.lds_bytes = nbx_jk_s4d_lds_bytes(pl.NB, pl.lpt, pl.dma);
     int64_t per_cu = (int64_t)(S4_LDS_PER_CU / (pl.lds_bytes + 256));
     // two waves per SIMD (the staging registers need the budget), one for the long-row instances
-    const int64_t by_waves = (pl.lpt >= 10 ? 4 : 8) / pl.NB;
+    const int64_t by_waves = pl.dma ? nbx_jk_s4d_per_cu(pl.dma) : (pl.lpt >= 10 ? 4 : 8) / pl.NB;
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
     pl.per_cu = (int)per_cu;
@@ -651,7 +667,11 @@ static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const
         if (ndm == 2) NBX_S4_GO(2, NB_, LPT_, PD_, DT_, WV_);                                                              \
         else NBX_S4_GO(1, NB_, LPT_, PD_, DT_, WV_);                                                                       \
     } while (0)
-        if (pl.s8) {
+        if (pl.dma && !pl.s8) {
+            const int rcd = nbx_jk_s4d_launch(ctx, pl.dma, N, p0, np, ndm, pl.lpt, d_packed, d_dm, dtp, d_jk, k1, k2, t_begin,
+                                              t_end, pl.wgs, pl.L, pl.S);
+            if (rcd != NBX_OK) return rcd;
+        } else if (pl.s8) {
             const int rc8 = nbx_jk_s8_launch(ctx, N, p0, np, ndm, d_packed, d_dm, dtp, d_jk, k1, k2, t_begin, t_end,
                                              pl.wgs, pl.L, pl.S);
             if (rc8 != NBX_OK) return rc8;

@@ -239,3 +239,25 @@ def test_jk_eightfold_experimental_vs_c_oracle():
     out = subprocess.run([sys.executable, str(Path(__file__).with_name("_p8_worker.py"))], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "P8 OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
+def test_jk_lds_dma_experimental_vs_c_oracle(variant):
+    """csrc/jk_s4d.hip (tiles streamed straight into LDS; opt-in) in a child process with
+    NBX_JK_DMA set: parity with the C oracle at the bench size; variants 1 and 2 keep the production kernel's
+    work distribution and give its numbers bit for bit (variant 3 runs three workgroups per CU: other partial
+    sums, other rounding)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    outs = {}
+    for v in (variant, "0") if variant != "3" else (variant,):
+        env = dict(os.environ, NBX_JK_DMA=v)
+        out = subprocess.run([sys.executable, str(Path(__file__).with_name("_s4d_worker.py"))], env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "S4D OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+        outs[v] = out.stdout.strip().splitlines()[-1].split(" ", 3)[3]
+    if variant != "3":
+        assert outs[variant] == outs["0"]
