@@ -471,6 +471,24 @@ int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, 
                   int refine_iters, int diis_mode, int diis_slot, int diis_nd, int dts_ready, double* h_out,
                   int* d_status_out);
 
+/* ------------------------------------------------------------------ quadrature grid producers
+ * What the reference gets from PySCF behind scf.UKS(...) (nbed/driver.py:86-104,315-431): `dft.gen_grid`'s Becke
+ * partition and `numint.eval_ao`.  Inputs of the exchange-correlation part of V_emb (driver.py:845-852), not of
+ * the SCF hot path; both one thread per grid point.
+ * nbx_becke_share: d_share[g] = w_owner / sum_i w_i of Becke's cell functions (three smoothing iterations, size
+ *   adjustment a_ij given by the caller) at the points d_pts (npts,3); d_centres (natm,3), d_aij and
+ *   d_inv_dist = 1 / |R_i - R_j| (any finite value on the diagonal) are (natm,natm); natm <= 128.
+ * nbx_eval_ao: values d_out (npts, ncart) and, if d_dout != NULL, gradients (3, npts, ncart) of the contracted
+ *   Cartesian Gaussians x^l y^m z^n sum_k c_k exp(-a_k r^2), l + m + n <= 3.  d_shell_i (nshell,4) =
+ *   {first component, components, first primitive, primitives}; d_shell_centre (nshell,3); d_comp_lmn (ncart,4)
+ *   = {l, m, n, offset of the component's coefficients in d_coefs}; max_prim = the largest primitive count
+ *   (<= 24, NBX_E_UNSUPPORTED beyond).  The spherical transform is the caller's GEMM.               */
+int nbx_becke_share(nbx_ctx* ctx, int64_t npts, const double* d_pts, int64_t natm, const double* d_centres,
+                    const double* d_aij, const double* d_inv_dist, int64_t owner, double* d_share);
+int nbx_eval_ao(nbx_ctx* ctx, int64_t npts, const double* d_pts, int64_t nshell, const int* d_shell_i,
+                const double* d_shell_centre, const int* d_comp_lmn, const double* d_exps, const double* d_coefs,
+                int64_t ncart, int64_t max_prim, double* d_out, double* d_dout);
+
 /* ------------------------------------------------------------------ density by purification
  * The projector P on the nocc LOWEST eigenvectors of each symmetric matrix d_f (batch, n, n; an orthonormal
  * basis), i.e. C_occ C_occ^T of `eigh` + aufbau occupation (nbed/scf/huzinaga_scf.py:166-174) without the

@@ -726,6 +726,46 @@ class HipBackend:
         self.last_eigh_status_d = status
         return w, c
 
+    def becke_share(self, pts, centres, aij, inv_dist, owner: int):
+        """Becke cell weight of atom ``owner`` at the device points ``pts`` (G, 3) -> device (G,) (nbx_becke_share)."""
+        out = self.empty(pts.shape[0])
+        self._call("nbx_becke_share", pts.shape[0], self._p(pts), centres.shape[0], self._p(centres), self._p(aij),
+                   self._p(inv_dist), int(owner), self._p(out))
+        return out
+
+    def eval_ao(self, pts, table, deriv: bool = True):
+        """Cartesian AO values (G, ncart) and gradients (3, G, ncart) at the device points ``pts`` (nbx_eval_ao);
+        ``table``: the device arrays of ``ao_table``."""
+        g, nc = int(pts.shape[0]), int(table["ncart"])
+        out = self.empty((g, nc))
+        dout = self.empty((3, g, nc)) if deriv else None
+        self._call("nbx_eval_ao", g, self._p(pts), table["nshell"], self._p(table["shell_i"]), self._p(table["centre"]),
+                   self._p(table["comp_lmn"]), self._p(table["exps"]), self._p(table["coefs"]), nc, table["max_prim"],
+                   self._p(out), self._p(dout))
+        return out, dout
+
+    def ao_table(self, basis):
+        """The shells of an ``integrals.Basis`` flattened into the device arrays nbx_eval_ao reads."""
+        torch = self.torch
+        shell_i, centre, comp, exps, coefs = [], [], [], [], []
+        for sh, ao0 in zip(basis.shells, basis.shell_ao0):
+            k0 = len(exps)
+            assert int(ao0) == len(comp), "shells in AO order"
+            exps.extend(float(a) for a in sh.exps)
+            shell_i.append([int(ao0), len(sh.cart), k0, len(sh.exps)])
+            centre.append([float(x) for x in sh.centre])
+            for ic, lmn in enumerate(sh.cart):
+                comp.append([int(lmn[0]), int(lmn[1]), int(lmn[2]), len(coefs)])
+                coefs.extend(float(c) for c in sh.coefs[ic])
+        assert len(comp) == basis.nao_cart
+
+        def dev(a, dtype):
+            return torch.as_tensor(np.asarray(a), dtype=dtype).contiguous().to(self.device)
+
+        return {"nshell": len(shell_i), "ncart": int(basis.nao_cart), "max_prim": max(s_[3] for s_ in shell_i),
+                "shell_i": dev(shell_i, torch.int32), "centre": dev(centre, torch.float64),
+                "comp_lmn": dev(comp, torch.int32), "exps": dev(exps, torch.float64), "coefs": dev(coefs, torch.float64)}
+
     def purify(self, f, nocc, max_iter: int = 0):
         """Projector on the ``nocc[b]`` lowest eigenvectors of each symmetric matrix of ``f`` (batch, n, n) by
         trace-correcting purification (nbx_purify) -> ``(p, status)`` device tensors; status[b] > 0 = steps."""

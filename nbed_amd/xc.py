@@ -79,11 +79,22 @@ def _radial_rule(n_rad: int, scale: float):
     return r, w * dr * r * r
 
 
+def _hip_backend(device):
+    """libnbx on a HIP device (None for the host: the torch expressions below are then the whole path)."""
+    if _torch().device(device).type != "cuda":
+        return None
+    from .backend import get_backend
+
+    return get_backend()
+
+
 def build_grid(atoms, n_rad: int = 96, n_theta: int = 28, device="cpu"):
     """(points (G, 3) in Bohr, weights (G,)) of the molecular grid.  The Becke cell functions -- a
-    (points x atoms x atoms) product -- are evaluated with torch on ``device`` in blocks of points."""
+    (points x atoms x atoms) product -- are evaluated on ``device``: by nbx_becke_share (one thread per point)
+    on a GPU, with torch in blocks of points on the host."""
     t = _torch()
     dev = t.device(device)
+    be = _hip_backend(dev)
     centres = np.array([pos for _, pos in atoms])
     radii = np.array([BRAGG[sym] / integrals.BOHR for sym, _ in atoms])
     ang_pts, ang_w = _angular_rule(n_theta)
@@ -104,7 +115,10 @@ def build_grid(atoms, n_rad: int = 96, n_theta: int = 28, device="cpu"):
         w = wr[:, None] * ang_w[None, :]
         pts = pts.reshape(-1, 3)
         w = w.reshape(-1)
-        if natm > 1:
+        if natm > 1 and be is not None:
+            share = be.to_host(be.becke_share(be.asarray(pts), centres_d, aij_d, inv_dist, ia))
+            w = w * share
+        elif natm > 1:
             share = np.empty(pts.shape[0])
             for g0 in range(0, pts.shape[0], 1 << 15):
                 p = t.as_tensor(pts[g0:g0 + (1 << 15)]).to(dev)
@@ -165,6 +179,18 @@ def eval_ao_torch(basis: "integrals.Basis", pts, deriv: int = 1):
     t = _torch()
     npts = pts.shape[0]
     kw = dict(dtype=t.float64, device=pts.device)
+    be = _hip_backend(pts.device)
+    if be is not None:  # nbx_eval_ao: one thread per point over all shells (the shell loop below is the host form)
+        table = getattr(basis, "_ao_table_device", None)
+        if table is None:
+            table = basis._ao_table_device = be.ao_table(basis)
+        ao, dao = be.eval_ao(pts.contiguous(), table, deriv=bool(deriv))
+        if not basis.pure_cartesian:
+            u = t.as_tensor(basis.cart2ao, **kw)
+            ao = ao @ u.T
+            if deriv:
+                dao = dao @ u.T
+        return ao, dao
     ao = t.zeros((npts, basis.nao_cart), **kw)
     dao = t.zeros((3, npts, basis.nao_cart), **kw) if deriv else None
     for sh, ao0 in zip(basis.shells, basis.shell_ao0):

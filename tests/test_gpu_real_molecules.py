@@ -112,3 +112,42 @@ def test_methyl_cation_ccpvtz_f_shells_end_to_end(be):
         nbed(NbedConfig(geometry=ch3, n_active_atoms=2, basis="cc-pvdz", xc_functional="b3lyp", spin=1, convergence=1e-7,
                         projector="huzinaga", max_hf_cycles=200, max_dft_cycles=200), provider=BuiltinHFProvider(be),
              backend=be)
+
+
+@pytest.mark.parametrize("basis", ["6-31g*", "cc-pvtz"])
+def test_grid_kernels_match_the_host_expressions(be, basis):
+    """nbx_eval_ao and nbx_becke_share (one thread per grid point) against the numpy / torch-on-host expressions of
+    nbed_amd.xc they replace on a GPU: s, p, d and f shells, Cartesian values and gradients, spherical AOs after
+    the caller's transform; Becke weights of every atom of a bent molecule."""
+    import torch
+
+    from nbed_amd import xc as xcmod
+
+    atoms = integrals.parse_geometry(WATER, "angstrom")
+    bs = integrals.Basis(atoms, basis)
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.normal(scale=2.0, size=(4000, 3)), np.array([pos for _, pos in atoms]) + 1e-3])
+    ao_h, dao_h = xcmod.eval_ao(bs, pts)
+    ao_d, dao_d = xcmod.eval_ao_torch(bs, torch.as_tensor(pts).to(be.device))
+    assert ao_d.shape == (pts.shape[0], bs.nao) and dao_d.shape == (3, pts.shape[0], bs.nao)
+    np.testing.assert_allclose(ao_d.cpu().numpy(), ao_h, rtol=0, atol=1e-13 * max(1.0, np.abs(ao_h).max()))
+    np.testing.assert_allclose(dao_d.cpu().numpy(), dao_h, rtol=0, atol=1e-12 * max(1.0, np.abs(dao_h).max()))
+    # values only (no gradient buffer)
+    ao_only, none = xcmod.eval_ao_torch(bs, torch.as_tensor(pts).to(be.device), deriv=0)
+    assert none is None
+    np.testing.assert_array_equal(ao_only.cpu().numpy(), ao_d.cpu().numpy())
+    # the molecular grid: same points, same weights as the host construction; integrates the electron count
+    p_h, w_h = xcmod.build_grid(atoms, 40, 12, device="cpu")
+    p_d, w_d = xcmod.build_grid(atoms, 40, 12, device=be.device)
+    # (points whose weight falls below 1e-22 are dropped: a handful differ between the two at rounding level)
+    assert abs(len(w_d) - len(w_h)) < 1e-3 * len(w_h)
+    # (a cell function near zero is 1 - f with f within rounding of 1, in both constructions: tiny weights agree
+    # absolutely, not relatively)
+    big_h, big_d = w_h > 1e-6, w_d > 1e-6
+    np.testing.assert_array_equal(p_d[big_d], p_h[big_h])
+    np.testing.assert_allclose(w_d[big_d], w_h[big_h], rtol=1e-10, atol=1e-7)
+    for centre, alpha in ((atoms[0][1], 0.7), (atoms[1][1], 0.3)):
+        f_h = (w_h * np.exp(-alpha * ((p_h - centre) ** 2).sum(axis=1))).sum()
+        f_d = (w_d * np.exp(-alpha * ((p_d - centre) ** 2).sum(axis=1))).sum()
+        assert abs(f_d - f_h) < 1e-12 * abs(f_h)
+        assert abs(f_h - (np.pi / alpha) ** 1.5) < 1e-4 * f_h  # (a coarse grid: 40 x 12)
