@@ -488,6 +488,15 @@ int nbx_becke_share(nbx_ctx* ctx, int64_t npts, const double* d_pts, int64_t nat
 int nbx_eval_ao(nbx_ctx* ctx, int64_t npts, const double* d_pts, int64_t nshell, const int* d_shell_i,
                 const double* d_shell_centre, const int* d_comp_lmn, const double* d_exps, const double* d_coefs,
                 int64_t ncart, int64_t max_prim, double* d_out, double* d_dout);
+/* The two passes of a Kohn-Sham potential evaluation over the stored AO values d_ao (npts,nao), d_dao (3,npts,nao),
+ * each array read once (what PySCF's numint does per block inside `get_veff`, driver.py:845-852):
+ * nbx_xc_density: d_rho[g] = sum_m c[g,m] ao[g,m], d_grad (3,npts) = 2 sum_m c[g,m] dao[a,g,m] for d_c = ao D (npts,nao);
+ * nbx_xc_half:    d_half[g,m] = 1/2 vr[g] ao[g,m] + sum_a vec[a,g] dao[a,g,m]; the rows of d_vec are vec_stride apart
+ *                 (v_xc = half^T ao + its transpose is the caller's GEMM).                                    */
+int nbx_xc_density(nbx_ctx* ctx, int64_t npts, int64_t nao, const double* d_ao, const double* d_dao, const double* d_c,
+                   double* d_rho, double* d_grad);
+int nbx_xc_half(nbx_ctx* ctx, int64_t npts, int64_t nao, const double* d_ao, const double* d_dao, const double* d_vr,
+                const double* d_vec, int64_t vec_stride, double* d_half);
 
 /* ------------------------------------------------------------------ density by purification
  * The projector P on the nocc LOWEST eigenvectors of each symmetric matrix d_f (batch, n, n; an orthonormal

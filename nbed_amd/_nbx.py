@@ -147,6 +147,8 @@ SIGNATURES = {
     "nbx_threshold_scale": (c_int, [_P, c_int64, c_double, c_double, _P]),
     "nbx_becke_share": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P]),
     "nbx_eval_ao": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int64, _P, _P]),
+    "nbx_xc_density": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, _P]),
+    "nbx_xc_half": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, c_int64, _P]),
     "nbx_purify_worksize": (c_size_t, [c_int64, c_int64]),
     "nbx_purify": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_size_t, c_int, _P]),
     "nbx_host_1e": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, _P, _P, _P]),

@@ -744,6 +744,17 @@ class HipBackend:
                    self._p(out), self._p(dout))
         return out, dout
 
+    def xc_density(self, ao, dao, c, rho, grad):
+        """rho (G,) and grad (3, G) views filled from c = ao D in one pass over ao / dao (nbx_xc_density)."""
+        self._call("nbx_xc_density", ao.shape[0], ao.shape[1], self._p(ao), self._p(dao), self._p(c), self._p(rho),
+                   self._p(grad))
+
+    def xc_half(self, ao, dao, vr, vec, vec_stride: int, out):
+        """out (G, nao) = vr/2 ao + vec . dao in one pass (nbx_xc_half); ``vec``: a (3, >=G) view, rows vec_stride apart."""
+        self._call("nbx_xc_half", ao.shape[0], ao.shape[1], self._p(ao), self._p(dao), self._p(vr), self._p(vec),
+                   int(vec_stride), self._p(out))
+        return out
+
     def ao_table(self, basis):
         """The shells of an ``integrals.Basis`` flattened into the device arrays nbx_eval_ao reads."""
         torch = self.torch

@@ -373,10 +373,17 @@ class XCProvider:
             return 0.0, np.zeros_like(dm)
         dmd = t.as_tensor(dm).to(self.device)
         dmd = 0.5 * (dmd + dmd.transpose(1, 2))
+        be = _hip_backend(self.device)  # (fused passes over the stored AO values on a GPU: nbx_xc_density / nbx_xc_half)
         rho, grad = [[], []], [[], []]
         for ao, dao in self._blocks:
             for x in range(2):
                 c = ao @ dmd[x]                                            # (g, nao)
+                if be is not None:
+                    rho_b, grad_b = ao.new_empty(ao.shape[0]), ao.new_empty((3, ao.shape[0]))
+                    be.xc_density(ao, dao, c, rho_b, grad_b)
+                    rho[x].append(rho_b)
+                    grad[x].append(grad_b)
+                    continue
                 rho[x].append((c * ao).sum(dim=1))
                 grad[x].append(2.0 * (dao * c[None]).sum(dim=2))           # D symmetric
         rho = [t.cat(r) for r in rho]
@@ -397,11 +404,15 @@ class XCProvider:
         vxc = t.zeros_like(dmd)
         for x, (vr, vs_same, gs, go) in enumerate(((vra, vsaa, ga, gb), (vrb, vsbb, gb, ga))):
             # v = v_rho phi_m phi_n + (2 v_ss grad rho_s + v_ab grad rho_other) . grad(phi_m phi_n)
-            vec = 2.0 * vs_same * gs + vsab * go                           # (3, G), weights included
+            vec = (2.0 * vs_same * gs + vsab * go).contiguous()            # (3, G), weights included
+            vr = vr.contiguous()
             g0 = 0
             for ao, dao in self._blocks:
                 g1 = g0 + ao.shape[0]
-                half = 0.5 * vr[g0:g1, None] * ao + (vec[:, g0:g1, None] * dao).sum(dim=0)
+                if be is not None:
+                    half = be.xc_half(ao, dao, vr[g0:g1], vec[:, g0:g1], vec.shape[1], t.empty_like(ao))
+                else:
+                    half = 0.5 * vr[g0:g1, None] * ao + (vec[:, g0:g1, None] * dao).sum(dim=0)
                 n = ao.shape[1]  # K = grid points is long and M = N = nao short: split K, batch, sum
                 vxc[x] += (ao.view(-1, self.SPLIT, n).transpose(1, 2) @ half.view(-1, self.SPLIT, n)).sum(dim=0)
                 g0 = g1

@@ -1095,3 +1095,25 @@ def test_eigh_approx_flags_vectors_it_could_not_separate(be):
             np.testing.assert_allclose(v_h[x].T @ v_h[x], np.eye(n), rtol=0, atol=1e-10)
         else:
             assert st[x] == -1
+
+
+@pytest.mark.parametrize("g,n", [(1000, 148), (257, 7), (64, 200)])
+def test_xc_grid_passes_match_the_tensor_expressions(be, g, n):
+    """nbx_xc_density / nbx_xc_half (each stored AO array read once) against the expressions they fuse."""
+    import torch
+
+    gen = torch.Generator(device="cpu").manual_seed(g + n)
+    ao = torch.randn(g, n, dtype=torch.float64, generator=gen).to(be.device)
+    dao = torch.randn(3, g, n, dtype=torch.float64, generator=gen).to(be.device)
+    c = torch.randn(g, n, dtype=torch.float64, generator=gen).to(be.device)
+    rho, grad = ao.new_empty(g), ao.new_empty((3, g))
+    be.xc_density(ao, dao, c, rho, grad)
+    torch.testing.assert_close(rho, (c * ao).sum(dim=1), rtol=0, atol=1e-12)
+    torch.testing.assert_close(grad, 2.0 * (dao * c[None]).sum(dim=2), rtol=0, atol=1e-12)
+    # a block of a longer grid: vr and vec are views into (G,) / (3, G) arrays
+    big = g + 300
+    vr = torch.randn(big, dtype=torch.float64, generator=gen).to(be.device)
+    vec = torch.randn(3, big, dtype=torch.float64, generator=gen).to(be.device)
+    half = be.xc_half(ao, dao, vr[100:100 + g], vec[:, 100:100 + g], big, torch.empty_like(ao))
+    want = 0.5 * vr[100:100 + g, None] * ao + (vec[:, 100:100 + g, None] * dao).sum(dim=0)
+    torch.testing.assert_close(half, want, rtol=0, atol=1e-12)
