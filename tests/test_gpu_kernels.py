@@ -1117,3 +1117,23 @@ def test_xc_grid_passes_match_the_tensor_expressions(be, g, n):
     half = be.xc_half(ao, dao, vr[100:100 + g], vec[:, 100:100 + g], big, torch.empty_like(ao))
     want = 0.5 * vr[100:100 + g, None] * ao + (vec[:, 100:100 + g, None] * dao).sum(dim=0)
     torch.testing.assert_close(half, want, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [64, 65, 128, 129, 150, 151, 176, 177, 198, 199, 208, 209])
+def test_cold_eigh_across_the_register_and_lds_kernel_instances(be, n):
+    """Cold nbx_eigh (tridiagonal route) on either side of every size at which a different instance of
+    tridiag_reg_kernel / invit_lds_kernel / backtransform_reg_kernel -- or the in-memory kernel -- takes over."""
+    rng = np.random.default_rng(n)
+    mats = []
+    for x in range(3):
+        q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+        lam = np.sort(rng.uniform(-15, 6, size=n))
+        f = (q * lam) @ q.T
+        mats.append(0.5 * (f + f.T))
+    a_h = np.stack(mats)
+    w, v = be.eigh(be.asarray(a_h))
+    w_h, v_h = be.to_host(w), be.to_host(v)
+    for x in range(3):
+        np.testing.assert_allclose(w_h[x], np.linalg.eigvalsh(a_h[x]), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(v_h[x].T @ v_h[x], np.eye(n), rtol=0, atol=1e-13)
+        assert np.abs(a_h[x] @ v_h[x] - v_h[x] * w_h[x]).max() < 1e-12
