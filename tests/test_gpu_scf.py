@@ -307,3 +307,71 @@ def test_huzinaga_scf_purified_early_cycles_equal_eigensolver_cycles(be, monkeyp
     np.testing.assert_allclose(d1, d0, rtol=0, atol=1e-11)
     np.testing.assert_allclose(hz1, hz0, rtol=0, atol=1e-11)
     np.testing.assert_allclose([x[0] for x in h1], [x[0] for x in h0], rtol=0, atol=1e-9)  # the same trajectory
+
+
+def test_huzinaga_scf_purification_failures_and_a_run_ending_on_a_purified_cycle(be, monkeypatch):
+    """(1) A purified cycle that reports no gap (status -1), or an initial guess that does, makes the loop repeat
+    the run with an eigensolver in every cycle: same bits as NBED_PURIFY=0.  (2) A run that stops on a purified
+    cycle (max_cycle reached before the density settled) still returns that cycle's orbitals: the eigenpairs of
+    the X F X it left behind, consistent with its density."""
+    from nbed_amd.scf import GpuUHF, Mole, huzinaga_scf
+
+    n, nocc, n_env = 104, (12, 11), 5
+    pr = synth.problem(n, nocc, n_env)
+    eri = be.synth_eri(n)
+
+    def run(max_cycle=100):
+        mf = GpuUHF(Mole(n, pr["nelec"]), pr["S"], pr["hcore"], eri, backend=be)
+        mf.max_cycle, mf.conv_tol = max_cycle, 1e-10
+        return huzinaga_scf(mf, pr["V_emb"], pr["D_env"], dm_conv_tol=1e-9)
+
+    monkeypatch.setenv("NBED_PURIFY", "0")
+    c0, e0, d0, hz0, conv0 = run()
+    monkeypatch.setenv("NBED_PURIFY", "1")
+    orig_cycle, orig_purify = be.huz_cycle, be.purify
+
+    class NoGap:
+        def __init__(self, inner):
+            self.inner = inner
+
+        def get(self):
+            return self.inner.get()
+
+        def get_extra(self):
+            return self.inner.get_extra() * 0 - 1
+
+    seen = {"purified": 0}
+
+    def failing_cycle(h, dm_in, c_in, out, tracked, *a, **k):
+        pend = orig_cycle(h, dm_in, c_in, out, tracked, *a, **k)
+        if tracked == 2 and tracked is not True:
+            seen["purified"] += 1
+            return NoGap(pend)
+        return pend
+
+    monkeypatch.setattr(be, "huz_cycle", failing_cycle)
+    c1, e1, d1, hz1, conv1 = run()
+    assert conv1 and seen["purified"] >= 1
+    np.testing.assert_array_equal(d1, d0)
+    np.testing.assert_array_equal(e1, e0)
+    monkeypatch.setattr(be, "huz_cycle", orig_cycle)
+
+    def failing_purify(f, nocc_, max_iter=0):
+        p, st = orig_purify(f, nocc_, max_iter)
+        return p, st * 0 - 1
+
+    monkeypatch.setattr(be, "purify", failing_purify)
+    c2, e2, d2, hz2, conv2 = run()
+    assert conv2
+    np.testing.assert_array_equal(d2, d0)
+    monkeypatch.setattr(be, "purify", orig_purify)
+
+    # (2) two cycles only: both purified; the orbitals handed back are those of the last cycle's Fock matrix
+    c3, e3, d3, hz3, conv3 = run(max_cycle=2)
+    assert not conv3
+    s = pr["S"]
+    for x in range(2):
+        occ = c3[x][:, :pr["nelec"][x]]
+        np.testing.assert_allclose(occ @ occ.T, d3[x], rtol=0, atol=1e-10)       # the purified density IS C_occ C_occ^T
+        np.testing.assert_allclose(c3[x].T @ s @ c3[x], np.eye(n), rtol=0, atol=1e-10)
+        assert np.all(np.diff(e3[x]) >= -1e-12)
