@@ -477,7 +477,7 @@ int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, 
  * the SCF hot path; both one thread per grid point.
  * nbx_becke_share: d_share[g] = w_owner / sum_i w_i of Becke's cell functions (three smoothing iterations, size
  *   adjustment a_ij given by the caller) at the points d_pts (npts,3); d_centres (natm,3), d_aij and
- *   d_inv_dist = 1 / |R_i - R_j| (any finite value on the diagonal) are (natm,natm); natm <= 128.
+ *   d_inv_dist = 1 / |R_i - R_j| (any finite value on the diagonal) are (natm,natm) (kept in LDS up to 96 atoms).
  * nbx_eval_ao: values d_out (npts, ncart) and, if d_dout != NULL, gradients (3, npts, ncart) of the contracted
  *   Cartesian Gaussians x^l y^m z^n sum_k c_k exp(-a_k r^2), l + m + n <= 3.  d_shell_i (nshell,4) =
  *   {first component, components, first primitive, primitives}; d_shell_centre (nshell,3); d_comp_lmn (ncart,4)

@@ -9,6 +9,8 @@ namespace {
 
 // share[g] = w_owner(r_g) / sum_i w_i(r_g),  w_i = prod_{j != i} s(mu_ij),  mu_ij = (r_i - r_j) / R_ij,
 // nu = mu + a_ij (1 - mu^2), s = (1 - p(p(p(nu)))) / 2, p(x) = (3 x - x^3) / 2          (Becke, JCP 88, 2547)
+// TABLES_IN_LDS: the two (natm x natm) tables fit the LDS (natm <= 96); otherwise they are read from L2
+template <bool TABLES_IN_LDS>
 __global__ __launch_bounds__(256) void becke_share_kernel(int64_t npts, const double* __restrict__ pts, int natm,
                                                           const double* __restrict__ centres,
                                                           const double* __restrict__ aij,
@@ -16,12 +18,18 @@ __global__ __launch_bounds__(256) void becke_share_kernel(int64_t npts, const do
                                                           double* __restrict__ share) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* cs = smem;                 // [natm][3]
-    double* as = cs + 3 * natm;        // [natm][natm]
-    double* rs = as + natm * natm;     // [natm][natm]
+    const double* as = aij;            // [natm][natm]
+    const double* rs = inv_dist;       // [natm][natm]
     for (int i = threadIdx.x; i < 3 * natm; i += blockDim.x) cs[i] = centres[i];
-    for (int i = threadIdx.x; i < natm * natm; i += blockDim.x) {
-        as[i] = aij[i];
-        rs[i] = inv_dist[i];
+    if (TABLES_IN_LDS) {
+        double* as_l = cs + 3 * natm;
+        double* rs_l = as_l + natm * natm;
+        for (int i = threadIdx.x; i < natm * natm; i += blockDim.x) {
+            as_l[i] = aij[i];
+            rs_l[i] = inv_dist[i];
+        }
+        as = as_l;
+        rs = rs_l;
     }
     __syncthreads();
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,17 +117,23 @@ __global__ __launch_bounds__(256) void eval_ao_kernel(int64_t npts, const double
 extern "C" int nbx_becke_share(nbx_ctx* ctx, int64_t npts, const double* d_pts, int64_t natm, const double* d_centres,
                                const double* d_aij, const double* d_inv_dist, int64_t owner, double* d_share) {
     NBX_CHECK_ARG(ctx && d_pts && d_centres && d_aij && d_inv_dist && d_share && npts >= 0);
-    NBX_CHECK_ARG(natm >= 1 && natm <= 128 && owner >= 0 && owner < natm);  // (3 natm + 2 natm^2 doubles of LDS)
+    NBX_CHECK_ARG(natm >= 1 && natm <= 4096 && owner >= 0 && owner < natm);
     if (npts == 0) return NBX_OK;
-    const size_t lds = (size_t)(3 * natm + 2 * natm * natm) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&becke_share_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    const dim3 grid((unsigned)nbx_cdiv(npts, 256));
+    if (natm <= 96) {  // 3 natm + 2 natm^2 doubles of LDS (<= 148 KB)
+        const size_t lds = (size_t)(3 * natm + 2 * natm * natm) * sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&becke_share_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(becke_share_kernel<true>, grid, dim3(256), lds, ctx->stream, npts, d_pts, (int)natm,
+                           d_centres, d_aij, d_inv_dist, (int)owner, d_share);
+    } else {
+        hipLaunchKernelGGL(becke_share_kernel<false>, grid, dim3(256), (size_t)(3 * natm) * sizeof(double), ctx->stream,
+                           npts, d_pts, (int)natm, d_centres, d_aij, d_inv_dist, (int)owner, d_share);
     }
-    hipLaunchKernelGGL(becke_share_kernel, dim3((unsigned)nbx_cdiv(npts, 256)), dim3(256), lds, ctx->stream, npts, d_pts,
-                       (int)natm, d_centres, d_aij, d_inv_dist, (int)owner, d_share);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

@@ -151,3 +151,30 @@ def test_grid_kernels_match_the_host_expressions(be, basis):
         f_d = (w_d * np.exp(-alpha * ((p_d - centre) ** 2).sum(axis=1))).sum()
         assert abs(f_d - f_h) < 1e-12 * abs(f_h)
         assert abs(f_h - (np.pi / alpha) ** 1.5) < 1e-4 * f_h  # (a coarse grid: 40 x 12)
+
+
+@pytest.mark.parametrize("natm", [3, 96, 100])
+def test_becke_share_kernel_against_the_formula(be, natm):
+    """nbx_becke_share on either side of the size at which its atom-pair tables leave LDS, against numpy."""
+    rng = np.random.default_rng(natm)
+    centres = rng.uniform(-6, 6, size=(natm, 3))
+    pts = rng.uniform(-7, 7, size=(300, 3))
+    chi = rng.uniform(0.5, 2.0, size=natm)
+    chi = chi[:, None] / chi[None, :]
+    uab = (chi - 1.0) / (chi + 1.0)
+    aij = np.clip(uab / (uab * uab - 1.0), -0.5, 0.5)
+    np.fill_diagonal(aij, 0.0)
+    dist = np.linalg.norm(centres[:, None] - centres[None], axis=-1)
+    inv = 1.0 / (dist + np.eye(natm))
+    rg = np.linalg.norm(pts[:, None, :] - centres[None], axis=-1)
+    mu = (rg[:, :, None] - rg[:, None, :]) * inv[None]
+    f = mu + aij[None] * (1.0 - mu * mu)
+    for _ in range(3):
+        f = 1.5 * f - 0.5 * f**3
+    s = 0.5 * (1.0 - f)
+    s[:, np.arange(natm), np.arange(natm)] = 1.0
+    cell = s.prod(axis=2)
+    for owner in (0, natm - 1):
+        want = cell[:, owner] / cell.sum(axis=1)
+        got = be.to_host(be.becke_share(be.asarray(pts), be.asarray(centres), be.asarray(aij), be.asarray(inv), owner))
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-13)
