@@ -766,6 +766,8 @@ class HipBackend:
             shell_i.append([int(ao0), len(sh.cart), k0, len(sh.exps)])
             centre.append([float(x) for x in sh.centre])
             for ic, lmn in enumerate(sh.cart):
+                if max(lmn) > 3:
+                    raise ValueError("nbx_eval_ao covers s, p, d and f shells")
                 comp.append([int(lmn[0]), int(lmn[1]), int(lmn[2]), len(coefs)])
                 coefs.extend(float(c) for c in sh.coefs[ic])
         assert len(comp) == basis.nao_cart
