@@ -203,6 +203,30 @@ class HipBackend:
                 ev.synchronize()  # the pinned buffers are about to be released
         return out.reshape(tuple(h.shape))
 
+    def asarray_many(self, arrays):
+        """Several small host arrays -> device arrays with ONE copy (a pageable upload costs ~50 us whatever its
+        size below a megabyte: an SCF that starts with four of them waits 0.2 ms for nothing)."""
+        hs = [np.ascontiguousarray(a, dtype=np.float64) for a in arrays]
+        starts, total = [], 0
+        for h in hs:  # every array starts on a 256-byte boundary, like an allocation of its own
+            starts.append(total)
+            total += (h.size + 31) & ~31
+        stage = np.zeros(total)
+        for h, o in zip(hs, starts):
+            stage[o:o + h.size] = h.reshape(-1)
+        flat = self.torch.from_numpy(stage).to(self.device)
+        return [flat[o:o + h.size].view(h.shape) for h, o in zip(hs, starts)]
+
+    def to_host_many(self, tensors):
+        """Several small device arrays -> host arrays with ONE copy (and one wait)."""
+        torch = self.torch
+        flat = torch.cat([t.reshape(-1) for t in tensors]).cpu().numpy()
+        out, off = [], 0
+        for t in tensors:
+            out.append(flat[off:off + t.numel()].reshape(tuple(t.shape)).copy())
+            off += t.numel()
+        return out
+
     def to_host(self, a) -> np.ndarray:
         if isinstance(a, self.torch.Tensor):
             if a.is_cuda and a.dtype == self.torch.float64 and a.numel() >= (1 << 26):

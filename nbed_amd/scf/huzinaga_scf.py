@@ -189,14 +189,33 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         x_d = be.sym_pow_fast(s_d, -0.5, s_h) if hasattr(be, "sym_pow_fast") else be.sym_pow(s_d, -0.5)
     adiis = DIIS(be) if use_DIIS else None
 
-    ds_occ = be.gemm(_as3(be, dm_environment_occupied), s_d)
-    ds_virt = None
-    if dm_environment_virtual is not None:
-        ds_virt = be.gemm(_as3(be, dm_environment_virtual), s_d)
-
     hcore_h = np.asarray(scf_method.get_hcore())
-    hcore_d = be.asarray(hcore_h)
-    vemb_d = be.asarray(embedding_potential)
+    if hasattr(be, "asarray_many"):  # one upload for the call's inputs
+        up = [np.asarray(dm_environment_occupied), hcore_h, embedding_potential]
+        if dm_environment_virtual is not None:
+            up.append(np.asarray(dm_environment_virtual))
+        up = be.asarray_many(up)
+        dm_occ_d, hcore_d, vemb_d = up[:3]
+        dm_virt_d = up[3] if dm_environment_virtual is not None else None
+    else:
+        dm_occ_d, hcore_d, vemb_d = (be.asarray(np.asarray(a)) for a in (dm_environment_occupied, hcore_h,
+                                                                         embedding_potential))
+        dm_virt_d = be.asarray(np.asarray(dm_environment_virtual)) if dm_environment_virtual is not None else None
+
+    def batch3(d):
+        return d if d.dim() == 3 else d.reshape(1, *d.shape)
+
+    def overlap_per_spin():
+        """S once per spin on the device (for the tracked solver): from the resident copy, not a second upload."""
+        if hasattr(be, "torch") and isinstance(s_d, be.torch.Tensor):
+            return be.torch.stack([s_d] * nb).contiguous()
+        return be.asarray(np.stack([s_h] * nb))
+
+    ds_occ = be.gemm(batch3(dm_occ_d), s_d)
+    ds_virt = None
+    if dm_virt_d is not None:
+        ds_virt = be.gemm(batch3(dm_virt_d), s_d)
+
     # h + V_emb broadcast to the batch shape (:139,157)
     hv = be.zeros((nb,) + s_h.shape)
     for x in range(nb):
@@ -212,7 +231,7 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         if warm["tracked"] and warm["c"] is not None:
             # refine (eps, C) of the previous cycle on the pencil (F, S) directly
             if s_b is None:
-                s_b = be.asarray(np.stack([s_h] * nb))
+                s_b = overlap_per_spin()
             e_d, c_new = be.geig_refine(fock3, s_b, warm["c"], refine_iters=warm["iters"])
             warm["c"] = c_new
             return e_d, c_new
@@ -237,7 +256,7 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
     # everything the loop will need from the host goes up now: an upload inside the loop waits for
     # the cycles queued ahead of it and leaves the GPU idle while the host catches up
     if can_track and allow_tracked:
-        s_b = be.asarray(np.stack([s_h] * nb))
+        s_b = overlap_per_spin()
     if adiis is not None and hasattr(adiis, "reserve"):
         adiis.reserve(nb * s_h.shape[0] * s_h.shape[1])
 
@@ -354,7 +373,7 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
 
     if use_cycle_call:
         if s_b is None:
-            s_b = be.asarray(np.stack([s_h] * nb))
+            s_b = overlap_per_spin()
         hstate = be.huz_cycle_state(s_h.shape[0], scf_method.mol.nelec, scf_method.eri_packed_device(), hv, ds_occ,
                                     s_b, x_d, dts_d)
         diis_state = {"first": True, "head": 0, "nd": 0, "space": 6}
@@ -475,15 +494,13 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
                 # the run ended on a purified cycle: its orbitals now, from the X F X it left behind (:166-169)
                 mo_energy_d, v_d = be.eigh(result["state"][8])
                 c_d = be.gemm(x_d, v_d)
-            mo_energy_h = be.to_host(mo_energy_d)
+            mo_energy_h = mo_energy_d  # (still on the device: it travels with the other results below)
 
     if conv_flag is False:
         logger.warning("Huzinaga SCF has NOT converged.")
 
-    return (
-        unbatch(be.to_host(c_d)),
-        unbatch(mo_energy_h),
-        unbatch(be.to_host(dm_d)),
-        unbatch(be.to_host(hz)),
-        conv_flag,
-    )
+    if hasattr(be, "to_host_many") and all(isinstance(a, be.torch.Tensor) for a in (c_d, mo_energy_h, dm_d, hz)):
+        c_h, mo_energy_h, dm_h, hz_h = be.to_host_many([c_d, mo_energy_h, dm_d, hz])  # one copy, one wait
+    else:
+        c_h, mo_energy_h, dm_h, hz_h = (be.to_host(a) for a in (c_d, mo_energy_h, dm_d, hz))
+    return unbatch(c_h), unbatch(mo_energy_h), unbatch(dm_h), unbatch(hz_h), conv_flag
