@@ -220,7 +220,13 @@ class HipBackend:
     def to_host_many(self, tensors):
         """Several small device arrays -> host arrays with ONE copy (and one wait)."""
         torch = self.torch
-        flat = torch.cat([t.reshape(-1) for t in tensors]).cpu().numpy()
+        total = sum(int(t.numel()) for t in tensors)
+        pin = getattr(self, "_pin_results", None)  # (a pageable destination costs a staging copy per call)
+        if pin is None or pin.numel() < total:
+            pin = self._pin_results = torch.empty(max(total, 1 << 17), dtype=torch.float64, pin_memory=True)
+        pin[:total].copy_(torch.cat([t.reshape(-1) for t in tensors]), non_blocking=True)
+        torch.cuda.current_stream(self.device_index).synchronize()
+        flat = pin[:total].numpy()
         out, off = [], 0
         for t in tensors:
             out.append(flat[off:off + t.numel()].reshape(tuple(t.shape)).copy())
