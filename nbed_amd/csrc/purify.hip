@@ -21,6 +21,7 @@
 namespace {
 
 constexpr int PUR_THREADS = 256;
+constexpr int PUR_ALL = 49;  // MFMA steps (4 k each) of a purification step whose operands are requested at once: N <= 196
 constexpr int PUR_MAX_ITER = 72;  // (also the stride of the trace log)
 constexpr double PUR_IDEM = 2.0e-12;  // tr(P - P^2) of the step before below this (a step squares the error on one
                                       // side of the gap and doubles it on the other: the result is good to ~2x this)
@@ -35,9 +36,12 @@ __global__ __launch_bounds__(PUR_THREADS) void pur_init_kernel(int N, const doub
     P += b * n2;
     double mn = 1.0e300, mx = -1.0e300;
     for (int i = threadIdx.x; i < N; i += PUR_THREADS) {
+        // the COLUMN discs (Gershgorin holds for them as for the rows, and F is symmetric to rounding anyway):
+        // consecutive threads read consecutive addresses, where the row sums were a stride-N walk per thread
         double r = 0.0;
         const double d = F[(int64_t)i * N + i];
-        for (int j = 0; j < N; ++j) r += (j == i) ? 0.0 : fabs(F[(int64_t)i * N + j]);
+#pragma unroll 4
+        for (int j = 0; j < N; ++j) r += (j == i) ? 0.0 : fabs(F[(int64_t)j * N + i]);
         mn = fmin(mn, d - r);
         mx = fmax(mx, d + r);
     }
@@ -53,10 +57,11 @@ __global__ __launch_bounds__(PUR_THREADS) void pur_init_kernel(int N, const doub
     }
     const double lmin = lo[0], lmax = hi[0];
     const double inv = 1.0 / (lmax - lmin);
-    for (int64_t e = threadIdx.x; e < n2; e += PUR_THREADS) {
-        const int i = (int)(e / N), j = (int)(e - (int64_t)i * N);
-        P[e] = ((i == j ? lmax : 0.0) - F[e]) * inv;
-    }
+    for (int i = threadIdx.x >> 6; i < N; i += PUR_THREADS >> 6)  // a wave per row: no index division
+        for (int j = threadIdx.x & 63; j < N; j += 64) {
+            const int64_t e = (int64_t)i * N + j;
+            P[e] = ((i == j ? lmax : 0.0) - F[e]) * inv;
+        }
     if (threadIdx.x == 0) status[b] = (lmax > lmin && isfinite(inv)) ? 0 : -2;
 }
 
@@ -82,6 +87,26 @@ __global__ __launch_bounds__(64) void pur_step_kernel(int N, const double* __res
     const int lane = threadIdx.x, fr = lane & 15, fk = lane >> 4;
     double t = 0.0;
     for (int i = lane; i < N; i += 64) t += cur[(int64_t)i * N + i];
+    // N <= 196: the operands of the whole product are requested NOW, behind the diagonal (loads return in order: the
+    // trace below does not wait for them) -- a step is then two memory latencies (status word, everything else)
+    // where the 16-wide trips of the general loop below were ten
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    const int col = j0 + fr;
+    const int row_a = i0 + fr;
+    const bool a_ok = row_a < N, b_ok = col < N;
+    const double* ap = cur + (int64_t)(a_ok ? row_a : 0) * N;  // A[row][k]: consecutive k
+    const double* bp = cur + (b_ok ? col : 0);                 // B[k][col]: stride N
+    const bool all_at_once = N <= 4 * PUR_ALL;
+    double av[PUR_ALL], bv[PUR_ALL];
+    if (all_at_once) {
+#pragma unroll
+        for (int j = 0; j < PUR_ALL; ++j) {
+            const int k = 4 * j + fk;
+            const bool in = k < N;
+            av[j] = (in && a_ok) ? ap[k] : 0.0;
+            bv[j] = (in && b_ok) ? bp[(int64_t)k * N] : 0.0;
+        }
+    }
     t = nbx_wave_sum(t);
     const double nocc = (double)(b == 0 ? nocc_a : nocc_b);
     const bool first_tile = blockIdx.x == 0 && blockIdx.y == 0;
@@ -96,8 +121,6 @@ __global__ __launch_bounds__(64) void pur_step_kernel(int N, const double* __res
         if (done) status[b] = iter + 1;
         else if (!finite || iter == max_iter - 1) status[b] = -1;
     }
-    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
-    const int col = j0 + fr;
     if (done) {
         if (col < N)
 #pragma unroll
@@ -108,14 +131,15 @@ __global__ __launch_bounds__(64) void pur_step_kernel(int N, const double* __res
         return;
     }
     const bool square = t > nocc;
-    const int row_a = i0 + fr;
-    const bool a_ok = row_a < N, b_ok = col < N;
-    const double* ap = cur + (int64_t)(a_ok ? row_a : 0) * N;  // A[row][k]: consecutive k
-    const double* bp = cur + (b_ok ? col : 0);                 // B[k][col]: stride N
     pur_v4 acc = (pur_v4){0.0, 0.0, 0.0, 0.0};
-    const int kfull = N & ~15;
+    if (all_at_once) {  // (steps past N multiply zeros)
+#pragma unroll
+        for (int j = 0; j < PUR_ALL; ++j)
+            if (4 * j < N) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j], acc, 0, 0, 0);
+    }
+    const int kfull = all_at_once ? 0 : (N & ~15);
     for (int k0 = 0; k0 < kfull; k0 += 16) {
-        double av[4], bv[4];
+        double av[4], bv[4];  // (shadow the single-trip arrays)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             av[j] = ap[k0 + 4 * j + fk];
@@ -125,7 +149,7 @@ __global__ __launch_bounds__(64) void pur_step_kernel(int N, const double* __res
         for (int j = 0; j < 4; ++j)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_ok ? av[j] : 0.0, b_ok ? bv[j] : 0.0, acc, 0, 0, 0);
     }
-    if (kfull < N) {
+    if (!all_at_once && kfull < N) {
         double av[4], bv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
