@@ -375,3 +375,28 @@ def test_huzinaga_scf_purification_failures_and_a_run_ending_on_a_purified_cycle
         np.testing.assert_allclose(occ @ occ.T, d3[x], rtol=0, atol=1e-10)       # the purified density IS C_occ C_occ^T
         np.testing.assert_allclose(c3[x].T @ s @ c3[x], np.eye(n), rtol=0, atol=1e-10)
         assert np.all(np.diff(e3[x]) >= -1e-12)
+
+
+@pytest.mark.parametrize("nocc,n_env", [((3, 1), 1), ((1, 0), 0)])
+def test_huzinaga_scf_purified_cycles_with_an_empty_spin_channel(be, monkeypatch, nocc, n_env):
+    """No beta electron in the active system: the purified cycles (projector of rank zero for that spin) give the
+    eigensolver-only run's numbers."""
+    from nbed_amd.scf import GpuUHF, Mole, huzinaga_scf
+
+    n = 104
+    pr = synth.problem(n, nocc, n_env)
+    assert pr["nelec"][1] == 0
+    eri = be.synth_eri(n)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NBED_PURIFY", mode)
+        mf = GpuUHF(Mole(n, pr["nelec"]), pr["S"], pr["hcore"], eri, backend=be)
+        mf.max_cycle, mf.conv_tol = 100, 1e-10
+        hist = []
+        out[mode] = (huzinaga_scf(mf, pr["V_emb"], pr["D_env"], dm_conv_tol=1e-9, history=hist), len(hist))
+    (c0, e0, d0, hz0, conv0), n0 = out["0"]
+    (c1, e1, d1, hz1, conv1), n1 = out["1"]
+    assert conv0 and conv1 and n0 == n1
+    np.testing.assert_allclose(d1, d0, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(e1, e0, rtol=0, atol=1e-11)
+    assert np.abs(d1[1]).max() < 1e-20  # (squared down to ~1e-33 by the purification, exactly 0 from the eigenvectors)
