@@ -441,7 +441,7 @@ int nbx_spinorb_scatter_range(nbx_ctx* ctx, int64_t n, const double* d_two_body,
  *          eigensolver's two status words; complete once the stream has passed this call.            */
 typedef struct nbx_huz_state {
     int64_t nao, nocc_a, nocc_b;
-    const double* d_packed; /* nbx_eri_pack of the whole tensor */
+    const double* d_packed; /* nbx_eri_pack of the whole tensor / of this rank's slab (NBX_HUZ_JK_PACKED) */
     const double* d_hv;     /* (2,N,N) hcore + V_emb */
     const double* d_ds;     /* (2,N,N) D_env S */
     const double* d_sb;     /* (2,N,N) the overlap, once per spin (tracked mode) */
@@ -454,7 +454,7 @@ typedef struct nbx_huz_state {
     double* d_tmp;          /* (2,N,N) guarded mode */
     double* d_fo;           /* (2,N,N) guarded mode */
     void* d_jk_work;
-    size_t jk_work_bytes;   /* nbx_jk_packed_worksize(nao, 0, nao, 2) */
+    size_t jk_work_bytes;   /* nbx_jk_packed_worksize / nbx_jk_dense_sym_worksize (nao, p0, p1, 2) */
     void* d_eig_work;
     size_t eig_work_bytes;  /* nbx_eigh_worksize(nao, 2) */
     void* d_geig_work;
@@ -465,11 +465,30 @@ typedef struct nbx_huz_state {
     double* d_diis_h;       /* (space+1)^2, initialised by the caller (row/column 0 = 1) */
     double* d_diis_coef;
     double* d_diis_xprev;   /* 2 N^2 */
+    /* which J/K kernel builds the Fock matrix, and on which rows of (pq|rs) */
+    int64_t jk_kind;        /* NBX_HUZ_JK_PACKED: d_packed (nbx_jk_packed[_fock]); NBX_HUZ_JK_SYM: d_eri, the dense
+                               tensor / row slab (nbx_jk_dense_sym: every N, falls to nbx_jk_dense inside) */
+    int64_t jk_p0, jk_p1;   /* this rank's slab rows [p0, p1) of the first AO index; 0, 0 = the whole tensor */
+    const double* d_eri;    /* NBX_HUZ_JK_SYM: slab rows [p0, p1) of the dense (N,N,N,N) tensor */
 } nbx_huz_state;
+#define NBX_HUZ_JK_PACKED 0
+#define NBX_HUZ_JK_SYM 1
 int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, const double* d_c_in,
                   double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out, double* d_hz_out, int mode,
                   int refine_iters, int diis_mode, int diis_slot, int diis_nd, int dts_ready, double* h_out,
                   int* d_status_out);
+/* The same cycle in two calls for runs over several GPUs (one process per GPU): the J/K
+ * contribution of this rank's slab of (pq|rs) rows into st->d_jk ((3,N,N), additive over slabs) --
+ *     nbx_huz_cycle_jk;   all-reduce (sum) of st->d_jk queued on the same stream by the caller (RCCL);
+ *     nbx_huz_cycle_post: Fock assembly from the summed J/K (nbx_fock_uhf) and the rest of the cycle exactly
+ * as nbx_huz_cycle queues it -- so every rank keeps the one-cycle look-ahead, the purified early cycles and the
+ * tracked eigensolver, and (the replicated part being deterministic) holds bitwise the same matrices.
+ * nbx_huz_cycle itself takes this route, without the collective, whenever the state is not "packed kernel on the
+ * whole tensor" (N < 100, sizes without a packed instance: NBX_HUZ_JK_SYM).  st->d_dts is not used by _jk. */
+int nbx_huz_cycle_jk(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in);
+int nbx_huz_cycle_post(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, const double* d_c_in,
+                       double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out, double* d_hz_out, int mode,
+                       int refine_iters, int diis_mode, int diis_slot, int diis_nd, double* h_out, int* d_status_out);
 
 /* ------------------------------------------------------------------ quadrature grid producers
  * What the reference gets from PySCF behind scf.UKS(...) (nbed/driver.py:86-104,315-431): `dft.gen_grid`'s Becke
@@ -503,7 +522,8 @@ int nbx_xc_half(nbx_ctx* ctx, int64_t npts, int64_t nao, const double* d_ao, con
  * basis), i.e. C_occ C_occ^T of `eigh` + aufbau occupation (nbed/scf/huzinaga_scf.py:166-174) without the
  * eigenvectors: trace-correcting purification (SP2), one (n x n) product per step, everything decided on
  * the device.  For SCF cycles whose Fock matrix still moves too much for a warm-started eigensolver.
- *   nocc_a, nocc_b : occupied levels of matrix 0 and of the others (batch = 2: alpha, beta)
+ *   nocc_a, nocc_b : occupied levels of matrix 0 and of the others (batch = 2: alpha, beta); a batch of more
+ *                    than two needs nocc_a == nocc_b (NBX_E_INVALID otherwise)
  *   d_p            : out (batch, n, n)
  *   d_work         : nbx_purify_worksize() bytes;  max_iter <= 0: the limit (72 steps)
  *   d_status[b]    : > 0 steps taken; < 0 no gap between levels nocc and nocc + 1 was resolved (or the

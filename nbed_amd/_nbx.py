@@ -22,6 +22,8 @@ NBX_E_NOMEM = -3
 NBX_E_NOCONV = -4
 NBX_E_UNSUPPORTED = -5
 
+HUZ_JK_PACKED, HUZ_JK_SYM = 0, 1
+
 PROF_JK_DENSE, PROF_AO2MO_Q1, PROF_AO2MO, PROF_EIGH, PROF_SVD, PROF_GEMM = range(6)
 
 
@@ -50,6 +52,7 @@ class HuzState(ctypes.Structure):
         ("d_geig_work", c_void_p), ("geig_work_bytes", c_size_t),
         ("diis_space", c_int64), ("d_diis_xs", c_void_p), ("d_diis_es", c_void_p), ("d_diis_h", c_void_p),
         ("d_diis_coef", c_void_p), ("d_diis_xprev", c_void_p),
+        ("jk_kind", c_int64), ("jk_p0", c_int64), ("jk_p1", c_int64), ("d_eri", c_void_p),
     ]
 
 
@@ -155,6 +158,9 @@ SIGNATURES = {
     "nbx_host_eri": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_double, c_int, _P]),
     "nbx_huz_cycle": (c_int, [_P, POINTER(HuzState), _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                               c_int, _P, _P]),
+    "nbx_huz_cycle_jk": (c_int, [_P, POINTER(HuzState), _P]),
+    "nbx_huz_cycle_post": (c_int, [_P, POINTER(HuzState), _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                   _P, _P]),
 }
 
 _lib = None

@@ -585,25 +585,39 @@ class HipBackend:
         return _PendingScalars(self.torch, None, ntail, host=h_out)
 
     # ------------------------------------------------------------------ fused SCF cycle (one call per cycle)
-    def huz_cycle_state(self, nao, nelec, packed, hv, ds, s_b, x, dts, diis_space: int = 6):
+    def huz_cycle_state(self, nao, nelec, packed, hv, ds, s_b, x, dts, diis_space: int = 6, eri=None, p0: int = 0,
+                        p1: int | None = None):
         """Everything one Huzinaga SCF keeps on the device for ``huz_cycle``: the state block of
         ``nbx_huz_cycle`` (workspaces, scratch matrices, the DIIS ring with its Pulay matrix) and three
         rotating sets of per-cycle results (the loop runs one cycle ahead and may hand back the cycle
-        before the last).  Returns a small holder object."""
+        before the last).  Returns a small holder object.
+
+        The J/K build of a cycle runs on ``packed`` (nbx_eri_pack of the rows [p0, p1) of the first AO index:
+        the packed kernel) or, with ``packed`` None, on ``eri`` (those rows of the dense tensor: the symmetric
+        kernel, every N); [p0, p1) = the whole range unless this rank holds a slab."""
         torch, lib = self.torch, self.lib
         n = int(nao)
         nsq = 2 * n * n
+        p1 = n if p1 is None else int(p1)
+        p0 = int(p0)
+        if packed is None and eri is None and p1 > p0:
+            raise ValueError("huz_cycle_state: the packed tiles or the dense (pq|rs) slab are needed")
 
         class Holder:
             pass
 
         h = Holder()
         h.n, h.nelec = n, (int(nelec[0]), int(nelec[1]))
-        h.keep = [packed, hv, ds, s_b, x, dts]
+        h.keep = [packed, eri, hv, ds, s_b, x, dts]
         h.jk = self.empty((3, n, n))
         h.fock, h.vhf, h.fock2, h.tmp, h.fo = (self.empty((2, n, n)) for _ in range(5))
-        h.jk_work = torch.empty(max(int(lib.nbx_jk_packed_worksize(n, 0, n, 2)), 256), dtype=torch.uint8, device=self.device)
-        h.eig_work = torch.empty(max(int(lib.nbx_eigh_worksize(n, 2)), 256), dtype=torch.uint8, device=self.device)
+        if packed is not None:
+            jk_bytes = int(lib.nbx_jk_packed_worksize(n, p0, p1, 2))
+        else:
+            jk_bytes = int(lib.nbx_jk_dense_sym_worksize(n, p0, p1, 2))
+        h.jk_work = torch.empty(max(jk_bytes, 256), dtype=torch.uint8, device=self.device)
+        eig_bytes = max(int(lib.nbx_eigh_worksize(n, 2)), int(lib.nbx_purify_worksize(n, 2)))
+        h.eig_work = torch.empty(max(eig_bytes, 256), dtype=torch.uint8, device=self.device)
         h.geig_work = torch.empty(max(int(lib.nbx_geig_refine_worksize(n, 2)), 256), dtype=torch.uint8, device=self.device)
         h.diis_xs, h.diis_es = self.empty((diis_space, nsq)), self.empty((diis_space, nsq))
         hm = np.zeros((diis_space + 1, diis_space + 1))
@@ -620,25 +634,40 @@ class HipBackend:
                         ("d_jk", h.jk), ("d_fock", h.fock), ("d_vhf", h.vhf), ("d_fock2", h.fock2), ("d_tmp", h.tmp),
                         ("d_fo", h.fo), ("d_jk_work", h.jk_work), ("d_eig_work", h.eig_work),
                         ("d_geig_work", h.geig_work), ("d_diis_xs", h.diis_xs), ("d_diis_es", h.diis_es),
-                        ("d_diis_h", h.diis_h), ("d_diis_coef", h.diis_coef), ("d_diis_xprev", h.diis_xprev)):
-            setattr(st, name, t.data_ptr() if t is not None else None)
+                        ("d_diis_h", h.diis_h), ("d_diis_coef", h.diis_coef), ("d_diis_xprev", h.diis_xprev),
+                        ("d_eri", eri if packed is None else None)):
+            setattr(st, name, (t.data_ptr() or None) if t is not None else None)
         st.jk_work_bytes, st.eig_work_bytes, st.geig_work_bytes = h.jk_work.numel(), h.eig_work.numel(), h.geig_work.numel()
         st.diis_space = diis_space
+        st.jk_kind = _nbx.HUZ_JK_PACKED if packed is not None else _nbx.HUZ_JK_SYM
+        st.jk_p0, st.jk_p1 = p0, p1
         h.st = st
         return h
 
     def huz_cycle(self, h, dm_in, c_in, out, tracked: bool, refine_iters: int, diis_mode: int, diis_slot: int,
-                  diis_nd: int, dts_ready: bool):
+                  diis_nd: int, dts_ready: bool, reduce=None):
         """Queue one SCF cycle (nbx_huz_cycle) writing into the result set ``out``; returns the handle of
         its scalars + status words (read one cycle late, like ``huz_cycle_scalars_async``).  ``tracked``:
         False / 0 guarded eigensolve, True / 1 tracked refinement, 2 density by purification (``refine_iters``
-        then caps its steps; no orbitals are written)."""
+        then caps its steps; no orbitals are written).
+
+        ``reduce``: for a run over several ranks -- a callable that sums the ranks' (3,N,N) J/K partials in
+        place with a collective queued on this stream (``Shards.all_reduce``); the cycle is then two C calls
+        around it (nbx_huz_cycle_jk, nbx_huz_cycle_post), with the same look-ahead as the one-rank cycle."""
         h_out = self._pin_ring[self._pin_next][:6]
         self._pin_next = (self._pin_next + 1) % self._PIN_SLOTS
-        self._call("nbx_huz_cycle", ctypes.byref(h.st), self._p(dm_in), self._p(c_in), self._p(out["dm"]),
-                   self._p(out["c"]), self._p(out["v"]), self._p(out["w"]), self._p(out["hz"]), int(tracked),
-                   int(refine_iters), int(diis_mode), int(diis_slot), int(diis_nd), 1 if dts_ready else 0,
-                   self._p(h_out), self._p(out["status"]))
+        if reduce is None:
+            self._call("nbx_huz_cycle", ctypes.byref(h.st), self._p(dm_in), self._p(c_in), self._p(out["dm"]),
+                       self._p(out["c"]), self._p(out["v"]), self._p(out["w"]), self._p(out["hz"]), int(tracked),
+                       int(refine_iters), int(diis_mode), int(diis_slot), int(diis_nd), 1 if dts_ready else 0,
+                       self._p(h_out), self._p(out["status"]))
+        else:
+            self._call("nbx_huz_cycle_jk", ctypes.byref(h.st), self._p(dm_in))
+            reduce(h.jk)
+            self._call("nbx_huz_cycle_post", ctypes.byref(h.st), self._p(dm_in), self._p(c_in), self._p(out["dm"]),
+                       self._p(out["c"]), self._p(out["v"]), self._p(out["w"]), self._p(out["hz"]), int(tracked),
+                       int(refine_iters), int(diis_mode), int(diis_slot), int(diis_nd), self._p(h_out),
+                       self._p(out["status"]))
         return _PendingScalars(self.torch, None, 2, host=h_out)
 
     def async_to_host(self, d_vals):
@@ -816,6 +845,8 @@ class HipBackend:
         f = f if f.dim() == 3 else f.reshape(1, *f.shape)
         batch, n = int(f.shape[0]), int(f.shape[-1])
         nocc = [int(nocc)] * 2 if np.isscalar(nocc) else [int(x) for x in nocc]
+        if len(nocc) not in (1, 2, batch) or (len(nocc) > 2 and len(set(nocc)) > 1) or (batch > 2 and len(set(nocc)) > 1):
+            raise ValueError("purify: one occupation per matrix; batches of more than two need equal occupations")
         p = torch.empty_like(f)
         status = torch.zeros(batch, dtype=torch.int32, device=self.device)
         nbytes = int(self.lib.nbx_purify_worksize(n, batch))

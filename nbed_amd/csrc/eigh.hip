@@ -329,17 +329,19 @@ extern "C" int nbx_eigh_warm_ex(nbx_ctx* ctx, int64_t n, int64_t batch, const do
     NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
     if (nbx_eigh_lds_supported(n)) {
         if (d_v0 == nullptr && eigh_cold_tridiag(n)) {
-            std::vector<double> q((size_t)batch, 0.0);
-            int rc = nbx_eigh_tridiag(ctx, n, batch, d_a, d_w, d_v, d_work, nbx_eigh_tridiag_worksize(n, batch), q.data());
-            if (rc != NBX_OK) return rc;
-            double worst = 0.0;
-            for (double v : q) worst = v > worst ? v : worst;
-            if (worst <= 1.0e-13) {  // accepted: "1 sweep" in the status words the LDS solver would have written
-                std::vector<int> ones((size_t)batch, 1);
-                return nbx_memcpy_h2d(ctx, const_cast<int*>(nbx_eigh_lds_status_ptr(n, batch, d_work)), ones.data(),
-                                      (size_t)batch * sizeof(int));
+            // Verdict and fallback on the device (this call sits inside queued SCF cycles -- nbx_huz_cycle -- and on
+            // side streams: it must not wait for the host).  The tridiagonal route leaves 1 ("one sweep") in the
+            // status word of every matrix it delivered to 1e-13, 0 otherwise (clustered spectrum the inverse
+            // iteration did not resolve, NaN); the Jacobi solver is queued behind it from scratch, skipping the
+            // delivered ones.  Its status words lie beyond the tridiagonal route's workspace.
+            int* status = const_cast<int*>(nbx_eigh_lds_status_ptr(n, batch, d_work));
+            int* skip = nbx_eigh_lds_skip_ptr(n, batch, d_work);
+            const size_t td = nbx_eigh_tridiag_worksize(n, batch);
+            if (nbx_eigh_lds_status_offset(n, batch) >= td) {
+                int rc = nbx_eigh_tridiag_dev(ctx, n, batch, d_a, d_w, d_v, d_work, td, status, skip);
+                if (rc != NBX_OK) return rc;
+                return nbx_eigh_lds(ctx, n, batch, d_a, nullptr, d_w, d_v, d_work, work_bytes, refine_iters, skip);
             }
-            // clustered spectrum the inverse iteration did not resolve (also NaN): the Jacobi solver, from scratch
         }
         return nbx_eigh_lds(ctx, n, batch, d_a, d_v0, d_w, d_v, d_work, work_bytes, refine_iters);
     }

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64) void eigh_apply_rot_kernel(const double* __rest
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct LdsLayout {
-    size_t rot_off, flag_off, nsteps_off, rank_off, status_off, a0_off, tmp_off, refine_off, total;
+    size_t rot_off, flag_off, nsteps_off, rank_off, status_off, skip_off, a0_off, tmp_off, refine_off, total;
     int64_t rot_stride, flag_stride;
 };
 
@@ -396,6 +396,7 @@ LdsLayout layout(int64_t n, int64_t batch) {
     L.nsteps_off = off; off += align256((size_t)batch * sizeof(int));
     L.rank_off = off; off += align256((size_t)(batch * np) * sizeof(int));
     L.status_off = off; off += align256((size_t)batch * sizeof(int));
+    L.skip_off = off; off += align256((size_t)batch * sizeof(int));
     L.a0_off = off; off += align256((size_t)(batch * n * n) * sizeof(double));
     L.tmp_off = off; off += align256((size_t)(batch * n * n) * sizeof(double));
     L.refine_off = off;
@@ -411,8 +412,10 @@ bool nbx_eigh_lds_supported(int64_t n) { return ((n + 1) & ~1ll) <= JL_MAX_NP; }
 size_t nbx_eigh_lds_worksize(int64_t n, int64_t batch) { return layout(n, batch).total; }
 
 // d_v0 == nullptr: cold start.  Otherwise Jacobi runs on V0^T A V0 and accumulates onto V0.
+// d_skip (cold starts only): device int[batch]; matrices with d_skip[b] > 0 were already delivered by a solver
+// queued ahead (nbx_eigh_tridiag_dev) and are left alone -- d_skip may be this solver's own status words.
 int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0, double* d_w,
-                 double* d_v, void* d_work, size_t work_bytes, int refine_iters) {
+                 double* d_v, void* d_work, size_t work_bytes, int refine_iters, const int* d_skip) {
     const LdsLayout L = layout(n, batch);
     if (d_work == nullptr || work_bytes < L.total) {
         nbx_set_error("nbx_eigh: workspace %zu < %zu bytes", work_bytes, L.total);
@@ -427,7 +430,7 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
     int* rank = reinterpret_cast<int*>(base + L.rank_off);
     int* status = reinterpret_cast<int*>(base + L.status_off);
     const double* a_use = d_a;
-    const int* gate = nullptr;
+    const int* gate = (d_v0 == nullptr) ? d_skip : nullptr;
     if (d_v0 != nullptr) {
         double* a0 = reinterpret_cast<double*>(base + L.a0_off);
         double* tmp = reinterpret_cast<double*>(base + L.tmp_off);
@@ -480,6 +483,11 @@ int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, cons
 }
 
 size_t nbx_eigh_lds_status_offset(int64_t n, int64_t batch) { return layout(n, batch).status_off; }
+
+// batch ints beside the status words for a caller's "already delivered" flags (nbx_eigh_lds d_skip)
+int* nbx_eigh_lds_skip_ptr(int64_t n, int64_t batch, void* d_work) {
+    return reinterpret_cast<int*>(static_cast<char*>(d_work) + layout(n, batch).skip_off);
+}
 
 const int* nbx_eigh_lds_status_ptr(int64_t n, int64_t batch, const void* d_work) {
     return reinterpret_cast<const int*>(static_cast<const char*>(d_work) + layout(n, batch).status_off);

@@ -900,6 +900,56 @@ extern "C" int nbx_eigh_approx(nbx_ctx* ctx, int64_t n, int64_t batch, const dou
     return nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, Z, n, n * n, W, n, n * n, 0.0, d_v, n, n * n, batch);
 }
 
+// status[b] = 1 when the Gram defect of the inverse-iteration vectors was small enough for one Newton-Schulz
+// step (<= 1e-6) AND the off-diagonal weight of V^T A V relative to its diagonal is <= 1e-13 (the host route's
+// acceptance test, nbx_eigh_tridiag + nbx_eigh_warm_ex); 0 otherwise (also NaN)
+__global__ void quality_status_kernel(const double* __restrict__ gram, const double* __restrict__ rq, int batch,
+                                      int* __restrict__ status, int* __restrict__ skip) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const bool ortho = gram[2 * b] <= 1.0e-6 && gram[2 * b + 1] <= 1.0e-6;
+    const double o = rq[2 * b], d = rq[2 * b + 1];
+    const double q = d > 0.0 ? o / d : o;
+    status[b] = skip[b] = (ortho && q <= 1.0e-13) ? 1 : 0;
+}
+
+// The tridiagonal route with its verdict left ON THE DEVICE (nbx_eigh_warm_ex's cold start inside a queued SCF
+// cycle must not wait for the host): eigenpairs as nbx_eigh_tridiag's accepted branch writes them (one
+// Newton-Schulz step on the inverse-iteration vectors), d_status[b] = d_skip[b] = 1 accepted / 0 not -- the caller
+// queues its fallback solver gated on d_skip (d_status is what that solver overwrites with its sweep count).  The Gram-Schmidt branch of the host route is not taken here: vectors that
+// clusters left nearly dependent simply count as not accepted.
+int nbx_eigh_tridiag_dev(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
+                         void* d_work, size_t work_bytes, int* d_status, int* d_skip) {
+    const TdLayout L = layout(n, batch);
+    int rc = td_check(n, batch, d_work, work_bytes, L);
+    if (rc != NBX_OK) return rc;
+    NBX_CHECK_ARG(4 * batch <= NBX_SCRATCH_DOUBLES && d_status && d_skip);
+    char* base = static_cast<char*>(d_work);
+    double* W = reinterpret_cast<double*>(base + L.w_off);
+    double* Z = reinterpret_cast<double*>(base + L.z_off);
+    const int N = (int)n;
+    nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
+    rc = td_pipeline(ctx, n, batch, d_a, d_w, L, base);  // Gram defect in d_scratch[0, 2 batch)
+    if (rc != NBX_OK) return rc;
+    const int64_t total = batch * n * n;
+    hipLaunchKernelGGL(ns_factor_kernel, dim3((unsigned)nbx_cdiv(total, 256)), dim3(256), 0, ctx->stream, W, N, total);
+    NBX_LAUNCH_CHECK();
+    rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, Z, n, n * n, W, n, n * n, 0.0, d_v, n, n * n, batch);
+    if (rc != NBX_OK) return rc;
+    // quality: R = V^T A V  (W and Z are free again)
+    rc = nbx_gemm(ctx, 'T', 'N', n, n, n, 1.0, d_v, n, n * n, d_a, n, n * n, 0.0, W, n, n * n, batch);
+    if (rc != NBX_OK) return rc;
+    rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, W, n, n * n, d_v, n, n * n, 0.0, Z, n, n * n, batch);
+    if (rc != NBX_OK) return rc;
+    double* rq = ctx->d_scratch + 2 * batch;
+    hipLaunchKernelGGL(offdiag_diag_max_kernel<0>, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, Z, N, rq);
+    NBX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(quality_status_kernel, dim3((unsigned)nbx_cdiv(batch, 64)), dim3(64), 0, ctx->stream,
+                       ctx->d_scratch, rq, (int)batch, d_status, d_skip);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
 // Approximate eigenpairs by the tridiagonal route: d_w (batch,N) ascending, d_v (batch,N,N) with
 // orthonormal columns.  h_quality[b] = max off-diagonal of V^T A V divided by max |diagonal|.
 int nbx_eigh_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,

@@ -37,9 +37,10 @@ struct nbx_ctx {
 bool nbx_eigh_lds_supported(int64_t n);
 size_t nbx_eigh_lds_worksize(int64_t n, int64_t batch);
 int nbx_eigh_lds(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, const double* d_v0, double* d_w,
-                 double* d_v, void* d_work, size_t work_bytes, int refine_iters);
+                 double* d_v, void* d_work, size_t work_bytes, int refine_iters, const int* d_skip = nullptr);
 const int* nbx_eigh_lds_status_ptr(int64_t n, int64_t batch, const void* d_work);
 size_t nbx_eigh_lds_status_offset(int64_t n, int64_t batch);
+int* nbx_eigh_lds_skip_ptr(int64_t n, int64_t batch, void* d_work);
 int nbx_apply_rotation_log_t(nbx_ctx* ctx, int n, int np_even, int steps, const void* d_rot, const int* d_flags,
                              const int* d_nsteps, const int* d_rank, double* d_vt);
 
@@ -87,6 +88,8 @@ constexpr int NBX_EIGH_REFINE_MAX = 6;    // most a caller can queue (eigh_refin
 size_t nbx_eigh_tridiag_worksize(int64_t n, int64_t batch);
 int nbx_eigh_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
                      void* d_work, size_t work_bytes, double* h_quality);
+int nbx_eigh_tridiag_dev(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,
+                         void* d_work, size_t work_bytes, int* d_status, int* d_skip);
 
 // HIP-event bracket around a launch, active only while profiling is enabled.
 struct nbx_prof_scope {

@@ -181,11 +181,13 @@ extern "C" size_t nbx_purify_worksize(int64_t n, int64_t batch) {
 
 // d_f: (batch, n, n) symmetric matrices (an orthonormal basis: plain eigenproblem); d_p: out, the projector on
 // the nocc lowest eigenvectors of each; d_status[b]: steps taken (> 0) or < 0 (no gap found / not finite).
-// batch <= 2 takes (nocc_a, nocc_b); larger batches use nocc_a for all.  max_iter <= 0: the limit (72).
+// matrix 0 takes nocc_a, every other matrix nocc_b: batches of more than two need nocc_a == nocc_b (refused
+// otherwise).  max_iter <= 0: the limit (72).
 extern "C" int nbx_purify(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_f, int64_t nocc_a, int64_t nocc_b, double* d_p,
                void* d_work, size_t work_bytes, int max_iter, int* d_status) {
     NBX_CHECK_ARG(ctx && d_f && d_p && d_work && d_status && n > 0 && batch > 0 && batch <= 64);
     NBX_CHECK_ARG(nocc_a >= 0 && nocc_a <= n && nocc_b >= 0 && nocc_b <= n);
+    NBX_CHECK_ARG(batch <= 2 || nocc_a == nocc_b);
     if (work_bytes < nbx_purify_worksize(n, batch)) {
         nbx_set_error("nbx_purify: workspace %zu < %zu bytes", work_bytes, nbx_purify_worksize(n, batch));
         return NBX_E_NOMEM;

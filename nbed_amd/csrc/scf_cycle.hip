@@ -9,22 +9,88 @@
 // same order, same operands): results are bit-identical to that path.
 #include "nbx_common.h"
 
+// This rank's J/K contribution from the density d_dm_in into st->d_jk: the whole tensor or the slab rows
+// [jk_p0, jk_p1) of it, additive over slabs (nbx_jk_packed / nbx_jk_dense_sym) -- the caller sums the ranks'
+// (3,N,N) partials with one all-reduce queued on the same stream, then calls nbx_huz_cycle_post.
+static int huz_jk_slab(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, int64_t p0, int64_t p1) {
+    const int64_t N = st->nao;
+    if (st->jk_kind == NBX_HUZ_JK_PACKED) {
+        NBX_CHECK_ARG(st->d_packed || p0 == p1);
+        return nbx_jk_packed(ctx, N, p0, p1, st->d_packed, d_dm_in, 2, st->d_jk, st->d_jk_work, st->jk_work_bytes);
+    }
+    NBX_CHECK_ARG(st->jk_kind == NBX_HUZ_JK_SYM);
+    NBX_CHECK_ARG(st->d_eri || p0 == p1);
+    return nbx_jk_dense_sym(ctx, N, p0, p1, st->d_eri, d_dm_in, 2, st->d_jk, st->d_jk_work, st->jk_work_bytes);
+}
+
+static bool huz_whole_tensor(const nbx_huz_state* st) {
+    return (st->jk_p0 == 0 && st->jk_p1 == 0) || (st->jk_p0 == 0 && st->jk_p1 == st->nao);
+}
+
+static int huz_cycle_rest(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, const double* d_c_in,
+                          double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out, double* d_hz_out,
+                          int mode, int refine_iters, int diis_mode, int diis_slot, int diis_nd, double* h_out,
+                          int* d_status_out);
+
+extern "C" int nbx_huz_cycle_jk(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in) {
+    NBX_CHECK_ARG(ctx && st && d_dm_in);
+    NBX_CHECK_ARG(st->nao > 0 && st->d_jk && st->d_jk_work);
+    const int64_t p0 = st->jk_p0, p1 = huz_whole_tensor(st) ? st->nao : st->jk_p1;
+    NBX_CHECK_ARG(p0 >= 0 && p0 <= p1 && p1 <= st->nao);
+    return huz_jk_slab(ctx, st, d_dm_in, p0, p1);
+}
+
+extern "C" int nbx_huz_cycle_post(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, const double* d_c_in,
+                                  double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out, double* d_hz_out,
+                                  int mode, int refine_iters, int diis_mode, int diis_slot, int diis_nd, double* h_out,
+                                  int* d_status_out) {
+    NBX_CHECK_ARG(ctx && st && d_dm_in && d_dm_out && d_c_out && d_w_out && d_hz_out && h_out);
+    NBX_CHECK_ARG(st->nao > 0 && st->d_hv && st->d_ds && st->d_jk && st->d_fock && st->d_vhf && st->d_fock2);
+    // ---- Fock assembly (:157-160) from the summed J/K: F[x] = (h + V_emb)[x] + J - K[x]
+    int rc = nbx_fock_uhf(ctx, st->nao, st->d_hv, 3, nullptr, st->d_jk, st->d_fock, st->d_vhf);
+    if (rc != NBX_OK) return rc;
+    return huz_cycle_rest(ctx, st, d_dm_in, d_c_in, d_dm_out, d_c_out, d_v_out, d_w_out, d_hz_out, mode, refine_iters,
+                          diis_mode, diis_slot, diis_nd, h_out, d_status_out);
+}
+
 extern "C" int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, const double* d_c_in,
                              double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out, double* d_hz_out,
                              int mode, int refine_iters, int diis_mode, int diis_slot, int diis_nd, int dts_ready,
                              double* h_out, int* d_status_out) {
     NBX_CHECK_ARG(ctx && st && d_dm_in && d_dm_out && d_c_out && d_w_out && d_hz_out && h_out);
-    NBX_CHECK_ARG(st->nao > 0 && st->d_packed && st->d_hv && st->d_ds && st->d_jk && st->d_fock && st->d_vhf &&
-                  st->d_fock2 && st->d_jk_work);
+    NBX_CHECK_ARG(st->nao > 0 && st->d_hv && st->d_ds && st->d_jk && st->d_fock && st->d_vhf && st->d_fock2 &&
+                  st->d_jk_work);
+    const int64_t N = st->nao;
+    int rc;
+
+    // ---- Fock build (:156-160)
+    if (st->jk_kind == NBX_HUZ_JK_PACKED && huz_whole_tensor(st)) {
+        // J/K on the packed integrals with the Fock assembly in its reduction
+        NBX_CHECK_ARG(st->d_packed);
+        rc = nbx_jk_packed_fock(ctx, N, st->d_packed, d_dm_in, st->d_hv, st->d_jk, st->d_fock, st->d_vhf, st->d_jk_work,
+                                st->jk_work_bytes, (dts_ready && st->d_dts) ? st->d_dts : nullptr);
+        if (rc != NBX_OK) return rc;
+    } else {
+        // the symmetric kernel on the dense tensor (N < 100; sizes the packed kernel has no instance for), or a
+        // one-rank "slab" run: J/K, then the Fock assembly as its own launch
+        rc = nbx_huz_cycle_jk(ctx, st, d_dm_in);
+        if (rc != NBX_OK) return rc;
+        rc = nbx_fock_uhf(ctx, N, st->d_hv, 3, nullptr, st->d_jk, st->d_fock, st->d_vhf);
+        if (rc != NBX_OK) return rc;
+    }
+    return huz_cycle_rest(ctx, st, d_dm_in, d_c_in, d_dm_out, d_c_out, d_v_out, d_w_out, d_hz_out, mode, refine_iters,
+                          diis_mode, diis_slot, diis_nd, h_out, d_status_out);
+}
+
+// Everything of a cycle after the Fock matrices st->d_fock / st->d_vhf exist.
+static int huz_cycle_rest(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, const double* d_c_in,
+                          double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out, double* d_hz_out,
+                          int mode, int refine_iters, int diis_mode, int diis_slot, int diis_nd, double* h_out,
+                          int* d_status_out) {
     NBX_CHECK_ARG(mode == 0 || mode == 1 || mode == 2);
     NBX_CHECK_ARG(diis_mode >= 0 && diis_mode <= 2);
     const int64_t N = st->nao, n2 = N * N;
     int rc;
-
-    // ---- Fock build (:156-160): J/K on the packed integrals with the Fock assembly in its reduction
-    rc = nbx_jk_packed_fock(ctx, N, st->d_packed, d_dm_in, st->d_hv, st->d_jk, st->d_fock, st->d_vhf, st->d_jk_work,
-                            st->jk_work_bytes, (dts_ready && st->d_dts) ? st->d_dts : nullptr);
-    if (rc != NBX_OK) return rc;
     // Huzinaga operator and F += Hz in one launch (:159-160); the operator of the pre-DIIS Fock matrix is
     // what the loop returns (:206)
     rc = nbx_huzinaga_fused(ctx, N, 2, st->d_fock, st->d_ds, 1.0, d_hz_out, st->d_fock2);

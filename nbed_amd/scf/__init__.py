@@ -2,7 +2,7 @@
 
 from .embedded_hcore_funcs import energy_elec
 from .gpu_scf import GpuRHF, GpuRKS, GpuUHF, GpuUKS, Mole
-from .huzinaga_scf import calculate_hf_energy, calculate_ks_energy, get_huzinaga_operator, huzinaga_scf
+from .huzinaga_scf import History, calculate_hf_energy, calculate_ks_energy, get_huzinaga_operator, huzinaga_scf
 
 __all__ = [
     "huzinaga_scf",
@@ -15,4 +15,5 @@ __all__ = [
     "GpuRKS",
     "GpuUKS",
     "Mole",
+    "History",
 ]

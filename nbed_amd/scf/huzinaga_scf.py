@@ -106,6 +106,16 @@ def _is_fused(scf_method) -> bool:
 MAX_REFINE_ITERS = 6  # the library's limit (nbx_eigh_warm_ex / nbx_geig_refine)
 
 
+class History(list):
+    """``history=`` argument of ``huzinaga_scf`` that also reports HOW the run went: ``info`` holds
+    ``cycle_call`` (one C call per cycle: nbx_huz_cycle), ``split`` (J/K slabs + all-reduce) and ``restarts``
+    (one reason per repetition of the whole SCF after a rejected purified / tracked cycle; normally empty)."""
+
+    def __init__(self, *args):
+        super().__init__(*args)
+        self.info = {"restarts": []}
+
+
 class _PurificationFailed(Exception):
     """A density taken from purification (initial guess or cycle) did not resolve a gap: the run is repeated
     with an eigensolver in every cycle."""
@@ -157,14 +167,18 @@ def huzinaga_scf(
     for _ in range(3):
         try:
             return _huzinaga_scf(*args, allow_tracked=tracked, allow_purify=purify)
-        except _TrackedEigensolveFailed:
+        except _TrackedEigensolveFailed as exc:
             logger.warning("tracked eigensolve rejected a cycle: repeating the SCF with the guarded solver")
             tracked = False
+            reason = f"tracked eigensolve rejected ({exc})"
         except _PurificationFailed as exc:
             logger.warning("purification cycle unusable (%s): repeating the SCF with an eigensolver in every cycle", exc)
             purify = "0"
+            reason = f"purification unusable ({exc})"
         if history is not None:
             del history[:]
+            if hasattr(history, "info"):
+                history.info.setdefault("restarts", []).append(reason)
     return _huzinaga_scf(*args, allow_tracked=False, allow_purify="0")
 
 
@@ -281,15 +295,21 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
         return a_h[0] if restricted else a_h
 
     dts_d, dts_ready = None, False
+    sh = getattr(scf_method, "shards", None)
+    split = sh is not None and (sh.world > 1 or sh.force_collective)  # J/K slabs summed by an all-reduce
     if lookahead and hasattr(scf_method, "dts_device") and scf_method.fused_fock_available(hv):
         dts_d = scf_method.dts_device()
     # One C call per cycle (nbx_huz_cycle) instead of 12-40 marshalled launches: the first cycles of an
     # SCF are host bound otherwise (the GPU idles 100-300 us per cycle until the eigensolver settles).
-    # Same kernels, order and operands as the step-by-step path below: bit-identical results.
-    use_cycle_call = (lookahead and ds_virt is None and dts_d is not None and hasattr(be, "huz_cycle")
+    # Same kernels, order and operands as the step-by-step path below: bit-identical results.  Every size
+    # (packed J/K kernel, or the symmetric one on the dense tensor) and every world size: over several ranks
+    # the cycle is two calls around the all-reduce of the J/K partials (nbx_huz_cycle_jk / _post).
+    use_cycle_call = (lookahead and ds_virt is None and hasattr(be, "huz_cycle") and sh is not None
                       and os.environ.get("NBED_CYCLE_CALL", "1") != "0")
     if not use_cycle_call:
         warm["purify"] = False  # (nbx_huz_cycle mode 2 only: the step-by-step path always solves the eigenproblem)
+    if history is not None and hasattr(history, "info"):
+        history.info.update(cycle_call=bool(use_cycle_call), split=bool(split))
 
     # ---- initial guess from the projected core Hamiltonian (:139-148)
     guess_status = None
@@ -374,8 +394,10 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
     if use_cycle_call:
         if s_b is None:
             s_b = overlap_per_spin()
-        hstate = be.huz_cycle_state(s_h.shape[0], scf_method.mol.nelec, scf_method.eri_packed_device(), hv, ds_occ,
-                                    s_b, x_d, dts_d)
+        packed_d = scf_method.eri_packed_device()
+        hstate = be.huz_cycle_state(s_h.shape[0], scf_method.mol.nelec, packed_d, hv, ds_occ, s_b, x_d, dts_d,
+                                    eri=None if packed_d is not None else scf_method.eri_device(), p0=sh.lo, p1=sh.hi)
+        reduce = (lambda jk: sh.all_reduce(be, jk)) if split else None
         diis_state = {"first": True, "head": 0, "nd": 0, "space": 6}
         for i in range(scf_method.max_cycle):
             if callback is not None:
@@ -397,16 +419,16 @@ def _huzinaga_scf(scf_method, embedding_potential, dm_environment_occupied, dm_e
                     diis_mode, diis_nd = 2, diis_state["nd"]
             if purify_now:  # density by purification: this cycle has no orbitals, X F X is left in out["v"]
                 pending_now = be.huz_cycle(hstate, dm_d, None, out, 2, warm["pur_iters"], diis_mode, diis_slot, diis_nd,
-                                           dts_ready)
+                                           dts_ready, reduce=reduce)
                 warm["c"] = warm["v"] = None
             else:
                 c_in = warm["c"] if tracked_now else warm["v"]
                 pending_now = be.huz_cycle(hstate, dm_d, c_in, out, tracked_now, warm["iters"], diis_mode, diis_slot,
-                                           diis_nd, dts_ready)
+                                           diis_nd, dts_ready, reduce=reduce)
                 warm["c"] = out["c"]
                 if not tracked_now:
                     warm["v"] = out["v"]
-            dts_ready = True
+            dts_ready = dts_d is not None
             dm_d, hz, c_d, mo_energy_h = out["dm"], out["hz"], out["c"], out["w"]
             state_now = (i, pending_now, out["c"], out["w"], out["dm"], out["hz"], tracked_now, purify_now, out["v"])
             if pending is not None and judge(pending):

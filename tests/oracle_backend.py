@@ -260,3 +260,140 @@ class OracleBackend:
     def spinorb_scatter(self, one_body, two_body, tol, h2_scale):
         h1, h2 = hamiltonian.spinorb_from_spatial(self._np(one_body), self._np(two_body), tol)
         return self.asarray(h1), self.asarray(h2 * h2_scale)
+
+
+class _Done:
+    """Handle of a 'queued' cycle's scalars (the HIP backend's _PendingScalars, already complete here)."""
+
+    def __init__(self, vals, extra=None):
+        self._vals = np.asarray(vals, dtype=np.float64)
+        self._extra = None if extra is None else np.asarray(extra, dtype=np.int64)
+
+    def get(self):
+        return self._vals.copy()
+
+    def get_extra(self):
+        return self._extra
+
+
+class OracleLookaheadBackend(OracleBackend):
+    """The checker backend WITH the look-ahead interface of HipBackend (``huz_cycle_state`` / ``huz_cycle``,
+    ``purify``, ``geig_refine``, ``density_occ``, ``huz_cycle_scalars_async``, ``async_to_host``): numpy
+    restatements of what nbx_huz_cycle / nbx_huz_cycle_jk + _post queue (csrc/scf_cycle.hip), step for step, with
+    the status words the device solvers would report (purification: steps; cold guarded solve: sweeps; accepted
+    refinement: 1000 + iterations).  CPU tests drive the product's one-call-per-cycle loop through it -- the
+    purified -> cold -> guarded -> tracked schedule, the DIIS ring bookkeeping the loop does itself, the
+    one-cycle-late convergence test, and (gloo, world 2) the all-reduce between the two halves of a cycle."""
+
+    use_sym = True
+    PURIFY_STEPS = 30
+
+    def density_occ(self, c, nocc):
+        cn = self._np(c)
+        return self.asarray(np.stack([cn[x][:, : int(nocc[x])] @ cn[x][:, : int(nocc[x])].T for x in range(cn.shape[0])]))
+
+    def async_to_host(self, d_vals):
+        return _Done(self._np(d_vals).reshape(-1))
+
+    def huz_cycle_scalars_async(self, hcore, vemb, vhf, hz, dm, dm_old, extra=None, dts=None):
+        vals = self.huz_cycle_scalars(hcore, vemb, vhf, hz, dm, dm_old)
+        return _Done(vals, None if extra is None else self._np(extra).reshape(-1))
+
+    def eigh(self, a, check=False, v0=None, refine_iters=3):
+        w, v = super().eigh(a, check=check, v0=v0)
+        batch = 1 if a.dim() == 2 else a.shape[0]
+        self.last_eigh_status_d = torch.full((batch,), 1 if v0 is None else 1001, dtype=torch.int32)
+        return w, v
+
+    def geig_refine(self, fock, ovlp_b, c0, refine_iters=1):
+        import scipy.linalg
+
+        self._count("geig_refine")
+        f, s = self._np(fock), self._np(ovlp_b)
+        res = [scipy.linalg.eigh(f[x], s[x]) for x in range(f.shape[0])]
+        self.last_eigh_status_d = torch.full((f.shape[0],), 1001, dtype=torch.int32)
+        return self.asarray(np.stack([r[0] for r in res])), self.asarray(np.stack([r[1] for r in res]))
+
+    def purify(self, f, nocc, max_iter=0):
+        self._count("purify")
+        fn = self._np(f if f.dim() == 3 else f.reshape(1, *f.shape))
+        nocc = [int(nocc)] * 2 if np.isscalar(nocc) else [int(x) for x in nocc]
+        ps = []
+        for x in range(fn.shape[0]):
+            _, v = np.linalg.eigh(fn[x])
+            k = nocc[min(x, len(nocc) - 1)]
+            ps.append(v[:, :k] @ v[:, :k].T)
+        return self.asarray(np.stack(ps)), torch.full((fn.shape[0],), self.PURIFY_STEPS, dtype=torch.int32)
+
+    def huz_cycle_state(self, nao, nelec, packed, hv, ds, s_b, x, dts, diis_space=6, eri=None, p0=0, p1=None):
+        class Holder:
+            pass
+
+        h = Holder()
+        n = int(nao)
+        h.n, h.nelec = n, (int(nelec[0]), int(nelec[1]))
+        h.eri, h.p0, h.p1 = eri, int(p0), n if p1 is None else int(p1)
+        h.hv, h.ds, h.s_b, h.x = hv, ds, s_b, x
+        h.space = diis_space
+        h.xs, h.es = np.zeros((diis_space, 2 * n * n)), np.zeros((diis_space, 2 * n * n))
+        h.H = np.zeros((diis_space + 1, diis_space + 1))
+        h.H[0, 1:] = h.H[1:, 0] = 1
+        h.xprev = None
+        h.jk = None
+        h.sets = [{"c": self.empty((2, n, n)), "v": self.empty((2, n, n)), "w": self.empty((2, n)),
+                   "dm": self.empty((2, n, n)), "hz": self.empty((2, n, n)),
+                   "status": torch.zeros(2, dtype=torch.int32)} for _ in range(3)]
+        return h
+
+    def huz_cycle(self, h, dm_in, c_in, out, tracked, refine_iters, diis_mode, diis_slot, diis_nd, dts_ready,
+                  reduce=None):
+        from nbed_amd.scf.diis import diis_coefficients
+
+        self._count("huz_cycle")
+        mode = int(tracked)
+        n = h.n
+        # ---- nbx_huz_cycle_jk, the all-reduce, nbx_fock_uhf
+        h.jk = self.jk_sym(h.eri, dm_in, h.p0, h.p1)
+        if reduce is not None:
+            reduce(h.jk)
+        fock, vhf = self.fock_uhf(h.hv, None, h.jk)
+        fds = self._np(fock) @ self._np(h.ds)
+        hz = -(fds + np.swapaxes(fds, -1, -2))
+        fock2 = self._np(fock) + hz
+        # ---- DIIS: pyscf.lib.diis.DIIS.update with the ring bookkeeping done by the caller
+        f_use = fock2
+        if diis_mode == 1:
+            h.xprev = fock2.reshape(-1).copy()
+        elif diis_mode == 2:
+            flat = fock2.reshape(-1)
+            h.xs[diis_slot] = flat
+            h.es[diis_slot] = flat - h.xprev
+            row = h.es[:diis_nd] @ h.es[diis_slot]
+            h.H[diis_slot + 1, 1: diis_nd + 1] = row
+            h.H[1: diis_nd + 1, diis_slot + 1] = row
+            coef = diis_coefficients(h.H[: diis_nd + 1, : diis_nd + 1])
+            h.xprev = coef[1:] @ h.xs[:diis_nd]
+            f_use = h.xprev.reshape(2, n, n)
+        xn = self._np(h.x)
+        if mode == 2:  # purified: no orbitals, X F X left in out["v"]
+            fo = xn @ f_use @ xn
+            out["v"].copy_(torch.from_numpy(fo))
+            p, st = self.purify(self.asarray(fo), h.nelec, refine_iters)
+            dm = xn @ self._np(p) @ xn
+            status = self._np(st).astype(np.int64)
+        else:
+            if mode == 1:
+                w, c = self.geig_refine(self.asarray(f_use), h.s_b, c_in, refine_iters)
+                status = np.array([1001, 1001])
+            else:
+                w, v = OracleBackend.eigh(self, self.asarray(xn @ f_use @ xn))
+                out["v"].copy_(v)
+                c = self.asarray(xn @ self._np(v))
+                status = np.array([1, 1] if c_in is None else [1001, 1001])
+            out["w"].copy_(w)
+            out["c"].copy_(c)
+            dm = self._np(self.density_occ(c, h.nelec))
+        out["dm"].copy_(torch.from_numpy(np.ascontiguousarray(dm)))
+        out["hz"].copy_(torch.from_numpy(hz))
+        vals = self.huz_cycle_scalars(h.hv, None, vhf, out["hz"], out["dm"], dm_in)
+        return _Done(vals, status)

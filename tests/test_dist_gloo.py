@@ -71,6 +71,29 @@ def test_symmetric_jk_slabs_all_reduce_match_single_rank(tmp_path):
         np.testing.assert_array_equal(ranks[0][key], ranks[1][key])
 
 
+def test_lookahead_cycle_call_over_two_ranks_matches_single_rank(tmp_path):
+    """World-2 gloo run of the ONE-CALL-PER-CYCLE loop (nbx_huz_cycle_jk | all-reduce | nbx_huz_cycle_post, restated
+    by the look-ahead checker backend): the ranks keep the purified early cycles, the tracked eigensolver and the
+    one-cycle-late convergence test, take the same number of cycles as one rank and end with the same bits."""
+    n = 10
+    (tmp_path / "w1").mkdir()
+    (tmp_path / "w2").mkdir()
+    single = run_world(tmp_path / "w1", 1, n, mode="lookahead")[0]
+    ranks = run_world(tmp_path / "w2", 2, n, mode="lookahead")
+    assert bool(single["cycle_call"]) and not bool(single["split"])
+    for r in ranks:
+        assert bool(r["cycle_call"]) and bool(r["split"]) and bool(r["conv"])
+        assert int(r["ncycles"]) == int(single["ncycles"]) and int(r["restarts"]) == 0
+        for key in ("e", "d", "hz", "h1", "h2"):
+            np.testing.assert_allclose(r[key], single[key], rtol=0, atol=1e-10, err_msg=key)
+    for key in ("e", "d", "hz", "h2"):
+        np.testing.assert_array_equal(ranks[0][key], ranks[1][key])
+    # the step-by-step loop on the plain checker backend reaches the same fixed point
+    plain = run_world(tmp_path / "w1", 1, n, mode="triangular")[0]
+    assert not bool(plain["cycle_call"])
+    np.testing.assert_allclose(single["d"], plain["d"], rtol=0, atol=1e-9)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_scf_and_transform_match_single_rank(tmp_path, world):
     n = 10  # 10 rows over 3 ranks -> 4,4,2: exercises the padded all-gather

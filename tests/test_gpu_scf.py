@@ -23,13 +23,15 @@ def be():
 
 @pytest.mark.parametrize("tag", ["uhf_n12_nodiis", "uhf_n12_diis", "uhf_n24_diis_open", "uhf_n24_nodiis_open"])
 def test_huzinaga_scf_golden(be, tag):
-    from nbed_amd.scf import GpuUHF, Mole, huzinaga_scf
+    from nbed_amd.scf import GpuUHF, History, Mole, huzinaga_scf
 
     g = load_golden(f"huzinaga_scf_{tag}")
     n = int(g["nao"])
     mf = GpuUHF(Mole(n, tuple(g["nelec"])), g["S"], g["hcore"], be.synth_eri(n), backend=be)
     mf.max_cycle, mf.conv_tol = int(g["max_cycle"]), float(g["conv_tol"])
-    c, e, d, hz, conv = huzinaga_scf(mf, g["V_emb"], g["D_env"], use_DIIS=bool(g["use_DIIS"]))
+    hist = History()
+    c, e, d, hz, conv = huzinaga_scf(mf, g["V_emb"], g["D_env"], use_DIIS=bool(g["use_DIIS"]), history=hist)
+    assert hist.info["cycle_call"]  # one nbx_huz_cycle per cycle at every size (N = 12, 24: symmetric J/K kernel)
     assert conv == bool(g["conv"])
     # without DIIS the trajectories agree to 1e-9 and better; with DIIS the late cycles run on a
     # Pulay matrix that is rank deficient to working precision, where pyscf.lib.diis' solve
@@ -194,6 +196,39 @@ def test_huzinaga_scf_tracked_eigensolve_equals_guarded(be, monkeypatch, n):
     (c2, e2, d2, hz2, conv2), h2 = run()
     assert conv2 and len(h2) == len(h0)
     np.testing.assert_array_equal(d2, d0)
+
+
+@pytest.mark.parametrize("n,nocc,n_env", [(7, (3, 3), 1), (12, (4, 3), 1), (24, (6, 5), 2), (47, (9, 9), 3),
+                                          (49, (9, 8), 3), (72, (12, 11), 5), (102, (17, 17), 6)])
+def test_one_call_cycle_at_every_size_equals_step_by_step(be, monkeypatch, n, nocc, n_env):
+    """nbx_huz_cycle is the loop at EVERY size -- symmetric kernel on the dense tensor (N < 100), plain kernel
+    behind it (odd N < 48), zero-padded packed kernel (odd N >= 48, N = 102) -- and queues the kernels the
+    step-by-step path launches one by one: bit-identical results; the purified early cycles change nothing beyond
+    rounding."""
+    from nbed_amd.scf import GpuUHF, History, Mole, huzinaga_scf
+
+    pr = synth.problem(n, nocc, n_env)
+
+    def run():
+        mf = GpuUHF(Mole(n, pr["nelec"]), pr["S"], pr["hcore"], be.synth_eri(n), backend=be)
+        mf.max_cycle, mf.conv_tol = 100, 1e-11
+        hist = History()
+        return huzinaga_scf(mf, pr["V_emb"], pr["D_env"], dm_conv_tol=1e-9, history=hist), hist
+
+    (c1, e1, d1, hz1, conv1), h1 = run()
+    assert conv1 and h1.info["cycle_call"] and not h1.info["split"]
+    monkeypatch.setenv("NBED_PURIFY", "0")
+    (c2, e2, d2, hz2, conv2), h2 = run()
+    monkeypatch.setenv("NBED_CYCLE_CALL", "0")
+    (c3, e3, d3, hz3, conv3), h3 = run()
+    assert conv2 and conv3 and h2.info["cycle_call"] and not h3.info["cycle_call"]
+    assert len(h2) == len(h3)
+    np.testing.assert_array_equal(d3, d2)
+    np.testing.assert_array_equal(e3, e2)
+    np.testing.assert_array_equal(hz3, hz2)
+    assert abs(len(h1) - len(h2)) <= 1
+    np.testing.assert_allclose(d1, d2, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(e1, e2, rtol=0, atol=1e-9)
 
 
 def test_gpu_uhf_kernel_vs_oracle(be):
