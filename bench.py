@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--no-n2000", action="store_true", help="skip the bounded N_AO=2000 streamed sample")
     ap.add_argument("--no-tts", action="store_true", help="skip the cold-start time-to-solution run")
     ap.add_argument("--no-real", action="store_true", help="skip the real-molecule leg (octane / 6-31G*, nothing injected)")
+    ap.add_argument("--no-small", action="store_true", help="skip the small-config legs (BASELINE configs[0], [1], [4] shape)")
+    ap.add_argument("--no-scaling", action="store_true", help="skip the scaling workloads (N_AO = 256 packed, 384 symmetric)")
     ap.add_argument("--n2000-rslabs", type=int, default=4, help="r-slabs of the N_AO=2000 transform per rank")
     ap.add_argument("--cpu-cycles", type=int, default=8)
     return ap.parse_args()
@@ -85,7 +87,8 @@ def transform_flops(N, n):
 
 
 def cpu_baseline_cycle(pr, eri_h, ncycles):
-    """The CPU oracle's cycle on the host cores: C/OpenMP one-pass J/K + numpy/LAPACK rest."""
+    """The CPU oracle's cycle on the host cores: C/OpenMP one-pass J/K + numpy/LAPACK rest.
+    ``pr``: dict with nao, nelec, S, hcore, V_emb, D_env (host arrays)."""
     import tempfile
 
     os.environ["OMP_NUM_THREADS"] = str(host_cores())  # libgomp reads it when the C oracle is loaded
@@ -93,10 +96,13 @@ def cpu_baseline_cycle(pr, eri_h, ncycles):
     from oracle.huzinaga import huzinaga_scf
     from oracle.pyscf_like import ToyMol, ToyUHF
 
-    try:
-        lib = cref.load(cref.build(tempfile.mkdtemp(prefix="jkref_")))
-    except Exception:
-        lib = cref.load()
+    lib = _CPU_LIB.get("lib")
+    if lib is None:
+        try:
+            lib = cref.load(cref.build(tempfile.mkdtemp(prefix="jkref_")))
+        except Exception:
+            lib = cref.load()
+        _CPU_LIB["lib"] = lib
 
     class CUHF(ToyUHF):
         def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0):
@@ -112,26 +118,46 @@ def cpu_baseline_cycle(pr, eri_h, ncycles):
     return ncycles / dt
 
 
-def real_molecule_leg(be, args) -> dict:
-    """BASELINE configs[2] on REAL integrals: octane / 6-31G* (148 AOs), 4 active atoms, SPADE + concentric
-    localization, B3LYP-in-HF -- integrals from libnbx's host engine, quadrature on the device, nothing
-    injected, nothing synthetic.  Reports the end-to-end time of ``nbed(config)`` and, with the bench's own
-    protocol (warm-up cycles untimed, stopping rule off, DIIS on), the cycles/s of the embedded Huzinaga SCF
-    of that molecule: the same kernels as ``value``, on the real tensor."""
+_CPU_LIB: dict = {}
+
+
+def timed_huzinaga_run(mf, emb_args, kw, warmup, steps, sync):
+    """The bench protocol on one SCF object: ONE huzinaga_scf run of warmup + steps cycles with the stopping rule
+    off and DIIS on; the clock starts (GPU drained) when cycle ``warmup`` is about to be queued and stops when the
+    run has returned its results to the host.  A run that the loop repeats (rejected purified / tracked cycle) is
+    timed from its LAST start and reported (``scf_restarts``)."""
+    from nbed_amd.scf import History, huzinaga_scf
+
+    mf.conv_tol, mf.max_cycle = -1.0, warmup + steps
+    hist, clock, stamps = History(), {}, []
+
+    def on_cycle(i):
+        if i == 0:
+            del stamps[:]  # (a repeated run starts over: its stamps must not mix with the discarded attempt's)
+        stamps.append(time.perf_counter())
+        if i == warmup:
+            sync()
+            clock["t0"] = time.perf_counter()
+
+    huzinaga_scf(mf, *emb_args, use_DIIS=True, history=hist, callback=on_cycle, **kw)
+    sync()
+    dt = time.perf_counter() - clock["t0"]
+    diffs = np.diff(stamps)
+    return {"cycles_per_sec": steps / dt, "ms_per_cycle": dt / steps * 1e3,
+            "ms_per_cycle_settled": float(np.median(diffs[-8:])) * 1e3 if len(diffs) else None,
+            "queue_pace_ms_first_cycles": [round(float(x) * 1e3, 3) for x in diffs[:12]],
+            "scf_restarts": list(hist.info.get("restarts", [])), "one_call_per_cycle": bool(hist.info.get("cycle_call")),
+            "energy_last_cycle": [float(x) for x in hist[-1][0]]}
+
+
+def embedded_molecule_run(be, cfg, prov):
+    """``nbed(cfg)`` end to end on the device with nothing injected; returns (driver, seconds, the arguments its
+    embedded Huzinaga SCF was called with)."""
     import torch
 
     import nbed_amd.driver as drv_mod
-    from nbed_amd import NbedConfig, nbed
-    from nbed_amd.driver import BuiltinHFProvider
-    from nbed_amd.scf import huzinaga_scf
+    from nbed_amd import nbed
 
-    sys.path.insert(0, str(Path(__file__).resolve().parent / "tools"))
-    from molecules import octane_xyz
-
-    cfg = NbedConfig(geometry=octane_xyz(), n_active_atoms=4, basis="6-31g*", xc_functional="b3lyp", convergence=1e-8,
-                     projector="huzinaga", localization="spade", virtual_localization="cl", max_shells=4,
-                     max_hf_cycles=100, max_dft_cycles=100)
-    prov = BuiltinHFProvider(be)
     seen = {}
     inner = drv_mod.huzinaga_scf
 
@@ -148,35 +174,156 @@ def real_molecule_leg(be, args) -> dict:
         e2e = time.perf_counter() - t0
     finally:
         drv_mod.huzinaga_scf = inner
-    kw = {k: v for k, v in seen["kwargs"].items() if k not in ("history", "callback", "dm_conv_tol", "use_DIIS")}
+    seen["kw"] = {k: v for k, v in seen["kwargs"].items() if k not in ("history", "callback", "dm_conv_tol", "use_DIIS")}
+    return drv, e2e, seen
+
+
+def small_configs_leg(be, args) -> list:
+    """BASELINE configs[0], [1] and the shape of [4] on REAL integrals (nothing injected): the embedded Huzinaga SCF
+    of each molecule by the bench's protocol -- cycles/s of the product loop (one nbx_huz_cycle per cycle; N = 7,
+    24, 72 run the symmetric J/K kernel on the dense tensor) -- beside the CPU oracle's loop on the same integrals,
+    embedding potential and environment density."""
+    import torch
+
+    from nbed_amd import NbedConfig
+    from nbed_amd.driver import BuiltinHFProvider
+
+    water = "3\n\nO   0.0000  0.000  0.115\nH   0.0000  0.754  -0.459\nH   0.0000  -0.754  -0.459"
+    ch3 = "4\n\nC 0 0 0\nH 1.079 0 0\nH -0.5395 0.9344 0\nH -0.5395 -0.9344 0"
+    cases = [
+        ("configs[0]: H2O / STO-3G, 1 active atom (tests/test_config.json), SPADE; Huzinaga SCF of the embedded system "
+         "(the config's mu-shift run is the same molecule through GpuUHF.kernel())",
+         dict(geometry=water, n_active_atoms=1, basis="sto-3g", projector="both")),
+        ("configs[1]: H2O / cc-pVDZ, Huzinaga projector", dict(geometry=water, n_active_atoms=2, basis="cc-pvdz",
+                                                              projector="huzinaga")),
+        ("configs[4] shape: CH3+ / cc-pVTZ (72 AOs, f shells), run unrestricted; the radical itself raises in the "
+         "reference's SPADE (ragged alpha/beta partition) and here",
+         dict(geometry=ch3, n_active_atoms=2, basis="cc-pvtz", projector="huzinaga", charge=1)),
+    ]
+    out = []
+    steps, warmup = max(args.steps, 40), args.warmup
+    for label, kw in cases:
+        try:
+            cfg = NbedConfig(xc_functional="b3lyp", convergence=1e-8, localization="spade", virtual_localization="cl",
+                             max_shells=4, max_hf_cycles=100, max_dft_cycles=100, **kw)
+            prov = BuiltinHFProvider(be)
+            drv, e2e, seen = embedded_molecule_run(be, cfg, prov)
+            mf = prov.local_hf(cfg, seen["mol"], backend=be)
+            run = timed_huzinaga_run(mf, seen["args"], seen["kw"], warmup, steps, torch.cuda.synchronize)
+            ints = prov._integrals(cfg)
+            n = int(ints["nao"])
+            entry = {"workload": label, "nao": n, "active_electrons": [int(x) for x in seen["mol"].nelec],
+                     "end_to_end_s": e2e, "e_rhf": float(drv.huzinaga["e_rhf"]), "steps": steps, "warmup": warmup,
+                     "embedded_scf_cycles_per_sec": run["cycles_per_sec"], **{k: run[k] for k in (
+                         "ms_per_cycle", "ms_per_cycle_settled", "scf_restarts", "one_call_per_cycle")}}
+            if not args.no_cpu_baseline:
+                v_emb, d_env = seen["args"][0], seen["args"][1]
+                prh = {"nao": n, "nelec": tuple(int(x) for x in seen["mol"].nelec), "S": ints["S"], "hcore": ints["hcore"],
+                       "V_emb": np.asarray(v_emb), "D_env": np.asarray(d_env)}
+                ncyc = 200 if n <= 24 else 40
+                entry["cpu_baseline"] = {
+                    "value": cpu_baseline_cycle(prh, np.asarray(ints["eri"]), ncyc), "unit": "cycles/s",
+                    "cores": host_cores(), "kind": "port",
+                    "sample": f"{ncyc} cycles of the oracle loop (C/OpenMP dense J/K + numpy/LAPACK) on the same integrals, "
+                              "V_emb and D_env"}
+            out.append(entry)
+        except Exception as exc:  # informative leg: never takes the bench line down
+            out.append({"workload": label, "error": f"{type(exc).__name__}: {exc}"})
+        be.release_workspaces()
+    return out
+
+
+def scaling_workload_leg(be, args, world, rank, distributed, barrier) -> list:
+    """Sizes at which sharding the J/K build pays (it grows as N^4, the replicated rest of a cycle as N^3), for every
+    --gpus N: N = 256 (packed kernel, 8.6 GB of tiles) and N = 384 (symmetric kernel on the dense tensor, 87 GB read
+    per build), each rank holding its equal-work slab of (pq|rs) rows; cycles/s of the product loop and the
+    all-reduce of the (3,N,N) J/K partials timed on its own."""
+    import torch
+    import torch.distributed as dist
+
+    from nbed_amd import synth
+    from nbed_amd.dist import Shards
+    from nbed_amd.scf import GpuUHF, Mole
+
+    out = []
+    for n_ao in (256, 384):
+        try:
+            nocc, nenv = n_ao // 6, n_ao // 12
+            pr = synth.problem(be, n_ao, (nocc, nocc), nenv)
+            sh = Shards(n_ao, world, rank, force_collective=distributed, balance="triangular")
+            eri = be.synth_eri(n_ao, sh.lo, sh.hi)
+            mf = GpuUHF(Mole(n_ao, pr["nelec"]), pr["S"], pr["hcore"], eri, backend=be, shards=sh)
+            packed = mf.eri_packed_device() is not None
+            if packed:
+                mf._eri_d = None  # (the packed tiles are what the loop reads: the dense slab can go)
+                del eri
+            steps, warmup = 10, 3
+            run = timed_huzinaga_run(mf, (pr["V_emb"], pr["D_env"]), {}, warmup, steps, barrier)
+            dt = steps / run["cycles_per_sec"]
+            ar_ms = None
+            if distributed:
+                buf = be.zeros((3, n_ao, n_ao))
+                for _ in range(3):
+                    dist.all_reduce(buf)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    dist.all_reduce(buf)
+                barrier()
+                ar_ms = (time.perf_counter() - t0) / 20 * 1e3
+            if world > 1:
+                tmax = torch.tensor([dt], dtype=torch.float64, device=be.device)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = float(tmax.item())
+            ntiles = (sh.hi * (sh.hi + 1) - sh.lo * (sh.lo + 1)) // 2
+            slab_bytes = float(be.lib.nbx_eri_packed_bytes(n_ao, sh.lo, sh.hi)) if packed else 8.0 * n_ao * n_ao * ntiles
+            out.append({"nao": n_ao, "jk_kernel": "jk_s4_kernel (4-fold packed tiles)" if packed else "jk_sym_kernel (dense tensor, tiles q <= p)",
+                        "cycles_per_sec": steps / dt, "ms_per_cycle": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+                        "n_gpus": world, "slab_rows": [int(sh.lo), int(sh.hi)], "slab_bytes_read_per_build": slab_bytes,
+                        "allreduce_ms_alone": ar_ms, "allreduce_bytes": 24 * n_ao * n_ao,
+                        "one_call_per_cycle": run["one_call_per_cycle"], "scf_restarts": run["scf_restarts"],
+                        "energy_last_cycle": run["energy_last_cycle"]})
+            del mf
+        except Exception as exc:
+            out.append({"nao": n_ao, "error": f"{type(exc).__name__}: {exc}"})
+        be.release_workspaces()
+        torch.cuda.empty_cache()
+    return out
+
+
+def real_molecule_leg(be, args) -> dict:
+    """BASELINE configs[2] on REAL integrals: octane / 6-31G* (148 AOs), 4 active atoms, SPADE + concentric
+    localization, B3LYP-in-HF -- integrals from libnbx's host engine, quadrature on the device, nothing
+    injected, nothing synthetic.  Reports the end-to-end time of ``nbed(config)`` and, with the bench's own
+    protocol (warm-up cycles untimed, stopping rule off, DIIS on), the cycles/s of the embedded Huzinaga SCF
+    of that molecule: the same kernels as ``value``, on the real tensor."""
+    import torch
+
+    from nbed_amd import NbedConfig
+    from nbed_amd.driver import BuiltinHFProvider
+    from nbed_amd.scf import History, huzinaga_scf
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "tools"))
+    from molecules import octane_xyz
+
+    cfg = NbedConfig(geometry=octane_xyz(), n_active_atoms=4, basis="6-31g*", xc_functional="b3lyp", convergence=1e-8,
+                     projector="huzinaga", localization="spade", virtual_localization="cl", max_shells=4,
+                     max_hf_cycles=100, max_dft_cycles=100)
+    prov = BuiltinHFProvider(be)
+    drv, e2e, seen = embedded_molecule_run(be, cfg, prov)
+    kw = seen["kw"]
     # time to solution of the embedded SCF as the driver runs it (Nbed's stopping rule, cold start), second of two runs
     for _ in range(2):
         mf_t = prov.local_hf(cfg, seen["mol"], backend=be)
         mf_t.conv_tol, mf_t.max_cycle = cfg.convergence, cfg.max_hf_cycles
-        hist_t = []
+        hist_t = History()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out_t = huzinaga_scf(mf_t, *seen["args"], dm_conv_tol=1e-6, use_DIIS=True, history=hist_t, **kw)
         torch.cuda.synchronize()
         tts_s = time.perf_counter() - t0
     mf = prov.local_hf(cfg, seen["mol"], backend=be)  # a fresh embedded object over the resident integrals
-    mf.conv_tol, mf.max_cycle = -1.0, args.warmup + args.steps
-    hist, clock = [], {}
-
-    def on_cycle(i):
-        if i == args.warmup:
-            torch.cuda.synchronize()
-            clock["t0"] = time.perf_counter()
-
-    stamps = []
-
-    def on_cycle2(i):
-        stamps.append(time.perf_counter())
-        on_cycle(i)
-
-    huzinaga_scf(mf, *seen["args"], use_DIIS=True, history=hist, callback=on_cycle2, **kw)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - clock["t0"]
+    run = timed_huzinaga_run(mf, seen["args"], kw, args.warmup, args.steps, torch.cuda.synchronize)
     res = drv.huzinaga
     return {
         "workload": "octane / 6-31G* (148 AOs, spherical d), 4 active atoms, SPADE + concentric localization, B3LYP-in-HF, "
@@ -190,10 +337,12 @@ def real_molecule_leg(be, args) -> dict:
         "embedded_scf_time_to_solution_ms": tts_s * 1e3,
         "embedded_scf_cycles_to_solution": len(hist_t),
         "embedded_scf_converged_cold_run": bool(out_t[4]),
-        "embedded_scf_cycles_per_sec": args.steps / dt,
-        "ms_per_cycle": dt / args.steps * 1e3,
-        "ms_per_cycle_settled": float(np.median(np.diff(stamps)[-8:])) * 1e3,
-        "queue_pace_ms_first_cycles": [round(float(x) * 1e3, 3) for x in np.diff(stamps)[:12]],
+        "embedded_scf_restarts_cold_run": list(hist_t.info.get("restarts", [])),
+        "embedded_scf_cycles_per_sec": run["cycles_per_sec"],
+        "ms_per_cycle": run["ms_per_cycle"],
+        "ms_per_cycle_settled": run["ms_per_cycle_settled"],
+        "queue_pace_ms_first_cycles": run["queue_pace_ms_first_cycles"],
+        "scf_restarts": run["scf_restarts"],
         "protocol": f"as value: {args.steps} cycles after {args.warmup} warm-up cycles of one huzinaga_scf run, DIIS on, stopping rule off; "
                     "the first cycles of a real molecule defeat the warm-started eigensolvers (levels 4e-4 Ha apart in the "
                     "virtual space, a Fock matrix that still moves), so the first cycles take their density from purification "
@@ -283,13 +432,15 @@ def main():
     # cold start from the projected core Hamiltonian, DIIS on.  The first call pays one-off costs
     # (code-object loading, first-touch workspaces) that belong to the process, not to an SCF: one
     # untimed run, then a fresh SCF object is timed from the call to the results on the host.
+    from nbed_amd.scf import History
+
     tts = None
     if not args.no_tts:
         for attempt in range(2):
             mf_t = GpuUHF(Mole(N, pr["nelec"]), pr["S"], pr["hcore"], eri, backend=be, shards=shards,
                           eri_packed=mf.eri_packed_device())  # the resident packed integrals are inputs
             mf_t.conv_tol, mf_t.max_cycle = 1e-6, 50
-            hist_t = []
+            hist_t = History()
             barrier()
             t_s = time.perf_counter()
             out_t = huzinaga_scf(mf_t, pr["V_emb"], pr["D_env"], dm_conv_tol=1e-6, use_DIIS=True, history=hist_t)
@@ -306,6 +457,7 @@ def main():
             "cycles_per_s_to_solution": len(hist_t) / dt_s,
             "stopping_rule": "|dE| < 1e-6 and |dD|_F < 1e-6 (nbed/config.py:110, nbed/driver.py:587), cold start, DIIS",
             "energy": [float(x) for x in hist_t[-1][0]],
+            "scf_restarts": list(hist_t.info.get("restarts", [])),
         }
         del mf_t, out_t
 
@@ -316,12 +468,16 @@ def main():
     # when the loop is about to queue cycle `warmup` the callback drains the GPU, and the clock
     # runs from there until the run has returned its results to the host.
     mf.max_cycle = args.warmup + args.steps
-    hist = []
+    from nbed_amd.scf import History
+
+    hist = History()
     clock = {}
 
     stamps = []
 
     def on_cycle(i):
+        if i == 0:
+            del stamps[:]  # (a run the loop repeats -- rejected purified / tracked cycle -- is timed from its last start)
         if i > args.warmup:
             stamps.append(time.perf_counter())
         if i == args.warmup:
@@ -335,6 +491,8 @@ def main():
     barrier()
     dt = time.perf_counter() - clock["t0"]
     be.profile(False)
+    scf_restarts = list(hist.info.get("restarts", []))
+    one_call = bool(hist.info.get("cycle_call"))
     hist = hist[args.warmup:]
     assert len(hist) == args.steps
     jk_ms, jk_cnt = be.profile_read(_nbx.PROF_JK_DENSE)
@@ -527,6 +685,21 @@ def main():
         del part, dmb, cb, cb2
         be.release_workspaces()
 
+    # what the roofline block below needs from the main workload, before its tensors are released
+    packed = mf.eri_packed_device() is not None
+    packed_bytes = float(be.lib.nbx_eri_packed_bytes(N, shards.lo, shards.hi)) if packed else None
+    ca_h = be.to_host(ca) if transform is not None else None
+    eri = full_eri = eri_rs = mf = None
+    if transform is not None:
+        ca = cb = None
+    be.release_workspaces()
+    torch.cuda.empty_cache()
+
+    # ---------------- sizes at which sharding the J/K build pays: every --gpus N
+    scaling = None
+    if not args.no_scaling:
+        scaling = scaling_workload_leg(be, args, world, rank, distributed, barrier)
+
     # ---------------- the same path on a REAL molecule (rank 0, N=1 only)
     real = None
     if rank == 0 and world == 1 and not args.no_real:
@@ -536,10 +709,15 @@ def main():
             real = {"error": f"{type(exc).__name__}: {exc}"}
         be.release_workspaces()
 
+    # ---------------- BASELINE configs[0], [1], [4]-shape on real integrals (rank 0, N=1 only)
+    small = None
+    if rank == 0 and world == 1 and not args.no_small:
+        small = small_configs_leg(be, args)
+
     # ---------------- CPU baseline (rank 0, N=1 only): the oracle on the host cores
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        eri_h = be.to_host(eri)  # bit-identical to oracle.synth.eri_dense(N), far faster to obtain
+        eri_h = be.to_host(be.synth_eri(N))  # bit-identical to oracle.synth.eri_dense(N), far faster to obtain
         cps = cpu_baseline_cycle(pr, eri_h, args.cpu_cycles)
         cpu = {
             "value": cps,
@@ -552,7 +730,6 @@ def main():
         if transform is not None:
             from oracle import hamiltonian
 
-            ca_h = be.to_host(ca)
             tcpu0 = time.perf_counter()
             hamiltonian.ao2mo_full(eri_h, ca_h[:, :32], ca_h, ca_h, ca_h)  # 1/4 of one block's quarter-1 work
             tcpu = time.perf_counter() - tcpu0
@@ -573,9 +750,8 @@ def main():
         alg_bytes = 8.0 * N * N * ntiles
         # The packed kernel (the one GpuUHF uses where it applies) reads q <= p AND s <= r: the packed
         # slab, once per build.
-        packed = mf.eri_packed_device() is not None
         if packed:
-            alg_bytes = float(be.lib.nbx_eri_packed_bytes(N, shards.lo, shards.hi))
+            alg_bytes = packed_bytes
         jk_kernel = "jk_s4_kernel" if packed else ("jk_sym_kernel" if sym else "jk_dense_kernel")
         achieved = alg_bytes / (jk_avg_ms * 1e-3) / 1e9 if jk_cnt else None
         traffic = None
@@ -606,7 +782,11 @@ def main():
                             + (", 4-fold packed for J/K (packed once, outside the timed region)" if packed else ""),
                 "nao": N,
                 "eri_bytes": 8 * N**4,
-                "parallelism": f"equal-work p-row slabs x{world} + RCCL all-reduce" if world > 1 else "single GPU",
+                "parallelism": (f"equal-work p-row slabs x{world} + "
+                                + ("gloo all-reduce, every rank on cuda:0 (NBED_BENCH_REHEARSE=1: a rehearsal of the code path, "
+                                   "not a measurement)" if os.environ.get("NBED_BENCH_REHEARSE") == "1" else "RCCL all-reduce")
+                                + "; one cycle = nbx_huz_cycle_jk | all-reduce | nbx_huz_cycle_post") if distributed
+                else "single GPU; one cycle = one nbx_huz_cycle call",
                 "diis": True,
             },
             "roofline": {
@@ -643,11 +823,14 @@ def main():
                 # from queueing the last cycle to the results on the host (C, eps, D, Hz downloaded)
                 "last_cycle_and_results": (dt - (stamps[-1] - stamps[0])) * 1e3 if world == 1 and stamps else None,
             },
-            "check": {"energy_last_cycle": e_last, "dm_change_last_cycle": dm_change_last},
+            "check": {"energy_last_cycle": e_last, "dm_change_last_cycle": dm_change_last, "scf_restarts": scf_restarts,
+                      "one_call_per_cycle": one_call},
             "time_to_solution": tts,
             "transform": transform,
             "n2000_streamed": n2000,
             "real_molecule": real,
+            "small_configs": small,
+            "scaling_workload": scaling,
         }
         print(json.dumps(out))
     if distributed:

@@ -91,3 +91,27 @@ def test_two_ranks_on_one_gpu_split_cycle(be, tmp_path, n):
     compare(ranks, single_process(be, n))
     for key in ("e", "d", "hz", "h2"):
         np.testing.assert_array_equal(ranks[0][key], ranks[1][key])
+
+
+def test_bench_child_process_over_single_rank_rccl(tmp_path):
+    """``bench.py`` itself with NBED_FORCE_DIST=1 in a child process: one rank, backend "nccl" -- process-group
+    init, the per-cycle all-reduce of the J/K partials inside the timed SCF (nbx_huz_cycle_jk | RCCL | _post), the
+    all-gather of the transform slabs, the all-reduces of the scaling workloads, barrier, destroy -- and ONE JSON line
+    that says so."""
+    import json
+
+    env = dict(os.environ, NBED_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(HERE.parent / "bench.py"), "--no-real", "--no-n2000", "--no-small", "--no-cpu-baseline",
+           "--no-tts", "--steps", "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["metric"] == "embedded_scf_cycles_per_sec" and out["n_gpus"] == 1 and out["steps"] == 3
+    assert "RCCL all-reduce" in out["config"]["parallelism"] and out["check"]["one_call_per_cycle"]
+    assert out["value"] > 0 and out["transform"]["value"] > 0
+    for leg in out["scaling_workload"]:
+        assert "error" not in leg, leg
+        assert leg["allreduce_ms_alone"] is not None and leg["allreduce_ms_alone"] > 0
