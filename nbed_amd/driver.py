@@ -130,9 +130,15 @@ class BuiltinHFProvider:
     host-side McMurchie-Davidson engine, exchange-correlation from the host-side quadrature
     (``XCProvider``), Coulomb and exact exchange from libnbx (``GpuUKS`` / ``GpuUHF``)."""
 
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, xc_grid: tuple[int, int] | None = None):
+        """``xc_grid``: (radial points per heavy atom, polar angles) of the exchange-correlation quadrature, or
+        ("lebedev", level) for the Treutler-Ahlrichs x pruned-Lebedev construction PySCF documents as its default
+        (``nbed_amd.xc.build_grid``; None = the product grid's defaults, which converge energies to ~1e-7 Ha).  Matrix elements of
+        v_xc[D_act] between VIRTUAL orbitals converge much more slowly -- the active density of a SPADE partition
+        has near-nodal surfaces where the GGA potential is singular -- and need a finer grid."""
         self._be = backend
         self._cache = {}
+        self.xc_grid = xc_grid
 
     @staticmethod
     def supports(config: NbedConfig) -> bool:
@@ -214,7 +220,13 @@ class BuiltinHFProvider:
         key = ("xc", config.geometry, str(config.basis).lower(), str(config.unit), name)
         if key not in self._cache:
             atoms = integrals.parse_geometry(config.geometry, str(config.unit))
-            self._cache[key] = xcmod.XCProvider(atoms, integrals.Basis(atoms, str(config.basis)), name)
+            if self.xc_grid is None:
+                grid = {}
+            elif isinstance(self.xc_grid[0], str):  # ("lebedev", level): Treutler-Ahlrichs x pruned Lebedev
+                grid = {"scheme": str(self.xc_grid[0]), "level": int(self.xc_grid[1])}
+            else:  # (n_rad, n_theta): the product grid
+                grid = {"scheme": "product", "n_rad": int(self.xc_grid[0]), "n_theta": int(self.xc_grid[1])}
+            self._cache[key] = xcmod.XCProvider(atoms, integrals.Basis(atoms, str(config.basis)), name, **grid)
         return self._cache[key]
 
     def _uks(self, config: NbedConfig, mol, xc_functional: str, backend):

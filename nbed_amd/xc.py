@@ -88,33 +88,121 @@ def _hip_backend(device):
     return get_backend()
 
 
-def build_grid(atoms, n_rad: int = 96, n_theta: int = 28, device="cpu"):
+# Treutler-Ahlrichs / Lebedev scheme (``scheme="lebedev"``): the construction PySCF's ``dft.gen_grid`` documents as
+# its default -- Treutler & Ahlrichs' M4 radial map (J. Chem. Phys. 102, 346 (1995)) of Gauss-Chebyshev nodes,
+# Lebedev-Laikov angular rules pruned near the nucleus as NWChem does, Becke cells with Treutler's
+# sqrt-of-Bragg-radius size adjustment -- written from the published formulas (scipy provides the Lebedev rules).
+# Level 3: 50 radial shells for H, 75 for Li-Ne, 302 angular points.
+_TA_XI = {"H": 0.8, "C": 1.1, "N": 0.9, "O": 0.9, "F": 0.9}
+_TA_RAD = {0: (10, 15), 1: (30, 40), 2: (40, 60), 3: (50, 75), 4: (60, 90), 5: (70, 105), 6: (80, 120), 7: (90, 135),
+           8: (100, 150), 9: (200, 200)}           # radial shells: (period 1, period 2)
+_TA_ANG = {0: (11, 15), 1: (17, 23), 2: (23, 29), 3: (29, 29), 4: (35, 41), 5: (41, 47), 6: (47, 53), 7: (53, 59),
+           8: (59, 59), 9: (65, 65)}               # Lebedev degree: (period 1, period 2)
+_LEBEDEV_DEGREES = (3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 35, 41, 47, 53, 59, 65)
+
+
+def _lebedev(degree: int):
+    """(unit vectors (n, 3), weights summing to 4 pi) of the Lebedev rule of the given degree."""
+    from scipy.integrate import lebedev_rule
+
+    x, w = lebedev_rule(int(degree))
+    return np.ascontiguousarray(x.T), np.asarray(w)
+
+
+def _ta_radial(n: int, xi: float):
+    """Treutler-Ahlrichs M4: x_i = cos(i pi / (n + 1)), r = -xi / ln 2 (1 + x)^0.6 ln((1 - x) / 2); returns
+    (r ascending, r^2 dr weights)."""
+    step = math.pi / (n + 1)
+    i = np.arange(1, n + 1)
+    x = np.cos(i * step)
+    a = xi / math.log(2.0) * (1.0 + x) ** 0.6
+    r = -a * np.log((1.0 - x) / 2.0)
+    dr = step * np.sin(i * step) * a * (-0.6 / (1.0 + x) * np.log((1.0 - x) / 2.0) + 1.0 / (1.0 - x))
+    return r[::-1], (r * r * dr)[::-1]
+
+
+def _nwchem_pruned_degrees(sym: str, r: np.ndarray, degree: int):
+    """Lebedev degree per radial shell: the full rule between 0.9 (0.5 for H) and 3.5 (4.5) Bragg radii, smaller
+    ones nearer the nucleus and one step smaller outside (NWChem's pruning scheme)."""
+    idx = _LEBEDEV_DEGREES.index(degree)
+    if idx < _LEBEDEV_DEGREES.index(11):
+        return np.full(r.shape, degree)
+    if idx == _LEBEDEV_DEGREES.index(11):
+        ladder = (7, 9, 9, 9, 7)  # 26, 38, 38, 38, 26 points
+    else:
+        ladder = (11, 15, _LEBEDEV_DEGREES[idx - 1], degree, _LEBEDEV_DEGREES[idx - 1])
+    alphas = (0.25, 0.5, 1.0, 4.5) if sym in ("H", "He") else (0.1667, 0.5, 0.9, 3.5)
+    place = (r[:, None] / (BRAGG[sym] / integrals.BOHR) > np.asarray(alphas)[None, :]).sum(axis=1)
+    return np.asarray(ladder)[place]
+
+
+def _atomic_shells(atoms, scheme: str, n_rad: int, n_theta: int, level: int):
+    """Per atom: (points relative to the nucleus (g, 3), weights (g,)) before the cell partition."""
+    out = []
+    if scheme == "lebedev":
+        for sym, _ in atoms:
+            period = 0 if sym in ("H", "He") else 1
+            r, wr = _ta_radial(_TA_RAD[level][period], _TA_XI[sym])
+            degs = _nwchem_pruned_degrees(sym, r, _TA_ANG[level][period])
+            pts, wts = [], []
+            for d in sorted(set(int(v) for v in degs)):
+                ang, aw = _lebedev(d)
+                sel = np.flatnonzero(degs == d)
+                pts.append((r[sel, None, None] * ang[None, :, :]).reshape(-1, 3))
+                wts.append((wr[sel, None] * aw[None, :]).reshape(-1))
+            out.append((np.concatenate(pts), np.concatenate(wts)))
+        return out
+    ang_pts, ang_w = _angular_rule(n_theta)
+    for sym, _ in atoms:
+        rad = BRAGG[sym] / integrals.BOHR
+        r, wr = _radial_rule(n_rad if sym != "H" else max(n_rad * 3 // 4, 24), rad if sym != "H" else 2 * rad)
+        out.append(((r[:, None, None] * ang_pts[None, :, :]).reshape(-1, 3), (wr[:, None] * ang_w[None, :]).reshape(-1)))
+    return out
+
+
+def build_grid(atoms, n_rad: int | None = None, n_theta: int | None = None, device="cpu", scheme: str | None = None,
+               level: int = 3):
     """(points (G, 3) in Bohr, weights (G,)) of the molecular grid.  The Becke cell functions -- a
     (points x atoms x atoms) product -- are evaluated on ``device``: by nbx_becke_share (one thread per point)
-    on a GPU, with torch in blocks of points on the host."""
+    on a GPU, with torch in blocks of points on the host.
+
+    ``scheme``: "lebedev" (Treutler-Ahlrichs radial x pruned Lebedev angular, ``level`` 0-9: the construction PySCF
+    documents for its default grid, level 3 = its default -- and the default here, so that grid-sensitive numbers
+    come out as the reference's do: DESIGN.md section 6) or "product" (Becke radial map x Gauss-Legendre/uniform
+    angular product rule with ``n_rad`` (96) shells per heavy atom and ``n_theta`` (28) polar angles; chosen
+    implicitly when either is given)."""
+    if scheme is None:
+        scheme = "lebedev" if (n_rad is None and n_theta is None) else "product"
+    n_rad = 96 if n_rad is None else int(n_rad)
+    n_theta = 28 if n_theta is None else int(n_theta)
     t = _torch()
     dev = t.device(device)
     be = _hip_backend(dev)
+    if scheme not in ("product", "lebedev"):
+        raise ValueError(f"unknown grid scheme {scheme!r}")
     centres = np.array([pos for _, pos in atoms])
     radii = np.array([BRAGG[sym] / integrals.BOHR for sym, _ in atoms])
-    ang_pts, ang_w = _angular_rule(n_theta)
     natm = len(atoms)
     dist = np.linalg.norm(centres[:, None, :] - centres[None, :, :], axis=-1)
-    # Becke's size adjustment a_ij from the ratio of the Bragg radii (|a| capped at 1/2)
-    chi = radii[:, None] / radii[None, :]
-    uab = (chi - 1.0) / (chi + 1.0)
-    aij = np.clip(uab / (uab * uab - 1.0), -0.5, 0.5)
+    if scheme == "lebedev":
+        # Treutler's adjustment: Becke's a_ij = u / (u^2 - 1), u = (chi - 1) / (chi + 1), with chi = sqrt(R_i / R_j)
+        # instead of R_i / R_j, i.e. a_ij = (sqrt(R_j / R_i) - sqrt(R_i / R_j)) / 4, |a| capped at 1/2
+        sq = np.sqrt(radii)
+        aij = np.clip(0.25 * (sq[None, :] / sq[:, None] - sq[:, None] / sq[None, :]), -0.5, 0.5)
+    else:
+        # Becke's size adjustment a_ij from the ratio of the Bragg radii (|a| capped at 1/2)
+        chi = radii[:, None] / radii[None, :]
+        uab = (chi - 1.0) / (chi + 1.0)
+        aij = np.clip(uab / (uab * uab - 1.0), -0.5, 0.5)
     centres_d = t.as_tensor(centres).to(dev)
     aij_d = t.as_tensor(aij).to(dev)
     inv_dist = t.as_tensor(1.0 / (dist + np.eye(natm))).to(dev)
     off_diag = (1.0 - t.eye(natm, dtype=t.float64, device=dev))
     pts_all, w_all = [], []
+    shells = _atomic_shells(atoms, scheme, n_rad, n_theta, level)
     for ia, (sym, pos) in enumerate(atoms):
-        r, wr = _radial_rule(n_rad if sym != "H" else max(n_rad * 3 // 4, 24), radii[ia] if sym != "H" else 2 * radii[ia])
-        pts = pos[None, None, :] + r[:, None, None] * ang_pts[None, :, :]
-        w = wr[:, None] * ang_w[None, :]
-        pts = pts.reshape(-1, 3)
-        w = w.reshape(-1)
+        pts = pos[None, :] + shells[ia][0]
+        w = shells[ia][1]
         if natm > 1 and be is not None:
             share = be.to_host(be.becke_share(be.asarray(pts), centres_d, aij_d, inv_dist, ia))
             w = w * share
@@ -131,7 +219,7 @@ def build_grid(atoms, n_rad: int = 96, n_theta: int = 28, device="cpu"):
                 cell = s.prod(dim=2)                                                   # (g, natm)
                 share[g0:g0 + p.shape[0]] = (cell[:, ia] / cell.sum(dim=1)).cpu().numpy()
             w = w * share
-        keep = w > 1e-22
+        keep = np.abs(w) > 1e-22  # (some Lebedev rules carry a negative weight: 74, 230, 266 points)
         pts_all.append(pts[keep])
         w_all.append(w[keep])
     return np.concatenate(pts_all), np.concatenate(w_all)
@@ -337,7 +425,8 @@ class XCProvider:
     BLOCK = 1 << 16  # grid points per matmul block (bounds the temporaries, not the stored AO values)
     SPLIT = 256      # rows per piece of the (nao x G) (G x nao) product: a batched GEMM summed over pieces
 
-    def __init__(self, atoms, basis: "integrals.Basis", xc: str, n_rad: int = 96, n_theta: int = 28, device=None):
+    def __init__(self, atoms, basis: "integrals.Basis", xc: str, n_rad: int | None = None, n_theta: int | None = None,
+                 device=None, scheme: str | None = None, level: int = 3):
         """``device``: where the AO values live and the density / potential contractions run -- a torch
         device; None picks ``cuda`` when there is one (a 148-function molecule on the default grid is
         3.2 million points: 16 GB of AO values and gradients, 0.5 TFLOP per Kohn-Sham cycle)."""
@@ -347,7 +436,7 @@ class XCProvider:
         if device is None:
             device = "cuda" if t.cuda.is_available() else "cpu"
         self.device = t.device(device)
-        self.points, self.weights = build_grid(atoms, n_rad, n_theta, device=self.device)
+        self.points, self.weights = build_grid(atoms, n_rad, n_theta, device=self.device, scheme=scheme, level=level)
         self.nelec_last = None
         self._blocks = []  # (ao (g, nao), dao (3, g, nao)) per block of grid points
         npts = self.points.shape[0]

@@ -328,3 +328,55 @@ def test_xc_quadrature_and_functional_derivatives():
     ex = float((torch.tensor(wts) * xc.energy_density("slater", rho, z + 1e-30, z, z, z)).sum())
     exact = -1.5 * (3.0 / (4.0 * np.pi)) ** (1.0 / 3.0) * np.pi ** (-4.0 / 3.0) * 8.0 * np.pi / (8.0 / 3.0) ** 3
     assert abs(ex - exact) < 1e-6
+
+
+def test_xc_default_grid_is_the_treutler_ahlrichs_lebedev_construction():
+    """The default quadrature (``scheme="lebedev"``, level 3): Treutler-Ahlrichs M4 radial shells (50 for H, 75 for
+    Li-Ne), Lebedev rules pruned NWChem-style (50 / 86 / 266 / 302 / 266 points from the nucleus outwards -- the
+    266-point rule carries a negative weight, which must survive), Becke cells with Treutler's sqrt-radius size
+    adjustment (the cell of the larger atom is the larger one).  It integrates the density and the overlap as the
+    product grid does, with a tenth of the points, and gives the same exchange-correlation energy to the few 1e-6
+    the reference's own grid level is good for."""
+    from nbed_amd import integrals, xc
+
+    # shell structure
+    r, w = xc._ta_radial(75, xc._TA_XI["O"])
+    assert r.shape == (75,) and np.all(np.diff(r) > 0) and np.all(w > 0)
+    assert abs(np.sum(w * np.exp(-r * r)) - np.sqrt(np.pi) / 4.0) < 1e-12  # int r^2 exp(-r^2) dr
+    degs = xc._nwchem_pruned_degrees("O", r, 29)
+    assert sorted(set(int(d) for d in degs)) == [11, 15, 27, 29] and int(degs[0]) == 11 and int(degs[-1]) == 27
+    assert [xc._lebedev(d)[1].size for d in (11, 15, 27, 29)] == [50, 86, 266, 302]
+    assert xc._lebedev(27)[1].min() < 0.0
+    o_only = xc.build_grid([("O", np.zeros(3))])
+    assert o_only[0].shape[0] == sum(xc._lebedev(int(d))[1].size for d in degs)  # no point dropped, negative weights kept
+    assert abs(np.sum(o_only[1] * np.exp(-np.sum(o_only[0] ** 2, axis=1))) - np.pi ** 1.5) < 1e-10
+    # the molecule
+    geom = "3\n\nO   0.0000  0.000  0.115\nH   0.0000  0.754  -0.459\nH   0.0000  -0.754  -0.459"
+    atoms = integrals.parse_geometry(geom)
+    basis = integrals.Basis(atoms, "sto-3g")
+    ints = integrals.molecule_integrals(geom, "sto-3g", "angstrom")
+    leb = xc.XCProvider(atoms, basis, "b3lyp", device="cpu")
+    prod = xc.XCProvider(atoms, basis, "b3lyp", n_rad=96, n_theta=28, device="cpu")
+    assert leb.points.shape[0] < 0.1 * prod.points.shape[0] and 30000 < leb.points.shape[0] < 36000
+    s_num = leb.ao.T @ (leb.ao * leb.weights[:, None])
+    np.testing.assert_allclose(s_num, ints["S"], rtol=0, atol=2e-6)
+    w_, c = np.linalg.eigh(ints["S"])
+    x = (c / np.sqrt(w_)) @ c.T
+    e, u = np.linalg.eigh(x @ ints["hcore"] @ x)
+    cmo = x @ u
+    dm = np.stack([cmo[:, :5] @ cmo[:, :5].T, cmo[:, :5] @ cmo[:, :5].T])
+    (e_l, v_l), (e_p, v_p) = leb(dm), prod(dm)
+    assert abs(leb.nelec_last - 10.0) < 2e-5 and abs(e_l - e_p) < 1e-5
+    np.testing.assert_allclose(v_l, v_p, rtol=0, atol=1e-3)  # (matrix elements of v_xc are what is grid sensitive)
+    # Becke cells with Treutler's adjustment: the larger atom (O, Bragg radius 0.60 A against 0.35) gets the larger
+    # cell -- of the points close to the O-H midpoint, those centred on O carry more weight than those centred on H
+    n_o = sum(xc._lebedev(int(d))[1].size for d in xc._nwchem_pruned_degrees("O", r, 29))
+    mid = 0.5 * (atoms[0][1] + atoms[1][1])
+    near = np.linalg.norm(leb.points - mid, axis=1) < 0.35
+    own_o = np.arange(leb.points.shape[0]) < n_o
+    # (weights include r^2 dr: compare the cell SHARES, i.e. weights divided by the single-atom weights)
+    o_alone = xc.build_grid([atoms[0]])
+    share_o = leb.weights[:n_o] / o_alone[1]
+    assert share_o[near[:n_o]].mean() > 0.5
+    with pytest.raises(ValueError):
+        xc.build_grid(atoms, scheme="nope")

@@ -55,9 +55,9 @@ def drivers(be, provider):
 def test_global_ks_b3lyp(drivers):
     """tests/test_driver.py:41-49."""
     ks = drivers["mu"]._global_ks
-    assert abs(ks.e_tot - (-75.3091447400438)) < 2e-6
+    assert abs(ks.e_tot - (-75.3091447400438)) < 2e-8  # (7e-10 on the Treutler-Ahlrichs / Lebedev level-3 grid)
     e_elec, e2 = ks.energy_elec()
-    assert abs(e_elec - (-84.59485896172163)) < 2e-6
+    assert abs(e_elec - (-84.59485896172163)) < 2e-8
     assert abs(e2 - 37.93302591280513) < 2e-5
     assert abs(ks.energy_nuc() - 9.285714221677825) < 1e-10
 
@@ -78,7 +78,7 @@ def test_embedded_fci_both_projectors(drivers, proj):
     res = getattr(drv, proj)
     fci = drv._run_emb_fci(drv.embedded_scf)
     e_emb = fci.e_tot + drv.e_env + drv.two_e_cross - res["correction"] - res["beta_correction"]
-    assert abs(e_emb - (-75.12858550813999)) < 1e-4
+    assert abs(e_emb - (-75.12858550813999)) < 5e-6  # (mu 8e-8, Huzinaga 8e-7)
     assert abs(res["e_fci"] - e_emb) < 1e-9
 
 
@@ -97,32 +97,103 @@ def test_dft_in_dft_reproduces_global_ks(drivers):
     huz_did = huz._dft_in_dft(ProjectorTypes.HUZ)
     e_ks = mu._global_ks.e_tot
     assert abs(mu_did["e_dft_in_dft"] - e_ks) < 5e-6
-    assert abs(huz_did["e_dft_in_dft"] - e_ks) < 5e-6
+    assert abs(huz_did["e_dft_in_dft"] - e_ks) < 1e-9
     assert abs(mu_did["e_dft_in_dft"] - huz_did["e_dft_in_dft"]) < 5e-6
 
 
+# docs/source/notebooks/usage.ipynb cell 4 output, copied: ``v_emb`` (:98-140), the one-body spin-orbital matrix
+# (:210-239; alpha rows/columns 0,2,.. beta 1,3,..: the non-zero entries) and entries of the two-body tensor (:240-330)
+NOTEBOOK_V_EMB = np.array([
+    [[2.40120585e+02, 9.74408104e+03, 6.04224934e-12, -1.98298031e-11, -1.05560147e+04, 1.02938801e+04, 1.02938801e+04],
+     [9.74408104e+03, 4.00928677e+05, 2.48630933e-10, -3.13666123e-10, -4.34365854e+05, 4.23574788e+05, 4.23574788e+05],
+     [6.04224934e-12, 2.48630933e-10, 2.54435216e+00, -1.73505885e-09, -2.69368028e-10, -7.59113406e-10, 1.28446461e-09],
+     [-1.85259550e-11, -3.14503152e-10, -1.73505885e-09, 7.85534797e+05, -3.99266698e-10, 4.62606474e+05, -4.62606474e+05],
+     [-1.05560147e+04, -4.34365854e+05, -2.69368028e-10, -4.22085540e-10, 4.70596664e+05, -4.58902672e+05, -4.58902672e+05],
+     [1.02938801e+04, 4.23574788e+05, -7.59113406e-10, 4.62606474e+05, -4.58902672e+05, 7.19934445e+05, 1.75069053e+05],
+     [1.02938801e+04, 4.23574788e+05, 1.28446461e-09, -4.62606474e+05, -4.58902672e+05, 1.75069053e+05, 7.19934445e+05]],
+    [[2.40124530e+02, 9.74457859e+03, -1.77078600e-12, 7.41996370e-11, -1.05559877e+04, 1.02937976e+04, 1.02937976e+04],
+     [9.74457859e+03, 4.00962941e+05, -7.28686142e-11, -1.59429891e-10, -4.34379683e+05, 4.23585960e+05, 4.23585960e+05],
+     [-1.77078600e-12, -7.28686142e-11, 2.54434746e+00, -2.13676477e-09, 7.89421346e-11, -1.33529095e-09, 1.18133021e-09],
+     [7.71962554e-11, -1.28721470e-10, -2.13676477e-09, 7.85561377e+05, -3.75123676e-10, 4.62605196e+05, -4.62605196e+05],
+     [-1.05559877e+04, -4.34379683e+05, 7.89421346e-11, -3.73646073e-10, 4.70586411e+05, -4.58890168e+05, -4.58890168e+05],
+     [1.02937976e+04, 4.23585960e+05, -1.33529095e-09, 4.62605196e+05, -4.58890168e+05, 7.19909085e+05, 1.75065139e+05],
+     [1.02937976e+04, 4.23585960e+05, 1.18133021e-09, -4.62605196e+05, -4.58890168e+05, 1.75065139e+05, 7.19909085e+05]]])
+NOTEBOOK_H1 = {"alpha_diag": [-29.37839333, -5.31656895, -4.92156382, -3.36953569, -3.09150505],
+               "beta_diag": [-29.37839567, -5.31655062, -4.92156851, -3.36944815, -3.09142187],
+               "alpha_offdiag": {(0, 1): 0.43431265, (0, 4): 0.34938094, (1, 4): 0.15141666},
+               "beta_offdiag": {(0, 1): 0.43429801, (0, 4): 0.3493805, (1, 4): 0.151425}}
+NOTEBOOK_H2 = {(0, 0, 0, 0): 2.38311873e+00, (0, 0, 0, 2): -1.93907508e-01, (0, 0, 0, 8): -1.24135876e-01,
+               (0, 0, 2, 2): 2.92287864e-02, (0, 0, 2, 8): 1.05001132e-02, (0, 0, 8, 8): 1.54798607e-02,
+               (0, 1, 1, 0): 2.38311937e+00, (0, 1, 1, 2): -1.93907582e-01, (0, 1, 1, 8): -1.24135939e-01,
+               (0, 2, 2, 0): 5.61155899e-01, (0, 2, 2, 2): 2.19955286e-03, (0, 2, 2, 8): -1.81195791e-02,
+               (0, 2, 8, 0): -3.35435622e-03, (0, 2, 8, 2): -4.26424017e-03, (0, 2, 8, 8): 2.20351628e-03,
+               (0, 8, 8, 0): 4.01314721e-01, (0, 8, 8, 2): -1.06559793e-02, (0, 8, 8, 8): 2.78523503e-03,
+               (0, 9, 9, 0): 4.01300974e-01, (0, 9, 9, 8): 2.78526952e-03}
+
+
 def test_usage_notebook_results(be, provider):
-    """docs/source/notebooks/usage.ipynb:141-160,205-209 (cell 4 output), config tests/test_config.json:
-    water / STO-3G, ONE active atom, mu projector, concentric localisation, DFT-in-DFT."""
+    """docs/source/notebooks/usage.ipynb:97-330 (cell 4 output), config tests/test_config.json: water / STO-3G, ONE
+    active atom, mu projector, concentric localisation, DFT-in-DFT -- every number the notebook prints: the scalars,
+    ``v_emb`` (2,7,7), the embedded MO energies before and after the environment is deleted (virtual levels included),
+    the full one-body spin-orbital matrix and the printed part of the two-body tensor.  The reference's output is
+    spin contaminated at 1.5e-5 (its global Kohn-Sham run stops at 1e-6: ``correction`` 8.1796227 against
+    ``beta_correction`` 8.1796081 for this closed-shell molecule); where the alpha and beta numbers differ ours,
+    which are spin pure, are held to their mean."""
     cfg = dict(NBED_ARGS, virtual_localization="cl", run_dft_in_dft=True, init_huzinaga_rhf_with_mu=False)
     drv = nbed(NbedConfig(**cfg), provider=provider, backend=be)
     res = drv.mu
-    for key, ref, tol in [("e_rhf", -75.12380801465767, 1e-5), ("classical_energy", -14.229086664077219, 1e-4),
-                          ("hf_emb", -60.89472135058044, 1e-4), ("correction", 8.179622720635962, 1e-4),
-                          ("beta_correction", 8.179608146077953, 1e-4), ("e_fci", -75.12858550813972, 1e-4),
-                          ("e_dft_in_dft", -75.30914544149083, 5e-6)]:
+    for key, ref, tol in [("e_rhf", -75.12380801465767, 5e-7), ("classical_energy", -14.229086664077219, 3e-5),
+                          ("hf_emb", -60.89472135058044, 3e-5), ("correction", 8.179622720635962, 2e-6),
+                          ("beta_correction", 8.179608146077953, 3e-5), ("e_fci", -75.12858550813972, 1e-6),
+                          ("e_dft_in_dft", -75.30914544149083, 5e-8)]:
         assert abs(res[key] - ref) < tol, (key, res[key], ref)
-    # occupied embedded MO energies after the environment is deleted (:147-150); the two environment
-    # orbitals sit at the level shift before (:141-146)
-    np.testing.assert_allclose(res["mo_energies_emb_post_del"][0][:3], [-20.22017755, -0.69240454, -0.36562695],
-                               rtol=0, atol=1e-4)
+    # the mean of the reference's two corrections is what a spin-pure run gives for either
+    assert abs(res["correction"] - 0.5 * (8.179622720635962 + 8.179608146077953)) < 8e-6
+    # embedded MO energies after the environment is deleted (:147-150) -- the two VIRTUAL levels too: they are
+    # matrix elements of v_xc[D_act] where the active density has a near-nodal surface, and depend on the
+    # quadrature grid at the 5e-3 level (product grid 96 x 28: 0.6393, 0.7552; converged product grid: 0.63698,
+    # 0.75464; the Treutler-Ahlrichs / pruned-Lebedev level-3 construction PySCF documents, the default here:
+    # these) -- and the two environment orbitals at the level shift before (:141-146)
+    ref_post = np.array([[-20.22017755, -0.69240454, -0.36562695, 0.63362753, 0.75419772],
+                         [-20.2201771, -0.6923889, -0.36562595, 0.63360661, 0.75419406]])
+    np.testing.assert_allclose(res["mo_energies_emb_post_del"][0], ref_post.mean(axis=0), rtol=0, atol=3e-5)
+    np.testing.assert_allclose(res["mo_energies_emb_post_del"][1], ref_post.mean(axis=0), rtol=0, atol=3e-5)
     np.testing.assert_allclose(res["mo_energies_emb_pre_del"][0][-2:], [9.99999537e05, 9.99999834e05], rtol=0,
-                               atol=0.02)
+                               atol=1e-3)  # (printed with nine digits)
+    np.testing.assert_allclose(res["mo_energies_emb_pre_del"][0][:5], res["mo_energies_emb_post_del"][0], rtol=0, atol=1e-12)
+    # v_emb = mu S D_env S + V_emb in the AO basis (O 1s 2s 2px 2py 2pz, H 1s, H 1s: PySCF's order and ours); the
+    # reference's alpha and beta matrices differ by 3.4e-5 relative, its "zeros" are 1e-9 .. 1e-12
+    v = np.asarray(res["v_emb"])
+    assert v.shape == (2, 7, 7)
+    ref_v = NOTEBOOK_V_EMB.mean(axis=0)
+    for x in range(2):
+        np.testing.assert_allclose(v[x], ref_v, rtol=2.5e-5, atol=1e-5)
     const, h1, h2 = res["second_quantised"]
     assert h1.shape == (10, 10) and h2.shape == (10,) * 4  # cell 23
     assert const == res["classical_energy"]
-    # one-body coefficients are gauge dependent; their spectrum is not: alpha and beta blocks agree
-    np.testing.assert_allclose(np.linalg.eigvalsh(h1[0::2, 0::2]), np.linalg.eigvalsh(h1[1::2, 1::2]), rtol=0, atol=1e-6)
+    # one-body matrix: diagonal and |off-diagonal| are gauge free (MO signs are not); everything else is zero
+    ha, hb = h1[0::2, 0::2], h1[1::2, 1::2]
+    assert np.all(h1[0::2, 1::2] == 0.0) and np.all(h1[1::2, 0::2] == 0.0)
+    ref_diag = 0.5 * (np.array(NOTEBOOK_H1["alpha_diag"]) + np.array(NOTEBOOK_H1["beta_diag"]))
+    np.testing.assert_allclose(np.diag(ha), ref_diag, rtol=0, atol=1e-4)  # (reference alpha vs beta: up to 9e-5)
+    np.testing.assert_allclose(np.diag(hb), ref_diag, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(np.diag(ha)[:3], ref_diag[:3], rtol=0, atol=1.5e-5)
+    ref_abs = np.diag(np.abs(ref_diag))
+    for (i, j), val in NOTEBOOK_H1["alpha_offdiag"].items():
+        ref_abs[i, j] = ref_abs[j, i] = 0.5 * (val + NOTEBOOK_H1["beta_offdiag"][(i, j)])
+    off = ~np.eye(5, dtype=bool)
+    np.testing.assert_allclose(np.abs(ha)[off], ref_abs[off], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(np.abs(hb)[off], ref_abs[off], rtol=0, atol=2e-5)
+    assert ha[0, 1] * ha[0, 4] * ha[1, 4] > 0  # (each orbital's sign enters twice: gauge free, positive in the notebook)
+    # two-body tensor: the printed entries; those with an orbital appearing an odd number of times carry its sign --
+    # fixed through the one-body entries of the same orbital pairs
+    sgn = np.ones(10)
+    for k, mo in ((2, 1), (8, 4)):
+        sgn[k] = sgn[k + 1] = np.sign(ha[0, mo]) * np.sign(NOTEBOOK_H1["alpha_offdiag"][(0, mo)])
+    for idx, val in NOTEBOOK_H2.items():
+        ours = h2[idx] * np.prod([sgn[k] for k in idx])
+        assert abs(ours - val) < 1.2e-5, (idx, ours, val)
+    assert abs(h2[0, 0, 0, 0] - 2.38311873) < 3e-6 and abs(h2[0, 2, 2, 0] - 0.561155899) < 3e-6
 
 
 def test_two_active_atoms_raw_xyz_and_subsystem_sum_rule(be):
@@ -133,7 +204,7 @@ def test_two_active_atoms_raw_xyz_and_subsystem_sum_rule(be):
                      localization="spade", convergence=1e-6, savefile=None, run_ccsd_emb=False, run_fci_emb=False)
     drv = NbedDriver(cfg, backend=be)
     drv.embed()
-    assert abs(drv.classical_energy - (-3.5867934952241356)) < 1e-4
+    assert abs(drv.classical_energy - (-3.5867934952241356)) < 5e-5
     assert drv.embedded_scf.mo_coeff.shape == (2, 7, 6)
     np.testing.assert_array_equal(drv.embedded_scf.mo_occ, np.array([[1, 1, 1, 1, 0, 0]] * 2))
     total = drv.e_act + drv.e_env + drv.two_e_cross + drv._global_ks.energy_nuc()
@@ -158,8 +229,8 @@ def test_global_and_embedded_ccsd(drivers):
         e_emb = emb_cc.e_tot + d.e_env + d.two_e_cross - res["correction"] - res["beta_correction"]
         # the same 1.5e-5 as the embedded FCI number (the reference's loosely converged, spin-contaminated
         # B3LYP inputs: module docstring); CCSD and FCI of this active space agree to 1.5e-7 here, to 5.8e-7 there
-        assert abs(e_emb - (-75.1285849238916)) < 3e-5
-        assert abs(ecorr - (-0.00477765364464925)) < 2e-5
+        assert abs(e_emb - (-75.1285849238916)) < 3e-6
+        assert abs(ecorr - (-0.00477765364464925)) < 2e-7
         fci_e = d._run_emb_fci(d.embedded_scf).e_tot
         assert abs(fci_e - emb_cc.e_tot) < 1e-6
 
@@ -193,8 +264,10 @@ def test_huzinaga_scf_outputs_of_test_scf(be, provider):
     embedding potential and environment density of the two-active-atom run on the H,O,H geometry
     (conftest.py:104-125) -- an unphysical but fully determined combination.  The loop never reads the object's
     own orbitals, so no ``kernel()`` is needed.  Occupied levels, the density and the operator agree to the
-    1e-5 the reference's inputs are good to; the level the projector pushes to +3.6 / +2.4 Ha is the most
-    sensitive to them (the reference's own alpha and beta differ by 6e-5 there) and agrees to 1.3e-3."""
+    1e-5 the reference's inputs are good to, the level the projector pushes to +3.6 / +2.4 Ha included (the
+    reference's own alpha and beta differ by 6e-5 there; it is a VIRTUAL-space matrix element of v_xc[D_act] and
+    came out 1.3e-3 off on the product quadrature grid: DESIGN.md section 6).  The core level carries the
+    reference's spin contamination (its alpha and beta are 1.3e-4 apart)."""
     from nbed_amd import integrals, xc
     from nbed_amd.scf import GpuRHF, GpuRKS, GpuUHF, GpuUKS, huzinaga_scf
 
@@ -208,16 +281,16 @@ def test_huzinaga_scf_outputs_of_test_scf(be, provider):
                                      dm_environment_occupied=denv[0], backend=be)
     ref = np.array([-19.346243, -0.59741322, 0.12747464, 0.6132579, 0.79561917, 3.56833278, 4.1655741])
     assert conv and c.shape == d.shape == hz.shape == (7, 7)
-    np.testing.assert_allclose(e[[0, 1, 2, 4, 6]], ref[[0, 1, 2, 4, 6]], rtol=0, atol=5e-5)
-    np.testing.assert_allclose(e, ref, rtol=0, atol=1.5e-3)
+    np.testing.assert_allclose(e[1:], ref[1:], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(e, ref, rtol=0, atol=1e-4)
     assert abs(np.mean(d) - 0.17985591319811933) < 5e-6 and abs(np.mean(hz) - (-0.01224642921175508)) < 1e-5
     c, e, d, hz, conv = huzinaga_scf(GpuUHF(mol, m["S"], m["hcore"], m["eri"], backend=be), embedding_potential=vemb,
                                      dm_environment_occupied=denv, backend=be)
     ref = np.array([[-19.18005207, -0.618383, 0.07366692, 0.39496279, 0.72192366, 2.44806433, 4.12874389],
                     [-19.17991953, -0.6183819, 0.07366408, 0.39491023, 0.72191934, 2.44812268, 4.12874047]])
     assert conv and c.shape == d.shape == hz.shape == (2, 7, 7)
-    np.testing.assert_allclose(e[:, [1, 2, 4, 6]], ref[:, [1, 2, 4, 6]], rtol=0, atol=6e-5)
-    np.testing.assert_allclose(e, ref, rtol=0, atol=1e-3)
+    np.testing.assert_allclose(e[:, 1:], ref[:, 1:], rtol=0, atol=1e-4)  # (the reference's alpha and beta: 6e-5 apart)
+    np.testing.assert_allclose(e, ref, rtol=0, atol=2e-4)                # (core level: 1.3e-4 apart there)
     np.testing.assert_allclose(e[0], e[1], rtol=0, atol=1e-9)  # closed shell: no spin contamination here
     assert abs(np.mean(d) - 0.0920247346776863) < 5e-6 and abs(np.mean(hz) - (-0.024315876434944768)) < 1e-5
     # Kohn-Sham objects of PySCF's default functional
@@ -227,15 +300,15 @@ def test_huzinaga_scf_outputs_of_test_scf(be, provider):
     c, e, d, hz, conv = huzinaga_scf(rks, embedding_potential=vemb[0], dm_environment_occupied=denv[0], backend=be)
     ref = np.array([-17.44629099, -0.27614116, 0.37893061, 0.89022282, 1.12092664, 3.32762378, 3.86532114])
     assert conv
-    np.testing.assert_allclose(e[[0, 1, 2, 4, 6]], ref[[0, 1, 2, 4, 6]], rtol=0, atol=5e-5)
-    np.testing.assert_allclose(e, ref, rtol=0, atol=1.5e-3)
+    np.testing.assert_allclose(e[1:], ref[1:], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(e, ref, rtol=0, atol=1e-4)
     assert abs(np.mean(d) - 0.1822057642580939) < 5e-6 and abs(np.mean(hz) - (-0.011214890666261626)) < 1e-5
     uks = GpuUKS(mol, m["S"], m["hcore"], m["eri"], backend=be, xc="lda,vwn", hyb=0.0, xc_provider=lda)
     c, e, d, hz, conv = huzinaga_scf(uks, embedding_potential=vemb, dm_environment_occupied=denv, backend=be)
     ref = np.array([-17.29060406, -0.28451256, 0.31504139, 0.60348835, 1.0520797, 2.22020625, 3.8346852])
     assert conv
-    np.testing.assert_allclose(e[0][[0, 1, 2, 4, 6]], ref[[0, 1, 2, 4, 6]], rtol=0, atol=5e-5)
-    np.testing.assert_allclose(e[0], ref, rtol=0, atol=1e-3)
+    np.testing.assert_allclose(e[0][1:], ref[1:], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(e[0], ref, rtol=0, atol=2e-4)
     assert abs(np.mean(d) - 0.09276688041715254) < 5e-6 and abs(np.mean(hz) - (-0.02251188710459783)) < 1e-5
 
 
