@@ -47,6 +47,9 @@ typedef struct nbx_ctx nbx_ctx;
 
 /* ------------------------------------------------------------------ context */
 int nbx_version(void);
+/* 1 for a `make EXPERIMENTAL=1` build (the J/K experiments of DESIGN.md section 9 are linked in and selectable
+ * through the environment), 0 for the shipped library. */
+int nbx_experimental(void);
 const char* nbx_last_error(void);
 int nbx_device_count(int* count);
 /* stream: the hipStream_t to launch on (e.g. torch's current stream; NULL = the device's

@@ -60,6 +60,7 @@ class HuzState(ctypes.Structure):
 _P = c_void_p
 SIGNATURES = {
     "nbx_version": (c_int, []),
+    "nbx_experimental": (c_int, []),
     "nbx_last_error": (c_char_p, []),
     "nbx_device_count": (c_int, [POINTER(c_int)]),
     "nbx_ctx_create": (c_int, [c_int, _P, c_int, POINTER(_P)]),

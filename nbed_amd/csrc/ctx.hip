@@ -14,6 +14,14 @@ extern "C" {
 
 int nbx_version(void) { return NBX_VERSION; }
 
+int nbx_experimental(void) {
+#ifdef NBX_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 const char* nbx_last_error(void) { return g_err; }
 
 int nbx_device_count(int* count) {

@@ -32,6 +32,10 @@
 #include "jk_s4_layout.h"
 #include "jk_s4_device.h"
 
+// The three EXPERIMENTAL forms of the NB = 4 / six-loads instance (parity green, all measured
+// slower than the kernel in this file) are linked only into a `make EXPERIMENTAL=1` build, where the environment
+// selects them (NBX_JK_P8 / NBX_JK_S8 / NBX_JK_DMA); the shipped library holds what runs.
+#ifdef NBX_EXPERIMENTAL
 // jk_p8.hip: the 8-fold form (truncated tiles) that serves whole tensors of the NB = 4 / six-loads sizes
 bool nbx_jk_p8_covers(int64_t N, int64_t p0, int64_t p1);
 size_t nbx_jk_p8_packed_bytes(int64_t N);
@@ -54,6 +58,25 @@ int nbx_jk_s4d_per_cu(int variant);
 int nbx_jk_s4d_launch(nbx_ctx* ctx, int variant, int64_t N, int64_t p0, int64_t np, int64_t ndm, int lpt,
                       const double* d_packed, const double* d_dm, const double* d_dts, double* d_j, double* k1, double* k2,
                       int64_t t_begin, int64_t t_end, int wgs, int L, int S);
+#else
+static inline bool nbx_jk_p8_covers(int64_t, int64_t, int64_t) { return false; }
+static inline size_t nbx_jk_p8_packed_bytes(int64_t) { return 0; }
+static inline size_t nbx_jk_p8_worksize(int64_t, int64_t) { return 0; }
+static inline int nbx_jk_p8_pack(nbx_ctx*, int64_t, const double*, double*) { return NBX_E_UNSUPPORTED; }
+static inline int nbx_jk_p8(nbx_ctx*, int64_t, const double*, const double*, int64_t, double*, void*, const double*, double*,
+                            double*, const double*) { return NBX_E_UNSUPPORTED; }
+static inline bool nbx_jk_s8_covers(int64_t) { return false; }
+static inline void nbx_jk_s8_plan(int64_t, int*, int*, int*) {}
+static inline int nbx_jk_s8_launch(nbx_ctx*, int64_t, int64_t, int64_t, int64_t, const double*, const double*, const double*,
+                                   double*, double*, double*, int64_t, int64_t, int, int, int) { return NBX_E_UNSUPPORTED; }
+static inline bool nbx_jk_s4d_covers(int, int) { return false; }
+static inline size_t nbx_jk_s4d_lds_bytes(int, int, int) { return 0; }
+static inline int nbx_jk_s4d_per_cu(int) { return 2; }
+static inline int nbx_jk_s4d_launch(nbx_ctx*, int, int64_t, int64_t, int64_t, int64_t, int, const double*, const double*,
+                                    const double*, double*, double*, double*, int64_t, int64_t, int, int, int) {
+    return NBX_E_UNSUPPORTED;
+}
+#endif
 
 namespace {
 
@@ -118,81 +141,6 @@ __global__ __launch_bounds__(256) void s4_dtot_kernel(const double* __restrict__
     *reinterpret_cast<double2*>(dts + 2 * (int64_t)i) = make_double2(out[0], out[1]);
 }
 
-// EXPERIMENTAL (compiled with -DNBX_S4_MFMA_WALK only; measured slower):
-// the same walk on the matrix pipe.  One chunk asks of wave w the product
-//       out[t][n] += sum_c M[t][c] X[c][n],   t, c in [0, s),
-// M = the symmetric s x s matrix this wave sees in the chunk (its triangle, or its side of the
-// rectangle it shares with block u), X[c] = (D^a_q, D^a_p, D^b_q, D^b_p)[u s + c]: a skinny GEMM.
-// v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4 x 4 blocks per instruction,
-//       D_b[i][j] += sum_k A_b[i][k] B_b[k][j],   operand lanes: A_b[i][k] at 16 k + 4 b + i,
-//       B_b[k][j] at 16 k + 4 b + j, D_b[i][j] at 16 i + 4 b + j   (measured: scratch/probe/mfma444.hip),
-// i.e. a 16 x 4 block of M against a 4 x 4 block of X: lane (m = lane & 15, k = lane >> 4) reads
-// M[16 i + m][4 j + k] straight from the LDS-resident chunk, whatever the stored orientation (row
-// side, column side, packed triangle: the address arithmetic differs, nothing else), and X[4 j + k]
-// [lane & 3] as B -- the 2 NDM columns of X fill the instruction (the 16x16x4 form would leave 12 of
-// its 16 columns idle and costs 3.5x the matrix-pipe time per instruction).  ceil(s/16) * ceil(s/4)
-// MFMAs and as many LDS reads replace s steps of ~10 VALU/scalar instructions each: the walk was
-// instruction-issue bound.  acc[i] of lane l holds row 16 i + 4 ((l >> 2) & 3)
-// + (l >> 4), column l & 3: K_p contributions in the even columns (kept while p is fixed), K_q ones
-// in the odd columns.
-// Rows >= s of the last strip and columns >= s of the last k-step: addresses are clamped to stay
-// on initialised LDS, the products land in rows nobody stores / meet a zero in X.
-// 16-row strips a block can have, from the kernel instance's loads per thread per chunk (which
-// bound the chunk size, hence s: LPT 2 -> s <= 22, 6 -> s <= 39, 10 and 17 -> s <= 64)
-constexpr int s4_strips(int lpt) { return lpt <= 2 ? 2 : lpt <= 6 ? 3 : 4; }
-
-template <int KIND, int NSTR, int XW>
-__device__ __forceinline__ void s4_walk_mfma(const double* lb, int ls, int s, const double* xs, int fr, int fk,
-                                             double (&acc)[NSTR]) {
-    // xs: this block's rows of the LDS-resident X table, XW doubles per row ([c][n]); lane reads
-    // column fr (folded onto the XW that exist: the surplus columns of the product are not used).
-    // One strip at a time (one A register, one address in flight: the kernel has no VGPRs to
-    // spare, and a spill reload waits for every streaming load in flight); the operands of step
-    // j + 1 are read from LDS while the MFMA of step j runs.
-    const int nk = (s + 3) >> 2;
-    const int xcol = fr & (XW - 1);
-    // column of step 0 for this lane, clamped copies for the last (partial) step
-    const int c_last = min(4 * (nk - 1) + fk, s - 1);
-    const bool last_ok = 4 * (nk - 1) + fk < s;
-#pragma unroll
-    for (int i = 0; i < NSTR; ++i) {
-        const int tt = 16 * i + fr;  // rows >= s: whatever LDS holds there lands in rows nobody stores
-        auto aoff = [&](int cc) {
-            if (KIND == 0) {
-                const int hi = max(tt, cc), lo = min(tt, cc);
-                return ((hi * (hi + 1)) >> 1) + lo;
-            }
-            return KIND == 1 ? tt * ls + cc : cc * ls + tt;
-        };
-        double a0 = lb[aoff(fk)], b0 = xs[fk * XW + xcol], a1, b1;
-        double d = acc[i];
-        int j = 0;
-        for (; j + 2 < nk; j += 2) {  // full steps only (the last one is peeled below)
-            const int c1 = 4 * (j + 1) + fk;
-            a1 = lb[aoff(c1)];
-            b1 = xs[c1 * XW + xcol];
-            d = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b0, d, 0, 0, 0);
-            const int c2 = 4 * (j + 2) + fk;
-            const bool fin = j + 3 == nk;  // step j + 2 is the last one: clamp / zero
-            const int c2c = fin ? c_last : c2;
-            a0 = lb[aoff(c2c)];
-            b0 = xs[c2c * XW + xcol];
-            if (fin && !last_ok) b0 = 0.0;
-            d = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1, d, 0, 0, 0);
-        }
-        if (j + 2 == nk) {  // two steps left: a0/b0 hold step j (full), the last one is step j + 1
-            a1 = lb[aoff(c_last)];
-            b1 = last_ok ? xs[c_last * XW + xcol] : 0.0;
-            d = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b0, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1, d, 0, 0, 0);
-        } else {  // one step left: a0/b0 hold it (already clamped / zeroed above, or nk == 1)
-            if (nk == 1 && !last_ok) b0 = 0.0;
-            d = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b0, d, 0, 0, 0);
-        }
-        acc[i] = d;
-    }
-}
-
 // NB waves, LPT 16-byte loads per thread per chunk, PD chunks of prefetch distance (PD == NB: one
 // whole tile ahead), DT_REG: the thread's Dtot' entries (the same for every tile) live in registers.
 template <int NDM, int NB, int LPT, int PD, bool DT_REG, int WV>
@@ -203,15 +151,9 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
                                                         int S) {
     constexpr int NCH = NB, BUFD = LPT * NB * 128;
     static_assert(PD == NCH || PD == 2 || PD == 1, "prefetch distance");
-    extern __shared__ __attribute__((aligned(16))) double smem[];  // buf[2][BUFD] | slack[128] | jred[2][NB] | xtab[2][N][XW]
+    extern __shared__ __attribute__((aligned(16))) double smem[];  // buf[2][BUFD] | slack[128] | jred[2][NB]
     double* slack = smem + 2 * BUFD;
     double* jred = slack + 128;
-    // X table of the MFMA walk: xtab[tile parity][c][n] = (D^0_q, D^0_p, D^1_q, D^1_p)[c] (NDM = 1: two
-    // columns), written for tile T + 1 at the end of tile T from values fetched at its start
-#ifdef NBX_S4_MFMA_WALK
-    constexpr int XW = 2 * NDM, XR = XW;  // N <= 64 NB (one wave walks a block): XW N <= XW threads-per-workgroup
-    double* xtab = jred + 2 * NB + ((2 * NB) & 1);
-#endif
 
     int64_t T = t_begin + (int64_t)blockIdx.x * L;
     const int64_t T_end = min(t_end, T + L);
@@ -263,7 +205,6 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
         issue_dt(dt[0], 0);
     }
 
-#ifndef NBX_S4_MFMA_WALK
     double kp[NDM];
 #pragma unroll
     for (int x = 0; x < NDM; ++x) kp[x] = 0.0;
@@ -276,50 +217,6 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
 #pragma unroll
         for (int x = 0; x < NDM; ++x) kp[x] = 0.0;
     };
-#else
-    // MFMA walk: accumulator fragments (see s4_walk_mfma): column lane & 3 of the product, row
-    // 4 ((lane >> 2) & 3) + (lane >> 4) of every 16-row strip
-    const int fr = lane & 15, fk = lane >> 4;
-    const int fcol = lane & 3, frow = 4 * ((lane >> 2) & 3) + fk;
-    const bool col_used = fcol < 2 * NDM, col_q = (fcol & 1) != 0;
-    const int col_x = (fcol >> 1) & (NDM - 1);
-    constexpr int NSTR = s4_strips(LPT);
-    double acc[NSTR];
-#pragma unroll
-    for (int i = 0; i < NSTR; ++i) acc[i] = 0.0;
-    // store the K_p (want_q = false) or K_q columns of the fragments to dst[x * N + w s + row], zero them
-    auto flush_cols = [&](double* dst, bool want_q, bool store) {
-        const bool mine = col_q == want_q;
-#pragma unroll
-        for (int i = 0; i < NSTR; ++i) {
-            const int row = 16 * i + frow;
-            if (store && mine && col_used && row < s) dst[col_x * N + w * s + row] = acc[i];
-            acc[i] = mine ? 0.0 : acc[i];
-        }
-    };
-    auto flush_p = [&](int prow) {
-        flush_cols(kpart1 + ((int64_t)blockIdx.x * S + (prow - p_first)) * NDM * N, false, true);
-    };
-    // entries e = tid + NB 64 r < XW N of a tile's X table: row c = e / XW, column n = e % XW
-    double xn[XR];
-    auto xfetch = [&](int pp, int qq) {
-#pragma unroll
-        for (int r = 0; r < XR; ++r) {
-            const int e = tid + NB * 64 * r;
-            const int c = min(e / XW, N - 1), n = e & (XW - 1);
-            xn[r] = dm[(int64_t)(n >> 1) * n2 + (int64_t)((n & 1) ? pp : qq) * N + c];
-        }
-    };
-    auto xstore = [&](double* dst) {
-#pragma unroll
-        for (int r = 0; r < XR; ++r) {
-            const int e = tid + NB * 64 * r;
-            if (e < XW * N) dst[e] = xn[r];
-        }
-    };
-    xfetch(p, q);
-    xstore(xtab + (T & 1) * (XW * N));  // ordered before the first walk by the barrier of chunk 0
-#endif
     auto store_j = [&](int par, int pj, int qj) {  // thread 0, after a barrier that follows the jred writes
         double tot = 0.0;
 #pragma unroll
@@ -339,28 +236,11 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
         // Dtot' is the same for every tile: without this the loads are hoisted out of the tile loop
         // into NB * LPT double2 registers (which is DT_REG, for the sizes that can afford it)
         if (!DT_REG) asm volatile("" : "+s"(dts_l));
-#ifndef NBX_S4_MFMA_WALK
         double kq[NDM];
 #pragma unroll
         for (int x = 0; x < NDM; ++x) kq[x] = 0.0;
         const double* dq = dm + (int64_t)q * N;
         const double* dp = dm + (int64_t)p * N;
-#else
-        const double* xt = xtab + (T & 1) * (XW * N);  // written at the end of the previous tile
-        // fetch the next tile's X entries now (they are written to LDS after this tile's walks)
-        {
-            int pn = p, qn = q + 1;
-            if (qn > pn) {
-                ++pn;
-                qn = 0;
-            }
-            if (T + 1 >= T_end) {  // no next tile: re-read this one's (never used)
-                pn = p;
-                qn = q;
-            }
-            xfetch(pn, qn);
-        }
-#endif
         double jacc = 0.0;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
@@ -385,7 +265,6 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
             if (ch == 0 && pj >= 0 && tid == 0) store_j(par ^ 1, pj, qj);
 
             // ---- the walk: s steps, element Lsym[trow][u*s + c]
-#ifndef NBX_S4_MFMA_WALK
             if (ch == 0) {
                 s4_walk<NDM, 0>(buf + w * g.tri, 0, il, tri_il, dq + w * s, dp + w * s, n2, s, kp, kq);
             } else {
@@ -394,16 +273,6 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
                 if (w > u) s4_walk<NDM, 1>(rect + il * ls, 1, il, tri_il, dq + u * s, dp + u * s, n2, s, kp, kq);
                 else s4_walk<NDM, 2>(rect + il, ls, il, tri_il, dq + u * s, dp + u * s, n2, s, kp, kq);
             }
-#else
-            if (ch == 0) {
-                s4_walk_mfma<0, NSTR, XW>(buf + w * g.tri, 0, s, xt + w * s * XW, fr, fk, acc);
-            } else {
-                const int u = w ^ ch;
-                const double* rect = buf + s4_slot(min(w, u), ch) * s * ls;
-                if (w > u) s4_walk_mfma<1, NSTR, XW>(rect, ls, s, xt + u * s * XW, fr, fk, acc);
-                else s4_walk_mfma<2, NSTR, XW>(rect, ls, s, xt + u * s * XW, fr, fk, acc);
-            }
-#endif
         }
         // J partial of this tile (summed by thread 0 after the next barrier)
         jacc = nbx_wave_sum(jacc);
@@ -411,18 +280,11 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
         pj = p;
         qj = q;
         par ^= 1;
-#ifndef NBX_S4_MFMA_WALK
         if (q < p && live) {
             double* k2 = kpart2 + ((T - t_begin) * NDM) * N + trow;  // tile order: sequential stores
 #pragma unroll
             for (int x = 0; x < NDM; ++x) k2[x * N] = kq[x];
         }
-#else
-        // K_q columns: to the tile's row-q partial (q < p), dropped on the diagonal (q == p: the
-        // K_p columns already carry the whole contribution)
-        flush_cols(kpart2 + ((T - t_begin) * NDM) * N, true, q < p);
-        xstore(xtab + ((T + 1) & 1) * (XW * N));
-#endif
         ++T;
         tile += g.M;
         if (++q > p) {
@@ -476,12 +338,8 @@ S4Plan s4_plan(int64_t N, int64_t p0, int64_t np, int64_t ndm) {
     pl.g = s4_geom((int)N, pl.NB);
     const int nt = pl.NB * 64;
     pl.lpt = s4_lpt_class((int)nbx_cdiv((pl.g.E0 > pl.g.Er ? pl.g.E0 : pl.g.Er) / 2, nt), pl.NB);
-    // chunk buffers, slack, J partials, and the MFMA walk's X tables (2 x N x 2 NDM doubles)
-#ifdef NBX_S4_MFMA_WALK
-    pl.lds_bytes = (size_t)(2 * pl.lpt * nt * 2 + 128 + 2 * pl.NB + 2 + 2 * (int64_t)N * 2 * ndm) * sizeof(double);
-#else
+    // chunk buffers, slack, J partials
     pl.lds_bytes = (size_t)(2 * pl.lpt * nt * 2 + 128 + 2 * pl.NB) * sizeof(double);
-#endif
     pl.dma = s4_use_dma(pl.NB, pl.lpt);
     if (pl.dma) pl.lds_bytes = nbx_jk_s4d_lds_bytes(pl.NB, pl.lpt, pl.dma);
     int64_t per_cu = (int64_t)(S4_LDS_PER_CU / (pl.lds_bytes + 256));

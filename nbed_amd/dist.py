@@ -28,6 +28,17 @@ from __future__ import annotations
 import math
 
 
+def _takes_out(fn) -> bool:
+    """Whether a backend's ``all_gather_stack`` accepts ``out=`` -- decided from its signature, never by trying the
+    collective (a failed attempt on one rank would leave the ranks out of step)."""
+    import inspect
+
+    try:
+        return "out" in inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+
+
 class Shards:
     """Contiguous partition of ``range(n)`` over the ranks of a process group."""
 
@@ -89,12 +100,9 @@ class Shards:
             return slab
         if self._cuts is not None:
             raise ValueError("all_gather needs uniform shards")
-        if out is not None and axis == 0 and self.n == self.chunk * self.world:
-            try:
-                be.all_gather_stack(slab, self.group, out=out)
-                return out
-            except TypeError:  # a backend whose all_gather_stack takes no ``out``
-                pass
+        if out is not None and axis == 0 and self.n == self.chunk * self.world and _takes_out(be.all_gather_stack):
+            be.all_gather_stack(slab, self.group, out=out)
+            return out
         padded = be.pad_axis(slab, axis, self.chunk)
         gathered = be.all_gather_stack(padded, self.group)  # (world, ...)
         return be.unstack_concat(gathered, axis, self.n)

@@ -365,8 +365,17 @@ class NbedDriver:
             if frozen is not None or 2 * n > ccsd.MAX_SPIN_ORBITALS:
                 raise
             const, h1, h2 = HamiltonianBuilder(scf_obj, scf_obj.energy_nuc(), backend=self.be).build()
+            # the reference determinant from the object's own occupations (alpha on the even spin-orbital indices):
+            # after the environment is deleted / the virtuals are re-ordered the occupied MOs need not lead
+            mo_occ = np.asarray(scf_obj.mo_occ)
+            if mo_occ.ndim == 1:
+                mo_occ = np.array((mo_occ > 1, mo_occ > 0), dtype=float)
+            occupied = ([2 * int(i) for i in np.flatnonzero(mo_occ[0] > 0)]
+                        + [2 * int(i) + 1 for i in np.flatnonzero(mo_occ[1] > 0)])
             na, nb = scf_obj.mol.nelec
-            occupied = [2 * i for i in range(na)] + [2 * i + 1 for i in range(nb)]  # aufbau, alpha on the even indices
+            if (int(np.sum(mo_occ[0] > 0)), int(np.sum(mo_occ[1] > 0))) != (int(na), int(nb)):
+                raise NbedDriverError(f"mo_occ holds {int(np.sum(mo_occ[0] > 0))} + {int(np.sum(mo_occ[1] > 0))} occupied "
+                                      f"orbitals, the molecule {na} + {nb} electrons")
             return ccsd.solve(const, h1, h2, occupied, conv_tol=min(self.config.convergence, 1e-8))
 
     @cached_property

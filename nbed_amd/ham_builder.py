@@ -82,15 +82,16 @@ class HamiltonianBuilder:
         return be.to_host(be.gemm(be.gemm(c_d, be.asarray(h3), "T", "N"), c_d))
 
     # ------------------------------------------------------------------ two body
-    def _two_body_device(self):
-        """(4, n, n, n, n) on device, physicist order, blocks aaaa, bbbb, aabb, bbaa."""
+    def _two_body_device(self, blocks: int = 4):
+        """(blocks, n, n, n, n) on device, physicist order: aaaa, bbbb, aabb and (``blocks`` = 4: the reference's
+        layout, nbed/ham_builder.py:119-124) bbaa; ``blocks`` = 3 neither forms nor allocates the fourth."""
         be = self.be
         c = self.scf_method.mo_coeff
         if self._restricted:
             eri = _ao_eri_device(self.scf_method, be)
             c_d = be.asarray(np.asarray(c))
             block = be.chem_to_phys(self._transform(eri, c_d, c_d, c_d, c_d))
-            return be.torch.stack([block] * 4)
+            return be.torch.stack([block] * blocks)
         n_a, n_b = np.shape(c[0])[1], np.shape(c[1])[1]
         if n_a != n_b:
             raise HamiltonianBuilderError("Must localize the same number of alpha and beta orbitals.")
@@ -103,6 +104,11 @@ class HamiltonianBuilder:
         bbbb = self._transform(eri, cb, cb, cb, cb)
         self._eri_rs = None  # (0.5 N^4 doubles: the builder keeps no reference beyond the build)
         n = n_a
+        if blocks == 3:  # aaaa, bbbb, aabb only: bbaa is the transpose of aabb and is neither formed nor stored
+            out = be.empty((3, n, n, n, n))
+            for i, blk in enumerate((aaaa, bbbb, aabb)):
+                out[i].copy_(be.chem_to_phys(blk))
+            return out
         # (bb|aa)[i,j,k,l] = (aa|bb)[k,l,i,j]: a transpose of the (n^2 x n^2) matrix
         bbaa = be.transpose(aabb.reshape(n * n, n * n)).reshape(n, n, n, n)
         out = be.empty((4, n, n, n, n))
@@ -177,7 +183,7 @@ class HamiltonianBuilder:
         be = self.be
         one = be.asarray(self._one_body_integrals)
         be.threshold_scale(one, EQ_TOLERANCE, 1.0)
-        two = self._two_body_device()[:3].contiguous()  # aaaa, bbbb, aabb (physicist order)
+        two = self._two_body_device(blocks=3)  # aaaa, bbbb, aabb (physicist order); bbaa is never formed
         be.threshold_scale(two, EQ_TOLERANCE, 0.5)
         return SpatialHamiltonian(self.constant_e_shift, be.to_host(one), be.to_host(two))
 

@@ -227,6 +227,18 @@ def test_fused_huzinaga_scf_bench_inputs_vs_oracle(be, eri148):
         assert abs(np.trace(d[x] @ s @ pr["D_env"][x] @ s)) < 1e-9
 
 
+def _experimental_build() -> bool:
+    """libnbx built with `make -C nbed_amd/csrc EXPERIMENTAL=1` (the J/K experiments of DESIGN.md section 9 linked in)."""
+    from nbed_amd import _nbx
+
+    return bool(_nbx.load_library().nbx_experimental())
+
+
+needs_experimental = pytest.mark.skipif("not _experimental_build()",
+                                        reason="the shipped libnbx.so holds no experiments: make EXPERIMENTAL=1")
+
+
+@needs_experimental
 def test_jk_eightfold_experimental_vs_c_oracle():
     """csrc/jk_p8.hip (8-fold tiles; opt-in, NBX_JK_P8=1 is read once per process: a child process) at
     N = 148 and 104 against oracle/c/jk_ref.c, the Fock epilogue included."""
@@ -241,6 +253,7 @@ def test_jk_eightfold_experimental_vs_c_oracle():
     assert out.returncode == 0 and "P8 OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+@needs_experimental
 @pytest.mark.parametrize("variant", ["1", "2", "3"])
 def test_jk_lds_dma_experimental_vs_c_oracle(variant):
     """csrc/jk_s4d.hip (tiles streamed straight into LDS; opt-in) in a child process with

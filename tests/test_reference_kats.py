@@ -330,3 +330,27 @@ def test_concentric_shell_numbers_water_631g(be, provider):
     assert list(virt.shells[0]) == [12, 13] and list(virt.shells[1]) == [12, 13]
     sv = virt.singular_values[0][0]
     assert np.sum(sv > 1 - 1e-10) == 4 and sv[-1] < 1e-15  # four virtual directions lie entirely on oxygen
+
+
+def test_ccsd_fallback_reads_the_reference_determinant_from_mo_occ(drivers):
+    """The small-space CCSD behind ``run_emb_ccsd`` takes its reference determinant from ``mo_occ``: an object whose
+    occupied orbitals are not the leading columns (re-ordered virtuals, a level-shifted orbital left in place)
+    gives the same energy as the aufbau-ordered one; occupations that do not match the electron count are refused."""
+    import copy
+
+    from nbed_amd.exceptions import NbedDriverError
+
+    drv = drivers["mu"]
+    hf = drv._global_hf
+    e_ref = drv._global_ccsd.e_tot
+    shuffled = copy.copy(hf)
+    perm = np.array([6, 0, 5, 1, 2, 4, 3])
+    shuffled.mo_coeff = np.asarray(hf.mo_coeff)[:, :, perm]
+    shuffled.mo_occ = np.asarray(hf.mo_occ)[:, perm]
+    shuffled.mo_energy = np.asarray(hf.mo_energy)[:, perm]
+    assert abs(drv._ccsd_of(shuffled).e_tot - e_ref) < 1e-9
+    broken = copy.copy(hf)
+    broken.mo_occ = np.asarray(hf.mo_occ).copy()
+    broken.mo_occ[0, 0] = 0
+    with pytest.raises(NbedDriverError):
+        drv._ccsd_of(broken)
