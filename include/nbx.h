@@ -493,6 +493,37 @@ int nbx_huz_cycle_post(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm
                        double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out, double* d_hz_out, int mode,
                        int refine_iters, int diis_mode, int diis_slot, int diis_nd, double* h_out, int* d_status_out);
 
+/* ------------------------------------------------------------------ exchange-correlation evaluation
+ * (E_xc, v_xc) of a two-spin density matrix on the stored grid arrays -- what the reference gets from PySCF's
+ * numint + libxc behind dft.UKS.get_veff (nbed/driver.py:155-191, 315-431, 845-852, 1138-1231): three passes,
+ * csrc/xc.hip.  d_ao (npts, nao) AO values, d_dao (3, npts, nao) their gradients (nbx_eval_ao, transformed to the
+ * working AOs by the caller), row-major; nothing is read back by these calls.
+ * nbx_xc_rho:  d_rho (2, npts) and d_grad (2, 3, npts) of d_dm (2, nao, nao; symmetric): rho_x = diag(ao D_x ao^T),
+ *   grad rho_x = 2 diag(ao D_x dao^T); c = ao D_x is formed tile by tile on the matrix cores for both spins and
+ *   reduced against ao / dao in the epilogue (each array read once).  nao <= 640.
+ * nbx_xc_functional:  energy density and first derivatives, written out analytically, of `code` (the semi-local part:
+ *   NBX_XC_SLATER; _LDA_VWN_RPA = Slater + VWN(RPA); _LDA_VWN5 = Slater + VWN5, PySCF's default "lda,vwn"; _B3LYP =
+ *   0.08 Slater + 0.72 B88 + 0.19 VWN(RPA) + 0.81 LYP, libxc's HYB_GGA_XC_B3LYP without its 0.2 exact exchange), d_w
+ *   (npts) the quadrature weights.  Densities are clamped from below at rho_floor / 2 and points with
+ *   rho_a + rho_b <= rho_floor carry no weight.  Out: d_vr (2, npts) = w dE/drho_x; d_vec (2, 3, npts) =
+ *   w (2 dE/dsigma_xx grad rho_x + dE/dsigma_ab grad rho_other); d_sums[0] = E_xc, d_sums[1] = the integrated
+ *   electron count (summed in a fixed order).  d_work: nbx_xc_functional_worksize() bytes.
+ * nbx_xc_vmat:  d_vxc (2, nao, nao) = V + V^T, V_x[m][n] = sum_g ao[g][m] (d_vr[x][g] / 2 ao[g][n] + sum_a
+ *   d_vec[x][a][g] dao[a][g][n]); the second factor is built on the fly as an operand of the product.  Split over
+ *   chunks of grid points whose partial matrices are added in a fixed order.  d_work: nbx_xc_vmat_worksize() bytes. */
+#define NBX_XC_SLATER 0
+#define NBX_XC_LDA_VWN_RPA 1
+#define NBX_XC_LDA_VWN5 2
+#define NBX_XC_B3LYP 3
+int nbx_xc_rho(nbx_ctx* ctx, int64_t npts, int64_t nao, const double* d_ao, const double* d_dao, const double* d_dm,
+               double* d_rho, double* d_grad);
+size_t nbx_xc_functional_worksize(int64_t npts);
+int nbx_xc_functional(nbx_ctx* ctx, int code, int64_t npts, const double* d_rho, const double* d_grad, const double* d_w,
+                      double rho_floor, double* d_vr, double* d_vec, double* d_sums, void* d_work, size_t work_bytes);
+size_t nbx_xc_vmat_worksize(int64_t npts, int64_t nao);
+int nbx_xc_vmat(nbx_ctx* ctx, int64_t npts, int64_t nao, const double* d_ao, const double* d_dao, const double* d_vr,
+                const double* d_vec, double* d_vxc, void* d_work, size_t work_bytes);
+
 /* ------------------------------------------------------------------ quadrature grid producers
  * What the reference gets from PySCF behind scf.UKS(...) (nbed/driver.py:86-104,315-431): `dft.gen_grid`'s Becke
  * partition and `numint.eval_ao`.  Inputs of the exchange-correlation part of V_emb (driver.py:845-852), not of
@@ -510,16 +541,6 @@ int nbx_becke_share(nbx_ctx* ctx, int64_t npts, const double* d_pts, int64_t nat
 int nbx_eval_ao(nbx_ctx* ctx, int64_t npts, const double* d_pts, int64_t nshell, const int* d_shell_i,
                 const double* d_shell_centre, const int* d_comp_lmn, const double* d_exps, const double* d_coefs,
                 int64_t ncart, int64_t max_prim, double* d_out, double* d_dout);
-/* The two passes of a Kohn-Sham potential evaluation over the stored AO values d_ao (npts,nao), d_dao (3,npts,nao),
- * each array read once (what PySCF's numint does per block inside `get_veff`, driver.py:845-852):
- * nbx_xc_density: d_rho[g] = sum_m c[g,m] ao[g,m], d_grad (3,npts) = 2 sum_m c[g,m] dao[a,g,m] for d_c = ao D (npts,nao);
- * nbx_xc_half:    d_half[g,m] = 1/2 vr[g] ao[g,m] + sum_a vec[a,g] dao[a,g,m]; the rows of d_vec are vec_stride apart
- *                 (v_xc = half^T ao + its transpose is the caller's GEMM).                                    */
-int nbx_xc_density(nbx_ctx* ctx, int64_t npts, int64_t nao, const double* d_ao, const double* d_dao, const double* d_c,
-                   double* d_rho, double* d_grad);
-int nbx_xc_half(nbx_ctx* ctx, int64_t npts, int64_t nao, const double* d_ao, const double* d_dao, const double* d_vr,
-                const double* d_vec, int64_t vec_stride, double* d_half);
-
 /* ------------------------------------------------------------------ density by purification
  * The projector P on the nocc LOWEST eigenvectors of each symmetric matrix d_f (batch, n, n; an orthonormal
  * basis), i.e. C_occ C_occ^T of `eigh` + aufbau occupation (nbed/scf/huzinaga_scf.py:166-174) without the

@@ -23,6 +23,7 @@ NBX_E_NOCONV = -4
 NBX_E_UNSUPPORTED = -5
 
 HUZ_JK_PACKED, HUZ_JK_SYM = 0, 1
+XC_CODES = {"slater": 0, "lda": 1, "lda,vwn_rpa": 1, "lda,vwn": 2, "lda,vwn5": 2, "svwn": 2, "b3lyp": 3}
 
 PROF_JK_DENSE, PROF_AO2MO_Q1, PROF_AO2MO, PROF_EIGH, PROF_SVD, PROF_GEMM = range(6)
 
@@ -151,8 +152,11 @@ SIGNATURES = {
     "nbx_threshold_scale": (c_int, [_P, c_int64, c_double, c_double, _P]),
     "nbx_becke_share": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P]),
     "nbx_eval_ao": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int64, _P, _P]),
-    "nbx_xc_density": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, _P]),
-    "nbx_xc_half": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, c_int64, _P]),
+    "nbx_xc_rho": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, _P]),
+    "nbx_xc_functional_worksize": (c_size_t, [c_int64]),
+    "nbx_xc_functional": (c_int, [_P, c_int, c_int64, _P, _P, _P, c_double, _P, _P, _P, _P, c_size_t]),
+    "nbx_xc_vmat_worksize": (c_size_t, [c_int64, c_int64]),
+    "nbx_xc_vmat": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, c_size_t]),
     "nbx_purify_worksize": (c_size_t, [c_int64, c_int64]),
     "nbx_purify": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_size_t, c_int, _P]),
     "nbx_host_1e": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, _P, _P, _P]),

@@ -803,15 +803,35 @@ class HipBackend:
                    self._p(out), self._p(dout))
         return out, dout
 
-    def xc_density(self, ao, dao, c, rho, grad):
-        """rho (G,) and grad (3, G) views filled from c = ao D in one pass over ao / dao (nbx_xc_density)."""
-        self._call("nbx_xc_density", ao.shape[0], ao.shape[1], self._p(ao), self._p(dao), self._p(c), self._p(rho),
-                   self._p(grad))
+    def xc_rho(self, ao, dao, dm):
+        """Spin densities (2, G) and their gradients (2, 3, G) on the grid from the stored AO values ``ao`` (G, nao),
+        gradients ``dao`` (3, G, nao) and a symmetric two-spin density matrix (nbx_xc_rho: c = ao D on the matrix
+        cores, reduced against ao / dao in the epilogue; both spins in one pass)."""
+        g, nao = int(ao.shape[0]), int(ao.shape[1])
+        rho, grad = self.empty((2, g)), self.empty((2, 3, g))
+        self._call("nbx_xc_rho", g, nao, self._p(ao), self._p(dao), self._p(dm), self._p(rho), self._p(grad))
+        return rho, grad
 
-    def xc_half(self, ao, dao, vr, vec, vec_stride: int, out):
-        """out (G, nao) = vr/2 ao + vec . dao in one pass (nbx_xc_half); ``vec``: a (3, >=G) view, rows vec_stride apart."""
-        self._call("nbx_xc_half", ao.shape[0], ao.shape[1], self._p(ao), self._p(dao), self._p(vr), self._p(vec),
-                   int(vec_stride), self._p(out))
+    def xc_functional(self, code: int, rho, grad, w, rho_floor: float):
+        """Weighted first derivatives of the exchange-correlation energy density on the grid (nbx_xc_functional,
+        analytic): ``(vr (2, G), vec (2, 3, G), sums)`` with ``sums`` a device pair (E_xc, integrated electrons)."""
+        g = int(rho.shape[-1])
+        vr, vec, sums = self.empty((2, g)), self.empty((2, 3, g)), self.empty(2)
+        nbytes = int(self.lib.nbx_xc_functional_worksize(g))
+        work = self._workspace("xc_fn", nbytes)
+        self._call("nbx_xc_functional", int(code), g, self._p(rho), self._p(grad), self._p(w), float(rho_floor), self._p(vr),
+                   self._p(vec), self._p(sums), self._p(work), work.numel())
+        return vr, vec, sums
+
+    def xc_vmat(self, ao, dao, vr, vec):
+        """v_xc (2, nao, nao), symmetrised, from the weighted derivatives of ``xc_functional`` (nbx_xc_vmat: the
+        ``half`` factor is built on the fly as an operand of the product)."""
+        g, nao = int(ao.shape[0]), int(ao.shape[1])
+        out = self.empty((2, nao, nao))
+        nbytes = int(self.lib.nbx_xc_vmat_worksize(g, nao))
+        work = self._workspace("xc_vmat", nbytes)
+        self._call("nbx_xc_vmat", g, nao, self._p(ao), self._p(dao), self._p(vr), self._p(vec), self._p(out), self._p(work),
+                   work.numel())
         return out
 
     def ao_table(self, basis):

@@ -153,80 +153,3 @@ extern "C" int nbx_eval_ao(nbx_ctx* ctx, int64_t npts, const double* d_pts, int6
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
-
-// ------------------------------------------------------------------ density and potential contractions on the grid
-// The two passes of a Kohn-Sham potential evaluation that touch the (G x nao) arrays, fused so that each array is
-// read once (torch expressions of the same thing: ~8 and ~7 passes with their temporaries):
-//   xc_density:  rho[g] = sum_m c[g,m] ao[g,m],  grad[a,g] = 2 sum_m c[g,m] dao[a,g,m]        (c = ao D, D symmetric)
-//   xc_half:     half[g,m] = 1/2 vr[g] ao[g,m] + sum_a vec[a,g] dao[a,g,m]
-// A wave per grid point (lanes along the AO index: coalesced rows).
-namespace {
-
-__global__ __launch_bounds__(256) void xc_density_kernel(int64_t npts, int nao, const double* __restrict__ ao,
-                                                         const double* __restrict__ dao, const double* __restrict__ c,
-                                                         double* __restrict__ rho, double* __restrict__ grad) {
-    const int lane = threadIdx.x & 63;
-    const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (g >= npts) return;
-    const int64_t plane = npts * (int64_t)nao;
-    const double* ar = ao + g * nao;
-    const double* dr = dao + g * nao;
-    const double* cr = c + g * nao;
-    double r = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-    for (int m = lane; m < nao; m += 64) {
-        const double cm = cr[m];
-        r = fma(cm, ar[m], r);
-        gx = fma(cm, dr[m], gx);
-        gy = fma(cm, dr[plane + m], gy);
-        gz = fma(cm, dr[2 * plane + m], gz);
-    }
-    r = nbx_wave_sum(r);
-    gx = nbx_wave_sum(gx);
-    gy = nbx_wave_sum(gy);
-    gz = nbx_wave_sum(gz);
-    if (lane == 0) {
-        rho[g] = r;
-        grad[g] = 2.0 * gx;
-        grad[npts + g] = 2.0 * gy;
-        grad[2 * npts + g] = 2.0 * gz;
-    }
-}
-
-__global__ __launch_bounds__(256) void xc_half_kernel(int64_t npts, int nao, const double* __restrict__ ao,
-                                                      const double* __restrict__ dao, const double* __restrict__ vr,
-                                                      const double* __restrict__ vec, int64_t vec_stride,
-                                                      double* __restrict__ half) {
-    const int lane = threadIdx.x & 63;
-    const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (g >= npts) return;
-    const int64_t plane = npts * (int64_t)nao;
-    const double* ar = ao + g * nao;
-    const double* dr = dao + g * nao;
-    double* hr = half + g * nao;
-    const double v0 = 0.5 * vr[g], vx = vec[g], vy = vec[vec_stride + g], vz = vec[2 * vec_stride + g];
-    for (int m = lane; m < nao; m += 64)
-        hr[m] = fma(v0, ar[m], fma(vx, dr[m], fma(vy, dr[plane + m], vz * dr[2 * plane + m])));
-}
-
-}  // namespace
-
-extern "C" int nbx_xc_density(nbx_ctx* ctx, int64_t npts, int64_t nao, const double* d_ao, const double* d_dao,
-                              const double* d_c, double* d_rho, double* d_grad) {
-    NBX_CHECK_ARG(ctx && d_ao && d_dao && d_c && d_rho && d_grad && npts >= 0 && nao >= 1 && nao <= (1 << 20));
-    if (npts == 0) return NBX_OK;
-    hipLaunchKernelGGL(xc_density_kernel, dim3((unsigned)nbx_cdiv(npts, 4)), dim3(256), 0, ctx->stream, npts, (int)nao,
-                       d_ao, d_dao, d_c, d_rho, d_grad);
-    NBX_LAUNCH_CHECK();
-    return NBX_OK;
-}
-
-extern "C" int nbx_xc_half(nbx_ctx* ctx, int64_t npts, int64_t nao, const double* d_ao, const double* d_dao,
-                           const double* d_vr, const double* d_vec, int64_t vec_stride, double* d_half) {
-    NBX_CHECK_ARG(ctx && d_ao && d_dao && d_vr && d_vec && d_half && npts >= 0 && nao >= 1 && nao <= (1 << 20));
-    NBX_CHECK_ARG(vec_stride >= npts);
-    if (npts == 0) return NBX_OK;
-    hipLaunchKernelGGL(xc_half_kernel, dim3((unsigned)nbx_cdiv(npts, 4)), dim3(256), 0, ctx->stream, npts, (int)nao, d_ao,
-                       d_dao, d_vr, d_vec, vec_stride, d_half);
-    NBX_LAUNCH_CHECK();
-    return NBX_OK;
-}

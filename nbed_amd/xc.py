@@ -273,11 +273,13 @@ def eval_ao_torch(basis: "integrals.Basis", pts, deriv: int = 1):
         if table is None:
             table = basis._ao_table_device = be.ao_table(basis)
         ao, dao = be.eval_ao(pts.contiguous(), table, deriv=bool(deriv))
-        if not basis.pure_cartesian:
-            u = t.as_tensor(basis.cart2ao, **kw)
-            ao = ao @ u.T
+        if not basis.pure_cartesian:  # Cartesian components -> the working (spherical) AOs: libnbx GEMMs
+            u = getattr(basis, "_cart2ao_device", None)
+            if u is None:
+                u = basis._cart2ao_device = t.as_tensor(basis.cart2ao, **kw).contiguous()
+            ao = be.gemm(ao, u, "N", "T")
             if deriv:
-                dao = dao @ u.T
+                dao = be.gemm(dao, u, "N", "T")
         return ao, dao
     ao = t.zeros((npts, basis.nao_cart), **kw)
     dao = t.zeros((3, npts, basis.nao_cart), **kw) if deriv else None
@@ -438,8 +440,21 @@ class XCProvider:
         self.device = t.device(device)
         self.points, self.weights = build_grid(atoms, n_rad, n_theta, device=self.device, scheme=scheme, level=level)
         self.nelec_last = None
-        self._blocks = []  # (ao (g, nao), dao (3, g, nao)) per block of grid points
+        self._blocks = []  # host form: (ao (g, nao), dao (3, g, nao)) per block of grid points
+        self._ao = self._dao = None  # HIP form: the whole grid, (G, nao) and (3, G, nao)
         npts = self.points.shape[0]
+        be = _hip_backend(self.device)
+        if self.xc != "hf" and be is not None:
+            # on a GPU the three passes of an evaluation are libnbx kernels over the whole stored arrays
+            # (csrc/xc.hip); the arrays are filled block by block (bounds eval_ao's temporaries)
+            nao = int(basis.nao)
+            self._ao, self._dao = be.empty((npts, nao)), be.empty((3, npts, nao))
+            for g0 in range(0, npts, self.BLOCK):
+                ao, dao = eval_ao_torch(basis, t.as_tensor(self.points[g0:g0 + self.BLOCK]).to(self.device))
+                self._ao[g0:g0 + ao.shape[0]].copy_(ao)
+                self._dao[:, g0:g0 + ao.shape[0]].copy_(dao)
+            self._w = t.as_tensor(self.weights).to(self.device)
+            return
         pad = (-npts) % self.SPLIT  # zero rows: the long-K product of __call__ splits into equal pieces
         if self.xc != "hf":
             for g0 in range(0, npts, self.BLOCK):
@@ -453,26 +468,39 @@ class XCProvider:
     @property
     def ao(self) -> np.ndarray:
         """AO values on the whole grid (G, nao), on the host (tests integrate the overlap with them)."""
+        if self._ao is not None:
+            return self._ao.cpu().numpy()
         return np.concatenate([b[0].cpu().numpy() for b in self._blocks])[: self.points.shape[0]]
+
+    def _call_hip(self, be, dm: np.ndarray):
+        """One evaluation on libnbx: nbx_xc_rho (densities and gradients, both spins, c = ao D on the matrix cores),
+        nbx_xc_functional (analytic energy density and derivatives, weights folded in, E_xc reduced on the device),
+        nbx_xc_vmat (the potential matrix with its ``half`` factor built on the fly).  Three kernels and two small
+        reductions per evaluation; the host sees E_xc, the electron count and the (2, nao, nao) result."""
+        from ._nbx import XC_CODES
+
+        dmd = be.asarray(0.5 * (dm + dm.transpose(0, 2, 1)))
+        rho, grad = be.xc_rho(self._ao, self._dao, dmd)
+        vr, vec, sums = be.xc_functional(XC_CODES[self.xc], rho, grad, self._w, self.RHO_FLOOR)
+        vxc = be.xc_vmat(self._ao, self._dao, vr, vec)
+        sums_h = be.to_host(sums)
+        self.nelec_last = float(sums_h[1])
+        return float(sums_h[0]), be.to_host(vxc)
 
     def __call__(self, dm):
         t = _torch()
         dm = np.asarray(dm, dtype=np.float64)
         if self.xc == "hf":
             return 0.0, np.zeros_like(dm)
+        if self._ao is not None:
+            return self._call_hip(_hip_backend(self.device), dm)
+        # host form (the CPU suite's checker; also the definition the HIP kernels are tested against)
         dmd = t.as_tensor(dm).to(self.device)
         dmd = 0.5 * (dmd + dmd.transpose(1, 2))
-        be = _hip_backend(self.device)  # (fused passes over the stored AO values on a GPU: nbx_xc_density / nbx_xc_half)
         rho, grad = [[], []], [[], []]
         for ao, dao in self._blocks:
             for x in range(2):
                 c = ao @ dmd[x]                                            # (g, nao)
-                if be is not None:
-                    rho_b, grad_b = ao.new_empty(ao.shape[0]), ao.new_empty((3, ao.shape[0]))
-                    be.xc_density(ao, dao, c, rho_b, grad_b)
-                    rho[x].append(rho_b)
-                    grad[x].append(grad_b)
-                    continue
                 rho[x].append((c * ao).sum(dim=1))
                 grad[x].append(2.0 * (dao * c[None]).sum(dim=2))           # D symmetric
         rho = [t.cat(r) for r in rho]
@@ -498,10 +526,7 @@ class XCProvider:
             g0 = 0
             for ao, dao in self._blocks:
                 g1 = g0 + ao.shape[0]
-                if be is not None:
-                    half = be.xc_half(ao, dao, vr[g0:g1], vec[:, g0:g1], vec.shape[1], t.empty_like(ao))
-                else:
-                    half = 0.5 * vr[g0:g1, None] * ao + (vec[:, g0:g1, None] * dao).sum(dim=0)
+                half = 0.5 * vr[g0:g1, None] * ao + (vec[:, g0:g1, None] * dao).sum(dim=0)
                 n = ao.shape[1]  # K = grid points is long and M = N = nao short: split K, batch, sum
                 vxc[x] += (ao.view(-1, self.SPLIT, n).transpose(1, 2) @ half.view(-1, self.SPLIT, n)).sum(dim=0)
                 g0 = g1

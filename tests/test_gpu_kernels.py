@@ -1097,26 +1097,78 @@ def test_eigh_approx_flags_vectors_it_could_not_separate(be):
             assert st[x] == -1
 
 
-@pytest.mark.parametrize("g,n", [(1000, 148), (257, 7), (64, 200)])
-def test_xc_grid_passes_match_the_tensor_expressions(be, g, n):
-    """nbx_xc_density / nbx_xc_half (each stored AO array read once) against the expressions they fuse."""
+@pytest.mark.parametrize("g,n", [(1000, 148), (257, 7), (64, 200), (3001, 24), (130, 72), (70, 165)])
+def test_xc_density_and_potential_passes_match_the_tensor_expressions(be, g, n):
+    """nbx_xc_rho (c = ao D on the matrix cores, rho / grad rho reduced in the epilogue, both spins) and nbx_xc_vmat
+    (ao^T half + its transpose with ``half`` built on the fly, split over chunks of grid points) against the tensor
+    expressions of nbed_amd.xc.XCProvider.__call__ they replace -- every tile-count / block-size instance."""
     import torch
 
     gen = torch.Generator(device="cpu").manual_seed(g + n)
-    ao = torch.randn(g, n, dtype=torch.float64, generator=gen).to(be.device)
-    dao = torch.randn(3, g, n, dtype=torch.float64, generator=gen).to(be.device)
-    c = torch.randn(g, n, dtype=torch.float64, generator=gen).to(be.device)
-    rho, grad = ao.new_empty(g), ao.new_empty((3, g))
-    be.xc_density(ao, dao, c, rho, grad)
-    torch.testing.assert_close(rho, (c * ao).sum(dim=1), rtol=0, atol=1e-12)
-    torch.testing.assert_close(grad, 2.0 * (dao * c[None]).sum(dim=2), rtol=0, atol=1e-12)
-    # a block of a longer grid: vr and vec are views into (G,) / (3, G) arrays
-    big = g + 300
-    vr = torch.randn(big, dtype=torch.float64, generator=gen).to(be.device)
-    vec = torch.randn(3, big, dtype=torch.float64, generator=gen).to(be.device)
-    half = be.xc_half(ao, dao, vr[100:100 + g], vec[:, 100:100 + g], big, torch.empty_like(ao))
-    want = 0.5 * vr[100:100 + g, None] * ao + (vec[:, 100:100 + g, None] * dao).sum(dim=0)
-    torch.testing.assert_close(half, want, rtol=0, atol=1e-12)
+    ao = torch.randn(g, n, dtype=torch.float64, generator=gen)
+    dao = torch.randn(3, g, n, dtype=torch.float64, generator=gen)
+    dm = torch.randn(2, n, n, dtype=torch.float64, generator=gen)
+    dm = 0.5 * (dm + dm.transpose(1, 2))
+    ao_d, dao_d = ao.to(be.device), dao.to(be.device)
+    rho, grad = be.xc_rho(ao_d, dao_d, dm.to(be.device))
+    c = torch.einsum("gm,xmn->xgn", ao, dm)
+    want_rho = (c * ao[None]).sum(dim=2)
+    want_grad = 2.0 * torch.einsum("xgn,agn->xag", c, dao)
+    scale = float(want_rho.abs().max())
+    torch.testing.assert_close(rho.cpu(), want_rho, rtol=0, atol=1e-12 * max(scale, 1.0))
+    torch.testing.assert_close(grad.cpu(), want_grad, rtol=0, atol=1e-12 * max(float(want_grad.abs().max()), 1.0))
+    vr = torch.randn(2, g, dtype=torch.float64, generator=gen)
+    vec = torch.randn(2, 3, g, dtype=torch.float64, generator=gen)
+    got = be.xc_vmat(ao_d, dao_d, vr.to(be.device), vec.to(be.device)).cpu()
+    half = 0.5 * vr[:, :, None] * ao[None] + torch.einsum("xag,agn->xgn", vec, dao)
+    v = torch.einsum("gm,xgn->xmn", ao, half)
+    want = v + v.transpose(1, 2)
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-12 * max(float(want.abs().max()), 1.0))
+    np.testing.assert_array_equal(got.numpy(), be.xc_vmat(ao_d, dao_d, vr.to(be.device), vec.to(be.device)).cpu().numpy())
+
+
+@pytest.mark.parametrize("name", ["b3lyp", "lda", "lda,vwn", "slater"])
+def test_xc_functional_kernel_matches_autograd(be, name):
+    """nbx_xc_functional -- energy density and first derivatives written out analytically (Slater, B88, VWN-RPA / VWN5,
+    LYP) -- against the torch expression it replaces: ``nbed_amd.xc.energy_density`` differentiated by autograd, with
+    XCProvider's conventions (clamped densities, weights folded in, empty points dropped).  Densities over eleven
+    orders of magnitude, spin polarisations up to 1e3, reduced gradients from 0.01 to 100."""
+    import torch
+
+    from nbed_amd import _nbx, xc
+
+    rng = np.random.default_rng(7)
+    g = 5000
+    ra = 10 ** rng.uniform(-9, 2, g)
+    rb = ra * 10 ** rng.uniform(-3, 3, g)
+    ga = rng.normal(size=(3, g)) * ra ** (4 / 3) * 10 ** rng.uniform(-2, 2, g)
+    gb = rng.normal(size=(3, g)) * rb ** (4 / 3) * 10 ** rng.uniform(-2, 2, g)
+    ra[:50] = 10 ** rng.uniform(-18, -14, 50)  # below the floor: clamped / dropped points
+    rb[:25] = 10 ** rng.uniform(-18, -14, 25)
+    w = rng.uniform(0.1, 2.0, g)
+    floor = xc.XCProvider.RHO_FLOOR
+    rho = torch.tensor(np.stack([ra, rb]))
+    grad = torch.tensor(np.stack([ga, gb]))
+    wt = torch.tensor(w)
+    keep = ((rho[0] + rho[1]) > floor).to(torch.float64)
+    tra = torch.clamp(rho[0], min=0.5 * floor).requires_grad_(True)
+    trb = torch.clamp(rho[1], min=0.5 * floor).requires_grad_(True)
+    saa = ((grad[0] * grad[0]).sum(dim=0) + 1e-40).requires_grad_(True)
+    sab = (grad[0] * grad[1]).sum(dim=0).requires_grad_(True)
+    sbb = ((grad[1] * grad[1]).sum(dim=0) + 1e-40).requires_grad_(True)
+    exc = (wt * keep * xc.energy_density(name, tra, trb, saa, sab, sbb)).sum()
+    vra, vrb, vsaa, vsab, vsbb = (x if x is not None else torch.zeros_like(wt) for x in torch.autograd.grad(
+        exc, (tra, trb, saa, sab, sbb), allow_unused=True))
+    want_vr = torch.stack([vra, vrb])
+    want_vec = torch.stack([2.0 * vsaa * grad[0] + vsab * grad[1], 2.0 * vsbb * grad[1] + vsab * grad[0]])
+    vr, vec, sums = be.xc_functional(_nbx.XC_CODES[name], rho.to(be.device), grad.to(be.device), wt.to(be.device), floor)
+    sums = sums.cpu().numpy()
+    assert abs(sums[0] - float(exc)) < 1e-12 * abs(float(exc))
+    assert abs(sums[1] - float((wt * (rho[0] + rho[1])).sum())) < 1e-12 * float((wt * (rho[0] + rho[1])).sum())
+    # 1e-11 relative to the size of each entry (the LYP derivative is a difference of terms up to 1e4 times larger)
+    err_r = ((vr.cpu() - want_vr).abs() / (want_vr.abs() + 1e-300)).max()
+    err_v = ((vec.cpu() - want_vec).abs() / (want_vec.abs() + 1e-300)).max()
+    assert float(err_r) < 5e-11 and float(err_v) < 5e-11, (float(err_r), float(err_v))
 
 
 @pytest.mark.parametrize("n", [64, 65, 128, 129, 150, 151, 176, 177, 198, 199, 208, 209])
