@@ -176,6 +176,8 @@ def load_library(path: os.PathLike | None = None) -> ctypes.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
+    if path is None and os.environ.get("NBX_LIB"):  # an alternative build of the library (A/B measurements)
+        path = os.environ["NBX_LIB"]
     p = Path(path) if path is not None else LIB_PATH
     if not p.exists():
         raise NbxUnavailableError(

@@ -32,6 +32,14 @@
 #include "jk_s4_layout.h"
 #include "jk_s4_device.h"
 
+// jk_m4.hip: the walk on the matrix cores (block-major tiles) for the sizes it has an instance for
+bool nbx_jk_m4_covers(int64_t N);
+size_t nbx_jk_m4_packed_bytes(int64_t N, int64_t p0, int64_t p1);
+size_t nbx_jk_m4_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm);
+int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
+int nbx_jk_m4(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
+              double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf);
+
 // The three EXPERIMENTAL forms of the NB = 4 / six-loads instance (parity green, all measured
 // slower than the kernel in this file) are linked only into a `make EXPERIMENTAL=1` build, where the environment
 // selects them (NBX_JK_P8 / NBX_JK_S8 / NBX_JK_DMA); the shipped library holds what runs.
@@ -375,6 +383,7 @@ extern "C" int nbx_jk_packed_supported(int64_t nao) {
 extern "C" size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1) {
     const int64_t NP = s4_padded(nao);
     if (NP == 0 || p0 < 0 || p1 < p0 || p1 > nao) return 0;
+    if (nbx_jk_m4_covers(nao)) return nbx_jk_m4_packed_bytes(nao, p0, p1);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_packed_bytes(nao);
     const S4Geom g = s4_geom((int)NP, s4_nb(NP));
     return (size_t)((s4_tri(p1) - s4_tri(p0)) * g.M) * sizeof(double);
@@ -390,6 +399,7 @@ extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
     }
     if (p0 == p1) return NBX_OK;
     NBX_CHECK_ARG(d_eri && d_packed);
+    if (nbx_jk_m4_covers(nao)) return nbx_jk_m4_pack(ctx, nao, p0, p1, d_eri, d_packed);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_pack(ctx, nao, d_eri, d_packed);
     const int64_t ntiles = s4_tri(p1) - s4_tri(p0);
     int rc = nbx_memset(ctx, d_packed, 0, nbx_eri_packed_bytes(nao, p0, p1));
@@ -403,6 +413,7 @@ extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
 extern "C" size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm) {
     const int64_t NP = s4_padded(nao);
     if (NP == 0 || p0 < 0 || p1 < p0 || p1 > nao || ndm <= 0) return 0;
+    if (nbx_jk_m4_covers(nao)) return nbx_jk_m4_worksize(nao, p0, p1, ndm);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_worksize(nao, ndm);
     size_t total = s4_plan(NP, p0, p1 - p0, ndm).total;
     if (NP != nao) total += s4_align256((size_t)((1 + 2 * ndm) * NP * NP) * sizeof(double));  // padded D and J/K
@@ -417,7 +428,7 @@ static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const
                         double* d_fock, double* d_vhf, const double* d_dts);
 
 extern "C" size_t nbx_jk_dts_bytes(int64_t nao) {
-    if (!s4_supported(nao)) return 0;  // (zero-padded sizes build their table themselves)
+    if (!s4_supported(nao) || nbx_jk_m4_covers(nao)) return 0;  // (zero-padded sizes and jk_m4.hip build their table themselves)
     const int NB = s4_nb(nao);
     return (size_t)(NB * NB * s4_lpt(nao) * 128) * sizeof(double);
 }
@@ -459,6 +470,7 @@ static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double
     }
     NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
     if (p1 == p0) return nbx_memset(ctx, d_jk, 0, (size_t)((1 + ndm) * nao * nao) * sizeof(double));
+    if (nbx_jk_m4_covers(nao)) return nbx_jk_m4(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8(ctx, nao, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
     if (NPAD != nao) {
         // Run as the NPAD x NPAD problem whose extra rows and columns are zero: the tiles (p, q) with
