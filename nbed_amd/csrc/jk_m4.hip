@@ -32,10 +32,7 @@
 
 namespace {
 
-constexpr int M4_THREADS = 512, M4_WAVES = M4_THREADS / 64, M4_CUS = 256, M4_NCH = 4;
-// ONE eight-wave workgroup per CU (two waves per SIMD: LDS and matrix-pipe latencies of one wave hide behind the other):
-// the per-thread share of the Dtot' table and of the staged tile is half that of a four-wave workgroup (48 + 48
-// registers), which is what lets two waves per SIMD fit the register file without spilling
+constexpr int M4_THREADS = 512, M4_PROD_THREADS = 256, M4_CUS = 256, M4_NCH = 4;  // 4 consumer + 4 producer waves
 constexpr int M4_PER_CU = 1;
 
 __host__ __device__ constexpr int m4_tri(int k) { return k * (k + 1) / 2; }
@@ -57,8 +54,8 @@ struct M4Geom {
         for (int k = 0; k < M4_NCH; ++k) m = blocks(k) > m ? blocks(k) : m;
         return m;
     }
-    static constexpr int LPT = (max_blocks() * 128 + M4_THREADS * 16 - 1) / (M4_THREADS * 16);  // 16-byte loads per thread
-    static constexpr int BUF = LPT * M4_THREADS * 2;                                            // doubles per LDS buffer
+    static constexpr int LPT = (max_blocks() * 128 + M4_PROD_THREADS * 16 - 1) / (M4_PROD_THREADS * 16);  // 16-byte loads per producer thread
+    static constexpr int BUF = LPT * M4_PROD_THREADS * 2;                                            // doubles per LDS buffer
 };
 
 typedef double m4_d2 __attribute__((ext_vector_type(2)));
@@ -100,9 +97,9 @@ template <int NB>
 __global__ __launch_bounds__(256) void m4_weights_kernel(const double* __restrict__ dm, int ndm, double* __restrict__ wt) {
     using G = M4Geom<NB>;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M4_NCH * G::LPT * M4_THREADS) return;
-    const int tid = i % M4_THREADS, s = (i / M4_THREADS) % G::LPT, k = (i / M4_THREADS) / G::LPT;
-    const int d0 = 16 * m4_tri(G::row0(k)) + (s * M4_THREADS + tid) * 2, dend = 16 * m4_tri(G::row0(k + 1));
+    if (i >= M4_NCH * G::LPT * M4_PROD_THREADS) return;
+    const int tid = i % M4_PROD_THREADS, s = (i / M4_PROD_THREADS) % G::LPT, k = (i / M4_PROD_THREADS) / G::LPT;
+    const int d0 = 16 * m4_tri(G::row0(k)) + (s * M4_PROD_THREADS + tid) * 2, dend = 16 * m4_tri(G::row0(k + 1));
     const int64_t n2 = (int64_t)G::N * G::N;
     double out[2] = {0.0, 0.0};
     for (int e = 0; e < 2; ++e) {
@@ -125,105 +122,153 @@ __global__ __launch_bounds__(256) void m4_weights_kernel(const double* __restric
 // ---------------------------------------------------------------------------------------------- the walk of one chunk
 // buf: the chunk in LDS (block (T, C) at 16 (tri(T) - tri(RA) + C)); xs: X[N][4] of this tile; acc[G]: this wave's partial
 // out rows 16 G + 4 b + a (D layout of the 4x4x4 product: lane 16 i + 4 b + j holds D_b[i][j]).
-// Eight waves: wave = 4 h + w4 takes the block columns C = 4 j + w4 with j = h (mod 2) of the row part and the block rows
-// T = RA + 4 j + w4 with j = 1 - h (mod 2) of the column part (HP = h: a template parameter, so that every bound stays static).
-template <int NB, int K, int HP>
+template <int NB, int K>
 __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, const double* __restrict__ xs, int w4, int a,
                                               int b, int c, double (&acc)[M4Geom<NB>::NG]) {
     using G_ = M4Geom<NB>;
     constexpr int RA = G_::row0(K), RB = G_::row0(K + 1), NG = G_::NG;
     constexpr int BASE = m4_tri(RA);
-    // ---- row part: items (G, C = 4 j + w4), C <= T = 4 G + b, T in [RA, RB)
+    // ---- row part: items (G, C = 4 j + w4), C <= T = 4 G + b, T in [RA, RB).  The operands of JB column groups are ALL
+    // read before their first MFMA (the memory clobber keeps the reads above it): a consumer wave has its SIMD to itself,
+    // so an LDS round trip per item -- what the scheduler's low-register order gives -- or per handful of items would be
+    // fully exposed (measured: 80 batches of ~6 reads per tile = 80 x ~120 cycles = the whole 4 us a tile took).
+    constexpr int JB = 1, NJR = (NB + 3) / 4, NJC = (RB - RA + 3) / 4;
     const int lo_row = 4 * a + c;
 #pragma unroll
-    for (int j = HP; j < (NB + 3) / 4; j += 2) {
-        if (4 * j >= RB) continue;  // static: no block of this column group lies in the chunk
-        const int C = 4 * j + w4;
-        if (4 * j + 3 >= NB && C >= NB) continue;  // scalar (last j only)
-        const double bx = xs[4 * (4 * C + a) + c];
+    for (int j0 = 0; j0 < NJR; j0 += JB) {
+        double av[JB][NG], bx[JB];
 #pragma unroll
-        for (int G = 0; G < NG; ++G) {
-            if (G < j || 4 * G + 3 < RA || 4 * G >= RB) continue;  // static
-            const int T = 4 * G + b;
-            double av;
-            const int addr = 16 * (m4_tri(4 * G) - BASE + 4 * j) + 16 * (G * 4 * b + m4_tri(b) + w4) + lo_row;
-            constexpr bool interior = true;
-            if (interior && 4 * G >= RA && 4 * G + 3 < RB && 4 * G + 3 < NB && j < G) {
-                av = buf[addr];
-            } else {
-                av = (T >= RA && T < RB && T < NB && C <= T) ? buf[addr] : 0.0;
+        for (int jj = 0; jj < JB; ++jj) {
+            const int j = j0 + jj;
+            if (j >= NJR || 4 * j >= RB) continue;  // static: no block of this column group lies in the chunk
+            const int C = min(4 * j + w4, NB - 1);  // (clamped: the surplus column group of the last j is masked below)
+            bx[jj] = xs[4 * (4 * C + a) + c];
+#pragma unroll
+            for (int G = 0; G < NG; ++G) {
+                if (G < j || 4 * G + 3 < RA || 4 * G >= RB) continue;  // static
+                // block (T = 4 G + b, C): tri(4 G + b) = tri(4 G) + 4 G b + tri(b).  The load is unconditional (LDS reads
+                // beyond the allocation return zero, everything else in the workgroup's LDS is finite data), the mask a select.
+                av[jj][G] = buf[16 * (m4_tri(4 * G) - BASE + 4 * j) + 16 * (G * 4 * b + m4_tri(b) + w4) + lo_row];
             }
-            acc[G] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bx, acc[G], 0, 0, 0);
         }
-        // (one column group at a time: the scheduler would otherwise hoist every LDS read of the chunk -- 100 of them --
-        // ahead of the first MFMA, and the kernel has no registers for that next to the Dtot' table)
-        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : : : "memory");
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+            const int j = j0 + jj;
+            if (j >= NJR || 4 * j >= RB) continue;
+            const int C = 4 * j + w4;
+            const bool c_ok = 4 * j + 3 < NB || C < NB;
+#pragma unroll
+            for (int G = 0; G < NG; ++G) {
+                if (G < j || 4 * G + 3 < RA || 4 * G >= RB) continue;  // static
+                double v = av[jj][G];
+                if (!(4 * G >= RA && 4 * G + 3 < RB && 4 * G + 3 < NB && j < G && 4 * j + 3 < NB)) {  // (static: else all valid)
+                    const int T = 4 * G + b;
+                    v = (c_ok && T >= RA && T < RB && T < NB && C <= T) ? v : 0.0;
+                }
+                acc[G] = __builtin_amdgcn_mfma_f64_4x4x4f64(v, bx[jj], acc[G], 0, 0, 0);
+            }
+        }
     }
     // ---- column part: items (T = RA + 4 j + w4, H), block columns 4 H + b < T, or == T with the strict lower part
     const int lo_col = 16 * b + 4 * c + a;
 #pragma unroll
-    for (int j = 1 - HP; j < (RB - RA + 3) / 4; j += 2) {
-        const int T = RA + 4 * j + w4;
-        if (RA + 4 * j + 3 >= RB && T >= RB) continue;  // scalar (last j only)
-        const double bt = xs[4 * (4 * T + a) + c];
-        const double* lt = buf + 16 * (m4_tri(T) - BASE) + lo_col;
+    for (int j0 = 0; j0 < NJC; j0 += JB) {
+        double av[JB][NG], bt[JB];
 #pragma unroll
-        for (int H = 0; H < NG; ++H) {
-            if (4 * H > RA + 4 * j + 3) continue;  // static: the whole group lies right of every T of this j
-            double av;
-            if (4 * H + 3 < RA + 4 * j) {
-                av = lt[64 * H];  // static: every block column of the group is left of T
-            } else {
-                const int cb = 4 * H + b;
-                av = (cb < T || (cb == T && c < a)) ? lt[64 * H] : 0.0;
+        for (int jj = 0; jj < JB; ++jj) {
+            const int j = j0 + jj;
+            if (j >= NJC) continue;
+            const int T = min(RA + 4 * j + w4, RB - 1);  // (clamped: the surplus block row of the last j is masked below)
+            bt[jj] = xs[4 * (4 * T + a) + c];
+            const double* lt = buf + 16 * (m4_tri(T) - BASE) + lo_col;
+#pragma unroll
+            for (int H = 0; H < NG; ++H) {
+                if (4 * H > RA + 4 * j + 3) continue;  // static: the whole group lies right of every T of this j
+                av[jj][H] = lt[64 * H];
             }
-            acc[H] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bt, acc[H], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : : : "memory");
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+            const int j = j0 + jj;
+            if (j >= NJC) continue;
+            const int T = RA + 4 * j + w4;
+            const bool t_ok = RA + 4 * j + 3 < RB || T < RB;
+#pragma unroll
+            for (int H = 0; H < NG; ++H) {
+                if (4 * H > RA + 4 * j + 3) continue;  // static
+                double v = av[jj][H];
+                if (!(4 * H + 3 < RA + 4 * j && RA + 4 * j + 3 < RB)) {  // (static: else every lane is valid)
+                    const int cb = 4 * H + b;
+                    v = (t_ok && (cb < T || (cb == T && c < a))) ? v : 0.0;
+                }
+                acc[H] = __builtin_amdgcn_mfma_f64_4x4x4f64(v, bt[jj], acc[H], 0, 0, 0);
+            }
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------- the kernel
+// One workgroup per CU, eight waves in two ROLES:
+//   waves 0-3  CONSUMERS: walk chunk g from LDS (one wave per SIMD: the walk has a SIMD's issue slots to itself) and hold
+//              the partial K rows in registers;
+//   waves 4-7  PRODUCERS: bring chunk g + 1 from the staging registers into the other LDS buffer, take its J contribution
+//              (Dtot' table in registers), re-issue the loads -- a whole tile in flight, and nothing but these few
+//              instructions between a chunk's arrival and the reload of its registers --, fetch the next tile's X, and do
+//              the consumers' end-of-tile reductions (row-q partial of the tile, row-p partial when the row changes, J).
+// One barrier per chunk step, executed by both roles.  (With every wave doing everything -- two four-wave workgroups per
+// CU, or one of eight -- the phases of a tile add up: ~1900 instructions per wave and tile, and a ring of loads that cannot
+// be re-issued before its consumer is done; measured 227-265 us at N = 148 against 152 us for the stream alone.)
+//
 // kpart1[(w S + slot) NDM + x][N]: row-p partial of workgroup w for the slot-th row of its range;
 // kpart2[(T - t_begin) NDM + x][N]: row-q partial of tile T (q < p); jfull (N, N): J[p][q] = J[q][p] of the tiles visited
 template <int NB, int NDM>
-__global__ __launch_bounds__(M4_THREADS, M4_PER_CU) void jk_m4_kernel(const double* __restrict__ packed, const double* __restrict__ dm,
+__global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __restrict__ packed, const double* __restrict__ dm,
                                                               const double* __restrict__ wtab, double* __restrict__ jfull,
                                                               double* __restrict__ kpart1, double* __restrict__ kpart2,
                                                               int64_t t_begin, int64_t t_end, int L, int S) {
     using G_ = M4Geom<NB>;
-    constexpr int N = G_::N, NG = G_::NG, LPT = G_::LPT, BUF = G_::BUF, TILE = G_::TILE;
+    constexpr int N = G_::N, NG = G_::NG, LPT = G_::LPT, BUF = G_::BUF, TILE = G_::TILE, PT = M4_PROD_THREADS;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* buf0 = smem;                 // [2][BUF] chunk buffers
     double* xs0 = smem + 2 * BUF;        // [2][N][4] X of the current / next tile
-    double* jred = xs0 + 2 * 4 * N;      // [8]
-    double* wlds = jred + 16;            // [NCH][LPT][M4_THREADS] double2: the Dtot' table in the staging order
+    double* redq = xs0 + 2 * 4 * N;      // [4][NG][32] consumers' row-q halves (odd columns) of the tile just walked
+    double* redp = redq + 4 * NG * 32;   // [4][NG][32] consumers' row-p halves (even columns) when the row ends
+    double* jred = redp + 4 * NG * 32;   // [2][4] producers' J partials per tile parity
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w4 = wave & 3, hp = wave >> 2;
+    const bool producer = wave >= 4;
+    const int ptid = tid - 256;  // producers: 0 .. 255
     const int64_t n2 = (int64_t)N * N;
+    (void)n2;
 
-    int64_t T = t_begin + (int64_t)blockIdx.x * L;
-    const int64_t T_end = min(t_end, T + L);
-    if (T >= T_end) return;  // uniform for the whole workgroup
-    const int p_first = m4_tri_row(T);
-    int p = p_first, q = (int)(T - (int64_t)p * (p + 1) / 2);
+    const int64_t T0 = t_begin + (int64_t)blockIdx.x * L;
+    const int64_t T_end = min(t_end, T0 + L);
+    if (T0 >= T_end) return;  // uniform for the whole workgroup
+    const int p_first = m4_tri_row(T0);
+    const int ntile = (int)(T_end - T0);
 
-    // the Dtot' table (the same for every tile, 96 KB) lives in LDS: one workgroup per CU leaves the room, and the
-    // registers it would take (48 per thread) are what the walk needs to run two waves per SIMD without spilling
-#pragma unroll
-    for (int k = 0; k < M4_NCH; ++k)
+    // ------------------------------------------------------------------ producer state
+    double2 wt[M4_NCH][LPT];   // the thread's Dtot' entries (the same for every tile)
+    double2 r[M4_NCH][LPT];    // staging: set k holds chunk k of the tile being staged; a whole tile in flight
+    double jacc = 0.0;
+    constexpr int XU = (4 * N + PT - 1) / PT;
+    auto load_chunk = [&](const double* tile, int k, bool real) {
+        const int begin = 16 * m4_tri(G_::row0(k)), end = 16 * m4_tri(G_::row0(k + 1));
 #pragma unroll
         for (int s = 0; s < LPT; ++s) {
-            const int o = 2 * ((k * LPT + s) * M4_THREADS + tid);
-            *reinterpret_cast<double2*>(wlds + o) = *reinterpret_cast<const double2*>(wtab + o);
+            int d = begin + (s * PT + ptid) * 2;
+            d = min(d, end - 2);
+            // `real` = false: the same number of loads from one cache line (nothing left to prefetch; a CONDITIONAL reload
+            // would make the compiler count the loads in flight for the path without it: every wait would over-drain)
+            r[k][s] = m4_ldnt(tile + (real ? d : 2 * (lane & 3)));
         }
-
+    };
     // X of a tile: xs[n][c] = D^{c / 2}[c & 1 ? p : q][n]  (NDM = 1: columns 2, 3 are zero)
-    constexpr int XU = (4 * N + M4_THREADS - 1) / M4_THREADS;
     auto fetch_x = [&](int pp, int qq, double (&v)[XU]) {
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int e = tid + M4_THREADS * u;  // element e = 4 n + c
+            const int e = ptid + PT * u;  // element e = 4 n + c
             const int n = e >> 2, cc = e & 3, x = cc >> 1;
             const int off = x * N * N + ((cc & 1) ? pp : qq) * N + n;  // (32-bit: scalar base + one offset register)
             v[u] = (e < 4 * N && x < NDM) ? dm[off] : 0.0;
@@ -232,159 +277,154 @@ __global__ __launch_bounds__(M4_THREADS, M4_PER_CU) void jk_m4_kernel(const doub
     auto store_x = [&](double* xs, const double (&v)[XU]) {
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int e = tid + M4_THREADS * u;
+            const int e = ptid + PT * u;
             if (e < 4 * N) xs[e] = v[u];
         }
     };
-    {
-        double v[XU];
-        fetch_x(p, q, v);
-        store_x(xs0, v);
-    }
-
-    // staging: chunk k of the tile at `tile` -> the k-th register set (clamped tail: the weights of those slots are
-    // zero).  A whole tile is in flight: set k is reloaded with chunk k of the NEXT tile as soon as it has been written
-    // to LDS (one workgroup per CU has to keep ~90 KB in flight to cover the HBM latency at 25 GB/s per CU).
-    double2 r[M4_NCH][LPT];
-    // `real` = false: the same number of loads from one cache line of the tile (the last tile of the range has nothing
-    // to prefetch; a CONDITIONAL reload would make the compiler count the loads in flight for the path without it, and
-    // every wait in the steady state would drain a chunk too many)
-    auto load_chunk = [&](const double* tile, int k, bool real) {
-        const int begin = 16 * m4_tri(G_::row0(k)), end = 16 * m4_tri(G_::row0(k + 1));
+    // chunk k of the staged tile: registers -> LDS buffer, its J contribution, reload of the set with the next tile's chunk k
+    auto stage = [&](double* buf, int k, const double* next_tile, bool next_real) {
 #pragma unroll
-        for (int s = 0; s < LPT; ++s) {
-            int d = begin + (s * M4_THREADS + tid) * 2;
-            d = min(d, end - 2);
-            r[k][s] = m4_ldnt(tile + (real ? d : 2 * (lane & 3)));
+        for (int s = 0; s < LPT; ++s) *reinterpret_cast<double2*>(buf + (s * PT + ptid) * 2) = r[k][s];
+#pragma unroll
+        for (int s = 0; s < LPT; ++s) jacc = fma(r[k][s].y, wt[k][s].y, fma(r[k][s].x, wt[k][s].x, jacc));
+        // the register set is dead from here: pinned, so that its reload lands in the SAME registers (a J product sunk
+        // below the loads keeps the old values alive, the loads get other registers, and the copy back costs a vmcnt(0))
+        asm volatile("" : "+v"(jacc) : : "memory");
+        load_chunk(next_tile, k, next_real);
+    };
+    // the consumers' partial rows of a finished tile: summed over the four consumer waves, in wave order
+    auto reduce_rows = [&](const double* red, int parity, double* dst) {  // dst[x N + row]
+        for (int e = ptid; e < NG * 32; e += PT) {
+            const int g = e >> 5, l = 2 * (e & 31) + parity;
+            const int row = 16 * g + 4 * ((l >> 2) & 3) + (l >> 4), x = (l & 3) >> 1;
+            if (row < N && x < NDM) dst[x * N + row] = (red[e] + red[NG * 32 + e]) + (red[2 * NG * 32 + e] + red[3 * NG * 32 + e]);
         }
     };
-    const double* tile = packed + (T - t_begin) * (int64_t)TILE;
-#pragma unroll
-    for (int k = 0; k < M4_NCH; ++k) {
-        load_chunk(tile, k, true);
-        // issued in chunk order, as the loop re-issues them: the wait before chunk k's first use is then the same count
-        // on the entry path and on the back edge (vmcnt is in order; a first fill in another order makes it 0 for good)
-        asm volatile("" : : : "memory");
-    }
 
+    // ------------------------------------------------------------------ consumer state
     double acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = 0.0;
-    double jacc = 0.0;
-    int par = 0;  // parity of the tile: which X buffer is current
 
-    for (; T < T_end; ++T) {
-        const double* xs = xs0 + par * 4 * N;
-        // next tile's indices and X values (in flight during this tile)
-        int pn = p, qn = q + 1;
-        if (qn > pn) {
-            ++pn;
-            qn = 0;
-        }
-        const bool more = T + 1 < T_end;
-        double xv[XU];
-        fetch_x(more ? pn : p, more ? qn : q, xv);  // (unconditional, as the chunk reloads)
+    // ------------------------------------------------------------------ prologue: tile 0 in flight, its chunk 0 and X in LDS
+    const double* tile0 = packed + (T0 - t_begin) * (int64_t)TILE;
+    int p = p_first, q = (int)(T0 - (int64_t)p * (p + 1) / 2);
+    if (producer) {
+#pragma unroll
+        for (int k = 0; k < M4_NCH; ++k)
+#pragma unroll
+            for (int s = 0; s < LPT; ++s) wt[k][s] = *reinterpret_cast<const double2*>(wtab + 2 * ((k * LPT + s) * PT + ptid));
+        if (ptid < 8) jred[ptid] = 0.0;
+        double v[XU];
+        fetch_x(p, q, v);
+        store_x(xs0, v);
 #pragma unroll
         for (int k = 0; k < M4_NCH; ++k) {
-            double* buf = buf0 + (k & 1) * BUF;
-            // chunk k: registers -> LDS, its J contribution, then the registers take the next chunk
-#pragma unroll
-            for (int s = 0; s < LPT; ++s) *reinterpret_cast<double2*>(buf + (s * M4_THREADS + tid) * 2) = r[k][s];
-#pragma unroll
-            for (int s = 0; s < LPT; ++s) {
-#ifndef NBX_M4_NO_J
-                const double2 w = *reinterpret_cast<const double2*>(wlds + 2 * ((k * LPT + s) * M4_THREADS + tid));
-                jacc = fma(r[k][s].y, w.y, fma(r[k][s].x, w.x, jacc));
-#endif
-            }
-            // the register set is dead from here: pinned, so that its reload lands in the SAME registers (a J product
-            // sunk below the loads keeps the old values alive, the loads then get other registers, and the copy back
-            // at the end of the tile costs a vmcnt(0) -- the whole prefetch drained once per tile)
-            asm volatile("" : "+v"(jacc) : : "memory");
-            load_chunk(more ? tile + TILE : tile, k, more);
-            __syncthreads();  // chunk k is in LDS; everyone is done with the buffer the next chunk will take
-#ifndef NBX_M4_NO_WALK
-            // (the lane is made opaque per chunk: the ~100 per-lane LDS addresses of a walk are loop invariant, and
-            // hoisted out of the tile loop they would occupy -- spill -- a register each)
-            int lane_o = lane;
-            asm volatile("" : "+v"(lane_o));
-            const int a = lane_o >> 4, b = (lane_o >> 2) & 3, c = lane_o & 3;
-            if (hp == 0) {
-                if (k == 0) m4_walk_chunk<NB, 0, 0>(buf, xs, w4, a, b, c, acc);
-                else if (k == 1) m4_walk_chunk<NB, 1, 0>(buf, xs, w4, a, b, c, acc);
-                else if (k == 2) m4_walk_chunk<NB, 2, 0>(buf, xs, w4, a, b, c, acc);
-                else m4_walk_chunk<NB, 3, 0>(buf, xs, w4, a, b, c, acc);
-            } else {
-                if (k == 0) m4_walk_chunk<NB, 0, 1>(buf, xs, w4, a, b, c, acc);
-                else if (k == 1) m4_walk_chunk<NB, 1, 1>(buf, xs, w4, a, b, c, acc);
-                else if (k == 2) m4_walk_chunk<NB, 2, 1>(buf, xs, w4, a, b, c, acc);
-                else m4_walk_chunk<NB, 3, 1>(buf, xs, w4, a, b, c, acc);
-            }
-#endif
+            load_chunk(tile0, k, true);
+            asm volatile("" : : : "memory");  // (issued in chunk order, as the loop re-issues them: vmcnt is in order)
         }
-        // ---- end of tile: J[p][q], and the row-q halves of the partial rows (odd columns c: they used D[p][:]) leave the
-        // registers -- the eight waves' partials are summed through LDS into the tile's row-q partial; the row-p halves
-        // (even c) stay in the registers until the row changes.  Scratch: the buffer of chunk 2 (walked by everyone,
-        // chunk 0 of the next tile is written there behind the second barrier).
-#ifndef NBX_M4_NO_EPI
-        double* red = buf0;  // [8][NG][32]
-        static_assert(M4_WAVES * NG * 32 <= BUF, "reduction scratch fits one chunk buffer");
-        const bool odd = lane & 1;
-        jacc = nbx_wave_sum(jacc);
-        if (lane == 0) jred[wave] = jacc;
-        jacc = 0.0;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (odd) red[(wave * NG + g) * 32 + (lane >> 1)] = acc[g];
-            acc[g] = odd ? 0.0 : acc[g];
+        stage(buf0, 0, ntile > 1 ? tile0 + TILE : tile0, ntile > 1);
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ the steps: tile t, chunk k -> step 4 t + k
+    // Two loops, one per role (so that the producers' registers -- Dtot' table, staged tile -- and the consumers' --
+    // accumulators, walk operands -- are never live together); both execute exactly one barrier per step.
+    auto next_pq = [](int& pp, int& qq) {
+        if (++qq > pp) {
+            ++pp;
+            qq = 0;
         }
-        if (more) store_x(xs0 + (par ^ 1) * 4 * N, xv);
-        __syncthreads();
-        if (tid == 0) {
-            double j = 0.0;
+    };
+    if (producer) {
+        for (int t = 0; t < ntile; ++t) {
+            const int64_t T = T0 + t;
+            int pn = p, qn = q;
+            next_pq(pn, qn);
+            const bool more = t + 1 < ntile;   // a tile t + 1 exists
+            const bool more2 = t + 2 < ntile;  // ... and a tile t + 2 (what the reload behind tile t + 1's chunk 0 fetches)
+            const double* tile = tile0 + (int64_t)t * TILE;
+            double xv[XU];
+            fetch_x(more ? pn : p, more ? qn : q, xv);  // X of tile t + 1: fetched now, stored one step on
 #pragma unroll
-            for (int w = 0; w < M4_WAVES; ++w) j += jred[w];
-            jfull[(int64_t)p * N + q] = j;
-            jfull[(int64_t)q * N + p] = j;
-        }
-        if (tid < NG * 32 && q < p) {
-            const int g = tid >> 5, l = 2 * (tid & 31) + 1;
-            const int row = 16 * g + 4 * ((l >> 2) & 3) + (l >> 4), x = (l & 3) >> 1;
-            if (row < N && x < NDM) {
-                double v = 0.0;
-#pragma unroll
-                for (int w = 0; w < M4_WAVES; ++w) v += red[w * NG * 32 + tid];
-                kpart2[((T - t_begin) * NDM + x) * (int64_t)N + row] = v;
-            }
-        }
-        __syncthreads();
-        if (pn != p || !more) {  // the row is complete for this workgroup: its row-p partial (even c) -> kpart1 slot
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (!odd) red[(wave * NG + g) * 32 + (lane >> 1)] = acc[g];
-                acc[g] = 0.0;
-            }
-            __syncthreads();
-            if (tid < NG * 32) {
-                const int g = tid >> 5, l = 2 * (tid & 31);
-                const int row = 16 * g + 4 * ((l >> 2) & 3) + (l >> 4), x = (l & 3) >> 1;
-                if (row < N && x < NDM) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int w = 0; w < M4_WAVES; ++w) v += red[w * NG * 32 + tid];
-                    kpart1[(((int64_t)blockIdx.x * S + (p - p_first)) * NDM + x) * N + row] = v;
+            for (int k = 0; k < M4_NCH; ++k) {
+                // step 4 t + k: chunk k + 1 of tile t (k < 3) or chunk 0 of tile t + 1 (k == 3) goes to the buffer the
+                // consumers are not walking
+                if (k == 0 && t > 0) {
+                    // the consumers' rows of tile t - 1 (written at its last step, behind that step's barrier)
+                    int pp = p, qq = q - 1;
+                    if (qq < 0) {
+                        pp = p - 1;
+                        qq = pp;
+                    }
+                    if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N);
+                    if (pp != p) reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N);
                 }
-            }
-            __syncthreads();
-        }
-#else
-        if (more) store_x(xs0 + (par ^ 1) * 4 * N, xv);
-        __syncthreads();
+#ifndef NBX_M4_NO_STAGE
+                if (k + 1 < M4_NCH) stage(buf0 + ((k + 1) & 1) * BUF, k + 1, more ? tile + TILE : tile, more);
+                else if (more) stage(buf0, 0, more2 ? tile + 2 * TILE : tile, more2);
 #endif
-        p = pn;
-        q = qn;
-        par ^= 1;
-        tile += TILE;
+                if (k == 1 && more) store_x(xs0 + ((t + 1) & 1) * 4 * N, xv);
+                if (k == 2) {  // chunk 3 of tile t has just been staged: this wave's share of the tile's J
+                    jacc = nbx_wave_sum(jacc);
+                    if (lane == 0) jred[(t & 1) * 4 + (wave - 4)] = jacc;
+                    jacc = 0.0;
+                }
+                if (k == 3 && ptid == 0) {
+                    const double* jr = jred + (t & 1) * 4;
+                    const double j = (jr[0] + jr[1]) + (jr[2] + jr[3]);
+                    jfull[(int64_t)p * N + q] = j;
+                    jfull[(int64_t)q * N + p] = j;
+                }
+                __syncthreads();
+            }
+            p = pn;
+            q = qn;
+        }
+        // the last tile's rows ((p, q) has moved one past it)
+        int pp = p, qq = q - 1;
+        if (qq < 0) {
+            pp = p - 1;
+            qq = pp;
+        }
+        if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T_end - 1 - t_begin) * NDM) * (int64_t)N);
+        reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N);
+    } else {
+        for (int t = 0; t < ntile; ++t) {
+            int pn = p, qn = q;
+            next_pq(pn, qn);
+            const bool row_ends = pn != p || t + 1 >= ntile;
+            const double* xs = xs0 + (t & 1) * 4 * N;
+#pragma unroll
+            for (int k = 0; k < M4_NCH; ++k) {
+                const double* buf = buf0 + (k & 1) * BUF;
+#ifndef NBX_M4_NO_WALK
+                // (the lane is made opaque per chunk: the ~100 per-lane LDS addresses of a walk are loop invariant, and
+                // hoisted out of the tile loop they would occupy -- spill -- a register each)
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));
+                const int a = lane_o >> 4, b = (lane_o >> 2) & 3, c = lane_o & 3;
+                if (k == 0) m4_walk_chunk<NB, 0>(buf, xs, wave, a, b, c, acc);
+                else if (k == 1) m4_walk_chunk<NB, 1>(buf, xs, wave, a, b, c, acc);
+                else if (k == 2) m4_walk_chunk<NB, 2>(buf, xs, wave, a, b, c, acc);
+                else m4_walk_chunk<NB, 3>(buf, xs, wave, a, b, c, acc);
+#endif
+                if (k == M4_NCH - 1) {
+                    // end of tile: the row-q halves (odd columns: they used D[p][:]) leave the registers; the row-p halves
+                    // (even columns) stay until the row changes.  The producers sum them up during the next step.
+                    const bool odd = lane & 1;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        if (odd) redq[(wave * NG + g) * 32 + (lane >> 1)] = acc[g];
+                        else if (row_ends) redp[(wave * NG + g) * 32 + (lane >> 1)] = acc[g];
+                        acc[g] = (odd || row_ends) ? 0.0 : acc[g];
+                    }
+                }
+                __syncthreads();
+            }
+            p = pn;
+            q = qn;
+        }
     }
 }
 
@@ -406,9 +446,9 @@ M4Plan m4_plan_nb(int64_t p0, int64_t np, int64_t ndm) {
     pl.L = (int)L;
     pl.wgs = (int)nbx_cdiv(ntiles, L);
     pl.S = (int)sqrt(2.0 * (double)L) + 3;
-    pl.lds_bytes = (size_t)(2 * G::BUF + 2 * 4 * G::N + 16 + M4_NCH * G::LPT * M4_THREADS * 2) * sizeof(double);
+    pl.lds_bytes = (size_t)(2 * G::BUF + 2 * 4 * G::N + 2 * 4 * G::NG * 32 + 16) * sizeof(double);
     size_t off = 0;
-    pl.wt_off = off; off += m4_align256((size_t)(M4_NCH * G::LPT * M4_THREADS * 2) * sizeof(double));
+    pl.wt_off = off; off += m4_align256((size_t)(M4_NCH * G::LPT * M4_PROD_THREADS * 2) * sizeof(double));
     pl.k1_off = off; off += m4_align256((size_t)((int64_t)pl.wgs * pl.S * ndm * G::N) * sizeof(double));
     pl.k2_off = off; off += m4_align256((size_t)(ntiles * ndm * G::N) * sizeof(double));
     pl.total = off;
@@ -429,7 +469,7 @@ int m4_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
         const int rc = nbx_memset(ctx, d_jk, 0, (size_t)n2 * sizeof(double));
         if (rc != NBX_OK) return rc;
     }
-    hipLaunchKernelGGL(m4_weights_kernel<NB>, dim3((unsigned)nbx_cdiv(M4_NCH * G::LPT * M4_THREADS, 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(m4_weights_kernel<NB>, dim3((unsigned)nbx_cdiv(M4_NCH * G::LPT * M4_PROD_THREADS, 256)), dim3(256), 0, ctx->stream,
                        d_dm, (int)ndm, wt);
     NBX_LAUNCH_CHECK();
     const int64_t t_begin = m4_tri((int)p0), t_end = m4_tri((int)p1);

@@ -274,3 +274,21 @@ def test_jk_lds_dma_experimental_vs_c_oracle(variant):
         outs[v] = out.stdout.strip().splitlines()[-1].split(" ", 3)[3]
     if variant != "3":
         assert outs[variant] == outs["0"]
+
+
+@needs_experimental
+def test_jk_mfma_walk_experimental_vs_symmetric_kernel():
+    """csrc/jk_m4.hip (the walk on v_mfma_f64_4x4x4_4b_f64 over block-major tiles, producer / consumer waves; opt-in,
+    NBX_JK_M4=1 is read once per process: a child process) at N = 148, both density counts and row slabs, against the
+    symmetric kernel (itself held to the C oracle above)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    env = dict(os.environ, NBX_JK_M4="1", PYTHONPATH=str(Path(__file__).resolve().parent.parent))
+    out = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "tools" / "time_jk_packed.py"), "148"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    errs = [float(ln.split("=")[3].split()[0]) for ln in out.stdout.splitlines() if "max|packed - sym|" in ln]
+    assert len(errs) == 2 and max(errs) < 1e-13, out.stdout
