@@ -86,6 +86,19 @@ def transform_flops(N, n):
     return 2.0 * n * N**4 + 2.0 * n**2 * N**3 + 2.0 * n**3 * N**2 + 2.0 * n**4 * N
 
 
+def gemm_traffic(N, n_act):
+    """HBM bytes of the quarter-1 GEMM launch from the committed PMC passes (profiles/r03/gemm_traffic.json:
+    FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), if they were taken at this shape."""
+    tfile = REPO / "profiles" / "r03" / "gemm_traffic.json"
+    try:
+        tj = json.loads(tfile.read_text())
+        if f"N_AO={N}, n_act={n_act}:" in tj.get("workload", ""):
+            return tj.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline_cycle(pr, eri_h, ncycles):
     """The CPU oracle's cycle on the host cores: C/OpenMP one-pass J/K + numpy/LAPACK rest.
     ``pr``: dict with nao, nelec, S, hcore, V_emb, D_env (host arrays)."""
@@ -605,7 +618,7 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": (q1_flops / (q1_ms / max(q1_cnt, 1) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS) if q1_cnt else None,
-                "traffic": None,
+                "traffic": gemm_traffic(N, n_act) if single else None,
             },
             "device_ms_per_block_all_quarters": all_ms / max(all_cnt, 1),
         }
