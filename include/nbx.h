@@ -207,11 +207,13 @@ int nbx_trace_prod(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_a, 
 int nbx_huz_cycle_scalars(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
                           const double* d_vemb, const double* d_vhf, const double* d_hz,
                           const double* d_dm, const double* d_dm_old, double* h_out);
-/* Same scalars (d_out[4 + tail_n], square roots applied) with no synchronisation, so that the
- * host can queue the next SCF cycle before it reads them.  One launch: the workgroup that arrives
- * last does the second stage.  d_out is device memory or pinned (device-mapped) host memory --
- * stored to host memory directly the values need no copy; they are complete once the stream has
- * passed the launch (record an event).
+/* Same scalars (square roots applied) with no synchronisation, so that the host can queue the
+ * next SCF cycle before it reads them.  One launch: the workgroup that arrives last does the
+ * second stage.  d_out: 4 + tail_n + 1 doubles of device memory or pinned (device-mapped) host
+ * memory -- stored to host memory directly the values need no copy.  The LAST word,
+ * d_out[4 + tail_n], receives 1.0 after everything before it is visible system-wide: a host that
+ * cleared it before the call can poll it instead of recording an event on the stream (an event
+ * between two cycles holds the next cycle's first kernel back by ~10 us on MI355X).
  * d_tail (optional): tail_n <= 64 device ints appended as doubles, e.g. the eigensolver status
  * words, so that they reach the host together.                                                */
 int nbx_huz_cycle_scalars_dev(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim,
@@ -232,7 +234,11 @@ int nbx_huz_cycle_scalars_dts(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
  * counts the vectors held including this one), solves H[:nd+1,:nd+1] c = (1,0,...) with
  * PySCF's rule (modes with |eigenvalue| < 1e-14 are dropped when there are any, otherwise an
  * LU solve), and overwrites d_xprev with sum_k c[k+1] xs[k]: the extrapolated vector.
- * d_coef (>= space doubles) receives c[1:]; 1 <= nd <= space <= 16.                           */
+ * d_coef: nbx_diis_coef_doubles(space) doubles, ZERO-INITIALISED by the caller before the first
+ * update of a ring and left alone afterwards: c[1:] in the first `space` of them, behind them
+ * the solver's own state (the eigenvector basis its Jacobi sweeps ended in, from which the next
+ * update's solve starts: one row / column of H changes per update).  1 <= nd <= space <= 16.   */
+size_t nbx_diis_coef_doubles(int64_t space);
 int nbx_diis_update(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_t nd,
                     const double* d_x, double* d_xprev, double* d_xs, double* d_es, double* d_h,
                     double* d_coef);
@@ -440,8 +446,9 @@ int nbx_spinorb_scatter_range(nbx_ctx* ctx, int64_t n, const double* d_two_body,
  *   diis_mode 0: no DIIS; 1: pyscf.lib.diis' first update (only remembers F); 2: nbx_diis_update with
  *          (diis_slot, diis_nd) -- the ring bookkeeping stays with the caller.
  *   dts_ready: st->d_dts holds the Dtot' table of d_dm_in (left by the previous call).
- *   h_out: 6 doubles of pinned (device-mapped) host memory: E_alpha, E_beta, |dD_alpha|, |dD_beta|, and the
- *          eigensolver's two status words; complete once the stream has passed this call.            */
+ *   h_out: 7 doubles of pinned (device-mapped) host memory: E_alpha, E_beta, |dD_alpha|, |dD_beta|, the
+ *          eigensolver's two status words, then 1.0 -- stored last, once the six are visible to the host, which
+ *          can clear that word before the call and poll it (see nbx_huz_cycle_scalars_dev).          */
 typedef struct nbx_huz_state {
     int64_t nao, nocc_a, nocc_b;
     const double* d_packed; /* nbx_eri_pack of the whole tensor / of this rank's slab (NBX_HUZ_JK_PACKED) */
@@ -466,6 +473,7 @@ typedef struct nbx_huz_state {
     double* d_diis_xs;      /* (space, 2 N^2) */
     double* d_diis_es;
     double* d_diis_h;       /* (space+1)^2, initialised by the caller (row/column 0 = 1) */
+                            /* d_diis_coef: nbx_diis_coef_doubles(space) doubles, zeroed by the caller */
     double* d_diis_coef;
     double* d_diis_xprev;   /* 2 N^2 */
     /* which J/K kernel builds the Fock matrix, and on which rows of (pq|rs) */

@@ -102,6 +102,7 @@ SIGNATURES = {
     "nbx_huz_cycle_scalars": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, _P, POINTER(c_double)]),
     "nbx_huz_cycle_scalars_dev": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64]),
     "nbx_huz_cycle_scalars_dts": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
+    "nbx_diis_coef_doubles": (c_size_t, [c_int64]),
     "nbx_diis_update": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),
     "nbx_diis_update_err": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "nbx_vo_sumsq": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P]),

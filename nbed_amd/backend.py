@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time
 from ctypes import c_double, c_int
 
 import numpy as np
@@ -41,29 +42,61 @@ def set_backend(backend) -> None:
 
 class _PendingScalars:
     """A few doubles on their way to pinned host memory: either a stream-ordered copy of ``d_vals``
-    or, with ``host`` given, values a queued kernel stores there itself (pinned memory is mapped
-    into the device's address space); an event marks the point after which they can be read."""
+    (an event marks the point after which they can be read) or, with ``host`` given, values a queued
+    kernel stores there itself (pinned memory is mapped into the device's address space) followed by
+    a word that turns 1.0 once they are all visible: ``get()`` polls that word.  No event goes on the
+    stream for those -- an event record between two SCF cycles holds the next cycle's first kernel
+    back by ~10 us."""
+
+    _POLL_TIMEOUT_S = 120.0
 
     def __init__(self, torch, d_vals, ntail=0, ncore=4, host=None):
         self._ncore = ncore
+        self._torch = torch
+        self._event = None
+        self._queried = False
         if host is None:
             self._host = torch.empty(d_vals.shape, dtype=d_vals.dtype, pin_memory=True)
             self._host.copy_(d_vals, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+            self._flag = None
         else:
-            self._host = host
-        self._event = torch.cuda.Event()
-        self._event.record()
+            self._host = host  # (ncore + ntail + 1,): the caller cleared the last word before queueing the kernel
+            self._flag = host.numpy()[ncore + ntail:ncore + ntail + 1]
         self._keep = d_vals  # the source must outlive the copy
         self._ntail = ntail
 
+    def _wait(self):
+        if self._event is not None:
+            self._event.synchronize()
+            return
+        flag = self._flag
+        if not self._queried:
+            # hipStreamQuery does not wait; it lets the runtime retire the commands that have finished.  Left
+            # to the end of a run they cost its last synchronisation 0.1-0.2 ms (measured at N = 148: 2590-2640
+            # cycles/s without the query, 2630-2670 with one every fourth cycle, 2640-2720 with one per cycle)
+            self._queried = True
+            self._torch.cuda.current_stream().query()
+        if flag[0] == 1.0:
+            return
+        deadline = time.monotonic() + self._POLL_TIMEOUT_S
+        spins = 0
+        while flag[0] != 1.0:
+            spins += 1
+            if (spins & 0xfff) == 0 and time.monotonic() > deadline:
+                self._torch.cuda.synchronize()  # surfaces a device fault, if that is why nothing arrived
+                if flag[0] != 1.0:
+                    raise RuntimeError("the SCF cycle's scalars never reached the host")
+
     def get(self) -> np.ndarray:
-        self._event.synchronize()
+        self._wait()
         self._keep = None
         return self._host.numpy()[: self._ncore].copy()
 
     def get_extra(self):
         """The appended status words (as ints), or None."""
-        self._event.synchronize()
+        self._wait()
         if not self._ntail:
             return None
         return self._host.numpy()[self._ncore:self._ncore + self._ntail].astype(np.int64)
@@ -73,7 +106,7 @@ class HipBackend:
     """libnbx on one MI355X."""
 
     name = "hip"
-    _PIN_SLOTS, _PIN_WIDTH = 256, 4 + 64  # 4 scalars + up to 64 status words (nbx_huz_cycle_scalars_dev)
+    _PIN_SLOTS, _PIN_WIDTH = 256, 4 + 64 + 4  # 4 scalars + up to 64 status words + the ready word (nbx_huz_cycle_scalars_dev)
 
     def __init__(self, device: int | None = None):
         import torch
@@ -99,6 +132,7 @@ class HipBackend:
         # _PIN_SLOTS further calls; the SCF loops read a handle one call late.
         self._pin_ring = torch.empty((self._PIN_SLOTS, self._PIN_WIDTH), dtype=torch.float64, pin_memory=True)
         self._pin_next = 0
+        self._pin_results = torch.empty(1 << 17, dtype=torch.float64, pin_memory=True)  # to_host_many's landing buffer
 
     def __del__(self):
         try:
@@ -574,9 +608,10 @@ class HipBackend:
         ntail = 0 if extra is None else int(extra.numel())
         # the kernel's last workgroup stores the results straight into pinned host memory: no copy
         # (a device-to-host copy per cycle costs a launch and a cache flush in the middle of the chain)
-        if ntail > self._PIN_WIDTH - 4:
+        if ntail > 64:
             raise ValueError("huz_cycle_scalars_async: at most 64 status words")
-        h_out = self._pin_ring[self._pin_next][: 4 + ntail]
+        h_out = self._pin_ring[self._pin_next][: 4 + ntail + 1]
+        h_out[4 + ntail] = 0.0  # the kernel's "all stored" word
         self._pin_next = (self._pin_next + 1) % self._PIN_SLOTS
         # ``dts``: a table from jk_dts_new() that the kernel fills with Dtot' of ``dm`` for the next
         # packed J/K build
@@ -623,7 +658,7 @@ class HipBackend:
         hm = np.zeros((diis_space + 1, diis_space + 1))
         hm[0, 1:] = hm[1:, 0] = 1
         h.diis_h = self.asarray(hm)
-        h.diis_coef = self.zeros(diis_space)
+        h.diis_coef = self.diis_coef_buffer(diis_space)
         h.diis_xprev = self.empty(nsq)
         h.sets = [{"c": self.empty((2, n, n)), "v": self.empty((2, n, n)), "w": self.empty((2, n)),
                    "dm": self.empty((2, n, n)), "hz": self.empty((2, n, n)),
@@ -654,7 +689,8 @@ class HipBackend:
         ``reduce``: for a run over several ranks -- a callable that sums the ranks' (3,N,N) J/K partials in
         place with a collective queued on this stream (``Shards.all_reduce``); the cycle is then two C calls
         around it (nbx_huz_cycle_jk, nbx_huz_cycle_post), with the same look-ahead as the one-rank cycle."""
-        h_out = self._pin_ring[self._pin_next][:6]
+        h_out = self._pin_ring[self._pin_next][:7]
+        h_out[6] = 0.0  # the kernel's "all stored" word
         self._pin_next = (self._pin_next + 1) % self._PIN_SLOTS
         if reduce is None:
             self._call("nbx_huz_cycle", ctypes.byref(h.st), self._p(dm_in), self._p(c_in), self._p(out["dm"]),
@@ -673,6 +709,11 @@ class HipBackend:
     def async_to_host(self, d_vals):
         """Stream-ordered copy of a small device tensor to pinned memory; ``.get()`` waits for it only."""
         return _PendingScalars(self.torch, d_vals, 0, ncore=int(d_vals.numel()))
+
+    def diis_coef_buffer(self, space: int):
+        """Zeroed device buffer for the coefficients of a DIIS ring of ``space`` vectors and, behind them, the
+        Pulay solver's warm-start state (nbx_diis_coef_doubles)."""
+        return self.zeros(int(self.lib.nbx_diis_coef_doubles(space)))
 
     def diis_update(self, space: int, slot: int, nd: int, x, xprev, xs, es, h, coef):
         """Device-resident pyscf.lib.diis.DIIS.update step; ``xprev`` becomes the extrapolated vector."""

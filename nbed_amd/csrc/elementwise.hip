@@ -186,8 +186,8 @@ __global__ void huzinaga_sym_kernel(const double* __restrict__ fds, int N, doubl
 // partial[blk*4 + {0,1}] = sum (h + v + 0.5 vhf + hz)[x][i,j] * D[x][j,i];  [2,3] = sum (D-Dold)^2
 // With `out`: the workgroup that arrives last (device-scope counter, left at zero) also does the
 // second stage in the fixed order of final_reduce_kernel -- out[0,1] the sums, out[2,3] the square
-// roots, then `tail_n` status words as doubles -- so the cycle's scalars cost one launch.  `out`
-// may be pinned host memory: the values then need no copy.
+// roots, then `tail_n` status words as doubles, then 1.0 (stored last, system scope) -- so the cycle's
+// scalars cost one launch.  `out` may be pinned host memory: the values then need no copy.
 template <int T>  // tile edge: 16 x 16 tiles give N = 148 a hundred workgroups instead of 25
 __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const double* __restrict__ vemb,
                                    const double* __restrict__ vhf, const double* __restrict__ hz,
@@ -196,60 +196,69 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
                                    const int* __restrict__ tail = nullptr, int tail_n = 0,
                                    int* __restrict__ counter = nullptr, double* __restrict__ dts = nullptr,
                                    int s4_nb_ = 0, int s4_lpt_ = 0) {
-    __shared__ double dt[T][T + 1];
-    __shared__ double red[4][4];
-    __shared__ double red2[17];
+    // A kernel on the SCF's critical path: everything it reads is requested in one trip to memory (both spins'
+    // tiles at once), the sums travel by lane moves, and the workgroup that arrives last adds the four columns
+    // of partials side by side -- three dependent round trips to L2 where there were nine.
+    __shared__ double dt[2][T][T + 1];
+    __shared__ double red[4][16];
     __shared__ int last;
     const int64_t n2 = (int64_t)N * N;
     const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    double out[4];
+    const int nthr = blockDim.x * blockDim.y, nwave = nthr / 64;
+    constexpr int R = T / 8;  // rows of the tile per thread (blockDim.y == 8)
+    double out[4] = {0.0, 0.0, 0.0, 0.0};
     // With `dts`: this kernel also leaves Dtot' of D (the density the NEXT J/K build contracts) in
     // the staging order of nbx_jk_packed -- sum_x (D_ab + D_ba) below the diagonal, sum_x D_aa on it
     // -- which saves that build its preparation launch.  Tiles on or below the diagonal write.
-    double dsum[T / 8], tsum[T / 8];
+    double dsum[R], tsum[R];
+    double ham[2][R], dv[2][R], dold[2][R];
 #pragma unroll
-    for (int k = 0; k < T / 8; ++k) dsum[k] = tsum[k] = 0.0;
-    for (int x = 0; x < 2; ++x) {
-        __syncthreads();
-        for (int r = threadIdx.y; r < T; r += blockDim.y) {  // dt[j][i] = D[x][j0+j][i0+i]
-            const int gr = j0 + r, gc = i0 + threadIdx.x;
-            dt[r][threadIdx.x] = (gr < N && gc < N) ? dm[x * n2 + (int64_t)gr * N + gc] : 0.0;
-        }
-        __syncthreads();
-        double e = 0.0, d2 = 0.0;
-        for (int r = threadIdx.y; r < T; r += blockDim.y) {
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int r = threadIdx.y + 8 * k;
+            const int gr = j0 + r, gc = i0 + threadIdx.x;  // dt[x][j][i] = D[x][j0+j][i0+i]
+            dt[x][r][threadIdx.x] = (gr < N && gc < N) ? dm[x * n2 + (int64_t)gr * N + gc] : 0.0;
             const int gi = i0 + r, gj = j0 + threadIdx.x;
-            if (gi < N && gj < N) {
-                const int64_t o = (int64_t)gi * N + gj;
-                double ham = h[h3d ? x * n2 + o : o] + 0.5 * vhf[x * n2 + o] + hz[x * n2 + o];
-                if (vemb) ham += vemb[x * n2 + o];
-                e = fma(ham, dt[threadIdx.x][r], e);
-                const double dv = dm[x * n2 + o];
-                const double dd = dv - dm_old[x * n2 + o];
-                d2 = fma(dd, dd, d2);
-                dsum[r / 8] += dv;
-                tsum[r / 8] += dt[threadIdx.x][r];
-            }
+            const bool in = gi < N && gj < N;
+            const int64_t o = in ? (int64_t)gi * N + gj : 0;
+            double hm = h[h3d ? x * n2 + o : o] + 0.5 * vhf[x * n2 + o] + hz[x * n2 + o];
+            if (vemb) hm += vemb[x * n2 + o];
+            ham[x][k] = in ? hm : 0.0;
+            dv[x][k] = in ? dm[x * n2 + o] : 0.0;
+            dold[x][k] = in ? dm_old[x * n2 + o] : 0.0;
         }
-        out[x] = e;
-        out[2 + x] = d2;
-    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < R; ++k) dsum[k] = tsum[k] = 0.0;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int r = threadIdx.y + 8 * k;
+            const double t = dt[x][threadIdx.x][r];
+            out[x] = fma(ham[x][k], t, out[x]);
+            const double dd = dv[x][k] - dold[x][k];
+            out[2 + x] = fma(dd, dd, out[2 + x]);
+            dsum[k] += dv[x][k];
+            tsum[k] += t;
+        }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const double v = nbx_wave_sum(out[k]);
-        if ((tid & 63) == 0) red[tid >> 6][k] = v;
+        const double v = nbx_wave_sum_dpp(out[k]);
+        if ((tid & 63) == 0) red[k][tid >> 6] = v;
     }
     __syncthreads();
     if (tid < 4) {
         double t = 0.0;
-        for (int w = 0; w < (int)(blockDim.x * blockDim.y) / 64; ++w) t += red[w][tid];
+        for (int w = 0; w < nwave; ++w) t += red[tid][w];
         partial[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + tid] = t;
     }
     if (dts != nullptr && i0 >= j0) {
         const S4Geom g = s4_geom(N, s4_nb_);
 #pragma unroll
-        for (int k = 0; k < T / 8; ++k) {
+        for (int k = 0; k < R; ++k) {
             const int gi = i0 + threadIdx.y + 8 * k, gj = j0 + threadIdx.x;
             if (gi < N && gj <= gi) dts[s4_dts_index(g, s4_lpt_, gi, gj)] = gi == gj ? dsum[k] : dsum[k] + tsum[k];
         }
@@ -266,21 +275,30 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
     __syncthreads();
     if (!last) return;
     __threadfence();
-    const int nthr = blockDim.x * blockDim.y;
     if (tid < tail_n) out_final[4 + tid] = (double)tail[tid];
+    double t4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = tid; b < nblocks; b += nthr)
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            t4[o] += __hip_atomic_load(partial + (int64_t)b * 4 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // (red is reused)
+#pragma unroll
     for (int o = 0; o < 4; ++o) {
-        double t = 0.0;
-        for (int b = tid; b < nblocks; b += nthr)
-            t += __hip_atomic_load(partial + (int64_t)b * 4 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t = nbx_wave_sum(t);  // (the workgroup is 2-D: nbx_block_sum's indexing does not apply)
-        if ((tid & 63) == 0) red2[tid >> 6] = t;
-        __syncthreads();
-        if (tid == 0) {
-            double tot = 0.0;
-            for (int w = 0; w < nthr / 64; ++w) tot += red2[w];
-            out_final[o] = (o >= 2) ? sqrt(tot) : tot;
-        }
-        __syncthreads();
+        const double v = nbx_wave_sum_dpp(t4[o]);
+        if ((tid & 63) == 0) red[o][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        double tot = 0.0;
+        for (int w = 0; w < nwave; ++w) tot += red[tid][w];
+        out_final[tid] = (tid >= 2) ? sqrt(tot) : tot;
+    }
+    __syncthreads();
+    // the word behind the results says they are all there: a host that polls it (pinned memory) needs no event
+    // on the stream -- an event record between two cycles holds the next cycle's first kernel back by ~10 us
+    if (tid == 0) {
+        __threadfence_system();
+        __hip_atomic_store(out_final + 4 + tail_n, 1.0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -321,12 +339,23 @@ __global__ void dots_kernel(int64_t n, int nvec, const double* __restrict__ x, c
 constexpr int DIIS_MAX_SPACE = 16;
 constexpr int DIIS_M = DIIS_MAX_SPACE + 1;
 constexpr int DIIS_SLOTS = ((DIIS_M + 1) * (DIIS_M + 1) + 63) / 64;  // matrix elements per lane
+// Behind the coefficients in d_coef: the 8 x 8 eigenvector basis the Pulay solve of the previous update ended
+// with and a word that says it is one (zero-initialised by the caller = none yet), twice: the copy being read
+// and the copy being written.
+constexpr int DIIS_STATE_HALF = 68;
+constexpr int DIIS_STATE_DOUBLES = 2 * DIIS_STATE_HALF;
+constexpr long long DIIS_STATE_MAGIC = 0x4e42585f44494953ll;
 
 // xs[slot] = x, es[slot] = e = (err given ? err : x - xprev), partial[blk*nd + k] = sum_i e[i] * es[k][i]
-__global__ void diis_push_kernel(int64_t n, int nd, int slot, const double* __restrict__ x,
-                                 const double* __restrict__ xprev, const double* __restrict__ err,
-                                 double* __restrict__ xs, double* __restrict__ es, double* __restrict__ partial) {
-    __shared__ double red[17];
+__global__ __launch_bounds__(256) void diis_push_kernel(int64_t n, int nd, int slot, const double* __restrict__ x,
+                                                        const double* __restrict__ xprev,
+                                                        const double* __restrict__ err, double* __restrict__ xs,
+                                                        double* __restrict__ es, double* __restrict__ partial,
+                                                        double* __restrict__ state) {
+    __shared__ double red[4][DIIS_MAX_SPACE];
+    // the solver's basis of the previous update becomes the one this update starts from (see
+    // diis_solve8_lincomb_kernel: its workgroups read one copy while workgroup 0 writes the other)
+    if (blockIdx.x == 0 && threadIdx.x < DIIS_STATE_HALF) state[threadIdx.x] = state[DIIS_STATE_HALF + threadIdx.x];
     double acc[DIIS_MAX_SPACE];
 #pragma unroll
     for (int k = 0; k < DIIS_MAX_SPACE; ++k) acc[k] = 0.0;
@@ -339,14 +368,19 @@ __global__ void diis_push_kernel(int64_t n, int nd, int slot, const double* __re
         for (int k = 0; k < DIIS_MAX_SPACE; ++k)
             if (k < nd) acc[k] = fma(e, (k == slot) ? e : es[(int64_t)k * n + i], acc[k]);
     }
+    // every sum of the block in one pass: the wavefronts' sums by lane moves (no LDS round trips), one barrier,
+    // then thread k adds the four of sum k in wave order
 #pragma unroll
     for (int k = 0; k < DIIS_MAX_SPACE; ++k) {
         if (k < nd) {  // uniform
-            const double t = nbx_block_sum(acc[k], red);
-            if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * nd + k] = t;
-            __syncthreads();
+            const double t = nbx_wave_sum_dpp(acc[k]);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = t;
         }
     }
+    __syncthreads();
+    if ((int)threadIdx.x < nd)
+        partial[(int64_t)blockIdx.x * nd + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 // Parallel-order Jacobi on a matrix of order <= 8 held ONE ELEMENT PER LANE (lane = 8 r + c: a =
@@ -675,6 +709,261 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(const double* __restrict
     if (lane >= 1 && lane < m) coef[lane - 1] = c_out[lane];
 }
 
+// ---- the Pulay solve for a space of at most 7 vectors (pyscf.lib.diis keeps 6), as one wavefront's work ----
+// Same rule as diis_solve_kernel above; what differs is how long the wavefront takes (30 us there, the longest
+// stage of a settled SCF cycle outside J/K):
+//   * the partial sums of the new Pulay row arrive in ONE trip to L2 (lane 8 g + c adds the blocks g, g + 8, ...
+//     of column c - 1; the eight lanes of a column meet in LDS) where the general kernel waited for sixteen
+//     loads one after the other;
+//   * the Jacobi steps exchange matrix elements through one LDS write and one batch of reads, and every lane
+//     works out BOTH rotations its element takes part in (its column's pair and its row's pair) instead of
+//     asking another lane for the second: one exchange per step, not two;
+//   * the rotation itself: tan of the angle from single-precision sqrt / rcp (one instruction each), two Newton
+//     steps on b t^2 + 2 d t - b = 0 in double, cos from a single-precision rsq with two Newton steps; the double
+//     precision sqrt, divide and rsqrt sequences it replaces are ~55 dependent instructions, this is ~30;
+//   * the sweep's convergence sums by lane moves (nbx_wave_sum_dpp).
+// Results agree with the general kernel to rounding (the same rotations to ~1e-16, sums in another order).
+__device__ __forceinline__ void diis_rotation(double app, double aqq, double apq, double& cs, double& sn) {
+    const double d = aqq - app, b = 2.0 * apq;
+    const double inv = __builtin_amdgcn_rcp(fmax(fabs(d), fabs(b)));  // t is scale invariant: approximate is fine
+    const double ds = d * inv, bs = b * inv;
+    // the root of smaller magnitude, t = b / (d + sgn(d) sqrt(d^2 + b^2)), first in single precision ...
+    const float dsf = (float)ds, bsf = (float)bs;
+    const float rt = __builtin_amdgcn_sqrtf(fmaf(dsf, dsf, bsf * bsf));
+    const float den = dsf + (ds >= 0.0 ? rt : -rt);  // |den| >= 1
+    double t = (double)(bsf * __builtin_amdgcn_rcpf(den));
+    // ... then Newton on g(t) = b t^2 + 2 d t - b, g'(t) / 2 = b t + d (|g'| / 2 = sqrt(d^2 + b^2) >= 1 at the
+    // root): relative error 3e-7 -> 1e-13 -> rounding.  The second step reuses the first step's 1 / g'.
+    const float rgp = __builtin_amdgcn_rcpf((float)fma(bs, t, ds));
+    double g = fma(fma(bs, t, 2.0 * ds), t, -bs);
+    t = fma(-0.5 * g, (double)rgp, t);
+    g = fma(fma(bs, t, 2.0 * ds), t, -bs);
+    t = fma(-0.5 * g, (double)rgp, t);
+    // c = (1 + t^2)^(-1/2), 1 <= 1 + t^2 <= 2
+    const double x = fma(t, t, 1.0), h = 0.5 * x;
+    double y = (double)__builtin_amdgcn_rsqf((float)x);
+    y = y * fma(-(h * y), y, 1.5);
+    y = y * fma(-(h * y), y, 1.5);
+    const bool rot = fabs(apq) > 1e-290;  // (also discards the NaNs of d = b = 0)
+    cs = rot ? y : 1.0;
+    sn = rot ? t * y : 0.0;
+}
+
+// lane = 8 r + c holds a = A[r][c], v = V[r][c]; on return the eigenvalues are the diagonal, V the vectors
+__device__ __forceinline__ void diis_jacobi8(double& a, double& v, int m, double fro, int lane, double* As,
+                                             double* Vs) {
+    const int r = lane >> 3, c = lane & 7;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        const double off = nbx_wave_sum_dpp((r < c) ? a * a : 0.0);
+        if (off <= 1e-31 * fro) break;
+        const double mind = nbx_wave_min_dpp((r == c && r < m) ? fabs(a) : 1.0e300);
+        if (mind - sqrt(2.0 * off) > 1.0e-14) break;  // Weyl: see diis_solve_kernel
+#pragma unroll
+        for (int step = 0; step < 7; ++step) {
+            // player 7 is fixed and meets `step`; k = step +- l (mod 7) meet each other
+            auto mate = [&](int k) {
+                int x = 2 * step - k;
+                x += x < 0 ? 7 : 0;
+                x -= x >= 7 ? 7 : 0;
+                return k == 7 ? step : (k == step ? 7 : x);
+            };
+            const int mc = mate(c), mr = mate(r);
+            As[lane] = a;
+            Vs[lane] = v;
+            __syncthreads();  // (one wavefront per workgroup: a wait on the LDS counter, no s_barrier)
+            const double a_cc = As[9 * c], a_mm = As[9 * mc], a_cm = As[8 * min(c, mc) + max(c, mc)];
+            const double a_rr = As[9 * r], a_nn = As[9 * mr], a_rn = As[8 * min(r, mr) + max(r, mr)];
+            const double a_rmc = As[8 * r + mc], a_mrc = As[8 * mr + c], a_mrmc = As[8 * mr + mc];
+            const double v_rmc = Vs[8 * r + mc];
+            __syncthreads();
+            double cc, sc, cr, sr;
+            diis_rotation(c < mc ? a_cc : a_mm, c < mc ? a_mm : a_cc, a_cm, cc, sc);
+            diis_rotation(r < mr ? a_rr : a_nn, r < mr ? a_nn : a_rr, a_rn, cr, sr);
+            // column k of A J is kc * col_k + ks * col_mate(k), ks = -sin for the smaller index of the pair
+            const double ks_c = (c < mc) ? -sc : sc, ks_r = (r < mr) ? -sr : sr;
+            const double x = cc * a + ks_c * a_rmc;       // (A J)[r][c]
+            const double y = cc * a_mrc + ks_c * a_mrmc;  // (A J)[mate(r)][c]
+            a = (ks_r != 0.0 && mr == c) ? 0.0 : cr * x + ks_r * y;  // the rotated pair is exactly 0
+            v = cc * v + ks_c * v_rmc;
+        }
+    }
+}
+
+// One wavefront per workgroup; EVERY workgroup solves the same system with the same instructions (the answer is
+// the same bits everywhere) and then extrapolates its share of the vector: the solve costs no launch of its own.
+// Workgroup 0 also stores the new row / column of H and the coefficients.  nd <= 7.
+constexpr int DIIS8_PER_LANE = 4;  // vector elements per lane
+__global__ __launch_bounds__(64) void diis_solve8_lincomb_kernel(const double* __restrict__ partial, int nblocks,
+                                                                 int nd, int slot, double* __restrict__ H, int ldh,
+                                                                 double* __restrict__ coef,
+                                                                 double* __restrict__ state, int64_t n,
+                                                                 const double* __restrict__ vecs, int64_t stride,
+                                                                 double* __restrict__ out) {
+    __shared__ double As[64], Vs[64], Ts[64];
+    __shared__ double A0[8][9], rhs_s[8], c_out[8];
+    __shared__ int lu_failed;
+    const int lane = threadIdx.x, r = lane >> 3, c = lane & 7;
+    const int m = nd + 1;
+    // the vector elements this lane extrapolates: requested now, used after the solve
+    const int64_t i0 = (int64_t)blockIdx.x * (64 * DIIS8_PER_LANE) + lane;
+    const bool inside = r < m && c < m;
+    const bool new_row = inside && r == slot + 1 && c >= 1, new_col = inside && c == slot + 1 && r >= 1;
+    const double hold = (inside && !new_row && !new_col) ? H[(int64_t)r * ldh + c] : 0.0;
+    double xv[DIIS8_PER_LANE][7];  // (in flight during the solve; 1e300 would show a use of an unloaded one)
+#pragma unroll
+    for (int j = 0; j < DIIS8_PER_LANE; ++j)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) xv[j][k] = (k < nd && i0 + 64 * j < n) ? vecs[k * stride + i0 + 64 * j] : 0.0;
+    const double v_prev = state[lane];
+    // (a basis of a LARGER system would mix the zero padding into the live indices: cold start then)
+    const bool warm = __double_as_longlong(state[64]) == DIIS_STATE_MAGIC && state[65] <= (double)(nd + 1);  // uniform
+    double acc = 0.0;
+    if (c >= 1 && c <= nd) {
+#pragma unroll 4
+        for (int b = r; b < nblocks; b += 8) acc += partial[(int64_t)b * nd + c - 1];
+    }
+    As[lane] = acc;
+    __syncthreads();
+    double row_c = 0.0, row_r = 0.0;  // <e_new, e_(c-1)> and <e_new, e_(r-1)>
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        row_c += As[8 * g + c];
+        row_r += As[8 * g + r];
+    }
+    __syncthreads();
+    double a = new_row ? row_c : (new_col ? row_r : hold);
+    if (blockIdx.x == 0 && (new_row || new_col)) H[(int64_t)r * ldh + c] = a;
+    A0[r][c] = a;
+    if (lane == 0) lu_failed = 0;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (warm) {
+        // Start from the basis the previous update's solve ended in: one row / column of H has changed since,
+        // so V^T H V is close to diagonal -- 0-3 sweeps where a cold start takes 4-7 (none at all once the error
+        // vectors have shrunk to rounding level, the settled cycles of a long run).  Any orthogonal V is a valid
+        // start; the rounding drift of many updates is removed first by one Newton-Schulz step,
+        // V <- V (3 I - V^T V) / 2 (departure from orthogonality e -> e^2).
+        Vs[lane] = v_prev;
+        __syncthreads();
+        double gram = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gram = fma(Vs[8 * k + r], Vs[8 * k + c], gram);
+        Ts[lane] = gram;
+        __syncthreads();
+        double vg = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vg = fma(Vs[8 * r + k], Ts[8 * k + c], vg);
+        v = 1.5 * v_prev - 0.5 * vg;
+        __syncthreads();
+        Vs[lane] = v;
+        As[lane] = a;
+        __syncthreads();
+        double hv = 0.0;  // (H V)[r][c]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hv = fma(As[8 * r + k], Vs[8 * k + c], hv);
+        Ts[lane] = hv;
+        __syncthreads();
+        double vhv = 0.0;  // (V^T H V)[r][c]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vhv = fma(Vs[8 * k + r], Ts[8 * k + c], vhv);
+        __syncthreads();
+        Ts[lane] = vhv;
+        __syncthreads();
+        a = 0.5 * (vhv + Ts[8 * c + r]);
+        __syncthreads();
+    }
+    const double fro = nbx_wave_sum_dpp(a * a);
+    diis_jacobi8(a, v, m, fro, lane, As, Vs);
+    As[lane] = a;
+    Vs[lane] = v;
+    if (blockIdx.x == 0) {
+        state[DIIS_STATE_HALF + lane] = v;
+        if (lane == 0) state[DIIS_STATE_HALF + 64] = __longlong_as_double(DIIS_STATE_MAGIC);
+        if (lane == 1) state[DIIS_STATE_HALF + 65] = (double)m;
+    }
+    __syncthreads();
+    const bool singular = __any(r == c && r < m && fabs(a) < 1e-14);
+    if (!singular) {
+        // Gaussian elimination with partial pivoting on A0, rhs e_0 (numpy.linalg.solve / dgesv): pivot search by
+        // a lane reduction, the row swap and the rank-one update spread over the lanes (each element sees the
+        // operations of the serial right-looking elimination), back substitution with lane-parallel dot products
+        if (lane < m) rhs_s[lane] = (lane == 0) ? 1.0 : 0.0;
+        __syncthreads();
+        for (int k = 0; k < m; ++k) {
+            double best = (lane >= k && lane < m) ? fabs(A0[lane][k]) : -1.0;  // first row with the largest |A0[i][k]|
+            int piv = lane;
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) {  // rows live in lanes 0..7
+                const double ob = __shfl_xor(best, o);
+                const int op = __shfl_xor(piv, o);
+                if (ob > best || (ob == best && op < piv)) {
+                    best = ob;
+                    piv = op;
+                }
+            }
+            best = nbx_readlane_f64(best, 0);
+            piv = __builtin_amdgcn_readlane(piv, 0);
+            if (best == 0.0) {
+                if (lane == 0) lu_failed = 1;
+                break;
+            }
+            if (piv != k) {
+                if (lane < m) {
+                    const double tmp = A0[k][lane];
+                    A0[k][lane] = A0[piv][lane];
+                    A0[piv][lane] = tmp;
+                }
+                if (lane == 0) {
+                    const double tmp = rhs_s[k];
+                    rhs_s[k] = rhs_s[piv];
+                    rhs_s[piv] = tmp;
+                }
+            }
+            __syncthreads();
+            const double inv = 1.0 / A0[k][k];
+            const bool below = r > k && r < m, right = c > k && c < m;
+            double upd = 0.0, rupd = 0.0;
+            if (below && right) upd = A0[r][c] - (A0[r][k] * inv) * A0[k][c];
+            if (below && c == 0) rupd = rhs_s[r] - (A0[r][k] * inv) * rhs_s[k];
+            __syncthreads();
+            if (below && right) A0[r][c] = upd;
+            if (below && c == 0) rhs_s[r] = rupd;
+            __syncthreads();
+        }
+        __syncthreads();
+        if (!lu_failed) {
+            for (int i = m - 1; i >= 0; --i) {
+                const double t = nbx_wave_sum_dpp((lane > i && lane < m) ? A0[i][lane] * c_out[lane] : 0.0);
+                if (lane == 0) c_out[i] = (rhs_s[i] - t) / A0[i][i];
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+    if (singular || lu_failed) {
+        // c = V_keep diag(1 / w_keep) V_keep^T e_0: lane (r, k) holds term k of c[r], the eight meet by lane moves
+        const double w = As[9 * c], v0 = Vs[c];
+        const bool keep = c < m && (!singular || fabs(w) > 1e-14);
+        const double t = nbx_sum8_dpp(keep ? v * (1.0 / w) * v0 : 0.0);
+        if (c == 0 && r < m) c_out[r] = t;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && lane >= 1 && lane < m) coef[lane - 1] = c_out[lane];
+    double cf[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) cf[k] = (k < nd) ? c_out[k + 1] : 0.0;
+#pragma unroll
+    for (int j = 0; j < DIIS8_PER_LANE; ++j) {
+        const int64_t i = i0 + 64 * j;
+        if (i < n) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                if (k < nd) t = fma(cf[k], xv[j][k], t);
+            out[i] = t;
+        }
+    }
+}
+
 // out[i] = sum_k coef[k] * vecs[k][i] with the coefficients read from device memory
 __global__ void lincomb_dev_kernel(int64_t n, int nvec, const double* __restrict__ coef,
                                    const double* __restrict__ vecs, int64_t stride, double* __restrict__ out) {
@@ -903,6 +1192,8 @@ int nbx_huz_cycle_scalars_dts(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
     return NBX_OK;
 }
 
+size_t nbx_diis_coef_doubles(int64_t space) { return space > 0 ? (size_t)(space + DIIS_STATE_DOUBLES) : 0; }
+
 int nbx_diis_update(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_t nd, const double* d_x,
                     double* d_xprev, double* d_xs, double* d_es, double* d_h, double* d_coef) {
     return nbx_diis_update_err(ctx, n, space, slot, nd, d_x, nullptr, d_xprev, d_xs, d_es, d_h, d_coef);
@@ -917,8 +1208,15 @@ int nbx_diis_update_err(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, in
     const unsigned blocks = grid1d(n, 256, 128);
     NBX_CHECK_ARG((int64_t)blocks * nd <= NBX_SCRATCH_DOUBLES - 64);
     hipLaunchKernelGGL(diis_push_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, (int)nd, (int)slot, d_x,
-                       d_xprev, d_err, d_xs, d_es, ctx->d_scratch);
+                       d_xprev, d_err, d_xs, d_es, ctx->d_scratch, d_coef + space);
     NBX_LAUNCH_CHECK();
+    if (nd <= 7 && nbx_cdiv(n, 64 * DIIS8_PER_LANE) <= 65535) {  // the usual case: solve and extrapolation in one launch
+        hipLaunchKernelGGL(diis_solve8_lincomb_kernel, dim3((unsigned)nbx_cdiv(n, 64 * DIIS8_PER_LANE)), dim3(64), 0,
+                           ctx->stream, ctx->d_scratch, (int)blocks, (int)nd, (int)slot, d_h, (int)(space + 1), d_coef,
+                           d_coef + space, n, d_xs, n, d_xprev);
+        NBX_LAUNCH_CHECK();
+        return NBX_OK;
+    }
     hipLaunchKernelGGL(diis_solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scratch, (int)blocks, (int)nd,
                        (int)slot, d_h, (int)(space + 1), d_coef);
     NBX_LAUNCH_CHECK();

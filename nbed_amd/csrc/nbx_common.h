@@ -146,6 +146,48 @@ __device__ __forceinline__ double nbx_wave_sum(double v) {
     return v;
 }
 
+// The same sums without the LDS crossbar: a ds_bpermute round trip is ~100 cycles and the butterfly above makes
+// six of them in a row, which is most of what a one-wavefront kernel on the SCF's critical path spends.  DPP
+// moves take the neighbour's value inside the VALU (quad permutes, then the mirrored half rows of 8 and 16 lanes:
+// a sum does not care which lane a term came from), and the four 16-lane rows meet through v_readlane.
+// EVERY lane of the wavefront must be active.  The order of the additions differs from nbx_wave_sum's, so the
+// two agree to rounding, not bit for bit; every lane returns the same bits.
+template <int CTRL>
+__device__ __forceinline__ double nbx_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int NBX_DPP_XOR1 = 0xB1, NBX_DPP_XOR2 = 0x4E, NBX_DPP_HALF_MIRROR = 0x141, NBX_DPP_MIRROR = 0x140;
+
+__device__ __forceinline__ double nbx_readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// sum over the aligned group of 8 lanes this lane belongs to (valid in all 8)
+__device__ __forceinline__ double nbx_sum8_dpp(double v) {
+    v += nbx_dpp_f64<NBX_DPP_XOR1>(v);
+    v += nbx_dpp_f64<NBX_DPP_XOR2>(v);
+    v += nbx_dpp_f64<NBX_DPP_HALF_MIRROR>(v);
+    return v;
+}
+
+__device__ __forceinline__ double nbx_wave_sum_dpp(double v) {
+    v = nbx_sum8_dpp(v);
+    v += nbx_dpp_f64<NBX_DPP_MIRROR>(v);
+    return (nbx_readlane_f64(v, 0) + nbx_readlane_f64(v, 16)) + (nbx_readlane_f64(v, 32) + nbx_readlane_f64(v, 48));
+}
+
+__device__ __forceinline__ double nbx_wave_min_dpp(double v) {
+    v = fmin(v, nbx_dpp_f64<NBX_DPP_XOR1>(v));
+    v = fmin(v, nbx_dpp_f64<NBX_DPP_XOR2>(v));
+    v = fmin(v, nbx_dpp_f64<NBX_DPP_HALF_MIRROR>(v));
+    v = fmin(v, nbx_dpp_f64<NBX_DPP_MIRROR>(v));
+    return fmin(fmin(nbx_readlane_f64(v, 0), nbx_readlane_f64(v, 16)),
+                fmin(nbx_readlane_f64(v, 32), nbx_readlane_f64(v, 48)));
+}
+
 // Sum over a workgroup of up to 1024 threads; result valid in every thread.
 // `smem` needs 17 doubles.
 __device__ __forceinline__ double nbx_block_sum(double v, double* smem) {

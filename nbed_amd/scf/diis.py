@@ -57,7 +57,7 @@ class DIIS:
             self._es = be.empty((self.space, n))
         if hasattr(be, "diis_update") and self.min_space <= 1 and self._Hd is None:
             self._Hd = be.asarray(self._H)
-            self._coef = be.zeros(self.space)
+            self._coef = be.diis_coef_buffer(self.space)
 
     def update(self, x):
         be = self.be
@@ -74,7 +74,7 @@ class DIIS:
         if hasattr(be, "diis_update") and self.min_space <= 1:
             if self._Hd is None:
                 self._Hd = be.asarray(self._H)
-                self._coef = be.zeros(self.space)
+                self._coef = be.diis_coef_buffer(self.space)
             self._head += 1
             self._nd = min(self._nd + 1, self.space)
             be.diis_update(self.space, slot, self._nd, flat, self._xprev, self._xs, self._es, self._Hd, self._coef)
@@ -122,7 +122,7 @@ class CDIIS:
                 h[0, 1:] = h[1:, 0] = 1
                 self._dev = {
                     "xs": be.empty((self.space, flat.numel())), "es": be.empty((self.space, flat.numel())),
-                    "h": be.asarray(h), "coef": be.zeros(self.space), "out": be.empty(flat.numel()),
+                    "h": be.asarray(h), "coef": be.diis_coef_buffer(self.space), "out": be.empty(flat.numel()),
                 }
             slot = self._head % self.space
             self._head += 1

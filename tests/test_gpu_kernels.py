@@ -182,7 +182,7 @@ def test_vector_algebra(be):
     np.testing.assert_allclose(be.to_host(y), 2.0 * vecs[0] - 0.5 * x, rtol=0, atol=1e-15)
 
 
-@pytest.mark.parametrize("case", ["generic", "converging", "wraparound"])
+@pytest.mark.parametrize("case", ["generic", "converging", "wraparound", "settled"])
 def test_diis_device_matches_pyscf_semantics(be, case):
     """nbx_diis_update against the oracle's pyscf.lib.diis.DIIS restatement, update by update:
     first call only stores x; slots wrap after `space`; near convergence the Pulay matrix has
@@ -193,10 +193,13 @@ def test_diis_device_matches_pyscf_semantics(be, case):
     n = 2 * 37 * 37
     dev, ref = DeviceDIIS(be), OracleDIIS()
     fixed = rnd(80, n)
-    nsteps = {"generic": 5, "converging": 9, "wraparound": 11}[case]
+    nsteps = {"generic": 5, "converging": 9, "wraparound": 11, "settled": 30}[case]
     for it in range(nsteps):
         if case == "converging":  # geometric approach to a fixed point: errors ~ 1e-1 ... 1e-9
             x = fixed + rnd(81 + it, n) * 10.0 ** (-1 - it)
+        elif case == "settled":  # a long run: errors halve down to rounding noise and stay there (the Pulay
+            # solve starts every update from the basis the one before ended in: nbx_diis_coef_doubles)
+            x = fixed + rnd(81 + it, n) * max(1e-3 * 0.5 ** it, 1e-13)
         else:
             x = fixed + rnd(81 + it, n) * 0.1
         got = be.to_host(dev.update(be.asarray(x)))
