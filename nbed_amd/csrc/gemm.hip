@@ -16,6 +16,9 @@
 #include "nbx_common.h"
 #include "synth_device.h"
 
+// (m0 is named as a clobber of the LDS-DMA asm in gemm_m4_tn_kernel; clang calls that a reserved register)
+#pragma clang diagnostic ignored "-Winline-asm"
+
 namespace {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -228,8 +231,12 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
             if constexpr (B_GEN) sb.generate(gen_rs, gen.seed, gen.scale, n0, (kt + 1) * BK, N, K);
             else sb.load(B, ldb, n0, (kt + 1) * BK, N, K, vec_b);
         }
+        // (the last k-tile of K = 148 holds 4 of its 16 columns: MFMA steps that would multiply the zero padding
+        // are skipped -- 7.5 % of the matrix-pipe work of every N = 148 product)
+        const int ksteps = more ? BK / 4 : (K - kt * BK + 3) / 4;
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
+            if (kk >= ksteps) break;  // uniform
             double af[MT], bf[NT];
             const int krow = kk * 4 + fk;
 #pragma unroll
@@ -265,6 +272,208 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
                     const double v = alpha * acc[i][j][r];
                     *c = (beta == 0.0) ? v : fma(beta, *c, v);
                     if (C2 != nullptr) C2[(int64_t)row * ldc + col] = v;  // pair scatter (beta = 0)
+                }
+            }
+        }
+    }
+}
+
+// ---- C = alpha A^T B + beta C for operands that are both contiguous along the non-contracted index (A: K x M,
+// B: K x N row-major: quarters 1, 2 and 4 of the transform), on the instruction that reaches the fp64 matrix peak of
+// gfx950 and with the k-tiles brought into LDS by the load unit itself.
+//   * v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks per instruction) issues once per 16.5 cycles per SIMD:
+//     75 TFLOP/s on the chip with registers only, where v_mfma_f64_16x16x4_f64 issues once per 104-143 cycles (38-48
+//     TFLOP/s; profiles/r03/fp64_rate_probe.txt).  The four blocks are four groups of four ROWS against the same four
+//     columns: the A operand is the 16-row fragment the big instruction takes (lane l: row l & 15, k = l >> 4), the B
+//     operand is B[k][col] replicated over the row groups (the broadcast controls CBSZ / ABID are ignored by this
+//     instruction: profiles/r03/mfma_f64_4x4x4_cbsz_probe.hip), and a lane reads the four adjacent columns
+//     4 (l & 3) .. + 3 of a 16-column fragment with one 32-byte LDS read: MFMA t of a fragment multiplies column
+//     4 (l & 3) + t, so the lane ends up with C[row 4 b + (l >> 4)][4 (l & 3) .. + 3] -- 32 contiguous bytes to store.
+//     2 x 2 waves of 64 x 64 outputs (128 accumulator registers), two workgroups per CU.
+//   * global_load_lds_dwordx4: lane l of a wave lands its 16 bytes at the instruction's LDS base + 16 l -- one
+//     instruction is one 128-double row of a tile, no staging registers, no ds_write, and the loads of three tiles
+//     are in flight while a fourth feeds the matrix pipe (a ring of four 8-row tiles per operand, 72 KB).  The
+//     register-staged kernel above holds ONE tile in flight and waits for it every 16 rows.
+//   * every load instruction is always issued (rows past K re-read row K - 1, lanes past the edge re-read column 0
+//     of their row: what they bring is never multiplied into a stored element), so a wave's tile is exactly four
+//     instructions and `s_waitcnt vmcnt(8)` means "my part of the tile two behind the newest has landed".
+//   * the fragments of a 4-row step are read from LDS while the step before it runs (two register sets), across
+//     tiles too: the barrier that publishes tile kt + 1 sits between the two steps of tile kt.
+// Needs K % 4 == 0 (MFMA steps past K are skipped, not zero-filled), M and N even, 16-byte aligned rows.
+// B_GEN: the B operand is not loaded but generated (GemmGen: the streamed quarter-1 of the synthetic tensor): every
+// thread makes its four values of tile kt + 3 and stores them into the ring while tile kt is on the matrix pipe.
+// Where the time goes (tools/build_gemm_variant.sh builds with NBX_TN_DBG, tools/time_gemm_q1.py; M = 128):
+//   K = 2000:  50.7 TFLOP/s as is (the 16 x 16 x 4 kernel: 50.4 on the same box, 46.9 with the small instruction and
+//              register staging); 53.5 without the loads in the loop; 55.2 without the barrier too; 62.8 without the
+//              LDS reads (12 instructions per 64 MFMAs: the B fragments are read four times over).
+//   K = 148:   43.7 as is (16 x 16 x 4 kernel: 40.4); 50.0 when nothing is stored; 55.8 when, in addition, the rows
+//              come from cache -- the product moves (K + M) / (2 K M) = 1 byte per 17 flops, 2.5 TB/s of reads AND
+//              writes at that rate: both rooflines at once.
+#ifndef NBX_TN_DBG
+#define NBX_TN_DBG 0  // measurement builds, bits: 1 no loads in the loop, 2 no barrier, 4 no LDS reads in the loop,
+#endif                // 8 nothing stored, 16 the same rows loaded again and again
+constexpr int DK = 8, DNB = 4, DLD = 128 + 16;
+typedef __attribute__((address_space(3))) void* gemm_lds_vp;
+
+template <bool B_GEN>
+__global__ __launch_bounds__(256, 2) void gemm_m4_tn_kernel(int M, int N, int K, double alpha, const double* __restrict__ A,
+                                                            int64_t lda, int64_t stride_a, const double* __restrict__ B,
+                                                            int64_t ldb, int64_t stride_b, double beta,
+                                                            double* __restrict__ C, int64_t ldc, int64_t stride_c,
+                                                            int pair_n, const int* __restrict__ gate, int gate_a,
+                                                            int gate_b, GemmGen gen = GemmGen{}) {
+    __shared__ __attribute__((aligned(32))) double smem[DNB * 2 * DK * DLD];
+    const int batch = blockIdx.z;
+    if (gate != nullptr) {
+        const int g = gate[batch];
+        if (g != gate_a && g != gate_b) return;
+    }
+    A += (int64_t)batch * stride_a;
+    if (!B_GEN) B += (int64_t)batch * stride_b;
+    C += (int64_t)batch * stride_c;
+    const uint64_t gen_rs = B_GEN ? nbx_tri((uint64_t)gen.r, (uint64_t)(gen.s0 + batch)) : 0;
+    double* C2 = nullptr;
+    if (pair_n > 0) {  // pair scatter: see GemmGen::pair_n
+        int pi = (int)((sqrt(8.0 * (double)batch + 1.0) - 1.0) * 0.5);
+        while (pi * (pi + 1) / 2 > batch) --pi;
+        while ((pi + 1) * (pi + 2) / 2 <= batch) ++pi;
+        const int pj = batch - pi * (pi + 1) / 2;
+        C += ((int64_t)pi * pair_n + pj - batch) * stride_c;
+        if (pi != pj) C2 = C + ((int64_t)pj * pair_n + pi - ((int64_t)pi * pair_n + pj)) * stride_c;
+    }
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fk = lane >> 4;
+
+    // this lane's 16 bytes of a row: doubles 2 lane, 2 lane + 1 of the tile (column 0 of the row past the edge)
+    const unsigned a_off = (m0 + 2 * lane < M) ? 16u * (unsigned)lane : 0u;
+    const unsigned b_off = (n0 + 2 * lane < N) ? 16u * (unsigned)lane : 0u;
+    const int nkt = (K + DK - 1) / DK;
+    auto issue = [&](int kt) {  // rows 2 wave, 2 wave + 1 of both operands' tile kt into ring slot kt % DNB
+        const int slot = kt & (DNB - 1);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int kl = 2 * wave + r;
+            int k = ((NBX_TN_DBG & 16) ? 0 : kt * DK) + kl;
+            k = k < K ? k : K - 1;
+            const double* asrc = A + (int64_t)k * lda + m0;
+            const unsigned a_lds = (unsigned)(size_t)(gemm_lds_vp)(smem + (slot * 2 + 0) * (DK * DLD) + kl * DLD);
+            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(a_off), "s"(asrc), "s"(a_lds) : "memory", "m0");
+            if constexpr (!B_GEN) {
+                const double* bsrc = B + (int64_t)k * ldb + n0;
+                const unsigned b_lds = (unsigned)(size_t)(gemm_lds_vp)(smem + (slot * 2 + 1) * (DK * DLD) + kl * DLD);
+                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(b_off), "s"(bsrc), "s"(b_lds) : "memory", "m0");
+            }
+        }
+        if constexpr (B_GEN) {
+            // element (k, x) = val(canon(k, x, r, s)) * scale, two adjacent x per item, two items per thread
+            double* bt = smem + (slot * 2 + 1) * (DK * DLD);
+#pragma unroll
+            for (int it = 0; it < (DK * 128 / 2) / 256; ++it) {
+                const int item = threadIdx.x + it * 256;
+                const int kl = item >> 6, x = (item & 63) * 2;
+                const int gk = kt * DK + kl, gx = n0 + x;
+                double2 v = make_double2(0.0, 0.0);
+                if (gk < K) {
+                    if (gx < N)
+                        v.x = nbx_synth_val(0, nbx_tri_u32(nbx_tri_pair_u32((uint32_t)gk, (uint32_t)gx), (uint32_t)gen_rs), gen.seed) * gen.scale;
+                    if (gx + 1 < N)
+                        v.y = nbx_synth_val(0, nbx_tri_u32(nbx_tri_pair_u32((uint32_t)gk, (uint32_t)(gx + 1)), (uint32_t)gen_rs), gen.seed) * gen.scale;
+                }
+                *reinterpret_cast<double2*>(&bt[kl * DLD + x]) = v;
+            }
+        }
+    };
+    // (a wave's tile is four load instructions, two when B is generated: the vmcnt immediates below)
+    auto wait_two_behind = [&]() {
+        if constexpr (B_GEN) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    auto read_frags = [&](int kt, int kk, double (&af)[4], v4f64 (&bq)[4]) {
+        const double* as = smem + ((kt & (DNB - 1)) * 2 + 0) * (DK * DLD);
+        const double* bs = smem + ((kt & (DNB - 1)) * 2 + 1) * (DK * DLD);
+        const int krow = kk * 4 + fk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = as[krow * DLD + wr * 64 + i * 16 + fr];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const v4f64*>(&bs[krow * DLD + wc * 64 + j * 16 + 4 * (lane & 3)]);
+    };
+    auto products = [&](const double (&af)[4], const v4f64 (&bq)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[i][j][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bq[j][t], acc[i][j][t], 0, 0, 0);
+    };
+    static_assert(DK == 8, "two steps per tile");
+    double af0[4], af1[4];
+    v4f64 bq0[4], bq1[4];
+    issue(0);
+    issue(1);
+    issue(2);
+    wait_two_behind();  // my loads of tile 0
+    __syncthreads();
+    issue(3);
+    read_frags(0, 0, af0, bq0);
+    if (NBX_TN_DBG & 4) read_frags(0, 1, af1, bq1);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool second = K - kt * DK > 4;  // (the last tile of K = 148 holds one step)
+        if (second && !(NBX_TN_DBG & 4)) read_frags(kt, 1, af1, bq1);
+        products(af0, bq0);
+        // tile kt + 1: my loads of it have landed (tiles kt + 2, kt + 3 may be in flight) ...
+        if (!(NBX_TN_DBG & 1)) wait_two_behind();
+        if (!(NBX_TN_DBG & 2)) __syncthreads();  // ... and everybody's; nobody reads tile kt - 1 any more: its slot takes tile kt + 4
+        if (!(NBX_TN_DBG & 1)) issue(kt + 4);
+        if (kt + 1 < nkt && !(NBX_TN_DBG & 4)) read_frags(kt + 1, 0, af0, bq0);
+        if (second) products(af1, bq1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the padding loads of the last iterations)
+
+    if ((NBX_TN_DBG & 8) && acc[0][0][0] != 12345.678) return;
+    // epilogue: the lane holds row 4 b + fk, columns 4 (lane & 3) .. + 3 of each 16 x 16 tile
+    const bool vec_c = ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(C2)) & 15) == 0 && ldc % 2 == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wr * 64 + i * 16 + 4 * ((lane >> 2) & 3) + fk;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wc * 64 + j * 16 + 4 * (lane & 3);
+            if (col >= N) continue;
+            double* c = C + (int64_t)row * ldc + col;
+            double v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = alpha * acc[i][j][t];
+            if (vec_c && col + 3 < N) {
+                if (beta != 0.0) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = fma(beta, c[t], v[t]);
+                }
+                *reinterpret_cast<double2*>(c) = make_double2(v[0], v[1]);
+                *reinterpret_cast<double2*>(c + 2) = make_double2(v[2], v[3]);
+                if (C2 != nullptr) {  // pair scatter (beta = 0)
+                    double* c2 = C2 + (int64_t)row * ldc + col;
+                    *reinterpret_cast<double2*>(c2) = make_double2(v[0], v[1]);
+                    *reinterpret_cast<double2*>(c2 + 2) = make_double2(v[2], v[3]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (col + t < N) {
+                        c[t] = (beta == 0.0) ? v[t] : fma(beta, c[t], v[t]);
+                        if (C2 != nullptr) C2[(int64_t)row * ldc + col + t] = v[t];
+                    }
                 }
             }
         }
@@ -409,6 +618,24 @@ void launch(nbx_ctx* ctx, bool a_kc, bool b_kc, int M, int N, int K, double alph
 #undef NBX_GEMM_GO
 }
 
+// gemm_m4_tn_kernel applies: 'T','N' operands with even extents, K a multiple of 4, 16-byte aligned rows
+// (NBX_GEMM_DMA=0: the register-staged 16 x 16 x 4 kernel instead, for comparison)
+inline bool tn_dma_ok(int64_t m, int64_t n, int64_t k, int vec_a, int vec_b) {
+    static const bool on = [] {
+        const char* e = getenv("NBX_GEMM_DMA");
+        return e == nullptr || e[0] != '0';
+    }();
+    return on && vec_a && vec_b && m > 64 && n > 64 && k % 4 == 0 && m % 2 == 0 && n % 2 == 0;
+}
+
+void launch_tn_dma(nbx_ctx* ctx, int M, int N, int K, double alpha, const double* A, int64_t lda, int64_t sa, const double* B,
+                   int64_t ldb, int64_t sb, double beta, double* C, int64_t ldc, int64_t sc, int batch, int pair_n,
+                   const int* gate, int gate_a, int gate_b) {
+    dim3 grid((unsigned)nbx_cdiv(N, 128), (unsigned)nbx_cdiv(M, 128), (unsigned)batch);
+    hipLaunchKernelGGL(gemm_m4_tn_kernel<false>, grid, dim3(256), 0, ctx->stream, M, N, K, alpha, A, lda, sa, B, ldb, sb, beta,
+                       C, ldc, sc, pair_n, gate, gate_a, gate_b, GemmGen{});
+}
+
 }  // namespace
 
 // Y[z] (m x n) = op(A) (m x k) . G_z (k x n),  G_z[p][q] = val(canon(p, q, r, s0 + z)) * scale,
@@ -422,7 +649,11 @@ int nbx_gemm_q1_synth(nbx_ctx* ctx, int64_t m, int64_t n, int64_t k, const doubl
     NBX_CHECK_ARG(m < (1ll << 31) && n < 92681 && k < 92681 && r + 1 < 92681 && s0 + batch < 92681);
     GemmGen gen{seed, scale, (int)r, (int)s0};
     const int vec_a = (aligned16(d_a) && lda % 2 == 0) ? 1 : 0;
-    if (m > 64 && n > 64) {
+    if (tn_dma_ok(m, n, k, vec_a, 1)) {  // A by LDS-DMA, the integrals made straight into the LDS ring
+        dim3 grid((unsigned)nbx_cdiv(n, 128), (unsigned)nbx_cdiv(m, 128), (unsigned)batch);
+        hipLaunchKernelGGL(gemm_m4_tn_kernel<true>, grid, dim3(256), 0, ctx->stream, (int)m, (int)n, (int)k, 1.0, d_a, lda,
+                           (int64_t)0, nullptr, (int64_t)0, (int64_t)0, 0.0, d_y, ldy, stride_y, 0, nullptr, 0, 0, gen);
+    } else if (m > 64 && n > 64) {
         dim3 grid((unsigned)nbx_cdiv(n, 128), (unsigned)nbx_cdiv(m, 128), (unsigned)batch);
         hipLaunchKernelGGL((gemm_f64_kernel<128, 128, 2, 4, false, false, true>), grid, dim3(512), 0, ctx->stream, (int)m,
                            (int)n, (int)k, 1.0, d_a, lda, (int64_t)0, nullptr, (int64_t)0, (int64_t)0, 0.0, d_y, ldy,
@@ -507,7 +738,10 @@ int nbx_gemm_pair_scatter(nbx_ctx* ctx, int64_t pair_n, int64_t m, int64_t n, in
     gen.pair_n = (int)pair_n;
     const int vec_a = (aligned16(d_a) && lda % 2 == 0) ? 1 : 0;
     const int vec_b = (aligned16(d_b) && ldb % 2 == 0 && stride_b % 2 == 0) ? 1 : 0;
-    if (m > 64 && n > 64)
+    if (tn_dma_ok(m, n, k, vec_a, vec_b))
+        launch_tn_dma(ctx, (int)m, (int)n, (int)k, 1.0, d_a, lda, 0, d_b, ldb, stride_b, 0.0, d_c, n, m * n, (int)npairs,
+                      (int)pair_n, nullptr, 0, 0);
+    else if (m > 64 && n > 64)
         launch<128, 128, 2, 4>(ctx, false, false, (int)m, (int)n, (int)k, 1.0, d_a, lda, 0, d_b, ldb, stride_b, 0.0, d_c, n,
                                m * n, (int)npairs, vec_a, vec_b, nullptr, 0, 0, gen);
     else
@@ -574,6 +808,9 @@ int nbx_gemm_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t 
                 else NBX_GEMM_SMALL(false, false);
             }
 #undef NBX_GEMM_SMALL
+        } else if (tiles128 >= 512 && !a_kc && !b_kc && tn_dma_ok(m, n, k, vec_a, vec_b)) {
+            launch_tn_dma(ctx, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c, nb,
+                          0, d_gate, gate_a, gate_b);
         } else if (tiles128 >= 512 && m > 64 && n > 64) {
             launch<128, 128, 2, 4>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
                              beta, C, ldc, stride_c, nb, vec_a, vec_b, d_gate, gate_a, gate_b);
