@@ -495,7 +495,7 @@ def main():
             stamps.append(time.perf_counter())
         if i == args.warmup:
             barrier()
-            be.profile(True, slots=[_nbx.PROF_JK_DENSE])  # HIP events around the J/K kernel only
+            be.profile(True, slots=[_nbx.PROF_JK_DENSE])  # HIP events around the J/K kernel only (they cost the cycle ~1 %)
             be.profile_reset()
             clock["t0"] = time.perf_counter()
             stamps.append(clock["t0"])

@@ -72,6 +72,7 @@ SIGNATURES = {
     "nbx_free": (c_int, [_P, _P]),
     "nbx_memcpy_h2d": (c_int, [_P, _P, _P, c_size_t]),
     "nbx_memcpy_d2h": (c_int, [_P, _P, _P, c_size_t]),
+    "nbx_gather_to_host": (c_int, [_P, c_int64, _P, _P, _P]),
     "nbx_memcpy_d2d": (c_int, [_P, _P, _P, c_size_t]),
     "nbx_memset": (c_int, [_P, _P, c_int, c_size_t]),
     "nbx_profile_enable": (c_int, [_P, c_int]),

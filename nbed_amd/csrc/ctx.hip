@@ -146,6 +146,46 @@ int nbx_memcpy_d2h(nbx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
     return NBX_OK;
 }
 
+namespace {
+struct GatherArgs {
+    const double* src[8];
+    int64_t n[8];
+    int count;
+};
+__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a, double* __restrict__ dst) {
+    int64_t off = 0;
+    for (int i = 0; i < a.count; ++i) {
+        const double* __restrict__ s = a.src[i];
+        for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.n[i]; j += (int64_t)gridDim.x * blockDim.x)
+            dst[off + j] = s[j];
+        off += a.n[i];
+    }
+}
+}  // namespace
+
+// Up to 8 device arrays of doubles, one after the other, into `h_dst` -- pinned (device-mapped) host memory the
+// kernel stores to directly: one launch and one wait for the results of an SCF run (C, eps, D, Hz), where a
+// concatenation kernel, a copy and their first-use costs took 0.3 ms of an 8 ms run.  Synchronises.
+int nbx_gather_to_host(nbx_ctx* ctx, int64_t count, const double* const* d_src, const int64_t* n_doubles, double* h_dst) {
+    NBX_CHECK_ARG(ctx && d_src && n_doubles && h_dst && count >= 1 && count <= 8);
+    GatherArgs a{};
+    a.count = (int)count;
+    int64_t total = 0;
+    for (int i = 0; i < count; ++i) {
+        NBX_CHECK_ARG(n_doubles[i] >= 0 && (n_doubles[i] == 0 || d_src[i] != nullptr));
+        a.src[i] = d_src[i];
+        a.n[i] = n_doubles[i];
+        total += n_doubles[i];
+    }
+    if (total > 0) {
+        const unsigned blocks = (unsigned)((total + 2047) / 2048 < 256 ? (total + 2047) / 2048 : 256);
+        hipLaunchKernelGGL(gather_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, ctx->stream, a, h_dst);
+        NBX_LAUNCH_CHECK();
+    }
+    NBX_HIP(hipStreamSynchronize(ctx->stream));
+    return NBX_OK;
+}
+
 int nbx_memcpy_d2d(nbx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
     NBX_CHECK_ARG(ctx != nullptr && (bytes == 0 || (d_dst != nullptr && d_src != nullptr)));
     if (bytes == 0) return NBX_OK;

@@ -30,10 +30,25 @@
 
 #include "nbx_common.h"
 
+// (m0 is named as a clobber of the LDS-DMA asm below; clang calls that a reserved register)
+#pragma clang diagnostic ignored "-Winline-asm"
+
 namespace {
 
 constexpr int M4_THREADS = 512, M4_PROD_THREADS = 256, M4_CUS = 256, M4_NCH = 4;  // 4 consumer + 4 producer waves
 constexpr int M4_PER_CU = 1;
+constexpr int M4_RING = 5;  // chunk buffers in LDS: one being walked, one landed (its J taken), three in flight
+typedef __attribute__((address_space(3))) void* m4_lds_vp;
+
+// at most three chunks' worth of this wave's chunk loads (LPT each) still in flight
+template <int LPT>
+__device__ __forceinline__ void m4_wait_three_chunks() {
+    static_assert(3 * LPT <= 63, "vmcnt is a 6-bit counter");
+    if constexpr (LPT == 6) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (LPT == 5) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    else if constexpr (LPT == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 __host__ __device__ constexpr int m4_tri(int k) { return k * (k + 1) / 2; }
 
@@ -128,85 +143,81 @@ __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, co
     using G_ = M4Geom<NB>;
     constexpr int RA = G_::row0(K), RB = G_::row0(K + 1), NG = G_::NG;
     constexpr int BASE = m4_tri(RA);
-    // ---- row part: items (G, C = 4 j + w4), C <= T = 4 G + b, T in [RA, RB).  The operands of JB column groups are ALL
-    // read before their first MFMA (the memory clobber keeps the reads above it): a consumer wave has its SIMD to itself,
-    // so an LDS round trip per item -- what the scheduler's low-register order gives -- or per handful of items would be
-    // fully exposed (measured: 80 batches of ~6 reads per tile = 80 x ~120 cycles = the whole 4 us a tile took).
-    constexpr int JB = 1, NJR = (NB + 3) / 4, NJC = (RB - RA + 3) / 4;
+    // ---- row part: items (G, C = 4 j + w4), C <= T = 4 G + b, T in [RA, RB); then the column part: items
+    // (T = RA + 4 j + w4, H), block columns 4 H + b < T, or == T with the strict lower part.
+    // A consumer wave shares its SIMD with one producer wave only, so an LDS round trip between the reads of an item group
+    // and its MFMAs is fully exposed: with one group read, waited for and multiplied at a time the walk took 4.7 us per
+    // tile in the kernel (1.65 us in isolation, where the compiler had batched the reads).  Two operand sets: the reads
+    // of group j + 1 are issued before the MFMAs of group j (the memory clobbers keep them there).
+    constexpr int NJR = (NB + 3) / 4, NJC = (RB - RA + 3) / 4;
     const int lo_row = 4 * a + c;
-#pragma unroll
-    for (int j0 = 0; j0 < NJR; j0 += JB) {
-        double av[JB][NG], bx[JB];
-#pragma unroll
-        for (int jj = 0; jj < JB; ++jj) {
-            const int j = j0 + jj;
-            if (j >= NJR || 4 * j >= RB) continue;  // static: no block of this column group lies in the chunk
-            const int C = min(4 * j + w4, NB - 1);  // (clamped: the surplus column group of the last j is masked below)
-            bx[jj] = xs[4 * (4 * C + a) + c];
-#pragma unroll
-            for (int G = 0; G < NG; ++G) {
-                if (G < j || 4 * G + 3 < RA || 4 * G >= RB) continue;  // static
-                // block (T = 4 G + b, C): tri(4 G + b) = tri(4 G) + 4 G b + tri(b).  The load is unconditional (LDS reads
-                // beyond the allocation return zero, everything else in the workgroup's LDS is finite data), the mask a select.
-                av[jj][G] = buf[16 * (m4_tri(4 * G) - BASE + 4 * j) + 16 * (G * 4 * b + m4_tri(b) + w4) + lo_row];
-            }
-        }
-        asm volatile("" : : : "memory");
-#pragma unroll
-        for (int jj = 0; jj < JB; ++jj) {
-            const int j = j0 + jj;
-            if (j >= NJR || 4 * j >= RB) continue;
-            const int C = 4 * j + w4;
-            const bool c_ok = 4 * j + 3 < NB || C < NB;
-#pragma unroll
-            for (int G = 0; G < NG; ++G) {
-                if (G < j || 4 * G + 3 < RA || 4 * G >= RB) continue;  // static
-                double v = av[jj][G];
-                if (!(4 * G >= RA && 4 * G + 3 < RB && 4 * G + 3 < NB && j < G && 4 * j + 3 < NB)) {  // (static: else all valid)
-                    const int T = 4 * G + b;
-                    v = (c_ok && T >= RA && T < RB && T < NB && C <= T) ? v : 0.0;
-                }
-                acc[G] = __builtin_amdgcn_mfma_f64_4x4x4f64(v, bx[jj], acc[G], 0, 0, 0);
-            }
-        }
-    }
-    // ---- column part: items (T = RA + 4 j + w4, H), block columns 4 H + b < T, or == T with the strict lower part
     const int lo_col = 16 * b + 4 * c + a;
+    auto row_live = [](int j) constexpr { return j < NJR && 4 * j < RB; };  // (static: a block of this column group lies in the chunk)
+    auto load_row = [&](int j, double (&av)[NG], double& bx) {
+        if (!row_live(j)) return;
+        const int C = min(4 * j + w4, NB - 1);  // (clamped: the surplus column group of the last j is masked below)
+        bx = xs[4 * (4 * C + a) + c];
 #pragma unroll
-    for (int j0 = 0; j0 < NJC; j0 += JB) {
-        double av[JB][NG], bt[JB];
-#pragma unroll
-        for (int jj = 0; jj < JB; ++jj) {
-            const int j = j0 + jj;
-            if (j >= NJC) continue;
-            const int T = min(RA + 4 * j + w4, RB - 1);  // (clamped: the surplus block row of the last j is masked below)
-            bt[jj] = xs[4 * (4 * T + a) + c];
-            const double* lt = buf + 16 * (m4_tri(T) - BASE) + lo_col;
-#pragma unroll
-            for (int H = 0; H < NG; ++H) {
-                if (4 * H > RA + 4 * j + 3) continue;  // static: the whole group lies right of every T of this j
-                av[jj][H] = lt[64 * H];
-            }
+        for (int G = 0; G < NG; ++G) {
+            if (G < j || 4 * G + 3 < RA || 4 * G >= RB) continue;  // static
+            // block (T = 4 G + b, C): tri(4 G + b) = tri(4 G) + 4 G b + tri(b).  The load is unconditional (LDS reads
+            // beyond the allocation return zero, everything else in the workgroup's LDS is finite data), the mask a select.
+            av[G] = buf[16 * (m4_tri(4 * G) - BASE + 4 * j) + 16 * (G * 4 * b + m4_tri(b) + w4) + lo_row];
         }
-        asm volatile("" : : : "memory");
+    };
+    auto mma_row = [&](int j, const double (&av)[NG], double bx) {
+        if (!row_live(j)) return;
+        const int C = 4 * j + w4;
+        const bool c_ok = 4 * j + 3 < NB || C < NB;
 #pragma unroll
-        for (int jj = 0; jj < JB; ++jj) {
-            const int j = j0 + jj;
-            if (j >= NJC) continue;
-            const int T = RA + 4 * j + w4;
-            const bool t_ok = RA + 4 * j + 3 < RB || T < RB;
-#pragma unroll
-            for (int H = 0; H < NG; ++H) {
-                if (4 * H > RA + 4 * j + 3) continue;  // static
-                double v = av[jj][H];
-                if (!(4 * H + 3 < RA + 4 * j && RA + 4 * j + 3 < RB)) {  // (static: else every lane is valid)
-                    const int cb = 4 * H + b;
-                    v = (t_ok && (cb < T || (cb == T && c < a))) ? v : 0.0;
-                }
-                acc[H] = __builtin_amdgcn_mfma_f64_4x4x4f64(v, bt[jj], acc[H], 0, 0, 0);
+        for (int G = 0; G < NG; ++G) {
+            if (G < j || 4 * G + 3 < RA || 4 * G >= RB) continue;  // static
+            double v = av[G];
+            if (!(4 * G >= RA && 4 * G + 3 < RB && 4 * G + 3 < NB && j < G && 4 * j + 3 < NB)) {  // (static: else all valid)
+                const int T = 4 * G + b;
+                v = (c_ok && T >= RA && T < RB && T < NB && C <= T) ? v : 0.0;
             }
+            acc[G] = __builtin_amdgcn_mfma_f64_4x4x4f64(v, bx, acc[G], 0, 0, 0);
         }
-    }
+    };
+    auto load_col = [&](int j, double (&av)[NG], double& bt) {
+        if (j >= NJC) return;
+        const int T = min(RA + 4 * j + w4, RB - 1);  // (clamped: the surplus block row of the last j is masked below)
+        bt = xs[4 * (4 * T + a) + c];
+        const double* lt = buf + 16 * (m4_tri(T) - BASE) + lo_col;
+#pragma unroll
+        for (int H = 0; H < NG; ++H) {
+            if (4 * H > RA + 4 * j + 3) continue;  // static: the whole group lies right of every T of this j
+            av[H] = lt[64 * H];
+        }
+    };
+    auto mma_col = [&](int j, const double (&av)[NG], double bt) {
+        if (j >= NJC) return;
+        const int T = RA + 4 * j + w4;
+        const bool t_ok = RA + 4 * j + 3 < RB || T < RB;
+#pragma unroll
+        for (int H = 0; H < NG; ++H) {
+            if (4 * H > RA + 4 * j + 3) continue;  // static
+            double v = av[H];
+            if (!(4 * H + 3 < RA + 4 * j && RA + 4 * j + 3 < RB)) {  // (static: else every lane is valid)
+                const int cb = 4 * H + b;
+                v = (t_ok && (cb < T || (cb == T && c < a))) ? v : 0.0;
+            }
+            acc[H] = __builtin_amdgcn_mfma_f64_4x4x4f64(v, bt, acc[H], 0, 0, 0);
+        }
+    };
+    // every operand of the chunk's row part is requested, then every operand of its column part, before the first MFMA
+    // of either: two LDS round trips per chunk instead of one per item group (~18 per chunk)
+    double avr[NJR][NG], bxr[NJR], avc[NJC][NG], btc[NJC];
+#pragma unroll
+    for (int j = 0; j < NJR; ++j) load_row(j, avr[j], bxr[j]);
+#pragma unroll
+    for (int j = 0; j < NJC; ++j) load_col(j, avc[j], btc[j]);
+    __builtin_amdgcn_sched_barrier(0);  // (nothing crosses: without it the scheduler sinks the reads between the MFMAs)
+#pragma unroll
+    for (int j = 0; j < NJR; ++j) mma_row(j, avr[j], bxr[j]);
+#pragma unroll
+    for (int j = 0; j < NJC; ++j) mma_col(j, avc[j], btc[j]);
 }
 
 // ---------------------------------------------------------------------------------------------- the kernel
@@ -231,11 +242,11 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
     using G_ = M4Geom<NB>;
     constexpr int N = G_::N, NG = G_::NG, LPT = G_::LPT, BUF = G_::BUF, TILE = G_::TILE, PT = M4_PROD_THREADS;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* buf0 = smem;                 // [2][BUF] chunk buffers
-    double* xs0 = smem + 2 * BUF;        // [2][N][4] X of the current / next tile
-    double* redq = xs0 + 2 * 4 * N;      // [4][NG][32] consumers' row-q halves (odd columns) of the tile just walked
-    double* redp = redq + 4 * NG * 32;   // [4][NG][32] consumers' row-p halves (even columns) when the row ends
-    double* jred = redp + 4 * NG * 32;   // [2][4] producers' J partials per tile parity
+    double* buf0 = smem;                     // [M4_RING][BUF] chunk buffers
+    double* xs0 = smem + M4_RING * BUF;      // [2][N][4] X of the current / next tile
+    double* redq = xs0 + 2 * 4 * N;          // [4][NG][32] consumers' row-q halves (odd columns) of the tile just walked
+    double* redp = redq + 4 * NG * 32;       // [4][NG][32] consumers' row-p halves (even columns) when the row ends
+    double* jred = redp + 4 * NG * 32;       // [2][4] producers' J partials per tile parity
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave >= 4;
     const int ptid = tid - 256;  // producers: 0 .. 255
@@ -247,28 +258,51 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
     if (T0 >= T_end) return;  // uniform for the whole workgroup
     const int p_first = m4_tri_row(T0);
     const int ntile = (int)(T_end - T0);
+    const int nstep = M4_NCH * ntile;
+    const double* tile0 = packed + (T0 - t_begin) * (int64_t)TILE;
 
     // ------------------------------------------------------------------ producer state
     double2 wt[M4_NCH][LPT];   // the thread's Dtot' entries (the same for every tile)
-    double2 r[M4_NCH][LPT];    // staging: set k holds chunk k of the tile being staged; a whole tile in flight
     double jacc = 0.0;
-    constexpr int XU = (4 * N + PT - 1) / PT;
-    auto load_chunk = [&](const double* tile, int k, bool real) {
+    // Chunk g = 4 t + k goes from HBM straight into ring slot g % M4_RING: global_load_lds_dwordx4, lane l of a wave
+    // lands its 16 bytes at the instruction's LDS base + 16 l -- no staging registers, no ds_write; slot s of the chunk
+    // is one instruction per producer wave, in the layout the register path had (thread ptid's two doubles of slot s at
+    // (s PT + ptid) 2).  Every chunk is LPT instructions per wave whatever its length (the tail re-reads the chunk's last
+    // 16 bytes, a chunk past the last tile re-reads the first tile: landed in a free slot, never read): a wait for
+    // `vmcnt(3 LPT)` means "my part of the chunk three behind the newest has landed".
+    auto issue = [&](int g) {
+        const int k = g & (M4_NCH - 1);
+        const bool real = g < nstep;
+        const double* tile = tile0 + (real ? (int64_t)(g >> 2) * TILE : 0);
         const int begin = 16 * m4_tri(G_::row0(k)), end = 16 * m4_tri(G_::row0(k + 1));
+        double* buf = buf0 + (g % M4_RING) * BUF;
 #pragma unroll
         for (int s = 0; s < LPT; ++s) {
             int d = begin + (s * PT + ptid) * 2;
             d = min(d, end - 2);
-            // `real` = false: the same number of loads from one cache line (nothing left to prefetch; a CONDITIONAL reload
-            // would make the compiler count the loads in flight for the path without it: every wait would over-drain)
-            r[k][s] = m4_ldnt(tile + (real ? d : 2 * (lane & 3)));
+            const unsigned off = 8u * (unsigned)d;
+            const unsigned lds_a = (unsigned)(size_t)(m4_lds_vp)(buf + (s * PT + (wave - 4) * 64) * 2);
+            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(off), "s"(tile), "s"(lds_a) : "memory", "m0");
         }
     };
-    // X of a tile: xs[n][c] = D^{c / 2}[c & 1 ? p : q][n]  (NDM = 1: columns 2, 3 are zero)
+    // the J contribution of a landed chunk: the thread reads back the 16 bytes its own wave brought in
+    auto jpass = [&](int g) {
+        const int k = g & (M4_NCH - 1);
+        const double* buf = buf0 + (g % M4_RING) * BUF;
+#pragma unroll
+        for (int s = 0; s < LPT; ++s) {
+            const double2 v = *reinterpret_cast<const double2*>(buf + (s * PT + ptid) * 2);
+            const double2 w = k == 0 ? wt[0][s] : (k == 1 ? wt[1][s] : (k == 2 ? wt[2][s] : wt[3][s]));
+            jacc = fma(v.y, w.y, fma(v.x, w.x, jacc));
+        }
+    };
+    // X of a tile: xs[n][c] = D^{c / 2}[c & 1 ? p : q][n]  (NDM = 1: columns 2, 3 are zero).  Fetched and stored by the
+    // CONSUMER waves: a load the compiler tracks would make a producer wait for its whole queue of chunk loads.
+    constexpr int XU = (4 * N + PT - 1) / PT;
     auto fetch_x = [&](int pp, int qq, double (&v)[XU]) {
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int e = ptid + PT * u;  // element e = 4 n + c
+            const int e = tid + PT * u;  // element e = 4 n + c
             const int n = e >> 2, cc = e & 3, x = cc >> 1;
             const int off = x * N * N + ((cc & 1) ? pp : qq) * N + n;  // (32-bit: scalar base + one offset register)
             v[u] = (e < 4 * N && x < NDM) ? dm[off] : 0.0;
@@ -277,20 +311,9 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
     auto store_x = [&](double* xs, const double (&v)[XU]) {
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int e = ptid + PT * u;
+            const int e = tid + PT * u;
             if (e < 4 * N) xs[e] = v[u];
         }
-    };
-    // chunk k of the staged tile: registers -> LDS buffer, its J contribution, reload of the set with the next tile's chunk k
-    auto stage = [&](double* buf, int k, const double* next_tile, bool next_real) {
-#pragma unroll
-        for (int s = 0; s < LPT; ++s) *reinterpret_cast<double2*>(buf + (s * PT + ptid) * 2) = r[k][s];
-#pragma unroll
-        for (int s = 0; s < LPT; ++s) jacc = fma(r[k][s].y, wt[k][s].y, fma(r[k][s].x, wt[k][s].x, jacc));
-        // the register set is dead from here: pinned, so that its reload lands in the SAME registers (a J product sunk
-        // below the loads keeps the old values alive, the loads get other registers, and the copy back costs a vmcnt(0))
-        asm volatile("" : "+v"(jacc) : : "memory");
-        load_chunk(next_tile, k, next_real);
     };
     // the consumers' partial rows of a finished tile: summed over the four consumer waves, in wave order
     auto reduce_rows = [&](const double* red, int parity, double* dst) {  // dst[x N + row]
@@ -306,8 +329,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = 0.0;
 
-    // ------------------------------------------------------------------ prologue: tile 0 in flight, its chunk 0 and X in LDS
-    const double* tile0 = packed + (T0 - t_begin) * (int64_t)TILE;
+    // ------------------------------------------------------------------ prologue: four chunks in flight, chunk 0 and X in LDS
     int p = p_first, q = (int)(T0 - (int64_t)p * (p + 1) / 2);
     if (producer) {
 #pragma unroll
@@ -315,21 +337,23 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
 #pragma unroll
             for (int s = 0; s < LPT; ++s) wt[k][s] = *reinterpret_cast<const double2*>(wtab + 2 * ((k * LPT + s) * PT + ptid));
         if (ptid < 8) jred[ptid] = 0.0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the table: nothing of the compiler's in the counter from here)
+        issue(0);
+        issue(1);
+        issue(2);
+        issue(3);
+        m4_wait_three_chunks<LPT>();  // my part of chunk 0
+        jpass(0);
+    } else {
         double v[XU];
         fetch_x(p, q, v);
         store_x(xs0, v);
-#pragma unroll
-        for (int k = 0; k < M4_NCH; ++k) {
-            load_chunk(tile0, k, true);
-            asm volatile("" : : : "memory");  // (issued in chunk order, as the loop re-issues them: vmcnt is in order)
-        }
-        stage(buf0, 0, ntile > 1 ? tile0 + TILE : tile0, ntile > 1);
     }
     __syncthreads();
 
-    // ------------------------------------------------------------------ the steps: tile t, chunk k -> step 4 t + k
-    // Two loops, one per role (so that the producers' registers -- Dtot' table, staged tile -- and the consumers' --
-    // accumulators, walk operands -- are never live together); both execute exactly one barrier per step.
+    // ------------------------------------------------------------------ the steps: tile t, chunk k -> step g = 4 t + k
+    // Two loops, one per role (so that the producers' registers -- Dtot' table -- and the consumers' -- accumulators,
+    // walk operands -- are never live together); both execute exactly one barrier per step.
     auto next_pq = [](int& pp, int& qq) {
         if (++qq > pp) {
             ++pp;
@@ -341,15 +365,11 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
             const int64_t T = T0 + t;
             int pn = p, qn = q;
             next_pq(pn, qn);
-            const bool more = t + 1 < ntile;   // a tile t + 1 exists
-            const bool more2 = t + 2 < ntile;  // ... and a tile t + 2 (what the reload behind tile t + 1's chunk 0 fetches)
-            const double* tile = tile0 + (int64_t)t * TILE;
-            double xv[XU];
-            fetch_x(more ? pn : p, more ? qn : q, xv);  // X of tile t + 1: fetched now, stored one step on
 #pragma unroll
             for (int k = 0; k < M4_NCH; ++k) {
-                // step 4 t + k: chunk k + 1 of tile t (k < 3) or chunk 0 of tile t + 1 (k == 3) goes to the buffer the
-                // consumers are not walking
+                const int g = M4_NCH * t + k;
+                // step g: the consumers walk chunk g; chunk g + 4 goes into the slot they left at the last barrier
+                // (chunk g - 1's), chunk g + 1 has landed and gives its J contribution
                 if (k == 0 && t > 0) {
                     // the consumers' rows of tile t - 1 (written at its last step, behind that step's barrier)
                     int pp = p, qq = q - 1;
@@ -361,11 +381,11 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                     if (pp != p) reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N);
                 }
 #ifndef NBX_M4_NO_STAGE
-                if (k + 1 < M4_NCH) stage(buf0 + ((k + 1) & 1) * BUF, k + 1, more ? tile + TILE : tile, more);
-                else if (more) stage(buf0, 0, more2 ? tile + 2 * TILE : tile, more2);
+                issue(g + 4);
+                m4_wait_three_chunks<LPT>();  // my part of chunk g + 1 (chunks g + 2 .. g + 4 may be in flight)
+                if (g + 1 < nstep) jpass(g + 1);
 #endif
-                if (k == 1 && more) store_x(xs0 + ((t + 1) & 1) * 4 * N, xv);
-                if (k == 2) {  // chunk 3 of tile t has just been staged: this wave's share of the tile's J
+                if (k == 2) {  // chunk 3 of tile t has just been taken: this wave's share of the tile's J
                     jacc = nbx_wave_sum(jacc);
                     if (lane == 0) jred[(t & 1) * 4 + (wave - 4)] = jacc;
                     jacc = 0.0;
@@ -381,6 +401,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
             p = pn;
             q = qn;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the padding chunks: nothing may land after the workgroup has gone)
         // the last tile's rows ((p, q) has moved one past it)
         int pp = p, qq = q - 1;
         if (qq < 0) {
@@ -390,14 +411,19 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T_end - 1 - t_begin) * NDM) * (int64_t)N);
         reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N);
     } else {
+        int slot = 0;  // ring slot of the chunk being walked
         for (int t = 0; t < ntile; ++t) {
             int pn = p, qn = q;
             next_pq(pn, qn);
-            const bool row_ends = pn != p || t + 1 >= ntile;
+            const bool more = t + 1 < ntile;
+            const bool row_ends = pn != p || !more;
             const double* xs = xs0 + (t & 1) * 4 * N;
+            double xv[XU];
+            fetch_x(more ? pn : p, more ? qn : q, xv);  // X of tile t + 1: fetched now, stored two steps on
 #pragma unroll
             for (int k = 0; k < M4_NCH; ++k) {
-                const double* buf = buf0 + (k & 1) * BUF;
+                const double* buf = buf0 + slot * BUF;
+                slot = slot + 1 == M4_RING ? 0 : slot + 1;
 #ifndef NBX_M4_NO_WALK
                 // (the lane is made opaque per chunk: the ~100 per-lane LDS addresses of a walk are loop invariant, and
                 // hoisted out of the tile loop they would occupy -- spill -- a register each)
@@ -409,6 +435,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                 else if (k == 2) m4_walk_chunk<NB, 2>(buf, xs, wave, a, b, c, acc);
                 else m4_walk_chunk<NB, 3>(buf, xs, wave, a, b, c, acc);
 #endif
+                if (k == 1 && more) store_x(xs0 + ((t + 1) & 1) * 4 * N, xv);
                 if (k == M4_NCH - 1) {
                     // end of tile: the row-q halves (odd columns: they used D[p][:]) leave the registers; the row-p halves
                     // (even columns) stay until the row changes.  The producers sum them up during the next step.
@@ -446,7 +473,7 @@ M4Plan m4_plan_nb(int64_t p0, int64_t np, int64_t ndm) {
     pl.L = (int)L;
     pl.wgs = (int)nbx_cdiv(ntiles, L);
     pl.S = (int)sqrt(2.0 * (double)L) + 3;
-    pl.lds_bytes = (size_t)(2 * G::BUF + 2 * 4 * G::N + 2 * 4 * G::NG * 32 + 16) * sizeof(double);
+    pl.lds_bytes = (size_t)(M4_RING * G::BUF + 2 * 4 * G::N + 2 * 4 * G::NG * 32 + 16) * sizeof(double);
     size_t off = 0;
     pl.wt_off = off; off += m4_align256((size_t)(M4_NCH * G::LPT * M4_PROD_THREADS * 2) * sizeof(double));
     pl.k1_off = off; off += m4_align256((size_t)((int64_t)pl.wgs * pl.S * ndm * G::N) * sizeof(double));
