@@ -41,7 +41,8 @@ if str(REPO) not in sys.path:
     sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (datasheet; v_mfma_f64_16x16x4_f64)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (datasheet); measured, registers only (profiles/r03/fp64_rate_probe.txt):
+#                               v_mfma_f64_4x4x4_4b_f64 75, v_mfma_f64_16x16x4_f64 38-48 TFLOP/s
 
 
 def parse_args():
@@ -613,7 +614,7 @@ def main():
                           "and quarters 3-4 use (ij|kl) = (ji|kl)",
             "roofline": {
                 "bound": "mfma",
-                "kernel": "gemm_f64_kernel<128,128> (quarter-1: (n x N).(N x N^3))",
+                "kernel": "gemm_m4_tn_kernel (quarter-1: (n x N).(N x N^3); v_mfma_f64_4x4x4_4b_f64, k-tiles by LDS-DMA)",
                 "achieved": q1_flops / (q1_ms / max(q1_cnt, 1) * 1e-3) / 1e12 if q1_cnt else None,
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
