@@ -209,6 +209,25 @@ def test_diis_device_matches_pyscf_semantics(be, case):
     assert dev.get_num_vec() == ref.get_num_vec()
 
 
+def test_results_gathered_to_host_in_one_launch(be):
+    """nbx_gather_to_host behind ``to_host_many`` (the four arrays an SCF run returns): values, shapes, empty and
+    non-contiguous members (those take the concatenation path)."""
+    import torch
+
+    arrs = [rnd(90, 2, 37, 37), rnd(91, 2, 37), rnd(92, 2, 37, 37), rnd(93, 5)]
+    dev = [be.asarray(a) for a in arrs]
+    for got, want in zip(be.to_host_many(dev), arrs):
+        assert got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
+    mixed = [dev[0].transpose(1, 2), dev[1], torch.empty(0, dtype=torch.float64, device=dev[0].device)]
+    out = be.to_host_many(mixed)
+    np.testing.assert_array_equal(out[0], arrs[0].transpose(0, 2, 1))
+    np.testing.assert_array_equal(out[1], arrs[1])
+    assert out[2].size == 0
+    big = be.asarray(rnd(94, 300000))  # larger than the landing buffer the backend starts with
+    np.testing.assert_array_equal(be.to_host_many([big, dev[3]])[0], be.to_host(big))
+
+
 def test_transpose_scale_and_chem_to_phys(be):
     a = rnd(72, 3, 45, 70)
     np.testing.assert_array_equal(be.to_host(be.transpose(be.asarray(a))), a.transpose(0, 2, 1))
