@@ -61,6 +61,8 @@ def parse_args():
     ap.add_argument("--no-real", action="store_true", help="skip the real-molecule leg (octane / 6-31G*, nothing injected)")
     ap.add_argument("--no-small", action="store_true", help="skip the small-config legs (BASELINE configs[0], [1], [4] shape)")
     ap.add_argument("--no-scaling", action="store_true", help="skip the scaling workloads (N_AO = 256 packed, 384 symmetric)")
+    ap.add_argument("--no-df", action="store_true", help="skip the density-fitted J/K build at N_AO = 2000 (an extra: the GEMM-shaped J/K)")
+    ap.add_argument("--df-naux", type=int, default=4000, help="auxiliary functions of the N_AO = 2000 density-fitted build (128 GB at 4000)")
     ap.add_argument("--n2000-rslabs", type=int, default=4, help="r-slabs of the N_AO=2000 transform per rank")
     ap.add_argument("--cpu-cycles", type=int, default=8)
     return ap.parse_args()
@@ -133,6 +135,52 @@ def cpu_baseline_cycle(pr, eri_h, ncycles):
 
 
 _CPU_LIB: dict = {}
+
+
+def df_jk_leg(be, args, sync):
+    """An EXTRA, not on the parity path of the exact integrals: one J/K build at N_AO = 2000 from a three-index factor
+    (pq|rs) ~ sum_L B_L[pq] B_L[rs] held in HBM (nbx_jk_df) -- the only form of J/K that is
+    GEMM shaped, and the only one a single GPU can hold at this size (the dense tensor is 128 TB)."""
+    import torch
+
+    from nbed_amd import synth
+
+    N, naux, nocc = 2000, int(args.df_naux), (512, 512)
+    need = (naux * N * N + 2 * 64 * max(nocc) * N + 8 * N * N) * 8.0
+    free, _total = torch.cuda.mem_get_info()
+    if need > 0.9 * free:
+        return {"skipped": f"needs {need / 1e9:.0f} GB of HBM, {free / 1e9:.0f} GB free"}
+    t0 = time.perf_counter()
+    b = be.df_synth(N, 0, naux)
+    sync()
+    t_gen = time.perf_counter() - t0
+    _w, c1 = be.eigh(be.asarray(synth.sym_matrix(11, N)))  # orthonormal columns
+    c = torch.stack([c1, torch.flip(c1, dims=[1])]).contiguous()
+    be.jk_df(b, c, nocc)  # first touch of the workspace
+    sync()
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        jk = be.jk_df(b, c, nocc)
+    sync()
+    dt = (time.perf_counter() - t0) / reps
+    flops = 4.0 * sum(nocc) * float(N) ** 2 * naux  # per spin: 2 nocc N^2 naux (B_L C) + 2 nocc N^2 naux (Y Y^T)
+    check = float(torch.linalg.norm(jk[0] - jk[0].T) / torch.linalg.norm(jk[0]))
+    out = {
+        "workload": f"N_AO={N}, N_aux={naux}, n_occ={nocc}: synthetic three-index factor B (N_aux, N, N) in HBM "
+                    f"({naux * N * N * 8 / 1e9:.0f} GB, generated on the device in {t_gen * 1e3:.0f} ms), orthonormal orbitals",
+        "note": "EXTRA: the GEMM-shaped J/K (density fitting); the exact-integral path of the reference is the streamed one above",
+        "ms_per_build": dt * 1e3,
+        "jk_df_tflops": flops / dt / 1e12,
+        "frac_of_fp64_mfma_peak": flops / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+        "flop_count": "8 n_occ N^2 N_aux: B_L C and (B_L C)(B_L C)^T per spin; J is two streaming passes on top",
+        "factor_bytes_read_per_build": 3.0 * naux * N * N * 8,
+        "j_symmetry_defect": check,
+    }
+    del b, c, jk
+    be.release_workspaces()
+    torch.cuda.empty_cache()
+    return out
 
 
 def timed_huzinaga_run(mf, emb_args, kw, warmup, steps, sync):
@@ -709,6 +757,16 @@ def main():
     be.release_workspaces()
     torch.cuda.empty_cache()
 
+    # ---------------- EXTRA: density-fitted J/K at N_AO = 2000 (rank 0, N=1 only)
+    df_leg = None
+    if rank == 0 and world == 1 and not args.no_df:
+        try:
+            df_leg = df_jk_leg(be, args, barrier)
+        except Exception as exc:  # informative leg: it must not take the bench line down with it
+            df_leg = {"error": f"{type(exc).__name__}: {exc}"}
+            be.release_workspaces()
+            torch.cuda.empty_cache()
+
     # ---------------- sizes at which sharding the J/K build pays: every --gpus N
     scaling = None
     if not args.no_scaling:
@@ -842,6 +900,7 @@ def main():
             "time_to_solution": tts,
             "transform": transform,
             "n2000_streamed": n2000,
+            "n2000_density_fitted_jk": df_leg,
             "real_molecule": real,
             "small_configs": small,
             "scaling_workload": scaling,

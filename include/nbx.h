@@ -70,6 +70,21 @@ int nbx_gather_to_host(nbx_ctx* ctx, int64_t count, const double* const* d_src, 
 int nbx_memcpy_d2d(nbx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 int nbx_memset(nbx_ctx* ctx, void* d_ptr, int value, size_t bytes);
 
+/* ------------------------------------------------------------------ density-fitted J/K (an extra)
+ * (pq|rs) ~ sum_L B_L[p][q] B_L[r][s] with symmetric B_L -- what PySCF contracts
+ * behind get_veff (huzinaga_scf.py:156, driver.py:344,847) when the mean-field object is built with
+ * .density_fit().  The reference never asks for that; this entry point is NOT on the parity path of the exact
+ * integrals.  It is the GEMM-shaped form of J/K, the only one there is at N_AO = 2000:
+ *   J = sum_L B_L <B_L, D_a + D_b>,   K^x = sum_L (B_L C^x)(B_L C^x)^T,   D^x = C^x C^x^T.
+ * d_b: (naux, N, N) the auxiliary functions this rank holds (results are additive over slabs of L);
+ * d_c: (ndm, N, N) orbital coefficients whose first nocc[x] COLUMNS are the occupied orbitals of spin x
+ *      (ndm = 1: closed shell, D_a = D_b); d_jk: (1 + ndm, N, N) = J, K_a[, K_b].
+ * nbx_df_synth: d_b[l - l0][p][q] = scale * val(stream 9, l N(N+1)/2 + tri(p, q)), l in [l0, l1).               */
+size_t nbx_jk_df_worksize(int64_t nao, int64_t ndm, int64_t nocc_max);
+int nbx_jk_df(nbx_ctx* ctx, int64_t nao, int64_t naux, const double* d_b, int64_t ndm, const double* d_c,
+              const int64_t* nocc, double* d_jk, void* d_work, size_t work_bytes);
+int nbx_df_synth(nbx_ctx* ctx, int64_t nao, int64_t l0, int64_t l1, uint64_t seed, double scale, double* d_b);
+
 /* ------------------------------------------------------------------ in-library kernel timing
  * While enabled, the listed launches are bracketed by HIP events recorded on the context's
  * stream; nbx_profile_read() waits for them and returns the accumulated milliseconds and

@@ -713,6 +713,36 @@ class HipBackend:
                        self._p(out["status"]))
         return _PendingScalars(self.torch, None, 2, host=h_out)
 
+    # ------------------------------------------------------------------ density-fitted J/K (an extra: SURVEY 7 step 5)
+    def df_synth(self, nao: int, l0: int, l1: int, scale: float | None = None, seed: int | None = None):
+        """(l1 - l0, N, N) synthetic three-index factor B_L (symmetric in its last two indices), generated on the
+        device: ``synth.df_factor`` is the same array on the host."""
+        from . import synth
+
+        out = self.empty((l1 - l0, nao, nao))
+        chunk = 32768
+        for a in range(l0, l1, chunk):
+            b = min(l1, a + chunk)
+            self._call("nbx_df_synth", nao, a, b, int(synth.SEED if seed is None else seed),
+                       float(synth.df_scale(nao) if scale is None else scale), self._p(out[a - l0:]))
+        return out
+
+    def jk_df(self, b, c, nocc):
+        """J and K from the factor ``b`` (naux, N, N) and the occupied orbitals: ``c`` is (N, N) or (ndm, N, N) with
+        the occupied orbitals in its first ``nocc[x]`` columns.  Returns (1 + ndm, N, N): J, K_a[, K_b] -- partial
+        sums if ``b`` is a slab of the auxiliary basis (nbx_jk_df)."""
+        c3 = c if c.dim() == 3 else c.unsqueeze(0)
+        ndm, n = int(c3.shape[0]), int(c3.shape[-1])
+        occ = [int(x) for x in (nocc if hasattr(nocc, "__len__") else [nocc])]
+        if len(occ) != ndm:
+            raise ValueError(f"jk_df: {ndm} coefficient matrices but {len(occ)} occupation counts")
+        out = self.empty((1 + ndm, n, n))
+        nbytes = int(self.lib.nbx_jk_df_worksize(n, ndm, max(occ) if occ else 0))
+        work = self._workspace("jk_df", nbytes)
+        self._call("nbx_jk_df", n, int(b.shape[0]), self._p(b), ndm, self._p(c3), (ctypes.c_int64 * ndm)(*occ), self._p(out),
+                   self._p(work), nbytes)
+        return out
+
     def async_to_host(self, d_vals):
         """Stream-ordered copy of a small device tensor to pinned memory; ``.get()`` waits for it only."""
         return _PendingScalars(self.torch, d_vals, 0, ncore=int(d_vals.numel()))

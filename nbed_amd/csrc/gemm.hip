@@ -808,7 +808,7 @@ int nbx_gemm_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t 
                 else NBX_GEMM_SMALL(false, false);
             }
 #undef NBX_GEMM_SMALL
-        } else if (tiles128 >= 512 && !a_kc && !b_kc && tn_dma_ok(m, n, k, vec_a, vec_b)) {
+        } else if ((tiles128 >= 512 || (tiles128 >= 128 && k >= 2048)) && !a_kc && !b_kc && tn_dma_ok(m, n, k, vec_a, vec_b)) {
             launch_tn_dma(ctx, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c, nb,
                           0, d_gate, gate_a, gate_b);
         } else if (tiles128 >= 512 && m > 64 && n > 64) {

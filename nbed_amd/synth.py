@@ -44,6 +44,24 @@ def sym_matrix(stream: int, n: int, seed: int = SEED):
     return val(stream, _tri(i, j), seed)
 
 
+STREAM_DF = 9
+
+
+def df_scale(nao: int) -> float:
+    """Magnitude of the synthetic three-index factor: (pq|pq) ~ naux / (3 N^2) stays of order 1 / N for naux ~ 3 N."""
+    return 1.0 / nao
+
+
+def df_factor(nao: int, l0: int, l1: int, scale: float | None = None, seed: int = SEED):
+    """B[l - l0][p][q] = scale * val(stream 9, l N(N+1)/2 + tri(p, q)): what nbx_df_synth generates on the device."""
+    npair = np.uint64(nao * (nao + 1) // 2)
+    i = np.arange(nao, dtype=np.uint64)[:, None]
+    j = np.arange(nao, dtype=np.uint64)[None, :]
+    tri = _tri(i, j)
+    ls = np.arange(l0, l1, dtype=np.uint64)[:, None, None]
+    return (df_scale(nao) if scale is None else scale) * val(STREAM_DF, ls * npair + tri[None], seed)
+
+
 def overlap(nao: int, seed: int = SEED):
     s = 0.1 * sym_matrix(STREAM_OVLP, nao, seed) / np.sqrt(nao)
     np.fill_diagonal(s, 1.0)

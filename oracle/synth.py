@@ -150,3 +150,22 @@ def problem(nao: int, nocc: tuple[int, int], n_env: int, seed: int = SEED) -> di
         "nocc_total": tuple(nocc),
         "n_env": n_env,
     }
+
+
+STREAM_DF = 9
+
+
+def df_factor(nao: int, l0: int, l1: int, scale: float | None = None, seed: int = SEED) -> np.ndarray:
+    """Synthetic three-index factor of the integrals, (pq|rs) ~ sum_L B_L[p][q] B_L[r][s] (the density-fitted form of
+    get_veff): B[l - l0][p][q] = scale * val(stream 9, l N(N+1)/2 + tri(p, q)), symmetric in
+    (p, q) by construction; scale defaults to 1 / N.  One auxiliary function at a time, element by element."""
+    npair = nao * (nao + 1) // 2
+    out = np.empty((l1 - l0, nao, nao))
+    rows, cols = np.tril_indices(nao)
+    flat = rows * (rows + 1) // 2 + cols
+    for l in range(l0, l1):
+        lower = val(STREAM_DF, np.uint64(l) * np.uint64(npair) + flat.astype(np.uint64), seed)
+        m = np.zeros((nao, nao))
+        m[rows, cols] = lower
+        out[l - l0] = m + np.tril(m, -1).T
+    return out * (1.0 / nao if scale is None else scale)

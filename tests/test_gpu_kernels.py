@@ -209,6 +209,40 @@ def test_diis_device_matches_pyscf_semantics(be, case):
     assert dev.get_num_vec() == ref.get_num_vec()
 
 
+@pytest.mark.parametrize("n,naux,nocc", [(24, 40, (5, 4)), (24, 7, (6,)), (148, 70, (70, 66)), (150, 130, (75, 0))])
+def test_density_fitted_jk_vs_numpy_and_dense_contraction(be, n, naux, nocc):
+    """nbx_jk_df (an extra: the GEMM-shaped J/K of SURVEY section 7 step 5) against its definition in numpy, the
+    generator against the host one, slabs of the auxiliary index against the whole, and -- at the small size -- against
+    the dense contraction of the integrals the factor stands for, (pq|rs) = sum_L B_L[pq] B_L[rs], through the oracle."""
+    b_h = synth.df_factor(n, 0, naux)
+    b_d = be.df_synth(n, 0, naux)
+    np.testing.assert_array_equal(be.to_host(b_d), b_h)
+    np.testing.assert_array_equal(b_h, b_h.transpose(0, 2, 1))
+    ndm = len(nocc)
+    c = np.stack([np.linalg.qr(rnd(95 + x, n, n))[0] for x in range(ndm)])
+    dms = np.stack([c[x][:, :nocc[x]] @ c[x][:, :nocc[x]].T for x in range(ndm)])
+    dtot = dms.sum(0) if ndm == 2 else 2.0 * dms[0]
+    j_ref = np.einsum("lpq,l->pq", b_h, np.einsum("lpq,pq->l", b_h, dtot))
+    k_ref = np.stack([np.einsum("lpr,rs,lsq->pq", b_h, dms[x], b_h, optimize=True) for x in range(ndm)])
+    got = be.to_host(be.jk_df(b_d, be.asarray(c), nocc))
+    scale = max(np.abs(j_ref).max(), np.abs(k_ref).max())
+    np.testing.assert_allclose(got[0], j_ref, rtol=0, atol=1e-12 * scale)
+    np.testing.assert_allclose(got[1:], k_ref, rtol=0, atol=1e-12 * scale)
+    # additive over slabs of the auxiliary basis (the multi-GPU split)
+    cut = naux // 3
+    parts = be.to_host(be.jk_df(b_d[:cut], be.asarray(c), nocc)) + be.to_host(be.jk_df(b_d[cut:], be.asarray(c), nocc))
+    np.testing.assert_allclose(parts, got, rtol=0, atol=1e-12 * scale)
+    if n == 24 and ndm == 2:
+        eri = np.einsum("lpq,lrs->pqrs", b_h, b_h)
+        j_d = np.einsum("pqrs,rs->pq", eri, dtot)
+        k_d = np.stack([np.einsum("prqs,rs->pq", eri, dms[x]) for x in range(2)])
+        jk_dev = be.to_host(be.jk(be.asarray(eri), be.asarray(dms)))
+        np.testing.assert_allclose(jk_dev[0], j_d, rtol=0, atol=1e-12 * scale)
+        np.testing.assert_allclose(got[0], jk_dev[0], rtol=0, atol=1e-12 * scale)
+        np.testing.assert_allclose(got[1:], jk_dev[1:], rtol=0, atol=1e-12 * scale)
+        np.testing.assert_allclose(k_d, jk_dev[1:], rtol=0, atol=1e-12 * scale)
+
+
 def test_results_gathered_to_host_in_one_launch(be):
     """nbx_gather_to_host behind ``to_host_many`` (the four arrays an SCF run returns): values, shapes, empty and
     non-contiguous members (those take the concatenation path)."""

@@ -228,3 +228,17 @@ def test_gpu_uhf_protocol_matches_oracle_scf(be):
     np.testing.assert_allclose(mf.mo_energy, ref.mo_energy, rtol=0, atol=1e-7)
     np.testing.assert_allclose(mf.make_rdm1(), ref.make_rdm1(), rtol=0, atol=1e-7)
     assert mf.copy().get_hcore is not None and mf() is mf
+
+
+def test_synthetic_df_factor_host_generators_agree():
+    """The product's vectorised generator of the three-index factor (nbed_amd.synth.df_factor, what nbx_df_synth makes
+    on the device) against the oracle's element-by-element one: the same doubles, symmetric, slabs of L consistent."""
+    from nbed_amd import synth as psynth
+    from oracle import synth as osynth
+
+    a = psynth.df_factor(13, 0, 9)
+    b = osynth.df_factor(13, 0, 9)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, a.transpose(0, 2, 1))
+    np.testing.assert_array_equal(psynth.df_factor(13, 4, 9), a[4:])
+    assert np.abs(a).max() <= 1.0 / 13
