@@ -289,7 +289,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_f64_kernel(
 //     instruction: profiles/r03/mfma_f64_4x4x4_cbsz_probe.hip), and a lane reads the four adjacent columns
 //     4 (l & 3) .. + 3 of a 16-column fragment with one 32-byte LDS read: MFMA t of a fragment multiplies column
 //     4 (l & 3) + t, so the lane ends up with C[row 4 b + (l >> 4)][4 (l & 3) .. + 3] -- 32 contiguous bytes to store.
-//     2 x 2 waves of 64 x 64 outputs (128 accumulator registers), two workgroups per CU.
+//     Four waves of 128 x 32 outputs each (128 accumulator registers; per 4-row step 8 A fragments and 2 x 32 bytes of
+//     B per lane: 8 LDS instructions for 64 MFMAs, where 64 x 64 per wave took 12), two workgroups per CU.
 //   * global_load_lds_dwordx4: lane l of a wave lands its 16 bytes at the instruction's LDS base + 16 l -- one
 //     instruction is one 128-double row of a tile, no staging registers, no ds_write, and the loads of three tiles
 //     are in flight while a fourth feeds the matrix pipe (a ring of four 8-row tiles per operand, 72 KB).  The
@@ -344,7 +345,8 @@ __global__ __launch_bounds__(256, 2) void gemm_m4_tn_kernel(int M, int N, int K,
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wc = wave;  // four waves side by side: 128 rows x 32 columns each (TM x TN fragments of 16)
+    constexpr int TM = 8, TN = 2;
     const int fr = lane & 15, fk = lane >> 4;
 
     // this lane's 16 bytes of a row: doubles 2 lane, 2 lane + 1 of the tile (column 0 of the row past the edge)
@@ -392,33 +394,33 @@ __global__ __launch_bounds__(256, 2) void gemm_m4_tn_kernel(int M, int N, int K,
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
 
-    v4f64 acc[4][4];
+    v4f64 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < TN; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
-    auto read_frags = [&](int kt, int kk, double (&af)[4], v4f64 (&bq)[4]) {
+    auto read_frags = [&](int kt, int kk, double (&af)[TM], v4f64 (&bq)[TN]) {
         const double* as = smem + ((kt & (DNB - 1)) * 2 + 0) * (DK * DLD);
         const double* bs = smem + ((kt & (DNB - 1)) * 2 + 1) * (DK * DLD);
         const int krow = kk * 4 + fk;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = as[krow * DLD + wr * 64 + i * 16 + fr];
+        for (int i = 0; i < TM; ++i) af[i] = as[krow * DLD + i * 16 + fr];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const v4f64*>(&bs[krow * DLD + wc * 64 + j * 16 + 4 * (lane & 3)]);
+        for (int j = 0; j < TN; ++j) bq[j] = *reinterpret_cast<const v4f64*>(&bs[krow * DLD + wc * 32 + j * 16 + 4 * (lane & 3)]);
     };
-    auto products = [&](const double (&af)[4], const v4f64 (&bq)[4]) {
+    auto products = [&](const double (&af)[TM], const v4f64 (&bq)[TN]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     acc[i][j][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[i], bq[j][t], acc[i][j][t], 0, 0, 0);
     };
     static_assert(DK == 8, "two steps per tile");
-    double af0[4], af1[4];
-    v4f64 bq0[4], bq1[4];
+    double af0[TM], af1[TM];
+    v4f64 bq0[TN], bq1[TN];
     issue(0);
     issue(1);
     issue(2);
@@ -444,12 +446,12 @@ __global__ __launch_bounds__(256, 2) void gemm_m4_tn_kernel(int M, int N, int K,
     // epilogue: the lane holds row 4 b + fk, columns 4 (lane & 3) .. + 3 of each 16 x 16 tile
     const bool vec_c = ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(C2)) & 15) == 0 && ldc % 2 == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + wr * 64 + i * 16 + 4 * ((lane >> 2) & 3) + fk;
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + i * 16 + 4 * ((lane >> 2) & 3) + fk;
         if (row >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wc * 64 + j * 16 + 4 * (lane & 3);
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wc * 32 + j * 16 + 4 * (lane & 3);
             if (col >= N) continue;
             double* c = C + (int64_t)row * ldc + col;
             double v[4];
