@@ -627,7 +627,7 @@ inline bool tn_dma_ok(int64_t m, int64_t n, int64_t k, int vec_a, int vec_b) {
         const char* e = getenv("NBX_GEMM_DMA");
         return e == nullptr || e[0] != '0';
     }();
-    return on && vec_a && vec_b && m > 64 && n > 64 && k % 4 == 0 && m % 2 == 0 && n % 2 == 0;
+    return on && vec_a && vec_b && m > 64 && n > 64 && k >= 4 && k % 4 == 0 && m % 2 == 0 && n % 2 == 0;
 }
 
 void launch_tn_dma(nbx_ctx* ctx, int M, int N, int K, double alpha, const double* A, int64_t lda, int64_t sa, const double* B,

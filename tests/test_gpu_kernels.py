@@ -124,6 +124,30 @@ def test_gemm_large_tile_path(be):
     np.testing.assert_allclose(got, a.T @ b, rtol=0, atol=1e-11)
 
 
+@pytest.mark.parametrize("mnk", [(256, 4096, 4), (130, 8190, 12), (200, 3000, 148), (128, 70000, 20), (66, 66 * 128, 2000)])
+def test_gemm_tn_lds_dma_kernel_edges(be, mnk):
+    """gemm_m4_tn_kernel ('T','N' operands, k-tiles by LDS-DMA, v_mfma_f64_4x4x4): a single 4-row step, a tile and a
+    half, edge tiles whose clamped loads bring columns nobody stores, a long k -- against numpy; batched with alpha and
+    beta; and the shapes it must hand back to the register-staged kernel (odd extents, k not a multiple of 4, k = 0)."""
+    m, n, k = mnk
+    a, b = rnd(57, k, m), rnd(58, k, n)
+    got = be.to_host(be.gemm(be.asarray(a), be.asarray(b), "T", "N"))
+    np.testing.assert_allclose(got, a.T @ b, rtol=0, atol=2e-13 * k)
+    if k == 148:
+        a3, b3, c0 = rnd(59, 5, k, m), rnd(60, 5, k, n), rnd(61, 5, m, n)
+        out = be.asarray(c0)
+        be.gemm(be.asarray(a3), be.asarray(b3), "T", "N", alpha=0.5, beta=-2.0, out=out)
+        np.testing.assert_allclose(be.to_host(out), 0.5 * np.einsum("bkm,bkn->bmn", a3, b3) - 2.0 * c0, rtol=0, atol=1e-11)
+        for mm, nn, kk in [(201, 3000, 148), (200, 3001, 148), (200, 3000, 150)]:
+            a2, b2 = rnd(62, kk, mm), rnd(63, kk, nn)
+            got2 = be.to_host(be.gemm(be.asarray(a2), be.asarray(b2), "T", "N"))
+            np.testing.assert_allclose(got2, a2.T @ b2, rtol=0, atol=1e-11)
+        c1 = rnd(64, m, n)
+        out = be.asarray(c1)
+        be.gemm_raw("T", "N", m, n, 0, 1.0, out, m, 0, out, n, 0, 0.5, out, n, 0, 1)  # k = 0: C <- beta C
+        np.testing.assert_allclose(be.to_host(out), 0.5 * c1, rtol=0, atol=0)
+
+
 # ---------------------------------------------------------------- element-wise / reductions
 def test_fock_and_huzinaga_and_scalars(be):
     n = 37
