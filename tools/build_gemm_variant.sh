@@ -1,6 +1,6 @@
 #!/bin/bash
 # An alternative libnbx.so whose gemm.hip is compiled with extra flags (A/B measurements through NBX_LIB):
-#   tools/build_gemm_variant.sh NAME "-DNBX_GEMM_DBG=1"   ->  scratch/libnbx_NAME.so
+#   tools/build_gemm_variant.sh NAME "-DNBX_TN_DBG=5"   ->  scratch/libnbx_NAME.so   (bits: see gemm.hip)
 set -e
 cd "$(dirname "$0")/../nbed_amd/csrc"
 mkdir -p ../../build/variants ../../scratch

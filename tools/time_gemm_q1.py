@@ -1,5 +1,5 @@
 """The quarter-1 product of the active-space transform as a bare GEMM: C (n x cols) = A^T (n x K) . B (K x cols) with
-n = 128 and K = 148 (octane / 6-31G*) or 2000, timed with events on the stream.  NBX_LIB / NBX_GEMM_M4 choose the
+n = 128 and K = 148 (octane / 6-31G*) or 2000, timed with events on the stream.  NBX_LIB / NBX_GEMM_DMA=0 choose the
 build and the MFMA form:   python tools/time_gemm_q1.py [K] [cols] [reps]"""
 import os
 import sys
