@@ -64,9 +64,11 @@ int nbx_free(nbx_ctx* ctx, void* d_ptr);
 int nbx_memcpy_h2d(nbx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int nbx_memcpy_d2h(nbx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronises */
 /* count <= 8 device arrays of doubles, one after the other, into h_dst: PINNED (device-mapped) host memory the
- * kernel stores to directly -- one launch, one wait (the results of an SCF run).  Synchronises. */
+ * kernel stores to directly -- one launch (the results of an SCF run).  h_dst: sum(n_doubles) + 1 doubles; the
+ * last one receives 1.0 once everything before it is visible to the host.  wait != 0: synchronises the stream;
+ * wait = 0: returns after the launch -- the caller cleared that word beforehand and polls it. */
 int nbx_gather_to_host(nbx_ctx* ctx, int64_t count, const double* const* d_src, const int64_t* n_doubles,
-                       double* h_dst);
+                       double* h_dst, int wait);
 int nbx_memcpy_d2d(nbx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 int nbx_memset(nbx_ctx* ctx, void* d_ptr, int value, size_t bytes);
 

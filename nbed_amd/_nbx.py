@@ -72,7 +72,7 @@ SIGNATURES = {
     "nbx_free": (c_int, [_P, _P]),
     "nbx_memcpy_h2d": (c_int, [_P, _P, _P, c_size_t]),
     "nbx_memcpy_d2h": (c_int, [_P, _P, _P, c_size_t]),
-    "nbx_gather_to_host": (c_int, [_P, c_int64, _P, _P, _P]),
+    "nbx_gather_to_host": (c_int, [_P, c_int64, _P, _P, _P, c_int]),
     "nbx_jk_df_worksize": (c_size_t, [c_int64, c_int64, c_int64]),
     "nbx_jk_df": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, POINTER(c_int64), _P, _P, c_size_t]),
     "nbx_df_synth": (c_int, [_P, c_int64, c_int64, c_int64, c_uint64, c_double, _P]),

@@ -102,6 +102,16 @@ class _PendingScalars:
         return self._host.numpy()[self._ncore:self._ncore + self._ntail].astype(np.int64)
 
 
+class _Deferred:
+    """Result of a call that is still running: ``get()`` waits for it and returns the value."""
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def get(self):
+        return self._fn()
+
+
 class HipBackend:
     """libnbx on one MI355X."""
 
@@ -252,27 +262,48 @@ class HipBackend:
         flat = self.torch.from_numpy(stage).to(self.device)
         return [flat[o:o + h.size].view(h.shape) for h, o in zip(hs, starts)]
 
-    def to_host_many(self, tensors):
-        """Several small device arrays -> host arrays with ONE copy (and one wait)."""
+    def to_host_many(self, tensors, wait: bool = True):
+        """Several small device arrays -> host arrays with ONE launch.  ``wait=False``: returns a handle at once --
+        the kernel stores straight into pinned memory and a word behind the data tells when it is all there -- whose
+        ``get()`` polls that word and hands out the arrays: host work in between overlaps the transfer."""
         torch = self.torch
         total = sum(int(t.numel()) for t in tensors)
         pin = getattr(self, "_pin_results", None)  # (a pageable destination costs a staging copy per call)
-        if pin is None or pin.numel() < total:
-            pin = self._pin_results = torch.empty(max(total, 1 << 17), dtype=torch.float64, pin_memory=True)
-        if len(tensors) <= 8 and all(t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() for t in tensors):
-            # one kernel that stores straight into the pinned buffer (nbx_gather_to_host), one wait
+        if pin is None or pin.numel() < total + 1:
+            pin = self._pin_results = torch.empty(max(total + 1, 1 << 17), dtype=torch.float64, pin_memory=True)
+        flat = pin.numpy()
+        direct = len(tensors) <= 8 and all(t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() for t in tensors)
+        if direct:
+            # one kernel that stores straight into the pinned buffer (nbx_gather_to_host)
+            flat[total] = 0.0
             srcs = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
             sizes = (ctypes.c_int64 * len(tensors))(*[int(t.numel()) for t in tensors])
-            self._call("nbx_gather_to_host", len(tensors), srcs, sizes, self._p(pin))
+            self._call("nbx_gather_to_host", len(tensors), srcs, sizes, self._p(pin), 1 if wait else 0)
         else:
             pin[:total].copy_(torch.cat([t.reshape(-1) for t in tensors]), non_blocking=True)
             torch.cuda.current_stream(self.device_index).synchronize()
-        flat = pin[:total].numpy()
-        out, off = [], 0
-        for t in tensors:
-            out.append(flat[off:off + t.numel()].reshape(tuple(t.shape)).copy())
-            off += t.numel()
-        return out
+        shapes = [tuple(t.shape) for t in tensors]
+
+        def collect():
+            if direct and not wait and flat[total] != 1.0:
+                deadline = time.monotonic() + 120.0
+                spins = 0
+                while flat[total] != 1.0:
+                    spins += 1
+                    if (spins & 0xfff) == 0 and time.monotonic() > deadline:
+                        torch.cuda.synchronize()
+                        if flat[total] != 1.0:
+                            raise RuntimeError("the gathered results never reached the host")
+            out, off = [], 0
+            for shp in shapes:
+                n = int(np.prod(shp)) if len(shp) else 1
+                out.append(flat[off:off + n].reshape(shp).copy())
+                off += n
+            return out
+
+        if wait:
+            return collect()
+        return _Deferred(collect)
 
     def to_host(self, a) -> np.ndarray:
         if isinstance(a, self.torch.Tensor):

@@ -152,7 +152,8 @@ struct GatherArgs {
     int64_t n[8];
     int count;
 };
-__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a, double* __restrict__ dst) {
+__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a, double* __restrict__ dst, int* __restrict__ counter) {
+    __shared__ int last;
     int64_t off = 0;
     for (int i = 0; i < a.count; ++i) {
         const double* __restrict__ s = a.src[i];
@@ -160,13 +161,30 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a, double* __res
             dst[off + j] = s[j];
         off += a.n[i];
     }
+    // the word behind the data says it is all there (as huz_scalars_kernel does): the workgroup that arrives last
+    // stores it, system scope, after every workgroup's stores have been made visible
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = prev == (int)gridDim.x - 1;
+        if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(dst + off, 1.0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 }  // namespace
 
 // Up to 8 device arrays of doubles, one after the other, into `h_dst` -- pinned (device-mapped) host memory the
-// kernel stores to directly: one launch and one wait for the results of an SCF run (C, eps, D, Hz), where a
-// concatenation kernel, a copy and their first-use costs took 0.3 ms of an 8 ms run.  Synchronises.
-int nbx_gather_to_host(nbx_ctx* ctx, int64_t count, const double* const* d_src, const int64_t* n_doubles, double* h_dst) {
+// kernel stores to directly: one launch for the results of an SCF run (C, eps, D, Hz), where a concatenation kernel, a
+// copy and their first-use costs took 0.3 ms of an 8 ms run.  h_dst holds sum(n_doubles) + 1 doubles: the last one
+// receives 1.0 after everything before it is visible to the host, which -- with wait = 0 -- can clear it before the
+// call, do other work and poll it.  wait != 0: synchronises the stream before returning.
+int nbx_gather_to_host(nbx_ctx* ctx, int64_t count, const double* const* d_src, const int64_t* n_doubles, double* h_dst,
+                       int wait) {
     NBX_CHECK_ARG(ctx && d_src && n_doubles && h_dst && count >= 1 && count <= 8);
     GatherArgs a{};
     a.count = (int)count;
@@ -177,12 +195,11 @@ int nbx_gather_to_host(nbx_ctx* ctx, int64_t count, const double* const* d_src, 
         a.n[i] = n_doubles[i];
         total += n_doubles[i];
     }
-    if (total > 0) {
-        const unsigned blocks = (unsigned)((total + 2047) / 2048 < 256 ? (total + 2047) / 2048 : 256);
-        hipLaunchKernelGGL(gather_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, ctx->stream, a, h_dst);
-        NBX_LAUNCH_CHECK();
-    }
-    NBX_HIP(hipStreamSynchronize(ctx->stream));
+    const unsigned blocks = (unsigned)((total + 2047) / 2048 < 256 ? (total + 2047) / 2048 : 256);
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, ctx->stream, a, h_dst,
+                       ctx->d_counters + NBX_COUNTERS - 2);
+    NBX_LAUNCH_CHECK();
+    if (wait) NBX_HIP(hipStreamSynchronize(ctx->stream));
     return NBX_OK;
 }
 

@@ -113,9 +113,9 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
             }
         }
     }
-    off2 = nbx_wave_sum(off2);
-    r2 = nbx_wave_sum(r2);
-    a2 = nbx_wave_sum(a2);
+    off2 = nbx_wave_sum_dpp(off2);  // (every lane is active here; lane moves instead of six LDS round trips each)
+    r2 = nbx_wave_sum_dpp(r2);
+    a2 = nbx_wave_sum_dpp(a2);
     __syncthreads();
     if (lane == 0) {
         red[wave] = off2;
@@ -216,11 +216,8 @@ __global__ __launch_bounds__(RF_THREADS) void refine_e_kernel(int N, const doubl
             }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        emax = fmax(emax, __shfl_xor(emax, o));
-        cmax = fmax(cmax, __shfl_xor(cmax, o));
-    }
+    emax = -nbx_wave_min_dpp(-emax);
+    cmax = -nbx_wave_min_dpp(-cmax);
     __syncthreads();
     if (lane == 0) {
         red[wave] = emax;

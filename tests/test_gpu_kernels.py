@@ -282,6 +282,9 @@ def test_results_gathered_to_host_in_one_launch(be):
     np.testing.assert_array_equal(out[0], arrs[0].transpose(0, 2, 1))
     np.testing.assert_array_equal(out[1], arrs[1])
     assert out[2].size == 0
+    later = be.to_host_many(dev, wait=False)  # returns at once; get() polls the word the kernel stores last
+    for got, want in zip(later.get(), arrs):
+        np.testing.assert_array_equal(got, want)
     big = be.asarray(rnd(94, 300000))  # larger than the landing buffer the backend starts with
     np.testing.assert_array_equal(be.to_host_many([big, dev[3]])[0], be.to_host(big))
 
