@@ -111,10 +111,15 @@ __global__ __launch_bounds__(64) void huzinaga_fused_kernel(const double* __rest
     const double* dsi = DS + (oki ? ri : 0);
     ew_v4f64 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
     const bool diag = ti == tj;
-    for (int k0 = 0; k0 < N; k0 += 16) {
-        double a1[4], b1[4], a2[4], b2[4];
+    // The operands of HZ_STEPS MFMA steps (4 k each) are requested in ONE trip to L2 -- N = 148 is two trips -- where a
+    // 16-wide k loop waited out a memory latency per trip: ten of them, the whole 11.6 us this kernel took on the SCF's
+    // critical path (the anti-pattern gemm_small_kernel was written to avoid).  One wavefront per workgroup: the
+    // 4 x HZ_STEPS operand registers are there.  Same k order, same MFMAs: bitwise the same result.
+    constexpr int HZ_STEPS = 20;
+    for (int k0 = 0; k0 < N; k0 += 4 * HZ_STEPS) {
+        double a1[HZ_STEPS], b1[HZ_STEPS], a2[HZ_STEPS], b2[HZ_STEPS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < HZ_STEPS; ++j) {
             const int k = k0 + 4 * j + fk;
             const bool in = k < N;
             a1[j] = (in && oki) ? fi[k] : 0.0;
@@ -123,9 +128,11 @@ __global__ __launch_bounds__(64) void huzinaga_fused_kernel(const double* __rest
             b2[j] = (in && oki && !diag) ? dsi[(int64_t)k * N] : 0.0;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], b1[j], acc1, 0, 0, 0);
-            if (!diag) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[j], b2[j], acc2, 0, 0, 0);
+        for (int j = 0; j < HZ_STEPS; ++j) {
+            if (k0 + 4 * j < N) {  // uniform (steps past N would multiply zeros; the old loop ran to the next multiple of 16)
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], b1[j], acc1, 0, 0, 0);
+                if (!diag) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[j], b2[j], acc2, 0, 0, 0);
+            }
         }
     }
     if (diag) acc2 = acc1;
