@@ -11,8 +11,12 @@
 //
 // Layout (nbx_eri_pack makes it for the sizes this kernel serves): the tiles T(p,q) = p(p+1)/2 + q, q <= p, in
 // sequence; a tile is the lower triangle of M in 4 x 4 BLOCKS, block (T, C <= T) at T(T+1)/2 + C, 16 doubles each,
-// element (row i, column k) at 4 k + i, the upper part of the diagonal blocks stored as zeros.  With lane = 16 a + 4 b + c
-// the operands of one MFMA are
+// element (row i, column k) at 4 (k ^ ((T ^ C) & 3)) + (i ^ k), the upper part of the diagonal blocks stored as zeros.
+// (The swizzle: an LDS pass serves 16 lanes = one value of a; with the plain order 4 k + i the row part's four 32-byte
+// runs start at the same bank and the column part's 16 elements sit 32 bytes apart -- 4-way conflicts both, more than
+// half of the LDS cycles of the kernel by the SQ counters, profiles/r03/jk_m4_sq_counters.txt.  With it the four runs
+// of the row part land in four different quarters of the 128-byte bank row and the column part's 16 elements in 16
+// different 8-byte slots.)  With lane = 16 a + 4 b + c the operands of one MFMA are
 //   row part    item (G, C):  A = block (4 G + b, C) element (c, a)    B = X[4 C + a][c]   D -> out rows 16 G + 4 b + a
 //   column part item (T, H):  A = block (T, 4 H + b) element (a, c)    B = X[4 T + a][c]   D -> out rows 16 H + 4 b + a
 // -- the column part reads four consecutive blocks (512 contiguous bytes, conflict free), the row part four runs of
@@ -98,8 +102,9 @@ __global__ __launch_bounds__(256) void m4_pack_kernel(const double* __restrict__
     const double* src = eri + ((int64_t)(p - p0) * G::N + q) * G::N * G::N;
     double* dst = out + (int64_t)blockIdx.x * G::TILE;
     for (int e = threadIdx.x; e < G::TILE; e += 256) {
-        const int blk = e >> 4, k = (e >> 2) & 3, i = e & 3;
+        const int blk = e >> 4;
         const int bt = m4_tri_row(blk), bc = blk - m4_tri(bt);
+        const int k = ((e >> 2) & 3) ^ ((bt ^ bc) & 3), i = (e & 3) ^ k;  // (the swizzle: see the layout note above)
         const int row = 4 * bt + i, col = 4 * bc + k;
         dst[e] = col <= row ? src[(int64_t)row * G::N + col] : 0.0;
     }
@@ -120,8 +125,9 @@ __global__ __launch_bounds__(256) void m4_weights_kernel(const double* __restric
     for (int e = 0; e < 2; ++e) {
         const int d = d0 + e;
         if (d >= dend) continue;
-        const int blk = d >> 4, kk = (d >> 2) & 3, ii = d & 3;
+        const int blk = d >> 4;
         const int bt = m4_tri_row(blk), bc = blk - m4_tri(bt);
+        const int kk = ((d >> 2) & 3) ^ ((bt ^ bc) & 3), ii = (d & 3) ^ kk;
         const int row = 4 * bt + ii, col = 4 * bc + kk;
         if (col > row) continue;
         double v = 0.0, vt = 0.0;
@@ -150,8 +156,9 @@ __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, co
     // tile in the kernel (1.65 us in isolation, where the compiler had batched the reads).  Two operand sets: the reads
     // of group j + 1 are issued before the MFMAs of group j (the memory clobbers keep them there).
     constexpr int NJR = (NB + 3) / 4, NJC = (RB - RA + 3) / 4;
-    const int lo_row = 4 * a + c;
-    const int lo_col = 16 * b + 4 * c + a;
+    // element (i, k) of block (T, C) sits at 4 (k ^ ((T ^ C) & 3)) + (i ^ k): the row part's T & 3 is b and its C & 3 is w4
+    const int lo_row = 4 * (a ^ b ^ w4) + (c ^ a);
+    const int lo_col0 = 16 * b + (a ^ c), cb_x = c ^ b;  // column part: + 4 (cb_x ^ (T & 3)) once T is known
     auto row_live = [](int j) constexpr { return j < NJR && 4 * j < RB; };  // (static: a block of this column group lies in the chunk)
     auto load_row = [&](int j, double (&av)[NG], double& bx) {
         if (!row_live(j)) return;
@@ -184,7 +191,7 @@ __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, co
         if (j >= NJC) return;
         const int T = min(RA + 4 * j + w4, RB - 1);  // (clamped: the surplus block row of the last j is masked below)
         bt = xs[4 * (4 * T + a) + c];
-        const double* lt = buf + 16 * (m4_tri(T) - BASE) + lo_col;
+        const double* lt = buf + 16 * (m4_tri(T) - BASE) + lo_col0 + 4 * (cb_x ^ (T & 3));
 #pragma unroll
         for (int H = 0; H < NG; ++H) {
             if (4 * H > RA + 4 * j + 3) continue;  // static: the whole group lies right of every T of this j
