@@ -143,55 +143,73 @@ __global__ __launch_bounds__(256) void m4_weights_kernel(const double* __restric
 // ---------------------------------------------------------------------------------------------- the walk of one chunk
 // buf: the chunk in LDS (block (T, C) at 16 (tri(T) - tri(RA) + C)); xs: X[N][4] of this tile; acc[G]: this wave's partial
 // out rows 16 G + 4 b + a (D layout of the 4x4x4 product: lane 16 i + 4 b + j holds D_b[i][j]).
+//
+// The walking wave is bound by the number of instructions it issues (one per ~9 cycles, alone on its SIMD next to a
+// loading wave), so the walk is written to issue few besides its reads and MFMAs:
+//   * addresses: lane.rowg[G] = 64 G b + 16 (tri(b) + w4) + 4 (a ^ b ^ w4) + (c ^ a) holds everything of a row-part
+//     operand's address that depends on the lane or the wave (ten registers for the whole kernel); the chunk's slot is
+//     added once per row group and chunk and the rest of every address is a constant in the instruction's offset field;
+//     the X operand likewise (lane.xrow + 64 j);
+//   * masks: a block row outside the chunk (the chunk boundaries cut through groups of four rows) or past the matrix is
+//     taken care of ONCE per row group and chunk by pointing that lane's base beyond the workgroup's LDS allocation
+//     -- reads there return zero -- instead of a select per operand; what is left are the selects of the items that
+//     touch the diagonal (C <= T, strict lower part of the diagonal blocks).
+struct M4Lane {
+    int a, b, c;      // lane = 16 a + 4 b + c
+    int rowg[16];     // row part: see above (NG <= 16)
+    int xrow;         // 4 a + c + 16 w4: the X element of block column C = 4 j + w4 is at xrow + 64 j
+    int col0, cbx;    // column part: 16 b + (a ^ c), c ^ b
+    int xlane;        // 4 a + c
+};
+constexpr int M4_LDS_OOB = 0x30000 / 8;  // (doubles) beyond any workgroup's allocation, with room for the offsets
+
 template <int NB, int K>
-__device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, const double* __restrict__ xs, int w4, int a,
-                                              int b, int c, double (&acc)[M4Geom<NB>::NG]) {
+__device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, const double* __restrict__ xs, int w4,
+                                              const M4Lane& ln, double (&acc)[M4Geom<NB>::NG]) {
     using G_ = M4Geom<NB>;
     constexpr int RA = G_::row0(K), RB = G_::row0(K + 1), NG = G_::NG;
     constexpr int BASE = m4_tri(RA);
-    // ---- row part: items (G, C = 4 j + w4), C <= T = 4 G + b, T in [RA, RB); then the column part: items
-    // (T = RA + 4 j + w4, H), block columns 4 H + b < T, or == T with the strict lower part.
-    // A consumer wave shares its SIMD with one producer wave only, so an LDS round trip between the reads of an item group
-    // and its MFMAs is fully exposed: with one group read, waited for and multiplied at a time the walk took 4.7 us per
-    // tile in the kernel (1.65 us in isolation, where the compiler had batched the reads).  Two operand sets: the reads
-    // of group j + 1 are issued before the MFMAs of group j (the memory clobbers keep them there).
     constexpr int NJR = (NB + 3) / 4, NJC = (RB - RA + 3) / 4;
-    // element (i, k) of block (T, C) sits at 4 (k ^ ((T ^ C) & 3)) + (i ^ k): the row part's T & 3 is b and its C & 3 is w4
-    const int lo_row = 4 * (a ^ b ^ w4) + (c ^ a);
-    const int lo_col0 = 16 * b + (a ^ c), cb_x = c ^ b;  // column part: + 4 (cb_x ^ (T & 3)) once T is known
+    const int a = ln.a, b = ln.b, c = ln.c;
+    // ---- row part: items (G, C = 4 j + w4), C <= T = 4 G + b, T in [RA, RB)
+    const double* bg[NG];
+#pragma unroll
+    for (int G = 0; G < NG; ++G) {
+        if (4 * G + 3 < RA || 4 * G >= RB) continue;  // static: the group has no row in the chunk
+        const bool whole = 4 * G >= RA && 4 * G + 3 < RB && 4 * G + 3 < NB;  // static
+        const int T = 4 * G + b;
+        bg[G] = buf + ((whole || (T >= RA && T < RB && T < NB)) ? ln.rowg[G] : M4_LDS_OOB);
+    }
+    const double* xr = xs + ln.xrow;
     auto row_live = [](int j) constexpr { return j < NJR && 4 * j < RB; };  // (static: a block of this column group lies in the chunk)
     auto load_row = [&](int j, double (&av)[NG], double& bx) {
         if (!row_live(j)) return;
-        const int C = min(4 * j + w4, NB - 1);  // (clamped: the surplus column group of the last j is masked below)
-        bx = xs[4 * (4 * C + a) + c];
+        bx = xr[64 * j];  // (C past the matrix: finite LDS data times the zeros of the masked operand below)
 #pragma unroll
         for (int G = 0; G < NG; ++G) {
             if (G < j || 4 * G + 3 < RA || 4 * G >= RB) continue;  // static
-            // block (T = 4 G + b, C): tri(4 G + b) = tri(4 G) + 4 G b + tri(b).  The load is unconditional (LDS reads
-            // beyond the allocation return zero, everything else in the workgroup's LDS is finite data), the mask a select.
-            av[G] = buf[16 * (m4_tri(4 * G) - BASE + 4 * j) + 16 * (G * 4 * b + m4_tri(b) + w4) + lo_row];
+            // block (T = 4 G + b, C): tri(4 G + b) = tri(4 G) + 4 G b + tri(b)
+            av[G] = bg[G][16 * (m4_tri(4 * G) - BASE + 4 * j)];
         }
     };
     auto mma_row = [&](int j, const double (&av)[NG], double bx) {
         if (!row_live(j)) return;
-        const int C = 4 * j + w4;
-        const bool c_ok = 4 * j + 3 < NB || C < NB;
 #pragma unroll
         for (int G = 0; G < NG; ++G) {
             if (G < j || 4 * G + 3 < RA || 4 * G >= RB) continue;  // static
             double v = av[G];
-            if (!(4 * G >= RA && 4 * G + 3 < RB && 4 * G + 3 < NB && j < G && 4 * j + 3 < NB)) {  // (static: else all valid)
-                const int T = 4 * G + b;
-                v = (c_ok && T >= RA && T < RB && T < NB && C <= T) ? v : 0.0;
-            }
+            if (G == j) v = (b >= w4 && 4 * j + w4 < NB) ? v : 0.0;  // the diagonal group: C <= T, and C inside the matrix
             acc[G] = __builtin_amdgcn_mfma_f64_4x4x4f64(v, bx, acc[G], 0, 0, 0);
         }
     };
+    // ---- column part: items (T = RA + 4 j + w4, H), block columns 4 H + b < T, or == T with the strict lower part
     auto load_col = [&](int j, double (&av)[NG], double& bt) {
         if (j >= NJC) return;
-        const int T = min(RA + 4 * j + w4, RB - 1);  // (clamped: the surplus block row of the last j is masked below)
-        bt = xs[4 * (4 * T + a) + c];
-        const double* lt = buf + 16 * (m4_tri(T) - BASE) + lo_col0 + 4 * (cb_x ^ (T & 3));
+        const int Tu = RA + 4 * j + w4;                // (uniform)
+        const bool t_ok = RA + 4 * j + 3 < RB || Tu < RB;
+        const int T = t_ok ? Tu : RB - 1;
+        bt = xs[16 * T + ln.xlane];
+        const double* lt = (t_ok ? buf : buf + M4_LDS_OOB) + 16 * (m4_tri(T) - BASE) + ln.col0 + 4 * (ln.cbx ^ (T & 3));
 #pragma unroll
         for (int H = 0; H < NG; ++H) {
             if (4 * H > RA + 4 * j + 3) continue;  // static: the whole group lies right of every T of this j
@@ -201,20 +219,19 @@ __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, co
     auto mma_col = [&](int j, const double (&av)[NG], double bt) {
         if (j >= NJC) return;
         const int T = RA + 4 * j + w4;
-        const bool t_ok = RA + 4 * j + 3 < RB || T < RB;
 #pragma unroll
         for (int H = 0; H < NG; ++H) {
             if (4 * H > RA + 4 * j + 3) continue;  // static
             double v = av[H];
-            if (!(4 * H + 3 < RA + 4 * j && RA + 4 * j + 3 < RB)) {  // (static: else every lane is valid)
+            if (!(4 * H + 3 < RA + 4 * j)) {  // (static: else every block column of the group is left of every T of this j)
                 const int cb = 4 * H + b;
-                v = (t_ok && (cb < T || (cb == T && c < a))) ? v : 0.0;
+                v = (cb < T || (cb == T && c < a)) ? v : 0.0;
             }
             acc[H] = __builtin_amdgcn_mfma_f64_4x4x4f64(v, bt, acc[H], 0, 0, 0);
         }
     };
     // every operand of the chunk's row part is requested, then every operand of its column part, before the first MFMA
-    // of either: two LDS round trips per chunk instead of one per item group (~18 per chunk)
+    // of either: two LDS round trips per chunk instead of one per item group
     double avr[NJR][NG], bxr[NJR], avc[NJC][NG], btc[NJC];
 #pragma unroll
     for (int j = 0; j < NJR; ++j) load_row(j, avr[j], bxr[j]);
@@ -335,6 +352,21 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
     double acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = 0.0;
+    M4Lane ln;
+    ln.a = lane >> 4;
+    ln.b = (lane >> 2) & 3;
+    ln.c = lane & 3;
+    {
+        const int w4 = wave & 3;
+        static_assert(NG <= 16, "M4Lane::rowg");
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            ln.rowg[g] = 64 * g * ln.b + 16 * (m4_tri(ln.b) + w4) + 4 * (ln.a ^ ln.b ^ w4) + (ln.c ^ ln.a);
+        ln.xlane = 4 * ln.a + ln.c;
+        ln.xrow = ln.xlane + 16 * w4;
+        ln.col0 = 16 * ln.b + (ln.a ^ ln.c);
+        ln.cbx = ln.c ^ ln.b;
+    }
 
     // ------------------------------------------------------------------ prologue: four chunks in flight, chunk 0 and X in LDS
     int p = p_first, q = (int)(T0 - (int64_t)p * (p + 1) / 2);
@@ -432,15 +464,10 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                 const double* buf = buf0 + slot * BUF;
                 slot = slot + 1 == M4_RING ? 0 : slot + 1;
 #ifndef NBX_M4_NO_WALK
-                // (the lane is made opaque per chunk: the ~100 per-lane LDS addresses of a walk are loop invariant, and
-                // hoisted out of the tile loop they would occupy -- spill -- a register each)
-                int lane_o = lane;
-                asm volatile("" : "+v"(lane_o));
-                const int a = lane_o >> 4, b = (lane_o >> 2) & 3, c = lane_o & 3;
-                if (k == 0) m4_walk_chunk<NB, 0>(buf, xs, wave, a, b, c, acc);
-                else if (k == 1) m4_walk_chunk<NB, 1>(buf, xs, wave, a, b, c, acc);
-                else if (k == 2) m4_walk_chunk<NB, 2>(buf, xs, wave, a, b, c, acc);
-                else m4_walk_chunk<NB, 3>(buf, xs, wave, a, b, c, acc);
+                if (k == 0) m4_walk_chunk<NB, 0>(buf, xs, wave, ln, acc);
+                else if (k == 1) m4_walk_chunk<NB, 1>(buf, xs, wave, ln, acc);
+                else if (k == 2) m4_walk_chunk<NB, 2>(buf, xs, wave, ln, acc);
+                else m4_walk_chunk<NB, 3>(buf, xs, wave, ln, acc);
 #endif
                 if (k == 1 && more) store_x(xs0 + ((t + 1) & 1) * 4 * N, xv);
                 if (k == M4_NCH - 1) {
