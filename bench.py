@@ -822,12 +822,16 @@ def main():
         alg_bytes = 8.0 * N * N * ntiles
         # The packed kernel (the one GpuUHF uses where it applies) reads q <= p AND s <= r: the packed
         # slab, once per build.
+        m4 = packed and N == 148 and os.environ.get("NBX_JK_M4", "1") != "0"  # (csrc/jk_m4.hip serves N = 148)
         if packed:
-            alg_bytes = packed_bytes
-        jk_kernel = "jk_s4_kernel" if packed else ("jk_sym_kernel" if sym else "jk_dense_kernel")
+            # the 4-fold unique integrals of the slab's tiles: N(N+1)/2 doubles per tile -- what jk_s4's layout holds
+            # exactly; jk_m4's 4 x 4 blocks store the zeros above the diagonal of the diagonal blocks as well
+            # (bytes_read_by_kernel), which are not required bytes
+            alg_bytes = 8.0 * ntiles * (N * (N + 1) // 2)
+        jk_kernel = ("jk_m4_kernel" if m4 else "jk_s4_kernel") if packed else ("jk_sym_kernel" if sym else "jk_dense_kernel")
         achieved = alg_bytes / (jk_avg_ms * 1e-3) / 1e9 if jk_cnt else None
         traffic = None
-        tfile = REPO / "profiles" / "jk_traffic.json"
+        tfile = REPO / "profiles" / ("r03/jk_m4_traffic.json" if m4 else "jk_traffic.json")
         if tfile.exists() and world == 1 and N == 148:
             try:
                 tj = json.loads(tfile.read_text())
@@ -870,6 +874,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_read_by_kernel": packed_bytes,
                 "algorithmic_bytes_note": (
                     "the 4-fold packed slab (q <= p, s <= r; (pq|rs) = (qp|rs) = (pq|sr)), read once per build: a "
                     "quarter of SURVEY 8d's 8 N^4; dense_equivalent_gbs prices the same launch at 8 N^4"

@@ -557,10 +557,10 @@ int m4_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
 
 }  // namespace
 
-// The sizes this kernel has an instance for (N = 4 NB).  Opt-in while it is being tuned: NBX_JK_M4=1 in the environment
-// (read once per process); otherwise jk_s4.hip serves every size.
+// The sizes this kernel has an instance for (N = 4 NB; every loop bound of the walk is a compile-time constant).
+// NBX_JK_M4=0 in the environment (read once per process) hands them back to jk_s4.hip.
 bool nbx_jk_m4_covers(int64_t N) {
-    static const bool on = getenv("NBX_JK_M4") != nullptr && atoi(getenv("NBX_JK_M4")) != 0;
+    static const bool on = getenv("NBX_JK_M4") == nullptr || atoi(getenv("NBX_JK_M4")) != 0;
     return on && N == 148;
 }
 

@@ -35,15 +35,16 @@
 // The EXPERIMENTAL forms of the packed kernel (parity green, none measurably faster than the
 // kernel in this file) are linked only into a `make EXPERIMENTAL=1` build, where the environment
 // selects them (NBX_JK_M4 / NBX_JK_P8 / NBX_JK_S8 / NBX_JK_DMA); the shipped library holds what runs.
-#ifdef NBX_EXPERIMENTAL
-// jk_m4.hip: the walk on the matrix cores (v_mfma_f64_4x4x4_4b_f64, block-major tiles, producer / consumer waves);
-// NBX_JK_M4=1, N = 148.  Parity green, 0.92-1.01 of this file's kernel time: DESIGN.md section 9
+// jk_m4.hip: the walk on the matrix cores (v_mfma_f64_4x4x4_4b_f64, block-major swizzled tiles streamed into LDS by the
+// load unit, loading / walking waves): serves N = 148 (the size it is instantiated for) unless NBX_JK_M4=0 -- 0.87 of this
+// file's kernel time there
 bool nbx_jk_m4_covers(int64_t N);
 size_t nbx_jk_m4_packed_bytes(int64_t N, int64_t p0, int64_t p1);
 size_t nbx_jk_m4_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm);
 int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
 int nbx_jk_m4(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
               double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf);
+#ifdef NBX_EXPERIMENTAL
 // jk_p8.hip: the 8-fold form (truncated tiles) that serves whole tensors of the NB = 4 / six-loads sizes
 bool nbx_jk_p8_covers(int64_t N, int64_t p0, int64_t p1);
 size_t nbx_jk_p8_packed_bytes(int64_t N);
@@ -67,12 +68,6 @@ int nbx_jk_s4d_launch(nbx_ctx* ctx, int variant, int64_t N, int64_t p0, int64_t 
                       const double* d_packed, const double* d_dm, const double* d_dts, double* d_j, double* k1, double* k2,
                       int64_t t_begin, int64_t t_end, int wgs, int L, int S);
 #else
-static inline bool nbx_jk_m4_covers(int64_t) { return false; }
-static inline size_t nbx_jk_m4_packed_bytes(int64_t, int64_t, int64_t) { return 0; }
-static inline size_t nbx_jk_m4_worksize(int64_t, int64_t, int64_t, int64_t) { return 0; }
-static inline int nbx_jk_m4_pack(nbx_ctx*, int64_t, int64_t, int64_t, const double*, double*) { return NBX_E_UNSUPPORTED; }
-static inline int nbx_jk_m4(nbx_ctx*, int64_t, int64_t, int64_t, const double*, const double*, int64_t, double*, void*,
-                            const double*, double*, double*) { return NBX_E_UNSUPPORTED; }
 static inline bool nbx_jk_p8_covers(int64_t, int64_t, int64_t) { return false; }
 static inline size_t nbx_jk_p8_packed_bytes(int64_t) { return 0; }
 static inline size_t nbx_jk_p8_worksize(int64_t, int64_t) { return 0; }

@@ -276,17 +276,17 @@ def test_jk_lds_dma_experimental_vs_c_oracle(variant):
         assert outs[variant] == outs["0"]
 
 
-@needs_experimental
-def test_jk_mfma_walk_experimental_vs_symmetric_kernel():
-    """csrc/jk_m4.hip (the walk on v_mfma_f64_4x4x4_4b_f64 over block-major tiles, producer / consumer waves; opt-in,
-    NBX_JK_M4=1 is read once per process: a child process) at N = 148, both density counts and row slabs, against the
-    symmetric kernel (itself held to the C oracle above)."""
+@pytest.mark.parametrize("m4", ["1", "0"])
+def test_jk_packed_n148_both_kernels_vs_symmetric_kernel(m4):
+    """N = 148 is served by csrc/jk_m4.hip (the walk on v_mfma_f64_4x4x4_4b_f64 over block-major tiles streamed into LDS by
+    the load unit) unless NBX_JK_M4=0 hands it back to csrc/jk_s4.hip -- the switch is read once per process: a child
+    process each -- both density counts and row slabs, against the symmetric kernel (itself held to the C oracle above)."""
     import os
     import subprocess
     import sys
     from pathlib import Path
 
-    env = dict(os.environ, NBX_JK_M4="1", PYTHONPATH=str(Path(__file__).resolve().parent.parent))
+    env = dict(os.environ, NBX_JK_M4=m4, PYTHONPATH=str(Path(__file__).resolve().parent.parent))
     out = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "tools" / "time_jk_packed.py"), "148"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
