@@ -382,7 +382,6 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         issue(2);
         issue(3);
         m4_wait_three_chunks<LPT>();  // my part of chunk 0
-        jpass(0);
     } else {
         double v[XU];
         fetch_x(p, q, v);
@@ -409,8 +408,11 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                 const int g = M4_NCH * t + k;
                 // step g: the consumers walk chunk g; chunk g + 4 goes into the slot they left at the last barrier
                 // (chunk g - 1's), chunk g + 1 has landed and gives its J contribution
+#ifndef NBX_M4_NO_STAGE
+                issue(g + 4);  // (first: the stream is what the kernel is bound by)
+#endif
                 if (k == 0 && t > 0) {
-                    // the consumers' rows of tile t - 1 (written at its last step, behind that step's barrier)
+                    // the consumers' rows of tile t - 1 (written at its last step, behind that step's barrier), and its J
                     int pp = p, qq = q - 1;
                     if (qq < 0) {
                         pp = p - 1;
@@ -418,23 +420,26 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                     }
                     if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N);
                     if (pp != p) reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N);
+                    if (ptid == 0) {
+                        const double* jr = jred + ((t - 1) & 1) * 4;
+                        const double j = (jr[0] + jr[1]) + (jr[2] + jr[3]);
+                        jfull[(int64_t)pp * N + qq] = j;
+                        jfull[(int64_t)qq * N + pp] = j;
+                    }
                 }
 #ifndef NBX_M4_NO_STAGE
-                issue(g + 4);
-                m4_wait_three_chunks<LPT>();  // my part of chunk g + 1 (chunks g + 2 .. g + 4 may be in flight)
-                if (g + 1 < nstep) jpass(g + 1);
+                // the J contribution of chunk g -- the one the consumers are walking: it landed a step ago, so nothing
+                // but the wait for chunk g + 1 stands between this wave and the barrier once that chunk is there
+                jpass(g);
 #endif
-                if (k == 2) {  // chunk 3 of tile t has just been taken: this wave's share of the tile's J
+                if (k == 3) {  // this wave's share of tile t's J
                     jacc = nbx_wave_sum(jacc);
                     if (lane == 0) jred[(t & 1) * 4 + (wave - 4)] = jacc;
                     jacc = 0.0;
                 }
-                if (k == 3 && ptid == 0) {
-                    const double* jr = jred + (t & 1) * 4;
-                    const double j = (jr[0] + jr[1]) + (jr[2] + jr[3]);
-                    jfull[(int64_t)p * N + q] = j;
-                    jfull[(int64_t)q * N + p] = j;
-                }
+#ifndef NBX_M4_NO_STAGE
+                m4_wait_three_chunks<LPT>();  // my part of chunk g + 1 (chunks g + 2 .. g + 4 may be in flight)
+#endif
                 __syncthreads();
             }
             p = pn;
@@ -449,6 +454,12 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         }
         if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T_end - 1 - t_begin) * NDM) * (int64_t)N);
         reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N);
+        if (ptid == 0) {  // the last tile's J (its partial sums were stored before the last barrier)
+            const double* jr = jred + ((ntile - 1) & 1) * 4;
+            const double j = (jr[0] + jr[1]) + (jr[2] + jr[3]);
+            jfull[(int64_t)pp * N + qq] = j;
+            jfull[(int64_t)qq * N + pp] = j;
+        }
     } else {
         int slot = 0;  // ring slot of the chunk being walked
         for (int t = 0; t < ntile; ++t) {
