@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--no-df", action="store_true", help="skip the density-fitted J/K build at N_AO = 2000 (an extra: the GEMM-shaped J/K)")
     ap.add_argument("--df-naux", type=int, default=4000, help="auxiliary functions of the N_AO = 2000 density-fitted build (128 GB at 4000)")
     ap.add_argument("--n2000-rslabs", type=int, default=4, help="r-slabs of the N_AO=2000 transform per rank")
+    ap.add_argument("--jk-event-every", type=int, default=4,
+                    help="HIP events bracket the J/K kernel of one timed cycle in this many (1 = every cycle)")
     ap.add_argument("--cpu-cycles", type=int, default=8)
     return ap.parse_args()
 
@@ -544,7 +546,9 @@ def main():
             stamps.append(time.perf_counter())
         if i == args.warmup:
             barrier()
-            be.profile(True, slots=[_nbx.PROF_JK_DENSE])  # HIP events around the J/K kernel only (they cost the cycle ~1 %)
+            # HIP events around the J/K kernel only, and around one launch in --jk-event-every: a pair of events holds
+            # the stream for ~11 us (two marker packets; rocprofv3 kernel trace with and without them), 4 % of a cycle
+            be.profile(True, slots=[_nbx.PROF_JK_DENSE], every=max(1, args.jk_event_every))
             be.profile_reset()
             clock["t0"] = time.perf_counter()
             stamps.append(clock["t0"])
@@ -889,6 +893,8 @@ def main():
                                         / HBM_PEAK_GBS) if (jk_cnt and world == 1) else None,
                 "avg_launch_ms": jk_avg_ms,
                 "launches": jk_cnt,
+                "launches_note": f"HIP events around the J/K launch of one timed cycle in {max(1, args.jk_event_every)} "
+                                 "(--jk-event-every; a bracket holds the stream ~11 us)",
             },
             "cpu_baseline": cpu,
             "breakdown_ms_per_cycle": {

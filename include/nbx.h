@@ -101,6 +101,11 @@ int nbx_df_synth(nbx_ctx* ctx, int64_t nao, int64_t l0, int64_t l1, uint64_t see
  * mask (an event pair costs a few microseconds of stream time, which matters inside an SCF
  * cycle: bench.py brackets the J/K kernel only).                                             */
 int nbx_profile_enable(nbx_ctx* ctx, int on);
+/* Bracket only one launch in `every` of each enabled slot (the first after nbx_profile_reset, then every
+ * `every`-th; default 1 = all of them).  An event pair holds the stream for ~11 us (two marker packets of ~6 us
+ * each, measured on a rocprofv3 kernel trace with and without them: profiles/r03/README.md), 4 % of a settled
+ * N_AO = 148 cycle: bench.py samples the J/K launch of every fourth cycle of its timed region.           */
+int nbx_profile_sample(nbx_ctx* ctx, int every);
 int nbx_profile_read(nbx_ctx* ctx, int slot, double* ms_sum, int64_t* count);
 int nbx_profile_reset(nbx_ctx* ctx);
 

@@ -383,8 +383,10 @@ class HipBackend:
         self._work.clear()
 
     # ------------------------------------------------------------------ in-library HIP-event timing
-    def profile(self, on: bool = True, slots=None):
-        """Bracket launches with HIP events; ``slots``: only these NBX_PROF_* slots."""
+    def profile(self, on: bool = True, slots=None, every: int = 1):
+        """Bracket launches with HIP events; ``slots``: only these NBX_PROF_* slots; ``every``: one launch in
+        this many of each slot (an event pair holds the stream ~11 us)."""
+        self._call("nbx_profile_sample", int(every))
         if on and slots is not None:
             mask = 0
             for sl in slots:

@@ -224,6 +224,12 @@ int nbx_profile_enable(nbx_ctx* ctx, int on) {
     return NBX_OK;
 }
 
+int nbx_profile_sample(nbx_ctx* ctx, int every) {
+    NBX_CHECK_ARG(ctx != nullptr && every >= 1);
+    ctx->prof_every = every;
+    return NBX_OK;
+}
+
 static int prof_drain(nbx_ctx* ctx, int slot) {
     nbx_prof_slot& ps = ctx->prof[slot];
     for (size_t i = 0; i < ps.start.size(); ++i) {
@@ -256,6 +262,7 @@ int nbx_profile_reset(nbx_ctx* ctx) {
         if (rc != NBX_OK) return rc;
         ctx->prof[s].ms_sum = 0.0;
         ctx->prof[s].count = 0;
+        ctx->prof[s].seen = 0;
     }
     return NBX_OK;
 }

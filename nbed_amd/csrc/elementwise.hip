@@ -4,6 +4,7 @@
 // accesses, transposed operands staged through a padded LDS tile, wavefront
 // reductions for the scalar outputs.
 #include "nbx_common.h"
+#include "jk_m4_layout.h"
 #include "jk_s4_layout.h"
 
 namespace {
@@ -202,7 +203,7 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
                                    double* __restrict__ partial, double* __restrict__ out_final = nullptr,
                                    const int* __restrict__ tail = nullptr, int tail_n = 0,
                                    int* __restrict__ counter = nullptr, double* __restrict__ dts = nullptr,
-                                   int s4_nb_ = 0, int s4_lpt_ = 0) {
+                                   int s4_nb_ = 0, int s4_lpt_ = 0, int dts_m4 = 0) {
     // A kernel on the SCF's critical path: everything it reads is requested in one trip to memory (both spins'
     // tiles at once), the sums travel by lane moves, and the workgroup that arrives last adds the four columns
     // of partials side by side -- three dependent round trips to L2 where there were nine.
@@ -262,7 +263,13 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
         for (int w = 0; w < nwave; ++w) t += red[tid][w];
         partial[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + tid] = t;
     }
-    if (dts != nullptr && i0 >= j0) {
+    if (dts != nullptr && i0 >= j0 && dts_m4) {  // (jk_m4.hip's order: N = 148)
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int gi = i0 + threadIdx.y + 8 * k, gj = j0 + threadIdx.x;
+            if (gi < N && gj <= gi) dts[m4_weight_index<37>(gi, gj)] = gi == gj ? dsum[k] : dsum[k] + tsum[k];
+        }
+    } else if (dts != nullptr && i0 >= j0) {
         const S4Geom g = s4_geom(N, s4_nb_);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -1178,6 +1185,7 @@ int nbx_huz_cycle_scalars_dts(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
                               const double* d_dm_old, double* d_out, const int* d_tail, int64_t tail_n,
                               double* d_dts) {
     NBX_CHECK_ARG(ctx && d_hcore && d_vhf && d_hz && d_dm && d_dm_old && d_out && nao > 0);
+    const int m4 = d_dts && nbx_jk_m4_covers(nao) ? 1 : 0;  // (N = 148: the table in jk_m4.hip's order)
     const int nb4 = d_dts ? s4_nb(nao) : 0, lpt4 = d_dts ? s4_lpt(nao) : 0;
     NBX_CHECK_ARG(d_dts == nullptr || lpt4 > 0);  // the table exists for sizes nbx_jk_packed covers
     NBX_CHECK_ARG(tail_n >= 0 && tail_n <= 64 && (tail_n == 0 || d_tail != nullptr));
@@ -1189,12 +1197,12 @@ int nbx_huz_cycle_scalars_dts(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
     if (fine)
         hipLaunchKernelGGL(huz_scalars_kernel<16>, dim3((unsigned)g, (unsigned)g), dim3(16, 8), 0, ctx->stream, d_hcore,
                            hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch,
-                           d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1, d_dts, nb4, lpt4);
+                           d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1, d_dts, nb4, lpt4, m4);
     else
         hipLaunchKernelGGL(huz_scalars_kernel<TILE>, dim3((unsigned)g, (unsigned)g), dim3(TILE, 8), 0, ctx->stream,
                            d_hcore, hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao,
                            ctx->d_scratch, d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1, d_dts, nb4,
-                           lpt4);
+                           lpt4, m4);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

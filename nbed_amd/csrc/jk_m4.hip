@@ -32,6 +32,7 @@
 // partials when the range crosses a row, both summed in a fixed order by jk_sym_reduce_kernel (with the Fock epilogue).
 #include <cstdlib>
 
+#include "jk_m4_layout.h"
 #include "nbx_common.h"
 
 // (m0 is named as a clobber of the LDS-DMA asm below; clang calls that a reserved register)
@@ -39,7 +40,7 @@
 
 namespace {
 
-constexpr int M4_THREADS = 512, M4_PROD_THREADS = 256, M4_CUS = 256, M4_NCH = 4;  // 4 consumer + 4 producer waves
+constexpr int M4_THREADS = 512, M4_CUS = 256;  // 4 consumer + 4 producer waves (M4_PROD_THREADS, M4_NCH: jk_m4_layout.h)
 constexpr int M4_PER_CU = 1;
 constexpr int M4_RING = 5;  // chunk buffers in LDS: one being walked, one landed (its J taken), three in flight
 typedef __attribute__((address_space(3))) void* m4_lds_vp;
@@ -53,29 +54,6 @@ __device__ __forceinline__ void m4_wait_three_chunks() {
     else if constexpr (LPT == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-
-__host__ __device__ constexpr int m4_tri(int k) { return k * (k + 1) / 2; }
-
-template <int NB>
-struct M4Geom {
-    static constexpr int N = 4 * NB, NG = (NB + 3) / 4, NBLK = m4_tri(NB), TILE = 16 * NBLK;
-    // chunk k holds the block rows [row0(k), row0(k + 1)): the first block row at which a quarter of the blocks is reached
-    static constexpr int row0(int k) {
-        if (k <= 0) return 0;
-        if (k >= M4_NCH) return NB;
-        int t = 0;
-        while (m4_tri(t) * M4_NCH < k * NBLK) ++t;
-        return t;
-    }
-    static constexpr int blocks(int k) { return m4_tri(row0(k + 1)) - m4_tri(row0(k)); }
-    static constexpr int max_blocks() {
-        int m = 0;
-        for (int k = 0; k < M4_NCH; ++k) m = blocks(k) > m ? blocks(k) : m;
-        return m;
-    }
-    static constexpr int LPT = (max_blocks() * 128 + M4_PROD_THREADS * 16 - 1) / (M4_PROD_THREADS * 16);  // 16-byte loads per producer thread
-    static constexpr int BUF = LPT * M4_PROD_THREADS * 2;                                            // doubles per LDS buffer
-};
 
 typedef double m4_d2 __attribute__((ext_vector_type(2)));
 
@@ -529,7 +507,7 @@ M4Plan m4_plan_nb(int64_t p0, int64_t np, int64_t ndm) {
 
 template <int NB>
 int m4_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm, double* d_jk,
-           void* d_work, const double* d_hv, double* d_fock, double* d_vhf) {
+           void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt_in) {
     using G = M4Geom<NB>;
     const int64_t np = p1 - p0, N = G::N, n2 = N * N;
     const M4Plan pl = m4_plan_nb<NB>(p0, np, ndm);
@@ -541,9 +519,13 @@ int m4_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
         const int rc = nbx_memset(ctx, d_jk, 0, (size_t)n2 * sizeof(double));
         if (rc != NBX_OK) return rc;
     }
-    hipLaunchKernelGGL(m4_weights_kernel<NB>, dim3((unsigned)nbx_cdiv(M4_NCH * G::LPT * M4_PROD_THREADS, 256)), dim3(256), 0, ctx->stream,
-                       d_dm, (int)ndm, wt);
-    NBX_LAUNCH_CHECK();
+    if (d_wt_in != nullptr) {  // the caller's table (left by nbx_huz_cycle_scalars_dts for this density)
+        wt = const_cast<double*>(d_wt_in);
+    } else {
+        hipLaunchKernelGGL(m4_weights_kernel<NB>, dim3((unsigned)nbx_cdiv(M4_NCH * G::LPT * M4_PROD_THREADS, 256)), dim3(256), 0,
+                           ctx->stream, d_dm, (int)ndm, wt);
+        NBX_LAUNCH_CHECK();
+    }
     const int64_t t_begin = m4_tri((int)p0), t_end = m4_tri((int)p1);
     {
         nbx_prof_scope prof(ctx, NBX_PROF_JK_DENSE);
@@ -591,8 +573,14 @@ int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double
     return NBX_OK;
 }
 
+// the Dtot' weights table of a density (m4_weight_index order; the entries nothing writes are zero weights)
+size_t nbx_jk_m4_weights_bytes(int64_t N) {
+    return (size_t)(M4_NCH * M4Geom<37>::LPT * M4_PROD_THREADS * 2) * sizeof(double);
+}
+
+// d_wt: NULL, or that table for d_dm (written by huz_scalars_kernel when it judged d_dm): saves the preparation launch
 int nbx_jk_m4(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
-              double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf) {
+              double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt) {
     NBX_CHECK_ARG(nbx_jk_m4_covers(N));
-    return m4_run<37>(ctx, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf);
+    return m4_run<37>(ctx, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_wt);
 }

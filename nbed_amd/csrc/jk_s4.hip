@@ -39,11 +39,12 @@
 // load unit, loading / walking waves): serves N = 148 (the size it is instantiated for) unless NBX_JK_M4=0 -- 0.87 of this
 // file's kernel time there
 bool nbx_jk_m4_covers(int64_t N);
+size_t nbx_jk_m4_weights_bytes(int64_t N);
 size_t nbx_jk_m4_packed_bytes(int64_t N, int64_t p0, int64_t p1);
 size_t nbx_jk_m4_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm);
 int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
 int nbx_jk_m4(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
-              double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf);
+              double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt);
 #ifdef NBX_EXPERIMENTAL
 // jk_p8.hip: the 8-fold form (truncated tiles) that serves whole tensors of the NB = 4 / six-loads sizes
 bool nbx_jk_p8_covers(int64_t N, int64_t p0, int64_t p1);
@@ -429,7 +430,8 @@ static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const
                         double* d_fock, double* d_vhf, const double* d_dts);
 
 extern "C" size_t nbx_jk_dts_bytes(int64_t nao) {
-    if (!s4_supported(nao) || nbx_jk_m4_covers(nao)) return 0;  // (zero-padded sizes and jk_m4.hip build their table themselves)
+    if (nbx_jk_m4_covers(nao)) return nbx_jk_m4_weights_bytes(nao);  // (the same table in jk_m4.hip's staging order)
+    if (!s4_supported(nao)) return 0;  // (zero-padded sizes build their table themselves)
     const int NB = s4_nb(nao);
     return (size_t)(NB * NB * s4_lpt(nao) * 128) * sizeof(double);
 }
@@ -471,7 +473,7 @@ static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double
     }
     NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
     if (p1 == p0) return nbx_memset(ctx, d_jk, 0, (size_t)((1 + ndm) * nao * nao) * sizeof(double));
-    if (nbx_jk_m4_covers(nao)) return nbx_jk_m4(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf);
+    if (nbx_jk_m4_covers(nao)) return nbx_jk_m4(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8(ctx, nao, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
     if (NPAD != nao) {
         // Run as the NPAD x NPAD problem whose extra rows and columns are zero: the tiles (p, q) with

@@ -18,6 +18,7 @@ struct nbx_prof_slot {
     std::vector<hipEvent_t> start, stop;  // recorded pairs not yet read
     double ms_sum = 0.0;
     int64_t count = 0;
+    int64_t seen = 0;  // launches of the slot since nbx_profile_reset (bracketed or not)
 };
 
 struct nbx_ctx {
@@ -30,6 +31,7 @@ struct nbx_ctx {
                             // synchronise across workgroups (each kernel leaves them zero again)
     bool profiling = false;
     unsigned prof_mask = ~0u;
+    int prof_every = 1;     // nbx_profile_sample: one launch in this many is bracketed
     nbx_prof_slot prof[NBX_PROF_SLOTS];
 };
 
@@ -100,6 +102,7 @@ struct nbx_prof_scope {
         if (!ctx->profiling || !((ctx->prof_mask >> slot) & 1u) ||
             (int)ctx->prof[slot].start.size() >= NBX_PROF_MAX_EVENTS)
             return;
+        if (ctx->prof[slot].seen++ % ctx->prof_every != 0) return;
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess) return;
         if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }

@@ -801,16 +801,12 @@ def test_jk_packed_fock_and_prepared_dtot_table(be, n):
     """nbx_jk_packed_fock (Fock assembly in the reduction) against J/K + nbx_fock_uhf, and the Dtot'
     table left by the scalars kernel (nbx_huz_cycle_scalars_dts) against the one the build makes
     itself: bit-identical Fock matrices, also when the table is reused for a second density.
-    (N = 148 is served by jk_m4.hip, which has no such table: the first half only.)"""
+    (N = 148 is served by jk_m4.hip, whose table has its own order: csrc/jk_m4_layout.h.)"""
     eri = be.synth_eri(n)
     packed = be.eri_pack(eri, n)
     hv = be.asarray(np.stack([symm(570, n), symm(571, n)]))
     zeros = be.asarray(np.zeros((2, n, n)))
-    try:
-        dts = be.jk_dts_new(n)
-    except ValueError:
-        assert n == 148
-        dts = None
+    dts = be.jk_dts_new(n)
     for seed in (572, 574):
         dm = be.asarray(np.stack([symm(seed, n), symm(seed + 1, n)]))
         fock0, vhf0 = be.jk_packed_fock(packed, dm, hv)
@@ -818,8 +814,6 @@ def test_jk_packed_fock_and_prepared_dtot_table(be, n):
         f_ref, v_ref = be.fock_uhf(hv, None, jk)
         np.testing.assert_array_equal(be.to_host(fock0), be.to_host(f_ref))
         np.testing.assert_array_equal(be.to_host(vhf0), be.to_host(v_ref))
-        if dts is None:
-            continue
         be.huz_cycle_scalars_async(hv, None, zeros, zeros, dm, dm, dts=dts).get()
         fock1, vhf1 = be.jk_packed_fock(packed, dm, hv, dts=dts)
         np.testing.assert_array_equal(be.to_host(fock1), be.to_host(fock0))
