@@ -143,7 +143,8 @@ constexpr int M4_LDS_OOB = 0x30000 / 8;  // (doubles) beyond any workgroup's all
 
 template <int NB, int K>
 __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, const double* __restrict__ xs, int w4,
-                                              const M4Lane& ln, double (&acc)[M4Geom<NB>::NG]) {
+                                              const M4Lane& ln, double (&acc)[M4Geom<NB>::NG],
+                                              double (&bxr)[(NB + 3) / 4]) {
     using G_ = M4Geom<NB>;
     constexpr int RA = G_::row0(K), RB = G_::row0(K + 1), NG = G_::NG;
     constexpr int BASE = m4_tri(RA);
@@ -160,9 +161,11 @@ __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, co
     }
     const double* xr = xs + ln.xrow;
     auto row_live = [](int j) constexpr { return j < NJR && 4 * j < RB; };  // (static: a block of this column group lies in the chunk)
+    // bxr[j] = X[4 (4 j + w4) + a][c], the B operand of the row part's items of block column 4 j + w4: the same for the
+    // four chunks of a tile, read with the first (a quarter of all LDS reads of the walk were these, once per chunk)
     auto load_row = [&](int j, double (&av)[NG], double& bx) {
+        if (K == 0) bx = xr[64 * j];  // (C past the matrix: finite LDS data times the zeros of the masked operand below)
         if (!row_live(j)) return;
-        bx = xr[64 * j];  // (C past the matrix: finite LDS data times the zeros of the masked operand below)
 #pragma unroll
         for (int G = 0; G < NG; ++G) {
             if (G < j || 4 * G + 3 < RA || 4 * G >= RB) continue;  // static
@@ -208,9 +211,16 @@ __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, co
             acc[H] = __builtin_amdgcn_mfma_f64_4x4x4f64(v, bt, acc[H], 0, 0, 0);
         }
     };
-    // every operand of the chunk's row part is requested, then every operand of its column part, before the first MFMA
-    // of either: two LDS round trips per chunk instead of one per item group
-    double avr[NJR][NG], bxr[NJR], avc[NJC][NG], btc[NJC];
+    // The four consumer waves start a chunk together (the barrier), and the chunk's operands are 25 KB of LDS reads per
+    // wave: requested all at once and waited for before the first MFMA, the CU alternates between a phase in which the
+    // LDS is saturated and the matrix pipe idle and one the other way round (measured with s_memtime: ~1900 cycles per
+    // step where either phase alone is ~800 / ~600).  So the operands come in four batches -- the halves of the row
+    // part, the halves of the column part --, two of them in flight, and a batch's MFMAs run while the next but one is
+    // being read; the scheduler may not move anything across the batch boundaries (it would sort the MFMAs by
+    // accumulator and wait for the last read first).
+    constexpr int JR = (NJR + 1) / 2, JC = NJC / 2;
+    double avr[NJR][NG], avc[NJC][NG], btc[NJC];
+#ifdef NBX_M4_ONE_BATCH
 #pragma unroll
     for (int j = 0; j < NJR; ++j) load_row(j, avr[j], bxr[j]);
 #pragma unroll
@@ -220,6 +230,30 @@ __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, co
     for (int j = 0; j < NJR; ++j) mma_row(j, avr[j], bxr[j]);
 #pragma unroll
     for (int j = 0; j < NJC; ++j) mma_col(j, avc[j], btc[j]);
+#else
+#pragma unroll
+    for (int j = 0; j < JR; ++j) load_row(j, avr[j], bxr[j]);
+#pragma unroll
+    for (int j = JR; j < NJR; ++j) load_row(j, avr[j], bxr[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < JR; ++j) mma_row(j, avr[j], bxr[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < JC; ++j) load_col(j, avc[j], btc[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = JR; j < NJR; ++j) mma_row(j, avr[j], bxr[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = JC; j < NJC; ++j) load_col(j, avc[j], btc[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < JC; ++j) mma_col(j, avc[j], btc[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = JC; j < NJC; ++j) mma_col(j, avc[j], btc[j]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- the kernel
@@ -327,9 +361,9 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
     };
 
     // ------------------------------------------------------------------ consumer state
-    double acc[NG];
+    double acc[NG], bxr[NG];  // (bxr: the row part's X operands of the tile being walked, m4_walk_chunk)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = 0.0;
+    for (int g = 0; g < NG; ++g) acc[g] = bxr[g] = 0.0;
     M4Lane ln;
     ln.a = lane >> 4;
     ln.b = (lane >> 2) & 3;
@@ -376,6 +410,13 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
             qq = 0;
         }
     };
+#ifdef NBX_M4_CLOCKS
+    long long ck[4] = {0, 0, 0, 0}, c0 = 0, c1 = 0;
+#define M4_CK(i) do { c1 = __builtin_amdgcn_s_memtime(); ck[i] += c1 - c0; c0 = c1; } while (0)
+    c0 = __builtin_amdgcn_s_memtime();
+#else
+#define M4_CK(i) do {} while (0)
+#endif
     if (producer) {
         for (int t = 0; t < ntile; ++t) {
             const int64_t T = T0 + t;
@@ -405,7 +446,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                         jfull[(int64_t)qq * N + pp] = j;
                     }
                 }
-#ifndef NBX_M4_NO_STAGE
+#if !defined(NBX_M4_NO_STAGE) && !defined(NBX_M4_NO_J)
                 // the J contribution of chunk g -- the one the consumers are walking: it landed a step ago, so nothing
                 // but the wait for chunk g + 1 stands between this wave and the barrier once that chunk is there
                 jpass(g);
@@ -415,10 +456,13 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                     if (lane == 0) jred[(t & 1) * 4 + (wave - 4)] = jacc;
                     jacc = 0.0;
                 }
+                M4_CK(0);  // issue + rows + J
 #ifndef NBX_M4_NO_STAGE
                 m4_wait_three_chunks<LPT>();  // my part of chunk g + 1 (chunks g + 2 .. g + 4 may be in flight)
 #endif
+                M4_CK(1);  // wait for the chunk
                 __syncthreads();
+                M4_CK(2);  // wait for the others
             }
             p = pn;
             q = qn;
@@ -453,11 +497,12 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                 const double* buf = buf0 + slot * BUF;
                 slot = slot + 1 == M4_RING ? 0 : slot + 1;
 #ifndef NBX_M4_NO_WALK
-                if (k == 0) m4_walk_chunk<NB, 0>(buf, xs, wave, ln, acc);
-                else if (k == 1) m4_walk_chunk<NB, 1>(buf, xs, wave, ln, acc);
-                else if (k == 2) m4_walk_chunk<NB, 2>(buf, xs, wave, ln, acc);
-                else m4_walk_chunk<NB, 3>(buf, xs, wave, ln, acc);
+                if (k == 0) m4_walk_chunk<NB, 0>(buf, xs, wave, ln, acc, bxr);
+                else if (k == 1) m4_walk_chunk<NB, 1>(buf, xs, wave, ln, acc, bxr);
+                else if (k == 2) m4_walk_chunk<NB, 2>(buf, xs, wave, ln, acc, bxr);
+                else m4_walk_chunk<NB, 3>(buf, xs, wave, ln, acc, bxr);
 #endif
+                M4_CK(0);  // the walk
                 if (k == 1 && more) store_x(xs0 + ((t + 1) & 1) * 4 * N, xv);
                 if (k == M4_NCH - 1) {
                     // end of tile: the row-q halves (odd columns: they used D[p][:]) leave the registers; the row-p halves
@@ -470,12 +515,26 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                         acc[g] = (odd || row_ends) ? 0.0 : acc[g];
                     }
                 }
+                M4_CK(1);  // X and row stores
+#ifndef NBX_M4_BARRIER_FLOATS
+                // (the MFMAs are register-only, so the scheduler is free to sink them below the barrier -- and does: every
+                // wave then waits for ALL its LDS reads, meets the others, and the four run their MFMAs at the same time
+                // with the LDS idle, then read at the same time with the matrix pipe idle.  Pinned here, a wave's MFMAs
+                // run as its operands arrive, under the other waves' reads)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 __syncthreads();
+                M4_CK(2);  // wait for the others
             }
             p = pn;
             q = qn;
         }
     }
+#ifdef NBX_M4_CLOCKS
+    if ((blockIdx.x == 3 || blockIdx.x == 200) && lane == 0 && (wave == 0 || wave == 2 || wave == 4 || wave == 6))
+        printf("m4 clocks wg %d wave %d tiles %d: per tile  work %lld  wait/store %lld  barrier %lld\n", (int)blockIdx.x, wave,
+               ntile, ck[0] / ntile, ck[1] / ntile, ck[2] / ntile);
+#endif
 }
 
 size_t m4_align256(size_t x) { return (x + 255) & ~(size_t)255; }
