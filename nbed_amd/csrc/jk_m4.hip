@@ -25,11 +25,14 @@
 // is read twice per tile.)  Wave w of the four takes block columns / block rows = w (mod 4), which makes every loop bound a
 // compile-time constant: straight-line code, LDS reads batched ahead of the MFMAs by the compiler.
 //
-// Streaming, work distribution and reductions as in jk_s4.hip: persistent workgroups over equal contiguous ranges of the
-// tile sequence, two per CU; a tile arrives in four chunks (whole block rows, equal block counts) through registers
-// (non-temporal 16-byte loads, a whole tile in flight) into two LDS buffers, one barrier per chunk; J is a flat dot
-// product of the staged registers with a Dtot' table held in registers; row-q partials go out per tile, row-p
-// partials when the range crosses a row, both summed in a fixed order by jk_sym_reduce_kernel (with the Fock epilogue).
+// Streaming, work distribution and reductions: persistent workgroups over equal contiguous ranges of the tile sequence,
+// one per CU, eight waves in two roles (see the kernel); a tile arrives in four chunks (whole block rows, equal block
+// counts) by LDS-DMA -- global_load_lds_dwordx4, HBM straight into a ring of five LDS buffers, three chunks in flight
+// behind the one that has landed --, one barrier per chunk; J is a flat dot product of the chunk (read back from LDS by
+// the loading waves) with a Dtot' table held in registers; row-q partials go out per tile, row-p partials when the range
+// crosses a row, both summed in a fixed order by jk_sym_reduce_kernel (with the Fock epilogue), as in jk_s4.hip.
+// This is the production kernel of the sizes nbx_jk_m4_covers() names (N = 148); DESIGN.md section 9 has the
+// measurements that led here and what is left (0.64-0.67 of the HBM roofline against jk_s4's 0.55).
 #include <cstdlib>
 
 #include "jk_m4_layout.h"
