@@ -355,11 +355,19 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         }
     };
     // the consumers' partial rows of a finished tile: summed over the four consumer waves, in wave order
-    auto reduce_rows = [&](const double* red, int parity, double* dst) {  // dst[x N + row]
+    // `last`: the last column that is stored.  K is symmetric (symmetric densities: include/nbx.h), so of the row-q
+    // partial of a tile only the columns <= q are needed -- jk_sym_reduce_kernel(k_lower) mirrors the sums -- which is
+    // a third of the 26 MB these per-tile rows come to at N = 148.  It is their memory traffic that costs: with the
+    // stores suppressed the kernel runs at the pace of its read stream (160 against 188 us on one box), with every tile's
+    // row written to the same cache-resident place as well (162); eight places per workgroup 176, forty 186.
+    auto reduce_rows = [&](const double* red, int parity, double* dst, int last) {  // dst[x N + row]
         for (int e = ptid; e < NG * 32; e += PT) {
             const int g = e >> 5, l = 2 * (e & 31) + parity;
             const int row = 16 * g + 4 * ((l >> 2) & 3) + (l >> 4), x = (l & 3) >> 1;
-            if (row < N && x < NDM) dst[x * N + row] = (red[e] + red[NG * 32 + e]) + (red[2 * NG * 32 + e] + red[3 * NG * 32 + e]);
+#ifdef NBX_M4_ROWS_NOSTORE  // (ablation, wrong results: the sums without the stores)
+            if (red[e] != 1.2345e300) continue;
+#endif
+            if (row <= last && x < NDM) dst[x * N + row] = (red[e] + red[NG * 32 + e]) + (red[2 * NG * 32 + e] + red[3 * NG * 32 + e]);
         }
     };
 
@@ -440,8 +448,15 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                         pp = p - 1;
                         qq = pp;
                     }
-                    if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N);
-                    if (pp != p) reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N);
+#ifdef NBX_M4_ROWS_SAMEPLACE  // (ablation, wrong results: every tile's row-q partial to the same, cache-resident place)
+#ifndef NBX_M4_ROWS_PLACES
+#define NBX_M4_ROWS_PLACES 1
+#endif
+                    if (qq < pp) reduce_rows(redq, 1, kpart2 + (((int64_t)blockIdx.x * NBX_M4_ROWS_PLACES + t % NBX_M4_ROWS_PLACES) * NDM) * (int64_t)N, N - 1);
+#else
+                    if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
+#endif
+                    if (pp != p) reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
                     if (ptid == 0) {
                         const double* jr = jred + ((t - 1) & 1) * 4;
                         const double j = (jr[0] + jr[1]) + (jr[2] + jr[3]);
@@ -477,8 +492,8 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
             pp = p - 1;
             qq = pp;
         }
-        if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T_end - 1 - t_begin) * NDM) * (int64_t)N);
-        reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N);
+        if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T_end - 1 - t_begin) * NDM) * (int64_t)N, qq);
+        reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
         if (ptid == 0) {  // the last tile's J (its partial sums were stored before the last barrier)
             const double* jr = jred + ((ntile - 1) & 1) * 4;
             const double j = (jr[0] + jr[1]) + (jr[2] + jr[3]);
@@ -607,7 +622,7 @@ int m4_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
                                d_packed, d_dm, wt, d_jk, k1, k2, t_begin, t_end, pl.L, pl.S);
     }
     NBX_LAUNCH_CHECK();
-    return nbx_jk_sym_reduce(ctx, k1, k2, d_jk + n2, N, p0, np, ndm, t_begin, pl.L, pl.S, d_jk, d_hv, d_fock, d_vhf, 1);
+    return nbx_jk_sym_reduce(ctx, k1, k2, d_jk + n2, N, p0, np, ndm, t_begin, pl.L, pl.S, d_jk, d_hv, d_fock, d_vhf, 1, 1);
 }
 
 }  // namespace

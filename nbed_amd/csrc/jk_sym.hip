@@ -246,11 +246,17 @@ __global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __rest
                                                             const double* __restrict__ hv = nullptr,
                                                             double* __restrict__ fock = nullptr,
                                                             double* __restrict__ vhf = nullptr,
-                                                            int k2_tile_order = 0) {
+                                                            int k2_tile_order = 0, int k_lower = 0) {
+    // k_lower: the producer kernel stored only the columns b <= row of its partial rows (K is symmetric for the
+    // symmetric densities the interface asks for: jk_m4.hip writes a third of the bytes); this kernel then sums the
+    // elements b <= row and writes each to both places.  Across slabs the partial outputs are symmetrised partials,
+    // whose sum is K all the same.
     __shared__ double part[4][64];
     const int row = blockIdx.x, x = blockIdx.y;
     const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
-    const int b = blockIdx.z * 64 + lane;
+    if (k_lower && (int)blockIdx.z * 64 > row) return;  // (uniform: nothing of this block lies on or below the diagonal)
+    const int b0 = blockIdx.z * 64 + lane;
+    const int b = (k_lower && b0 > row) ? N : b0;  // (lanes right of the diagonal: idle)
     const int pl_lo = max(0, row + 1 - p0);  // first local p with global p > row
     double t = 0.0;
     if (b < N && k2_tile_order) {
@@ -303,6 +309,16 @@ __global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __rest
             const double v = jfull[(int64_t)row * N + b] - tot;
             fock[o] = hv[o] + v;
             if (vhf != nullptr) vhf[o] = v;
+        }
+        if (k_lower && b < row) {  // the mirrored element (J is symmetric too: jfull holds both [p][q] and [q][p])
+            double* dst2 = kout + ((int64_t)x * N + b) * N + row;
+            *dst2 = accumulate ? *dst2 + tot : tot;
+            if (fock != nullptr) {
+                const int64_t o = ((int64_t)x * N + b) * N + row;
+                const double v = jfull[(int64_t)b * N + row] - tot;
+                fock[o] = hv[o] + v;
+                if (vhf != nullptr) vhf[o] = v;
+            }
         }
     }
 }
@@ -494,10 +510,10 @@ bool nbx_jk_sym_supported(int64_t nao) { return nao >= 2 && nao % 2 == 0 && nao 
 // K[x][row][b] from the row-p / row-q partial buffers (shared with jk_s4.hip, same layouts)
 int nbx_jk_sym_reduce(nbx_ctx* ctx, const double* k1, const double* k2, double* d_k, int64_t N, int64_t p0, int64_t np,
                       int64_t ndm, int64_t t_begin, int L, int S, const double* d_j, const double* d_hv, double* d_fock,
-                      double* d_vhf, int k2_tile_order) {
+                      double* d_vhf, int k2_tile_order, int k_lower) {
     hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
                        ctx->stream, k1, k2, d_k, (int)N, (int)p0, (int)np, (int)ndm, t_begin, L, S, 0, d_j, d_hv, d_fock,
-                       d_vhf, k2_tile_order);
+                       d_vhf, k2_tile_order, k_lower);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

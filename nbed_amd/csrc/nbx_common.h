@@ -74,7 +74,7 @@ bool nbx_jk_sym_supported(int64_t nao);
 int nbx_jk_sym_reduce(nbx_ctx* ctx, const double* k1, const double* k2, double* d_k, int64_t N, int64_t p0, int64_t np,
                       int64_t ndm, int64_t t_begin, int L, int S, const double* d_j = nullptr,
                       const double* d_hv = nullptr, double* d_fock = nullptr, double* d_vhf = nullptr,
-                      int k2_tile_order = 0);
+                      int k2_tile_order = 0, int k_lower = 0);
 
 // eigh_refine.hip
 bool nbx_eigh_refine_supported(int64_t n, int64_t batch);
