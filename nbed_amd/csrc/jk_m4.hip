@@ -286,6 +286,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
     double* redq = xs0 + 2 * 4 * N;          // [4][NG][32] consumers' row-q halves (odd columns) of the tile just walked
     double* redp = redq + 4 * NG * 32;       // [4][NG][32] consumers' row-p halves (even columns) when the row ends
     double* jred = redp + 4 * NG * 32;       // [2][4] producers' J partials per tile parity
+    double* jstage = jred + 16;              // [L] J of the tiles done, stored at the end of the range
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave >= 4;
     const int ptid = tid - 256;  // producers: 0 .. 255
@@ -366,6 +367,9 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
             const int row = 16 * g + 4 * ((l >> 2) & 3) + (l >> 4), x = (l & 3) >> 1;
 #ifdef NBX_M4_ROWS_NOSTORE  // (ablation, wrong results: the sums without the stores)
             if (red[e] != 1.2345e300) continue;
+#endif
+#ifdef NBX_M4_ROWS_FRACTION  // (ablation, wrong results: only the first 1 / NBX_M4_ROWS_FRACTION of the columns stored)
+            if (row > last / NBX_M4_ROWS_FRACTION) continue;
 #endif
             if (row <= last && x < NDM) dst[x * N + row] = (red[e] + red[NG * 32 + e]) + (red[2 * NG * 32 + e] + red[3 * NG * 32 + e]);
         }
@@ -457,11 +461,9 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                     if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
 #endif
                     if (pp != p) reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
-                    if (ptid == 0) {
+                    if (ptid == 0) {  // (J of the tile: kept in LDS until the range is done -- two scattered stores less per tile)
                         const double* jr = jred + ((t - 1) & 1) * 4;
-                        const double j = (jr[0] + jr[1]) + (jr[2] + jr[3]);
-                        jfull[(int64_t)pp * N + qq] = j;
-                        jfull[(int64_t)qq * N + pp] = j;
+                        jstage[t - 1] = (jr[0] + jr[1]) + (jr[2] + jr[3]);
                     }
                 }
 #if !defined(NBX_M4_NO_STAGE) && !defined(NBX_M4_NO_J)
@@ -494,11 +496,18 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         }
         if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T_end - 1 - t_begin) * NDM) * (int64_t)N, qq);
         reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
-        if (ptid == 0) {  // the last tile's J (its partial sums were stored before the last barrier)
-            const double* jr = jred + ((ntile - 1) & 1) * 4;
-            const double j = (jr[0] + jr[1]) + (jr[2] + jr[3]);
-            jfull[(int64_t)pp * N + qq] = j;
-            jfull[(int64_t)qq * N + pp] = j;
+        if (wave == 4) {  // J of every tile of the range: lane i stores tile i's (one wave: its LDS operations are in order)
+            if (lane == 0) {  // the last tile's J (its partial sums were stored before the last barrier)
+                const double* jr = jred + ((ntile - 1) & 1) * 4;
+                jstage[ntile - 1] = (jr[0] + jr[1]) + (jr[2] + jr[3]);
+            }
+            for (int i = lane; i < ntile; i += 64) {
+                const int64_t Ti = T0 + i;
+                const int pi = m4_tri_row(Ti), qi = (int)(Ti - (int64_t)pi * (pi + 1) / 2);
+                const double j = jstage[i];
+                jfull[(int64_t)pi * N + qi] = j;
+                jfull[(int64_t)qi * N + pi] = j;
+            }
         }
     } else {
         int slot = 0;  // ring slot of the chunk being walked
@@ -573,7 +582,7 @@ M4Plan m4_plan_nb(int64_t p0, int64_t np, int64_t ndm) {
     pl.L = (int)L;
     pl.wgs = (int)nbx_cdiv(ntiles, L);
     pl.S = (int)sqrt(2.0 * (double)L) + 3;
-    pl.lds_bytes = (size_t)(M4_RING * G::BUF + 2 * 4 * G::N + 2 * 4 * G::NG * 32 + 16) * sizeof(double);
+    pl.lds_bytes = (size_t)(M4_RING * G::BUF + 2 * 4 * G::N + 2 * 4 * G::NG * 32 + 16 + pl.L) * sizeof(double);
     size_t off = 0;
     pl.wt_off = off; off += m4_align256((size_t)(M4_NCH * G::LPT * M4_PROD_THREADS * 2) * sizeof(double));
     pl.k1_off = off; off += m4_align256((size_t)((int64_t)pl.wgs * pl.S * ndm * G::N) * sizeof(double));
