@@ -238,7 +238,8 @@ void jk_sym_kernel(const double* __restrict__ eri, const double* __restrict__ dm
 //                                     + sum over slab rows p > row of kpart2[row][p - p0][x][b]
 // grid (N, NDM, ceil(N/64)); 256 threads = 4 row-chunks x 64 column lanes, 8 independent loads in
 // flight per thread; fixed summation order.
-__global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __restrict__ kpart1,
+template <int NCH>  // row-chunks per workgroup (64 NCH threads): the sum over p is NCH interleaved partial sums, added in order
+__global__ __launch_bounds__(64 * NCH) void jk_sym_reduce_kernel(const double* __restrict__ kpart1,
                                                             const double* __restrict__ kpart2,
                                                             double* __restrict__ kout, int N, int p0, int np, int ndm,
                                                             int64_t t_begin, int L, int S, int accumulate,
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __rest
     // symmetric densities the interface asks for: jk_m4.hip writes a third of the bytes); this kernel then sums the
     // elements b <= row and writes each to both places.  Across slabs the partial outputs are symmetrised partials,
     // whose sum is K all the same.
-    __shared__ double part[4][64];
+    __shared__ double part[NCH][64];
     const int row = blockIdx.x, x = blockIdx.y;
     const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
     if (k_lower && (int)blockIdx.z * 64 > row) return;  // (uniform: nothing of this block lies on or below the diagonal)
@@ -270,31 +271,33 @@ __global__ __launch_bounds__(256) void jk_sym_reduce_kernel(const double* __rest
             return src[(pg * (pg + 1) / 2 + row - t_begin) * stride];
         };
         int pl = pl_lo + chunk;
-        for (; pl + 28 < np; pl += 32) {
+        for (; pl + 7 * NCH < np; pl += 8 * NCH) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = at(pl + 4 * u);
+            for (int u = 0; u < 8; ++u) v[u] = at(pl + NCH * u);
 #pragma unroll
             for (int u = 0; u < 8; ++u) t += v[u];
         }
-        for (; pl < np; pl += 4) t += at(pl);
+        for (; pl < np; pl += NCH) t += at(pl);
     } else if (b < N) {
         const double* src = kpart2 + (((int64_t)row * np) * ndm + x) * N + b;
         const int64_t stride = (int64_t)ndm * N;
         int pl = pl_lo + chunk;
-        for (; pl + 28 < np; pl += 32) {
+        for (; pl + 7 * NCH < np; pl += 8 * NCH) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(pl + 4 * u) * stride];
+            for (int u = 0; u < 8; ++u) v[u] = src[(pl + NCH * u) * stride];
 #pragma unroll
             for (int u = 0; u < 8; ++u) t += v[u];
         }
-        for (; pl < np; pl += 4) t += src[pl * stride];
+        for (; pl < np; pl += NCH) t += src[pl * stride];
     }
     part[chunk][lane] = t;
     __syncthreads();
     if (chunk == 0 && b < N) {
-        double tot = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        double tot = part[0][lane];
+#pragma unroll
+        for (int c = 1; c < NCH; ++c) tot += part[c][lane];
         if (row >= p0 && row < p0 + np) {
             const int64_t w_lo = (tri_index(row, 0) - t_begin) / L, w_hi = (tri_index(row, row) - t_begin) / L;
             for (int64_t w = w_lo; w <= w_hi; ++w) {
@@ -511,9 +514,14 @@ bool nbx_jk_sym_supported(int64_t nao) { return nao >= 2 && nao % 2 == 0 && nao 
 int nbx_jk_sym_reduce(nbx_ctx* ctx, const double* k1, const double* k2, double* d_k, int64_t N, int64_t p0, int64_t np,
                       int64_t ndm, int64_t t_begin, int L, int S, const double* d_j, const double* d_hv, double* d_fock,
                       double* d_vhf, int k2_tile_order, int k_lower) {
-    hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
-                       ctx->stream, k1, k2, d_k, (int)N, (int)p0, (int)np, (int)ndm, t_begin, L, S, 0, d_j, d_hv, d_fock,
-                       d_vhf, k2_tile_order, k_lower);
+    if (k_lower)  // (jk_m4.hip: sixteen row-chunks -- the sum over p in two trips to memory instead of five)
+        hipLaunchKernelGGL(jk_sym_reduce_kernel<16>, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(1024), 0,
+                           ctx->stream, k1, k2, d_k, (int)N, (int)p0, (int)np, (int)ndm, t_begin, L, S, 0, d_j, d_hv, d_fock,
+                           d_vhf, k2_tile_order, k_lower);
+    else
+        hipLaunchKernelGGL(jk_sym_reduce_kernel<4>, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
+                           ctx->stream, k1, k2, d_k, (int)N, (int)p0, (int)np, (int)ndm, t_begin, L, S, 0, d_j, d_hv, d_fock,
+                           d_vhf, k2_tile_order, k_lower);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
@@ -602,7 +610,7 @@ extern "C" int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p
 #undef NBX_JS_GO
     }
     NBX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
+    hipLaunchKernelGGL(jk_sym_reduce_kernel<4>, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
                        ctx->stream, k1, k2,
                        d_jk + n2, (int)N, (int)p0, (int)np, (int)ndm, t_begin, pl.L, pl.S, 0);
     NBX_LAUNCH_CHECK();
@@ -697,7 +705,7 @@ extern "C" int nbx_jk_synth_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p
 #undef NBX_GS_GO
         }
         NBX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(jk_sym_reduce_kernel, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
+        hipLaunchKernelGGL(jk_sym_reduce_kernel<4>, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
                            ctx->stream, k1, k2, d_jk + n2, (int)N, (int)c0, (int)np, (int)ndm, t_begin, pl.L, pl.S, 1);
         NBX_LAUNCH_CHECK();
     }
