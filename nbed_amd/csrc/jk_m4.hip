@@ -458,7 +458,11 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
 #endif
                     if (qq < pp) reduce_rows(redq, 1, kpart2 + (((int64_t)blockIdx.x * NBX_M4_ROWS_PLACES + t % NBX_M4_ROWS_PLACES) * NDM) * (int64_t)N, N - 1);
 #else
+#ifdef NBX_M4_ROWS_EVERY  // (ablation, wrong results: the row-q partial of one tile in NBX_M4_ROWS_EVERY only)
+                    if (qq < pp && t % NBX_M4_ROWS_EVERY == 0) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
+#else
                     if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
+#endif
 #endif
                     if (pp != p) reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
                     if (ptid == 0) {  // (J of the tile: kept in LDS until the range is done -- two scattered stores less per tile)
