@@ -290,7 +290,8 @@ __global__ __launch_bounds__(NB * 64) __attribute__((amdgpu_waves_per_eu(WV, WV)
         pj = p;
         qj = q;
         par ^= 1;
-        if (q < p && live) {
+        if (q < p && live && trow <= q) {  // (columns <= q only: K is symmetric, jk_sym_reduce_kernel(k_lower) mirrors the sums --
+                                           //  a third of the bytes these per-tile rows come to: DESIGN.md section 9 (xii))
             double* k2 = kpart2 + ((T - t_begin) * NDM) * N + trow;  // tile order: sequential stores
 #pragma unroll
             for (int x = 0; x < NDM; ++x) k2[x * N] = kq[x];
@@ -566,5 +567,5 @@ static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const
 #undef NBX_S4_GO
     }
     NBX_LAUNCH_CHECK();
-    return nbx_jk_sym_reduce(ctx, k1, k2, d_jk + n2, N, p0, np, ndm, t_begin, pl.L, pl.S, d_jk, d_hv, d_fock, d_vhf, 1);
+    return nbx_jk_sym_reduce(ctx, k1, k2, d_jk + n2, N, p0, np, ndm, t_begin, pl.L, pl.S, d_jk, d_hv, d_fock, d_vhf, 1, 1);
 }
