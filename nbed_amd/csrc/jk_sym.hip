@@ -218,7 +218,7 @@ void jk_sym_kernel(const double* __restrict__ eri, const double* __restrict__ dm
             const int rem = i - x * QB * N;
             const int j = rem / N;
             const int b = rem - j * N;
-            if (j < nq && q + j < p) {
+            if (j < nq && q + j < p && b <= q + j) {  // (columns <= the row only: K is symmetric, the reduction mirrors the sums)
                 double tot = 0.0;
                 for (int g = 0; g < R; ++g) tot += kred[(((size_t)g * NDM + x) * QB + j) * N + b];
                 kpart2[(((int64_t)(q + j) * np + (p - p0)) * NDM + x) * N + b] = tot;
@@ -612,7 +612,8 @@ extern "C" int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p
     NBX_LAUNCH_CHECK();
     hipLaunchKernelGGL(jk_sym_reduce_kernel<4>, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
                        ctx->stream, k1, k2,
-                       d_jk + n2, (int)N, (int)p0, (int)np, (int)ndm, t_begin, pl.L, pl.S, 0);
+                       d_jk + n2, (int)N, (int)p0, (int)np, (int)ndm, t_begin, pl.L, pl.S, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                       1);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
