@@ -106,6 +106,9 @@ int nbx_profile_enable(nbx_ctx* ctx, int on);
  * each, measured on a rocprofv3 kernel trace with and without them: profiles/r03/README.md), 4 % of a settled
  * N_AO = 148 cycle: bench.py samples the J/K launch of every fourth cycle of its timed region.           */
 int nbx_profile_sample(nbx_ctx* ctx, int every);
+/* Test support: fills the LDS of every CU with `value` (tests pass a NaN) so that a kernel reading LDS it has not
+ * written fails its parity test instead of depending on what ran on the CU before (tests/test_gpu_kernels.py).   */
+int nbx_debug_fill_lds(nbx_ctx* ctx, double value);
 int nbx_profile_read(nbx_ctx* ctx, int slot, double* ms_sum, int64_t* count);
 int nbx_profile_reset(nbx_ctx* ctx);
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     "nbx_memset": (c_int, [_P, _P, c_int, c_size_t]),
     "nbx_profile_enable": (c_int, [_P, c_int]),
     "nbx_profile_sample": (c_int, [_P, c_int]),
+    "nbx_debug_fill_lds": (c_int, [_P, c_double]),
     "nbx_profile_read": (c_int, [_P, c_int, POINTER(c_double), POINTER(c_int64)]),
     "nbx_profile_reset": (c_int, [_P]),
     "nbx_synth_eri": (c_int, [_P, c_int64, c_int64, c_int64, c_uint64, _P]),

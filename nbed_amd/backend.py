@@ -395,6 +395,10 @@ class HipBackend:
         else:
             self._call("nbx_profile_enable", 1 if on else 0)
 
+    def debug_fill_lds(self, value: float = float("nan")):
+        """Test support: every CU's LDS filled with ``value`` (nbx_debug_fill_lds)."""
+        self._call("nbx_debug_fill_lds", float(value))
+
     def profile_reset(self):
         self._call("nbx_profile_reset")
 

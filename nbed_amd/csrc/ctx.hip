@@ -224,6 +224,29 @@ int nbx_profile_enable(nbx_ctx* ctx, int on) {
     return NBX_OK;
 }
 
+// Test support: every CU's LDS filled with `value` (a NaN, say), so that a kernel that reads LDS it has not written shows
+// it in its results instead of depending on what ran before it.
+__global__ __launch_bounds__(256) void fill_lds_kernel(double value, double* sink) {
+    extern __shared__ double lds_all[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 8; i += 256) lds_all[i] = value;
+    __syncthreads();
+    if (lds_all[(threadIdx.x * 37) % (160 * 1024 / 8)] == 1.2345e300) *sink = 0.0;  // (keeps the stores alive)
+}
+
+int nbx_debug_fill_lds(nbx_ctx* ctx, double value) {
+    NBX_CHECK_ARG(ctx != nullptr);
+    static bool attr_set = false;
+    if (!attr_set) {
+        NBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fill_lds_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    // one workgroup per CU at a time (it takes the whole LDS); eight rounds over the chip
+    hipLaunchKernelGGL(fill_lds_kernel, dim3(2048), dim3(256), 160 * 1024, ctx->stream, value, ctx->d_scratch);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
 int nbx_profile_sample(nbx_ctx* ctx, int every) {
     NBX_CHECK_ARG(ctx != nullptr && every >= 1);
     ctx->prof_every = every;

@@ -167,7 +167,14 @@ __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, co
     // bxr[j] = X[4 (4 j + w4) + a][c], the B operand of the row part's items of block column 4 j + w4: the same for the
     // four chunks of a tile, read with the first (a quarter of all LDS reads of the walk were these, once per chunk)
     auto load_row = [&](int j, double (&av)[NG], double& bx) {
-        if (K == 0) bx = xr[64 * j];  // (C past the matrix: finite LDS data times the zeros of the masked operand below)
+        // (a block column past the matrix -- 4 j + w4 >= NB, the last j of waves 1..3 -- has no X row: the read would land
+        //  behind the X of this tile, in LDS that nothing has written yet when the first tile of a range starts, and a NaN
+        //  left there by an earlier kernel times the zero of the masked operand is a NaN.  Zero, not whatever is there.)
+#ifdef NBX_M4_TEST_UNINIT_BX  // (negative control of tests' LDS-poisoning check: the read as it was)
+        if (K == 0) bx = xr[64 * j];
+#else
+        if (K == 0) bx = (4 * j + w4 < NB) ? xr[64 * j] : 0.0;
+#endif
         if (!row_live(j)) return;
 #pragma unroll
         for (int G = 0; G < NG; ++G) {

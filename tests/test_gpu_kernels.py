@@ -1273,3 +1273,83 @@ def test_cold_eigh_across_the_register_and_lds_kernel_instances(be, n):
         np.testing.assert_allclose(w_h[x], np.linalg.eigvalsh(a_h[x]), rtol=0, atol=1e-12)
         np.testing.assert_allclose(v_h[x].T @ v_h[x], np.eye(n), rtol=0, atol=1e-13)
         assert np.abs(a_h[x] @ v_h[x] - v_h[x] * w_h[x]).max() < 1e-12
+
+
+def test_kernel_timing_brackets_and_sampling(be):
+    """nbx_profile_enable / nbx_profile_sample / nbx_profile_read (include/nbx.h "in-library kernel timing"): HIP
+    events around the J/K kernel of every launch, or of one launch in `every`; what bench.py's roofline uses."""
+    from nbed_amd import _nbx
+
+    n = 24
+    eri = be.synth_eri(n)
+    dm = be.asarray(np.stack([symm(880, n), symm(881, n)]))
+    be.profile(True, slots=[_nbx.PROF_JK_DENSE])
+    be.profile_reset()
+    for _ in range(8):
+        be.jk_sym(eri, dm)
+    ms_all, cnt_all = be.profile_read(_nbx.PROF_JK_DENSE)
+    assert cnt_all == 8 and 0.0 < ms_all < 50.0
+    be.profile(True, slots=[_nbx.PROF_JK_DENSE], every=4)
+    be.profile_reset()
+    for _ in range(8):
+        be.jk_sym(eri, dm)
+    ms_s, cnt_s = be.profile_read(_nbx.PROF_JK_DENSE)
+    assert cnt_s == 2 and 0.0 < ms_s < 50.0  # the first launch after the reset, then every fourth
+    be.profile(True, slots=[_nbx.PROF_EIGH])  # a slot that is not enabled records nothing
+    be.profile_reset()
+    be.jk_sym(eri, dm)
+    assert be.profile_read(_nbx.PROF_JK_DENSE)[1] == 0
+    be.profile(False)
+    be.profile_reset()
+    be.jk_sym(eri, dm)
+    assert be.profile_read(_nbx.PROF_JK_DENSE)[1] == 0
+
+
+def test_kernels_do_not_depend_on_what_lds_held(be):
+    """Every CU's LDS filled with NaN (nbx_debug_fill_lds) before each launch: the J/K kernels, the transform and the
+    eigensolver give the bits they gave before.  (A kernel that multiplies something it masked to zero by LDS it has not
+    written passes every parity test until an earlier kernel happens to have left a NaN there.)"""
+    nan = float("nan")
+
+    def same(fn):
+        ref = be.to_host(fn())
+        assert np.isfinite(ref).all()
+        for _ in range(2):
+            be.debug_fill_lds(nan)
+            np.testing.assert_array_equal(be.to_host(fn()), ref)
+
+    for n in (128, 148):
+        eri = be.synth_eri(n)
+        packed = be.eri_pack(eri, n)
+        for ndm in (2, 1):
+            dm = be.asarray(np.stack([symm(900 + x, n) for x in range(ndm)]))
+            same(lambda: be.jk_packed(packed, dm))
+            same(lambda: be.jk_sym(eri, dm))
+        h = n // 3
+        slab = be.eri_pack(eri[h:], n, h, n)
+        dm = be.asarray(np.stack([symm(902, n), symm(903, n)]))
+        same(lambda: be.jk_packed(slab, dm, h, n))
+        del eri, packed, slab
+    n = 24
+    eri = be.synth_eri(n)
+    dm = be.asarray(np.stack([symm(904, n), symm(905, n)]))
+    same(lambda: be.jk(eri, dm))
+    same(lambda: be.jk_sym(eri, dm))
+    a = be.asarray(np.stack([symm(906, 72), symm(907, 72)]))
+    same(lambda: be.eigh(a)[0])
+    same(lambda: be.eigh(a)[1])
+    same(lambda: be.purify(be.asarray(np.stack([symm(906, 72), symm(907, 72)]) / 40.0), (20, 19))[0])
+    same(lambda: be.huzinaga_fused(a, be.asarray(np.stack([symm(908, 72), symm(909, 72)])), 1.0)[0])
+    # the transform's products at the benchmark shape (the 'T','N' kernel with its k-tiles written into LDS by the load
+    # unit, the tiled and the small GEMM) and a streamed one with the integrals generated in registers
+    n, na = 148, 128
+    eri = be.synth_eri(n)
+    c = be.asarray(np.linalg.qr(symm(910, n))[0][:, :na].copy())
+    same(lambda: be.ao2mo(eri, c, c, c, c))
+    del eri
+    c6 = be.asarray(np.linalg.qr(symm(911, 96))[0][:, :16].copy())
+    same(lambda: be.ao2mo_synth(96, c6, c6, c6, c6))
+    for m, k, nn in ((148, 148, 148), (300, 20, 70), (33, 257, 129)):
+        x, y = be.asarray(symm(912, max(m, k))[:m, :k].copy()), be.asarray(symm(913, max(k, nn))[:k, :nn].copy())
+        same(lambda: be.gemm(x, y))
+        same(lambda: be.gemm(y, x, "T", "T"))
