@@ -553,6 +553,8 @@ def main():
             clock["t0"] = time.perf_counter()
             stamps.append(clock["t0"])
 
+    if os.environ.get("NBED_BENCH_POISON_LDS") == "1":  # (debug knob: every CU's LDS holds NaN when the run starts)
+        be.debug_fill_lds(float("nan"))
     huzinaga_scf(mf, pr["V_emb"], pr["D_env"], use_DIIS=True, history=hist, callback=on_cycle)
     barrier()
     dt = time.perf_counter() - clock["t0"]
