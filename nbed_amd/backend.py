@@ -135,6 +135,7 @@ class HipBackend:
         _nbx.check(self.lib, self.lib.nbx_ctx_create(self.device_index, ctypes.c_void_p(stream), 0, ctypes.byref(ctx)))
         self.ctx = ctx
         self._work: dict[str, object] = {}
+        self._poison = os.environ.get("NBED_POISON_EMPTY") == "1"
         # result slots for kernels that store straight into host memory (huz_cycle_scalars_async): a ring
         # owned by the backend for its whole life, so that a handle dropped before its kernel ran
         # (look-ahead cycles discarded after convergence) can never leave a queued kernel writing
@@ -190,7 +191,10 @@ class HipBackend:
         self.torch.cuda.current_stream(self.device_index).wait_event(ev)
 
     def empty(self, *shape):
-        return self.torch.empty(*shape, dtype=self.torch.float64, device=self.device)
+        t = self.torch.empty(*shape, dtype=self.torch.float64, device=self.device)
+        if self._poison:  # (NBED_POISON_EMPTY=1, a test knob: what a kernel does not write reads as NaN)
+            t.fill_(float("nan"))
+        return t
 
     def zeros(self, *shape):
         return self.torch.zeros(*shape, dtype=self.torch.float64, device=self.device)
@@ -377,6 +381,8 @@ class HipBackend:
             self._work[key] = None
             buf = self.torch.empty(max(int(nbytes), 256), dtype=self.torch.uint8, device=self.device)
             self._work[key] = buf
+        if self._poison:  # every use of a workspace starts from NaN bit patterns (0xff bytes)
+            buf.fill_(255)
         return buf
 
     def release_workspaces(self):
