@@ -19,14 +19,14 @@ __device__ __forceinline__ void wait_vm() {
 
 // W waves, ring of R chunks, D chunks in flight (D <= R - 1)
 template <int W, int R, int D, bool BARRIER, int POL, int MODE = 0>
-__global__ __launch_bounds__(MODE == 3 ? 512 : W * 64, 1) void dma_kernel(const char* __restrict__ src, double* __restrict__ out, long per_wg) {
+__global__ __launch_bounds__(MODE >= 3 ? 512 : W * 64, 1) void dma_kernel(const char* __restrict__ src, double* __restrict__ out, long per_wg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LPT = CHUNK / (W * 64 * 16);  // instructions per wave and chunk
     static_assert(LPT * W * 64 * 16 == CHUNK, "chunk");
     int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const char* base = src + (long)blockIdx.x * per_wg;
     const int nchunk = (int)(per_wg / CHUNK);
-    if (MODE == 3) {  // eight waves, the upper four load
+    if (MODE >= 3) {  // eight waves, the upper four load
         if (wave < 4) {
             for (int g = 0; g < nchunk; ++g) __syncthreads();
             __syncthreads();
@@ -57,7 +57,14 @@ __global__ __launch_bounds__(MODE == 3 ? 512 : W * 64, 1) void dma_kernel(const 
     for (int g = 0; g < D; ++g) issue(g);
     for (int g = 0; g < nchunk; ++g) {
         issue(g + D);
-        if (MODE >= 2 && (g & 3) == 0) out[4096 + (long)blockIdx.x * 1024 + tid] = (double)g;  // (a tile's partial row leaves)
+        if ((MODE == 2 || MODE == 3) && (g & 3) == 0) out[4096 + (long)blockIdx.x * 1024 + tid] = (double)g;  // (a tile's partial row leaves: same place every tile)
+        if (MODE >= 4 && (g & 3) == 0) {  // the same 2.4 KB to FRESH lines, tile after tile (what jk_m4's row-q partials do)
+            double* dst = out + 4096 + ((long)blockIdx.x * (nchunk / 4 + 1) + (g >> 2)) * 296;
+            if (MODE == 4 || tid <= ((g >> 2) * 7) % 148) {  // MODE 5: a third of the row on average (columns <= q)
+                dst[tid] = (double)g;
+                if (tid < 40) dst[256 + tid] = (double)g;
+            }
+        }
         wait_vm<D * LPT>();  // chunk g has landed
         if (BARRIER) __syncthreads();
     }
@@ -121,7 +128,7 @@ int main() {
     char* d;
     double* o;
     hipMalloc(&d, n + (1 << 20));
-    hipMalloc(&o, 8 << 20);
+    hipMalloc(&o, 64 << 20);
     hipMemset(d, 0, n + (1 << 20));
     run("dma  4 waves ring 5, 3 chunks in flight, barrier", dma_kernel<4, 5, 3, true, 0>, 256, 5 * CHUNK, d, o, n);
     run("dma  4 waves ring 5, 3 in flight, no barrier", dma_kernel<4, 5, 3, false, 0>, 256, 5 * CHUNK, d, o, n);
@@ -136,6 +143,8 @@ int main() {
     run("dma  4 waves ring 5, 3 in flight, barrier, ragged chunks", dma_kernel<4, 5, 3, true, 0, 1>, 256, 5 * CHUNK, d, o, n);
     run("dma  4 waves ring 5, 3 in flight, barrier, ragged + store", dma_kernel<4, 5, 3, true, 0, 2>, 256, 5 * CHUNK, d, o, n);
     run("dma  ragged + store, 512-thread workgroup, waves 4-7 load", dma_kernel<4, 5, 3, true, 0, 3>, 512, 5 * CHUNK, d, o, n);
+    run("dma  512 threads, ragged, 2.4 KB per tile to FRESH lines", dma_kernel<4, 5, 3, true, 0, 4>, 512, 5 * CHUNK, d, o, n);
+    run("dma  512 threads, ragged, 0.8 KB per tile to fresh lines", dma_kernel<4, 5, 3, true, 0, 5>, 512, 5 * CHUNK, d, o, n);
     run("dma  the same with 153 KB of LDS", dma_kernel<4, 5, 3, true, 0, 3>, 512, 153 * 1024, d, o, n);
     run("dma  the same, 153 KB, 251 workgroups", dma_kernel<4, 5, 3, true, 0, 3>, 512, 153 * 1024, d, o, n, 251);
     run("reg  4 waves, 2 chunks in registers, barrier", reg_kernel<4, 2, true>, 256, 2 * CHUNK, d, o, n);
