@@ -263,21 +263,28 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
         for (int w = 0; w < nwave; ++w) t += red[tid][w];
         partial[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + tid] = t;
     }
-    if (dts != nullptr && i0 >= j0 && dts_m4) {  // (jk_m4.hip's order: N = 148)
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int gi = i0 + threadIdx.y + 8 * k, gj = j0 + threadIdx.x;
-            if (gi < N && gj <= gi) dts[m4_weight_index<37>(gi, gj)] = gi == gj ? dsum[k] : dsum[k] + tsum[k];
+    // (the Dtot' table: stored AFTER the workgroup has announced its partial sums -- nobody but the next kernel reads
+    //  it, and ahead of the fence the stores' completion sat on the path to the last workgroup's final sums)
+    auto store_dts = [&]() {
+        if (dts != nullptr && i0 >= j0 && dts_m4) {  // (jk_m4.hip's order: N = 148)
+    #pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int gi = i0 + threadIdx.y + 8 * k, gj = j0 + threadIdx.x;
+                if (gi < N && gj <= gi) dts[m4_weight_index<37>(gi, gj)] = gi == gj ? dsum[k] : dsum[k] + tsum[k];
+            }
+        } else if (dts != nullptr && i0 >= j0) {
+            const S4Geom g = s4_geom(N, s4_nb_);
+    #pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int gi = i0 + threadIdx.y + 8 * k, gj = j0 + threadIdx.x;
+                if (gi < N && gj <= gi) dts[s4_dts_index(g, s4_lpt_, gi, gj)] = gi == gj ? dsum[k] : dsum[k] + tsum[k];
+            }
         }
-    } else if (dts != nullptr && i0 >= j0) {
-        const S4Geom g = s4_geom(N, s4_nb_);
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int gi = i0 + threadIdx.y + 8 * k, gj = j0 + threadIdx.x;
-            if (gi < N && gj <= gi) dts[s4_dts_index(g, s4_lpt_, gi, gj)] = gi == gj ? dsum[k] : dsum[k] + tsum[k];
-        }
+    };
+    if (out_final == nullptr) {
+        store_dts();
+        return;
     }
-    if (out_final == nullptr) return;
     const int nblocks = gridDim.x * gridDim.y;
     __threadfence();  // the partials above are visible device-wide before the arrival is
     __syncthreads();
@@ -287,7 +294,10 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
         if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (!last) return;
+    if (!last) {
+        store_dts();
+        return;
+    }
     __threadfence();
     if (tid < tail_n) out_final[4 + tid] = (double)tail[tid];
     double t4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -314,6 +324,7 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
         __threadfence_system();
         __hip_atomic_store(out_final + 4 + tail_n, 1.0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    store_dts();  // (this workgroup's part of the table, last of all)
 }
 
 __global__ void axpby_kernel(int64_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
