@@ -59,6 +59,10 @@ __device__ __forceinline__ void m4_wait_three_chunks() {
 }
 
 typedef double m4_d2 __attribute__((ext_vector_type(2)));
+#ifndef NBX_M4_NO_HOLD  // (-DNBX_M4_NO_HOLD: every tile's row-q partial stored when it is complete, as before -- for A/B)
+#define NBX_M4_HOLD_ROWS
+#endif
+constexpr int M4_HOLD_TILES = 32, M4_HOLD_FIRST = 12;  // tiles [FIRST, FIRST + TILES) of a range: the first few go out at once  // tiles of a range whose row-q partials wait in the loading waves' registers
 
 __device__ __forceinline__ double2 m4_ldnt(const double* p) {
     const m4_d2 t = __builtin_nontemporal_load(reinterpret_cast<const m4_d2*>(p));
@@ -323,9 +327,15 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         const double* tile = tile0 + (real ? (int64_t)(g >> 2) * TILE : 0);
         const int begin = 16 * m4_tri(G_::row0(k)), end = 16 * m4_tri(G_::row0(k + 1));
         double* buf = buf0 + (g % M4_RING) * BUF;
+#ifdef NBX_M4_HOLD_ROWS
+        int pt_ = ptid;  // (opaque per chunk: the 24 clamped offsets of a tile are recomputed, not kept in registers)
+        asm volatile("" : "+v"(pt_));
+#else
+        const int pt_ = ptid;
+#endif
 #pragma unroll
         for (int s = 0; s < LPT; ++s) {
-            int d = begin + (s * PT + ptid) * 2;
+            int d = begin + (s * PT + pt_) * 2;
             d = min(d, end - 2);
             const unsigned off = 8u * (unsigned)d;
             const unsigned lds_a = (unsigned)(size_t)(m4_lds_vp)(buf + (s * PT + (wave - 4) * 64) * 2);
@@ -381,6 +391,70 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
             if (row <= last && x < NDM) dst[x * N + row] = (red[e] + red[NG * 32 + e]) + (red[2 * NG * 32 + e] + red[3 * NG * 32 + e]);
         }
     };
+
+#ifdef NBX_M4_HOLD_ROWS
+    // Row-q partials held back until the range is done.  Thread ptid owns element e = ptid of a tile's row (row groups
+    // 0..7: rows < 128; the few rows above are stored at once), one register pair per tile for M4_HOLD_TILES tiles of the
+    // range -- as many as the registers of a loading wave take next to its Dtot' table without a spill (the first
+    // M4_HOLD_FIRST tiles of a range go out as they are finished).
+    // Why: bytes written to fresh lines WHILE the chip streams cost nine times what a byte read costs; written when the
+    // range's stream is over they cost what a write costs (profiles/r03/lds_dma_stream_probe.txt: +12 us against +2 for
+    // all of them; the bursts have to come at the END -- twenty tiles' rows together in mid-stream cost what they cost
+    // one by one).  176 -> 170 us.
+    double hold0 = 0.0, hold1 = 0.0, hold2 = 0.0, hold3 = 0.0, hold4 = 0.0, hold5 = 0.0, hold6 = 0.0, hold7 = 0.0, hold8 = 0.0, hold9 = 0.0, hold10 = 0.0, hold11 = 0.0, hold12 = 0.0, hold13 = 0.0, hold14 = 0.0, hold15 = 0.0, hold16 = 0.0, hold17 = 0.0, hold18 = 0.0, hold19 = 0.0, hold20 = 0.0, hold21 = 0.0, hold22 = 0.0, hold23 = 0.0, hold24 = 0.0, hold25 = 0.0, hold26 = 0.0, hold27 = 0.0, hold28 = 0.0, hold29 = 0.0, hold30 = 0.0, hold31 = 0.0;
+    auto hold_put = [&](int t, double v) {  // t uniform, 0 .. M4_HOLD_TILES - 1.  (Selects, not a switch: a switch is turned
+        // into an indexed array in scratch memory, and a scratch access waits behind the whole load queue)
+        hold0 = t == 0 ? v : hold0;
+        hold1 = t == 1 ? v : hold1;
+        hold2 = t == 2 ? v : hold2;
+        hold3 = t == 3 ? v : hold3;
+        hold4 = t == 4 ? v : hold4;
+        hold5 = t == 5 ? v : hold5;
+        hold6 = t == 6 ? v : hold6;
+        hold7 = t == 7 ? v : hold7;
+        hold8 = t == 8 ? v : hold8;
+        hold9 = t == 9 ? v : hold9;
+        hold10 = t == 10 ? v : hold10;
+        hold11 = t == 11 ? v : hold11;
+        hold12 = t == 12 ? v : hold12;
+        hold13 = t == 13 ? v : hold13;
+        hold14 = t == 14 ? v : hold14;
+        hold15 = t == 15 ? v : hold15;
+        hold16 = t == 16 ? v : hold16;
+        hold17 = t == 17 ? v : hold17;
+        hold18 = t == 18 ? v : hold18;
+        hold19 = t == 19 ? v : hold19;
+        hold20 = t == 20 ? v : hold20;
+        hold21 = t == 21 ? v : hold21;
+        hold22 = t == 22 ? v : hold22;
+        hold23 = t == 23 ? v : hold23;
+        hold24 = t == 24 ? v : hold24;
+        hold25 = t == 25 ? v : hold25;
+        hold26 = t == 26 ? v : hold26;
+        hold27 = t == 27 ? v : hold27;
+        hold28 = t == 28 ? v : hold28;
+        hold29 = t == 29 ? v : hold29;
+        hold30 = t == 30 ? v : hold30;
+        hold31 = t == 31 ? v : hold31;
+    };
+    // element e of a row-q partial -> (row, spin) as in reduce_rows (parity 1)
+    auto rowq_of = [&](int e, int& row, int& x) {
+        const int g = e >> 5, l = 2 * (e & 31) + 1;
+        row = 16 * g + 4 * ((l >> 2) & 3) + (l >> 4);
+        x = (l & 3) >> 1;
+    };
+    // tile tt's row-q partial: summed as in reduce_rows; rows < 128 into the registers, the others stored now
+    auto hold_rows = [&](int tt, int qq_, double* dst) {
+        hold_put(tt, (redq[ptid] + redq[NG * 32 + ptid]) + (redq[2 * NG * 32 + ptid] + redq[3 * NG * 32 + ptid]));
+        const int e = PT + ptid;
+        if (e < NG * 32) {
+            int row, x;
+            rowq_of(e, row, x);
+            if (row <= qq_ && row < N && x < NDM)
+                dst[x * N + row] = (redq[e] + redq[NG * 32 + e]) + (redq[2 * NG * 32 + e] + redq[3 * NG * 32 + e]);
+        }
+    };
+#endif
 
     // ------------------------------------------------------------------ consumer state
     double acc[NG], bxr[NG];  // (bxr: the row part's X operands of the tile being walked, m4_walk_chunk)
@@ -467,6 +541,13 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
 #else
 #ifdef NBX_M4_ROWS_EVERY  // (ablation, wrong results: the row-q partial of one tile in NBX_M4_ROWS_EVERY only)
                     if (qq < pp && t % NBX_M4_ROWS_EVERY == 0) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
+#elif defined(NBX_M4_HOLD_ROWS)
+                    if (qq < pp) {
+                        if (t - 1 >= M4_HOLD_FIRST && t - 1 < M4_HOLD_FIRST + M4_HOLD_TILES)
+                            hold_rows(t - 1 - M4_HOLD_FIRST, qq, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N);
+                        else
+                            reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
+                    }
 #else
                     if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
 #endif
@@ -507,6 +588,53 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         }
         if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T_end - 1 - t_begin) * NDM) * (int64_t)N, qq);
         reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
+#ifdef NBX_M4_HOLD_ROWS
+        {  // the rows held back: tiles 0 .. ntile - 2 of the range, (p, q) walked from its start
+            int pt = p_first, qt = (int)(T0 - (int64_t)pt * (pt + 1) / 2);
+            for (int i = 0; i < M4_HOLD_FIRST; ++i) next_pq(pt, qt);
+            int row, x;
+            rowq_of(ptid, row, x);
+            double* dst = kpart2 + ((T0 + M4_HOLD_FIRST - t_begin) * NDM) * (int64_t)N + x * N + row;
+#define M4_FLUSH_HELD(t_)                                                      \
+    if (M4_HOLD_FIRST + (t_) + 1 < ntile) {                                    \
+        if (qt < pt && row <= qt && x < NDM) dst[(int64_t)(t_) * NDM * N] = hold##t_; \
+        next_pq(pt, qt);                                                       \
+    }
+            M4_FLUSH_HELD(0);
+            M4_FLUSH_HELD(1);
+            M4_FLUSH_HELD(2);
+            M4_FLUSH_HELD(3);
+            M4_FLUSH_HELD(4);
+            M4_FLUSH_HELD(5);
+            M4_FLUSH_HELD(6);
+            M4_FLUSH_HELD(7);
+            M4_FLUSH_HELD(8);
+            M4_FLUSH_HELD(9);
+            M4_FLUSH_HELD(10);
+            M4_FLUSH_HELD(11);
+            M4_FLUSH_HELD(12);
+            M4_FLUSH_HELD(13);
+            M4_FLUSH_HELD(14);
+            M4_FLUSH_HELD(15);
+            M4_FLUSH_HELD(16);
+            M4_FLUSH_HELD(17);
+            M4_FLUSH_HELD(18);
+            M4_FLUSH_HELD(19);
+            M4_FLUSH_HELD(20);
+            M4_FLUSH_HELD(21);
+            M4_FLUSH_HELD(22);
+            M4_FLUSH_HELD(23);
+            M4_FLUSH_HELD(24);
+            M4_FLUSH_HELD(25);
+            M4_FLUSH_HELD(26);
+            M4_FLUSH_HELD(27);
+            M4_FLUSH_HELD(28);
+            M4_FLUSH_HELD(29);
+            M4_FLUSH_HELD(30);
+            M4_FLUSH_HELD(31);
+#undef M4_FLUSH_HELD
+        }
+#endif
         if (wave == 4) {  // J of every tile of the range: lane i stores tile i's (one wave: its LDS operations are in order)
             if (lane == 0) {  // the last tile's J (its partial sums were stored before the last barrier)
                 const double* jr = jred + ((ntile - 1) & 1) * 4;

@@ -18,7 +18,7 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // W waves, ring of R chunks, D chunks in flight (D <= R - 1)
-template <int W, int R, int D, bool BARRIER, int POL, int MODE = 0>
+template <int W, int R, int D, bool BARRIER, int POL, int MODE = 0, int BURST = 0>
 __global__ __launch_bounds__(MODE >= 3 ? 512 : W * 64, 1) void dma_kernel(const char* __restrict__ src, double* __restrict__ out, long per_wg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LPT = CHUNK / (W * 64 * 16);  // instructions per wave and chunk
@@ -58,17 +58,35 @@ __global__ __launch_bounds__(MODE >= 3 ? 512 : W * 64, 1) void dma_kernel(const 
     for (int g = 0; g < nchunk; ++g) {
         issue(g + D);
         if ((MODE == 2 || MODE == 3) && (g & 3) == 0) out[4096 + (long)blockIdx.x * 1024 + tid] = (double)g;  // (a tile's partial row leaves: same place every tile)
-        if (MODE >= 4 && (g & 3) == 0) {  // the same 2.4 KB to FRESH lines, tile after tile (what jk_m4's row-q partials do)
+        if ((MODE == 4 || MODE == 5) && (g & 3) == 0) {  // the same 2.4 KB to FRESH lines, tile after tile (what jk_m4's row-q partials do)
             double* dst = out + 4096 + ((long)blockIdx.x * (nchunk / 4 + 1) + (g >> 2)) * 296;
             if (MODE == 4 || tid <= ((g >> 2) * 7) % 148) {  // MODE 5: a third of the row on average (columns <= q)
                 dst[tid] = (double)g;
                 if (tid < 40) dst[256 + tid] = (double)g;
             }
         }
+        if (BURST > 0 && (g & 3) == 3 && ((g >> 2) + 1) % BURST == 0) {  // the rows of the last BURST tiles, together, mid-stream
+            for (int t = (g >> 2) + 1 - BURST; t <= (g >> 2); ++t) {
+                double* dst = out + 4096 + ((long)blockIdx.x * (nchunk / 4 + 1) + t) * 296;
+                if (tid <= (t * 7) % 148) {
+                    dst[tid] = (double)t;
+                    if (tid < 40) dst[256 + tid] = (double)t;
+                }
+            }
+        }
         wait_vm<D * LPT>();  // chunk g has landed
         if (BARRIER) __syncthreads();
     }
     wait_vm<0>();
+    if (MODE >= 6) {  // every tile's row at the END of the range, one burst (the rows would have waited in registers)
+        for (int t = 0; t < nchunk / 4; ++t) {
+            double* dst = out + 4096 + ((long)blockIdx.x * (nchunk / 4 + 1) + t) * 296;
+            if (MODE == 6 || tid <= (t * 7) % 148) {
+                dst[tid] = (double)t;
+                if (tid < 40) dst[256 + tid] = (double)t;
+            }
+        }
+    }
     __syncthreads();
     const double v = reinterpret_cast<const double*>(smem)[tid];
     if (v == 12345.678) out[blockIdx.x] = v;
@@ -145,6 +163,11 @@ int main() {
     run("dma  ragged + store, 512-thread workgroup, waves 4-7 load", dma_kernel<4, 5, 3, true, 0, 3>, 512, 5 * CHUNK, d, o, n);
     run("dma  512 threads, ragged, 2.4 KB per tile to FRESH lines", dma_kernel<4, 5, 3, true, 0, 4>, 512, 5 * CHUNK, d, o, n);
     run("dma  512 threads, ragged, 0.8 KB per tile to fresh lines", dma_kernel<4, 5, 3, true, 0, 5>, 512, 5 * CHUNK, d, o, n);
+    run("dma  512 threads, ragged, 2.4 KB per tile, all at the END", dma_kernel<4, 5, 3, true, 0, 6>, 512, 5 * CHUNK, d, o, n);
+    run("dma  512 threads, ragged, 0.8 KB per tile, all at the END", dma_kernel<4, 5, 3, true, 0, 7>, 512, 5 * CHUNK, d, o, n);
+    run("dma  512 threads, ragged, 0.8 KB per tile in bursts of 20 tiles", dma_kernel<4, 5, 3, true, 0, 3, 20>, 512, 5 * CHUNK, d, o, n);
+    run("dma  512 threads, ragged, 0.8 KB per tile in bursts of 10 tiles", dma_kernel<4, 5, 3, true, 0, 3, 10>, 512, 5 * CHUNK, d, o, n);
+    run("dma  512 threads, ragged, 0.8 KB per tile in bursts of 4 tiles", dma_kernel<4, 5, 3, true, 0, 3, 4>, 512, 5 * CHUNK, d, o, n);
     run("dma  the same with 153 KB of LDS", dma_kernel<4, 5, 3, true, 0, 3>, 512, 153 * 1024, d, o, n);
     run("dma  the same, 153 KB, 251 workgroups", dma_kernel<4, 5, 3, true, 0, 3>, 512, 153 * 1024, d, o, n, 251);
     run("reg  4 waves, 2 chunks in registers, barrier", reg_kernel<4, 2, true>, 256, 2 * CHUNK, d, o, n);
