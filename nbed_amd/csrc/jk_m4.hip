@@ -62,7 +62,11 @@ typedef double m4_d2 __attribute__((ext_vector_type(2)));
 #ifndef NBX_M4_NO_HOLD  // (-DNBX_M4_NO_HOLD: every tile's row-q partial stored when it is complete, as before -- for A/B)
 #define NBX_M4_HOLD_ROWS
 #endif
-constexpr int M4_HOLD_TILES = 32, M4_HOLD_FIRST = 12;  // tiles [FIRST, FIRST + TILES) of a range: the first few go out at once  // tiles of a range whose row-q partials wait in the loading waves' registers
+// Row-q partials that wait for the end of the range (see the kernel): tiles [M4_HOLD_FIRST, M4_HOLD_FIRST + M4_HOLD_TILES) of a
+// range in the loading waves' registers -- as many as fit next to the Dtot' table without a spill: check private_seg_size
+// after touching this --, the M4_HOLD_LDS tiles before them in what is left of LDS (2 KB each); the first few go out at once.
+constexpr int M4_HOLD_TILES = 34, M4_HOLD_FIRST = 10;
+constexpr int M4_HOLD_LDS = 5;
 
 __device__ __forceinline__ double2 m4_ldnt(const double* p) {
     const m4_d2 t = __builtin_nontemporal_load(reinterpret_cast<const m4_d2*>(p));
@@ -298,6 +302,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
     double* redp = redq + 4 * NG * 32;       // [4][NG][32] consumers' row-p halves (even columns) when the row ends
     double* jred = redp + 4 * NG * 32;       // [2][4] producers' J partials per tile parity
     double* jstage = jred + 16;              // [L] J of the tiles done, stored at the end of the range
+    double* hold_lds = jstage + L;           // [M4_HOLD_LDS][PT] row-q partials of tiles M4_HOLD_FIRST - M4_HOLD_LDS .. M4_HOLD_FIRST - 1
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave >= 4;
     const int ptid = tid - 256;  // producers: 0 .. 255
@@ -346,8 +351,11 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
     auto jpass = [&](int g) {
         const int k = g & (M4_NCH - 1);
         const double* buf = buf0 + (g % M4_RING) * BUF;
+        // (in two halves: the read-back of a whole chunk at once is 24 registers, and every register pair this wave can
+        //  spare holds one more tile's row partial until the range is done)
 #pragma unroll
         for (int s = 0; s < LPT; ++s) {
+            if (s == (LPT + 1) / 2) __builtin_amdgcn_sched_barrier(0);
             const double2 v = *reinterpret_cast<const double2*>(buf + (s * PT + ptid) * 2);
             const double2 w = k == 0 ? wt[0][s] : (k == 1 ? wt[1][s] : (k == 2 ? wt[2][s] : wt[3][s]));
             jacc = fma(v.y, w.y, fma(v.x, w.x, jacc));
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
     // range's stream is over they cost what a write costs (profiles/r03/lds_dma_stream_probe.txt: +12 us against +2 for
     // all of them; the bursts have to come at the END -- twenty tiles' rows together in mid-stream cost what they cost
     // one by one).  176 -> 170 us.
-    double hold0 = 0.0, hold1 = 0.0, hold2 = 0.0, hold3 = 0.0, hold4 = 0.0, hold5 = 0.0, hold6 = 0.0, hold7 = 0.0, hold8 = 0.0, hold9 = 0.0, hold10 = 0.0, hold11 = 0.0, hold12 = 0.0, hold13 = 0.0, hold14 = 0.0, hold15 = 0.0, hold16 = 0.0, hold17 = 0.0, hold18 = 0.0, hold19 = 0.0, hold20 = 0.0, hold21 = 0.0, hold22 = 0.0, hold23 = 0.0, hold24 = 0.0, hold25 = 0.0, hold26 = 0.0, hold27 = 0.0, hold28 = 0.0, hold29 = 0.0, hold30 = 0.0, hold31 = 0.0;
+    double hold0 = 0.0, hold1 = 0.0, hold2 = 0.0, hold3 = 0.0, hold4 = 0.0, hold5 = 0.0, hold6 = 0.0, hold7 = 0.0, hold8 = 0.0, hold9 = 0.0, hold10 = 0.0, hold11 = 0.0, hold12 = 0.0, hold13 = 0.0, hold14 = 0.0, hold15 = 0.0, hold16 = 0.0, hold17 = 0.0, hold18 = 0.0, hold19 = 0.0, hold20 = 0.0, hold21 = 0.0, hold22 = 0.0, hold23 = 0.0, hold24 = 0.0, hold25 = 0.0, hold26 = 0.0, hold27 = 0.0, hold28 = 0.0, hold29 = 0.0, hold30 = 0.0, hold31 = 0.0, hold32 = 0.0, hold33 = 0.0;
     auto hold_put = [&](int t, double v) {  // t uniform, 0 .. M4_HOLD_TILES - 1.  (Selects, not a switch: a switch is turned
         // into an indexed array in scratch memory, and a scratch access waits behind the whole load queue)
         hold0 = t == 0 ? v : hold0;
@@ -436,6 +444,8 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         hold29 = t == 29 ? v : hold29;
         hold30 = t == 30 ? v : hold30;
         hold31 = t == 31 ? v : hold31;
+        hold32 = t == 32 ? v : hold32;
+        hold33 = t == 33 ? v : hold33;
     };
     // element e of a row-q partial -> (row, spin) as in reduce_rows (parity 1)
     auto rowq_of = [&](int e, int& row, int& x) {
@@ -444,8 +454,10 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         x = (l & 3) >> 1;
     };
     // tile tt's row-q partial: summed as in reduce_rows; rows < 128 into the registers, the others stored now
-    auto hold_rows = [&](int tt, int qq_, double* dst) {
-        hold_put(tt, (redq[ptid] + redq[NG * 32 + ptid]) + (redq[2 * NG * 32 + ptid] + redq[3 * NG * 32 + ptid]));
+    auto hold_rows = [&](int tt, int qq_, double* dst) {  // tt < 0: LDS slot tt + M4_HOLD_LDS
+        const double mine = (redq[ptid] + redq[NG * 32 + ptid]) + (redq[2 * NG * 32 + ptid] + redq[3 * NG * 32 + ptid]);
+        if (tt < 0) hold_lds[(tt + M4_HOLD_LDS) * PT + ptid] = mine;
+        else hold_put(tt, mine);
         const int e = PT + ptid;
         if (e < NG * 32) {
             int row, x;
@@ -543,7 +555,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                     if (qq < pp && t % NBX_M4_ROWS_EVERY == 0) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
 #elif defined(NBX_M4_HOLD_ROWS)
                     if (qq < pp) {
-                        if (t - 1 >= M4_HOLD_FIRST && t - 1 < M4_HOLD_FIRST + M4_HOLD_TILES)
+                        if (t - 1 >= M4_HOLD_FIRST - M4_HOLD_LDS && t - 1 < M4_HOLD_FIRST + M4_HOLD_TILES)
                             hold_rows(t - 1 - M4_HOLD_FIRST, qq, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N);
                         else
                             reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
@@ -591,9 +603,14 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
 #ifdef NBX_M4_HOLD_ROWS
         {  // the rows held back: tiles 0 .. ntile - 2 of the range, (p, q) walked from its start
             int pt = p_first, qt = (int)(T0 - (int64_t)pt * (pt + 1) / 2);
-            for (int i = 0; i < M4_HOLD_FIRST; ++i) next_pq(pt, qt);
             int row, x;
             rowq_of(ptid, row, x);
+            for (int i = 0; i < M4_HOLD_FIRST; ++i) {
+                const int sl = i - (M4_HOLD_FIRST - M4_HOLD_LDS);  // (this thread's own LDS entries: no barrier needed)
+                if (sl >= 0 && i + 1 < ntile && qt < pt && row <= qt && x < NDM)
+                    kpart2[((T0 + i - t_begin) * NDM) * (int64_t)N + x * N + row] = hold_lds[sl * PT + ptid];
+                next_pq(pt, qt);
+            }
             double* dst = kpart2 + ((T0 + M4_HOLD_FIRST - t_begin) * NDM) * (int64_t)N + x * N + row;
 #define M4_FLUSH_HELD(t_)                                                      \
     if (M4_HOLD_FIRST + (t_) + 1 < ntile) {                                    \
@@ -632,6 +649,8 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
             M4_FLUSH_HELD(29);
             M4_FLUSH_HELD(30);
             M4_FLUSH_HELD(31);
+            M4_FLUSH_HELD(32);
+            M4_FLUSH_HELD(33);
 #undef M4_FLUSH_HELD
         }
 #endif
@@ -721,7 +740,7 @@ M4Plan m4_plan_nb(int64_t p0, int64_t np, int64_t ndm) {
     pl.L = (int)L;
     pl.wgs = (int)nbx_cdiv(ntiles, L);
     pl.S = (int)sqrt(2.0 * (double)L) + 3;
-    pl.lds_bytes = (size_t)(M4_RING * G::BUF + 2 * 4 * G::N + 2 * 4 * G::NG * 32 + 16 + pl.L) * sizeof(double);
+    pl.lds_bytes = (size_t)(M4_RING * G::BUF + 2 * 4 * G::N + 2 * 4 * G::NG * 32 + 16 + pl.L + M4_HOLD_LDS * M4_PROD_THREADS) * sizeof(double);
     size_t off = 0;
     pl.wt_off = off; off += m4_align256((size_t)(M4_NCH * G::LPT * M4_PROD_THREADS * 2) * sizeof(double));
     pl.k1_off = off; off += m4_align256((size_t)((int64_t)pl.wgs * pl.S * ndm * G::N) * sizeof(double));
