@@ -828,7 +828,7 @@ def main():
         alg_bytes = 8.0 * N * N * ntiles
         # The packed kernel (the one GpuUHF uses where it applies) reads q <= p AND s <= r: the packed
         # slab, once per build.
-        m4 = packed and N == 148 and os.environ.get("NBX_JK_M4", "1") != "0"  # (csrc/jk_m4.hip serves N = 148)
+        m4 = packed and N % 4 == 0 and 100 <= N <= 148 and os.environ.get("NBX_JK_M4", "1") != "0"  # (the sizes csrc/jk_m4.hip serves)
         if packed:
             # the 4-fold unique integrals of the slab's tiles: N(N+1)/2 doubles per tile -- what jk_s4's layout holds
             # exactly; jk_m4's 4 x 4 blocks store the zeros above the diagonal of the diagonal blocks as well

@@ -266,11 +266,11 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
     // (the Dtot' table: stored AFTER the workgroup has announced its partial sums -- nobody but the next kernel reads
     //  it, and ahead of the fence the stores' completion sat on the path to the last workgroup's final sums)
     auto store_dts = [&]() {
-        if (dts != nullptr && i0 >= j0 && dts_m4) {  // (jk_m4.hip's order: N = 148)
+        if (dts != nullptr && i0 >= j0 && dts_m4) {  // (jk_m4.hip's order; s4_nb_, s4_lpt_, dts_m4 = r1, r2, r3 << 8 | LPT of nbx_jk_m4_weight_layout)
     #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int gi = i0 + threadIdx.y + 8 * k, gj = j0 + threadIdx.x;
-                if (gi < N && gj <= gi) dts[m4_weight_index<37>(gi, gj)] = gi == gj ? dsum[k] : dsum[k] + tsum[k];
+                if (gi < N && gj <= gi) dts[m4_weight_index_rt(s4_nb_, s4_lpt_, dts_m4 >> 8, dts_m4 & 255, gi, gj)] = gi == gj ? dsum[k] : dsum[k] + tsum[k];
             }
         } else if (dts != nullptr && i0 >= j0) {
             const S4Geom g = s4_geom(N, s4_nb_);
@@ -1196,8 +1196,14 @@ int nbx_huz_cycle_scalars_dts(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
                               const double* d_dm_old, double* d_out, const int* d_tail, int64_t tail_n,
                               double* d_dts) {
     NBX_CHECK_ARG(ctx && d_hcore && d_vhf && d_hz && d_dm && d_dm_old && d_out && nao > 0);
-    const int m4 = d_dts && nbx_jk_m4_covers(nao) ? 1 : 0;  // (N = 148: the table in jk_m4.hip's order)
-    const int nb4 = d_dts ? s4_nb(nao) : 0, lpt4 = d_dts ? s4_lpt(nao) : 0;
+    int m4 = 0, nb4 = d_dts ? s4_nb(nao) : 0, lpt4 = d_dts ? s4_lpt(nao) : 0;
+    if (d_dts && nbx_jk_m4_covers(nao)) {  // (the table in jk_m4.hip's order: its layout parameters travel in these three)
+        int wl[4];
+        nbx_jk_m4_weight_layout(nao, wl);
+        nb4 = wl[0];
+        lpt4 = wl[1];
+        m4 = (wl[2] << 8) | wl[3];
+    }
     NBX_CHECK_ARG(d_dts == nullptr || lpt4 > 0);  // the table exists for sizes nbx_jk_packed covers
     NBX_CHECK_ARG(tail_n >= 0 && tail_n <= 64 && (tail_n == 0 || d_tail != nullptr));
     NBX_CHECK_ARG(hcore_ndim == 2 || hcore_ndim == 3);

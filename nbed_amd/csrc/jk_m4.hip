@@ -31,7 +31,8 @@
 // behind the one that has landed --, one barrier per chunk; J is a flat dot product of the chunk (read back from LDS by
 // the loading waves) with a Dtot' table held in registers; row-q partials go out per tile, row-p partials when the range
 // crosses a row, both summed in a fixed order by jk_sym_reduce_kernel (with the Fock epilogue), as in jk_s4.hip.
-// This is the production kernel of the sizes nbx_jk_m4_covers() names (N = 148); DESIGN.md section 9 has the
+// This is the production kernel of the sizes nbx_jk_m4_covers() names (N = 100 .. 148 in steps of four, one instance each:
+// the tile has to fit the five-buffer ring in four chunks and its Dtot' table a loading wave's registers); DESIGN.md section 9 has the
 // measurements that led here and what is left (0.64-0.67 of the HBM roofline against jk_s4's 0.55).
 #include <cstdlib>
 
@@ -55,6 +56,8 @@ __device__ __forceinline__ void m4_wait_three_chunks() {
     if constexpr (LPT == 6) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     else if constexpr (LPT == 5) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
     else if constexpr (LPT == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (LPT == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (LPT == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -796,35 +799,81 @@ int m4_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
 
 // The sizes this kernel has an instance for (N = 4 NB; every loop bound of the walk is a compile-time constant).
 // NBX_JK_M4=0 in the environment (read once per process) hands them back to jk_s4.hip.
+#ifndef NBX_M4_SIZES
+#define NBX_M4_SIZES(X) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37)  // N = 100 .. 148
+#endif
+#define M4_DISPATCH(N_, EXPR)            \
+    switch ((int)((N_) / 4)) {           \
+        NBX_M4_SIZES(M4_CASE_##EXPR)     \
+        default: break;                  \
+    }
 bool nbx_jk_m4_covers(int64_t N) {
     static const bool on = getenv("NBX_JK_M4") == nullptr || atoi(getenv("NBX_JK_M4")) != 0;
-    return on && N == 148;
+    if (!on || N % 4 != 0) return false;
+#define M4_CASE_covers(NB_) case NB_: return true;
+    M4_DISPATCH(N, covers)
+#undef M4_CASE_covers
+    return false;
 }
 
 size_t nbx_jk_m4_packed_bytes(int64_t N, int64_t p0, int64_t p1) {
     const int64_t ntiles = m4_tri((int)p1) - m4_tri((int)p0);
-    return (size_t)(ntiles * M4Geom<37>::TILE) * sizeof(double) + 256;  // (+ slack: the staging of the last tile prefetches nothing beyond)
+    // (+ slack: the staging of the last tile prefetches nothing beyond)
+#define M4_CASE_bytes(NB_) case NB_: return (size_t)(ntiles * M4Geom<NB_>::TILE) * sizeof(double) + 256;
+    M4_DISPATCH(N, bytes)
+#undef M4_CASE_bytes
+    return 0;
 }
 
-size_t nbx_jk_m4_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm) { return m4_plan_nb<37>(p0, p1 - p0, ndm).total; }
+size_t nbx_jk_m4_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm) {
+#define M4_CASE_work(NB_) case NB_: return m4_plan_nb<NB_>(p0, p1 - p0, ndm).total;
+    M4_DISPATCH(N, work)
+#undef M4_CASE_work
+    return 0;
+}
 
 int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_eri, double* d_packed) {
     NBX_CHECK_ARG(nbx_jk_m4_covers(N) && d_eri && d_packed);
     const int64_t ntiles = m4_tri((int)p1) - m4_tri((int)p0);
-    hipLaunchKernelGGL(m4_pack_kernel<37>, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, d_eri, d_packed, (int)p0,
-                       (int64_t)m4_tri((int)p0));
+#define M4_CASE_pack(NB_)                                                                                                  \
+    case NB_:                                                                                                              \
+        hipLaunchKernelGGL(m4_pack_kernel<NB_>, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, d_eri, d_packed, (int)p0, \
+                           (int64_t)m4_tri((int)p0));                                                                      \
+        break;
+    M4_DISPATCH(N, pack)
+#undef M4_CASE_pack
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
 
 // the Dtot' weights table of a density (m4_weight_index order; the entries nothing writes are zero weights)
 size_t nbx_jk_m4_weights_bytes(int64_t N) {
-    return (size_t)(M4_NCH * M4Geom<37>::LPT * M4_PROD_THREADS * 2) * sizeof(double);
+#define M4_CASE_wbytes(NB_) case NB_: return (size_t)(M4_NCH * M4Geom<NB_>::LPT * M4_PROD_THREADS * 2) * sizeof(double);
+    M4_DISPATCH(N, wbytes)
+#undef M4_CASE_wbytes
+    return 0;
+}
+
+// what huz_scalars_kernel needs to write that table for size N: the first block rows of chunks 1..3 and the slots per chunk
+void nbx_jk_m4_weight_layout(int64_t N, int out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+#define M4_CASE_wl(NB_)                     \
+    case NB_:                               \
+        out[0] = M4Geom<NB_>::row0(1);      \
+        out[1] = M4Geom<NB_>::row0(2);      \
+        out[2] = M4Geom<NB_>::row0(3);      \
+        out[3] = M4Geom<NB_>::LPT;          \
+        break;
+    M4_DISPATCH(N, wl)
+#undef M4_CASE_wl
 }
 
 // d_wt: NULL, or that table for d_dm (written by huz_scalars_kernel when it judged d_dm): saves the preparation launch
 int nbx_jk_m4(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
               double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt) {
     NBX_CHECK_ARG(nbx_jk_m4_covers(N));
-    return m4_run<37>(ctx, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_wt);
+#define M4_CASE_run(NB_) case NB_: return m4_run<NB_>(ctx, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_wt);
+    M4_DISPATCH(N, run)
+#undef M4_CASE_run
+    return NBX_E_UNSUPPORTED;
 }

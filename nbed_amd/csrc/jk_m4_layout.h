@@ -49,8 +49,19 @@ __host__ __device__ __forceinline__ int m4_weight_index(int row, int col) {
     return k * G::LPT * M4_PROD_THREADS * 2 + d - 16 * m4_tri(rk);
 }
 
+// the same with the chunk boundaries (r1, r2, r3 = first block rows of chunks 1..3) and LPT as run-time values
+// (nbx_jk_m4_weight_layout): the scalars kernel serves every size with one instance
+__host__ __device__ __forceinline__ int m4_weight_index_rt(int r1, int r2, int r3, int lpt, int row, int col) {
+    const int bt = row >> 2, bc = col >> 2, ii = row & 3, kk = col & 3;
+    const int k = (bt >= r1) + (bt >= r2) + (bt >= r3);
+    const int rk = k == 0 ? 0 : k == 1 ? r1 : k == 2 ? r2 : r3;
+    const int d = 16 * (m4_tri(bt) + bc) + 4 * (kk ^ ((bt ^ bc) & 3)) + (ii ^ kk);
+    return k * lpt * M4_PROD_THREADS * 2 + d - 16 * m4_tri(rk);
+}
+
 }  // namespace
 
 // jk_m4.hip
+void nbx_jk_m4_weight_layout(int64_t N, int out[4]);
 bool nbx_jk_m4_covers(int64_t N);
 size_t nbx_jk_m4_weights_bytes(int64_t N);

@@ -57,7 +57,7 @@ def test_no_gpu_means_no_backend():
 def test_streaming_jk_kernels_have_no_scratch(tmp_path):
     """jk_m4_kernel keeps the row partials of a range in the loading waves' registers, 254 of 256 of them: one register
     more and the compiler spills -- and a scratch access in that loop waits behind the whole queue of chunk loads
-    (DESIGN.md section 9 (xiv)).  The cross-compiled ISA must say private_seg_size 0 for both instances."""
+    (DESIGN.md section 9 (xiv)).  The cross-compiled ISA must say private_seg_size 0 for every instance (N = 100 .. 148, one or two densities)."""
     import re
     import shutil
     import subprocess
@@ -73,6 +73,6 @@ def test_streaming_jk_kernels_have_no_scratch(tmp_path):
     subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", f"-I{root / 'include'}", "-S", "--cuda-device-only",
                     str(root / "nbed_amd" / "csrc" / "jk_m4.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=600)
     text = asm.read_text()
-    sizes = re.findall(r"jk_m4_kernelILi37ELi([12])E\S*\.private_seg_size, (\d+)", text)
-    assert sorted(k for k, _ in sizes) == ["1", "2"], sizes
-    assert all(int(v) == 0 for _, v in sizes), f"jk_m4_kernel spills: {sizes}"
+    sizes = re.findall(r"jk_m4_kernelILi(\d+)ELi([12])E\S*\.private_seg_size, (\d+)", text)
+    assert ("37", "1") in {(nb, k) for nb, k, _ in sizes} and ("37", "2") in {(nb, k) for nb, k, _ in sizes}, sizes
+    assert len(sizes) >= 2 and all(int(v) == 0 for _, _, v in sizes), f"jk_m4_kernel spills: {sizes}"

@@ -784,10 +784,11 @@ def test_jk_packed_vs_oracle(be, n, ndm):
     assert float(be.jk_packed(be.eri_pack(eri[:0], n, 3, 3), be.asarray(dm), 3, 3).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("n", [128, 148, 192, 256])
+@pytest.mark.parametrize("n", [100, 104, 116, 124, 128, 132, 140, 144, 148, 152, 192, 256])
 def test_jk_packed_full_size(be, n):
-    """The four kernel instances of the larger sizes (N = 148 is the bench size) against the plain
-    streaming kernel on the generated tensor, both spins."""
+    """The kernel instances of the larger sizes against the plain streaming kernel on the generated tensor, both
+    spins: N = 100 .. 148 in steps of four are jk_m4.hip's (one instance per size; 148 is the bench size; the sizes here
+    cover its chunk-length classes LPT = 3 .. 6), the others jk_s4.hip's."""
     eri = be.synth_eri(n)
     dmd = be.asarray(np.stack([symm(532, n), symm(533, n)]))
     a = be.to_host(be.jk_packed(be.eri_pack(eri, n), dmd))
@@ -796,12 +797,12 @@ def test_jk_packed_full_size(be, n):
     np.testing.assert_array_equal(a[0], a[0].T)
 
 
-@pytest.mark.parametrize("n", [24, 72, 128, 148])
+@pytest.mark.parametrize("n", [24, 72, 104, 128, 136, 148, 192])
 def test_jk_packed_fock_and_prepared_dtot_table(be, n):
     """nbx_jk_packed_fock (Fock assembly in the reduction) against J/K + nbx_fock_uhf, and the Dtot'
     table left by the scalars kernel (nbx_huz_cycle_scalars_dts) against the one the build makes
     itself: bit-identical Fock matrices, also when the table is reused for a second density.
-    (N = 148 is served by jk_m4.hip, whose table has its own order: csrc/jk_m4_layout.h.)"""
+    (N = 100 .. 148 in steps of four are served by jk_m4.hip, whose table has its own order: csrc/jk_m4_layout.h.)"""
     eri = be.synth_eri(n)
     packed = be.eri_pack(eri, n)
     hv = be.asarray(np.stack([symm(570, n), symm(571, n)]))
@@ -1318,7 +1319,7 @@ def test_kernels_do_not_depend_on_what_lds_held(be):
             be.debug_fill_lds(nan)
             np.testing.assert_array_equal(be.to_host(fn()), ref)
 
-    for n in (128, 148):
+    for n in (100, 116, 128, 148):
         eri = be.synth_eri(n)
         packed = be.eri_pack(eri, n)
         for ndm in (2, 1):
