@@ -159,7 +159,8 @@ int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const do
  * tensors of N = 100..156, N % 4 == 0 are stored 8-fold instead -- of every tile only the entries
  * (r,s) <= (p,q), csrc/jk_p8.hip; same entry points and results, experimental: DESIGN.md section 9.)
  * N = 100, 104, ..., 148 have a layout and a kernel of their own (csrc/jk_m4.hip, one instance per size, the contraction on
- * v_mfma_f64_4x4x4_4b_f64): a tile is the
+ * v_mfma_f64_4x4x4_4b_f64; N = 97 .. 147 that are not multiples of four run as the next multiple with the extra rows and
+ * columns zero -- the padding is internal, as for jk_s4.hip's padded sizes): a tile is the
  * lower triangle in 4 x 4 blocks, block (T, C <= T) at T(T+1)/2 + C, element (i, k) at 4 (k ^ ((T ^ C) & 3)) + (i ^ k),
  * zeros above the diagonal of the diagonal blocks; NBX_JK_M4=0 in the environment keeps the layout above.  Either way the
  * packed buffer is opaque to the caller: nbx_eri_packed_bytes / nbx_eri_pack / nbx_jk_packed agree on it per process.

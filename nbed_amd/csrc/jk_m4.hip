@@ -85,20 +85,22 @@ __host__ __device__ __forceinline__ int m4_tri_row(int64_t T) {
 
 // ---------------------------------------------------------------------------------------------- pack and weights
 // slab rows [p0, p0 + np) of the dense tensor -> block-major tiles; one workgroup per tile
+// (nsrc <= N: the dense tensor's own size -- a size that is not a multiple of four runs as the next one that is, with the
+//  extra rows and columns zero: only the tiles p < nsrc exist, and their elements beyond nsrc are stored as zeros)
 template <int NB>
 __global__ __launch_bounds__(256) void m4_pack_kernel(const double* __restrict__ eri, double* __restrict__ out, int p0,
-                                                      int64_t t_begin) {
+                                                      int64_t t_begin, int nsrc) {
     using G = M4Geom<NB>;
     const int64_t T = t_begin + blockIdx.x;
     const int p = m4_tri_row(T), q = (int)(T - (int64_t)p * (p + 1) / 2);
-    const double* src = eri + ((int64_t)(p - p0) * G::N + q) * G::N * G::N;
+    const double* src = eri + ((int64_t)(p - p0) * nsrc + q) * nsrc * nsrc;
     double* dst = out + (int64_t)blockIdx.x * G::TILE;
     for (int e = threadIdx.x; e < G::TILE; e += 256) {
         const int blk = e >> 4;
         const int bt = m4_tri_row(blk), bc = blk - m4_tri(bt);
         const int k = ((e >> 2) & 3) ^ ((bt ^ bc) & 3), i = (e & 3) ^ k;  // (the swizzle: see the layout note above)
         const int row = 4 * bt + i, col = 4 * bc + k;
-        dst[e] = col <= row ? src[(int64_t)row * G::N + col] : 0.0;
+        dst[e] = (col <= row && row < nsrc) ? src[(int64_t)row * nsrc + col] : 0.0;
     }
 }
 
@@ -832,13 +834,13 @@ size_t nbx_jk_m4_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm) {
     return 0;
 }
 
-int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_eri, double* d_packed) {
-    NBX_CHECK_ARG(nbx_jk_m4_covers(N) && d_eri && d_packed);
+int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed) {
+    NBX_CHECK_ARG(nbx_jk_m4_covers(N) && d_eri && d_packed && nsrc <= N && nsrc > N - 4 && p1 <= nsrc);
     const int64_t ntiles = m4_tri((int)p1) - m4_tri((int)p0);
 #define M4_CASE_pack(NB_)                                                                                                  \
     case NB_:                                                                                                              \
         hipLaunchKernelGGL(m4_pack_kernel<NB_>, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, d_eri, d_packed, (int)p0, \
-                           (int64_t)m4_tri((int)p0));                                                                      \
+                           (int64_t)m4_tri((int)p0), (int)nsrc);                                                           \
         break;
     M4_DISPATCH(N, pack)
 #undef M4_CASE_pack

@@ -42,7 +42,7 @@ bool nbx_jk_m4_covers(int64_t N);
 size_t nbx_jk_m4_weights_bytes(int64_t N);
 size_t nbx_jk_m4_packed_bytes(int64_t N, int64_t p0, int64_t p1);
 size_t nbx_jk_m4_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm);
-int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
+int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
 int nbx_jk_m4(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
               double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt);
 #ifdef NBX_EXPERIMENTAL
@@ -378,6 +378,13 @@ S4Plan s4_plan(int64_t N, int64_t p0, int64_t np, int64_t ndm) {
 
 }  // namespace
 
+// The size jk_m4.hip runs nao as: nao itself or the next multiple of four (at most three zero rows / columns more), if that
+// size has an instance; 0: jk_s4.hip's business
+static int64_t m4_padded(int64_t nao) {
+    const int64_t n4 = (nao + 3) / 4 * 4;
+    return (nao > 0 && nbx_jk_m4_covers(n4)) ? n4 : 0;
+}
+
 // 1: a kernel instance serves N; 2: served as the next covered size with zero rows/columns; 0: no
 extern "C" int nbx_jk_packed_supported(int64_t nao) {
     return s4_supported(nao) ? 1 : (s4_padded(nao) > 0 ? 2 : 0);
@@ -386,7 +393,7 @@ extern "C" int nbx_jk_packed_supported(int64_t nao) {
 extern "C" size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1) {
     const int64_t NP = s4_padded(nao);
     if (NP == 0 || p0 < 0 || p1 < p0 || p1 > nao) return 0;
-    if (nbx_jk_m4_covers(nao)) return nbx_jk_m4_packed_bytes(nao, p0, p1);
+    if (m4_padded(nao)) return nbx_jk_m4_packed_bytes(m4_padded(nao), p0, p1);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_packed_bytes(nao);
     const S4Geom g = s4_geom((int)NP, s4_nb(NP));
     return (size_t)((s4_tri(p1) - s4_tri(p0)) * g.M) * sizeof(double);
@@ -402,7 +409,7 @@ extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
     }
     if (p0 == p1) return NBX_OK;
     NBX_CHECK_ARG(d_eri && d_packed);
-    if (nbx_jk_m4_covers(nao)) return nbx_jk_m4_pack(ctx, nao, p0, p1, d_eri, d_packed);
+    if (m4_padded(nao)) return nbx_jk_m4_pack(ctx, m4_padded(nao), nao, p0, p1, d_eri, d_packed);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_pack(ctx, nao, d_eri, d_packed);
     const int64_t ntiles = s4_tri(p1) - s4_tri(p0);
     int rc = nbx_memset(ctx, d_packed, 0, nbx_eri_packed_bytes(nao, p0, p1));
@@ -416,7 +423,8 @@ extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
 extern "C" size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm) {
     const int64_t NP = s4_padded(nao);
     if (NP == 0 || p0 < 0 || p1 < p0 || p1 > nao || ndm <= 0) return 0;
-    if (nbx_jk_m4_covers(nao)) return nbx_jk_m4_worksize(nao, p0, p1, ndm);
+    if (const int64_t n4 = m4_padded(nao))  // (+ the padded densities and J/K of a size that is not a multiple of four)
+        return nbx_jk_m4_worksize(n4, p0, p1, ndm) + (n4 != nao ? s4_align256((size_t)((1 + 2 * ndm) * n4 * n4) * sizeof(double)) : 0);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_worksize(nao, ndm);
     size_t total = s4_plan(NP, p0, p1 - p0, ndm).total;
     if (NP != nao) total += s4_align256((size_t)((1 + 2 * ndm) * NP * NP) * sizeof(double));  // padded D and J/K
@@ -475,6 +483,24 @@ static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double
     NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
     if (p1 == p0) return nbx_memset(ctx, d_jk, 0, (size_t)((1 + ndm) * nao * nao) * sizeof(double));
     if (nbx_jk_m4_covers(nao)) return nbx_jk_m4(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
+    if (const int64_t n4 = m4_padded(nao)) {
+        // as the n4 x n4 problem whose extra rows and columns are zero (tiles with p >= nao are neither stored nor visited):
+        // D padded on the way in, J/K cropped on the way out, the Fock assembly its own launch
+        char* tail = static_cast<char*>(d_work) + nbx_jk_m4_worksize(n4, p0, p1, ndm);
+        double* dm_pad = reinterpret_cast<double*>(tail);
+        double* jk_pad = dm_pad + ndm * n4 * n4;
+        const int64_t tin = ndm * n4 * n4, tout = (1 + ndm) * nao * nao;
+        hipLaunchKernelGGL(s4_pad_square_kernel, dim3((unsigned)nbx_cdiv(tin, 256)), dim3(256), 0, ctx->stream, d_dm,
+                           dm_pad, (int)nao, (int)n4, (int)ndm);
+        NBX_LAUNCH_CHECK();
+        const int rc = nbx_jk_m4(ctx, n4, p0, p1, d_packed, dm_pad, ndm, jk_pad, d_work, nullptr, nullptr, nullptr, nullptr);
+        if (rc != NBX_OK) return rc;
+        hipLaunchKernelGGL(s4_crop_square_kernel, dim3((unsigned)nbx_cdiv(tout, 256)), dim3(256), 0, ctx->stream,
+                           jk_pad, d_jk, (int)nao, (int)n4, (int)(1 + ndm));
+        NBX_LAUNCH_CHECK();
+        if (d_fock != nullptr) return nbx_fock_uhf(ctx, nao, d_hv, 3, nullptr, d_jk, d_fock, d_vhf);
+        return NBX_OK;
+    }
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8(ctx, nao, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
     if (NPAD != nao) {
         // Run as the NPAD x NPAD problem whose extra rows and columns are zero: the tiles (p, q) with

@@ -784,11 +784,12 @@ def test_jk_packed_vs_oracle(be, n, ndm):
     assert float(be.jk_packed(be.eri_pack(eri[:0], n, 3, 3), be.asarray(dm), 3, 3).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("n", [100, 104, 116, 124, 128, 132, 140, 144, 148, 152, 192, 256])
+@pytest.mark.parametrize("n", [100, 104, 116, 118, 124, 128, 130, 132, 140, 144, 148, 152, 192, 256])
 def test_jk_packed_full_size(be, n):
     """The kernel instances of the larger sizes against the plain streaming kernel on the generated tensor, both
     spins: N = 100 .. 148 in steps of four are jk_m4.hip's (one instance per size; 148 is the bench size; the sizes here
-    cover its chunk-length classes LPT = 3 .. 6), the others jk_s4.hip's."""
+    cover its chunk-length classes LPT = 3 .. 6; 118 and 130 run as 120 and 132 with zero rows and columns), the others
+    jk_s4.hip's."""
     eri = be.synth_eri(n)
     dmd = be.asarray(np.stack([symm(532, n), symm(533, n)]))
     a = be.to_host(be.jk_packed(be.eri_pack(eri, n), dmd))
@@ -833,7 +834,7 @@ def test_jk_packed_unsupported_sizes(be):
         be.eri_pack(eri, 7)
 
 
-@pytest.mark.parametrize("n", [17, 22, 49, 75, 102, 149, 150])
+@pytest.mark.parametrize("n", [17, 22, 49, 75, 97, 102, 117, 147, 149, 150])
 def test_jk_packed_zero_padded_sizes_vs_oracle(be, n):
     """Sizes the packed kernel has no instance for (odd N; N = 22, 102, 150: no fitting block
     geometry) run as the next covered size with zero rows/columns (include/nbx.h): J and K against
