@@ -143,7 +143,11 @@ class HipBackend:
         # _PIN_SLOTS further calls; the SCF loops read a handle one call late.
         self._pin_ring = torch.empty((self._PIN_SLOTS, self._PIN_WIDTH), dtype=torch.float64, pin_memory=True)
         self._pin_next = 0
-        self._pin_results = torch.empty(1 << 17, dtype=torch.float64, pin_memory=True)  # to_host_many's landing buffer
+        # to_host_many's landing buffer: 4 MB of pinned memory, enough for the results of an SCF up to N_AO ~ 290 (C, D, Hz
+        # of two spins + eps).  It was 1 MB -- 648 bytes short of an N = 148 run's results, so the first SCF of a process
+        # ended on a hipHostMalloc of a bigger one: 0.35 ms behind its last cycle, 6 % of a 20-cycle benchmark run.
+        self._pin_results = torch.empty(1 << 19, dtype=torch.float64, pin_memory=True)
+        self._gather_args = ((ctypes.c_void_p * 8)(), (ctypes.c_int64 * 8)())
         self.to_host_many([torch.zeros(1, dtype=torch.float64, device=self.device)])  # (first launch of its kernel: 0.1 ms)
 
     def __del__(self):
@@ -274,14 +278,18 @@ class HipBackend:
         total = sum(int(t.numel()) for t in tensors)
         pin = getattr(self, "_pin_results", None)  # (a pageable destination costs a staging copy per call)
         if pin is None or pin.numel() < total + 1:
-            pin = self._pin_results = torch.empty(max(total + 1, 1 << 17), dtype=torch.float64, pin_memory=True)
+            pin = self._pin_results = torch.empty(max(total + 1, 1 << 19), dtype=torch.float64, pin_memory=True)
         flat = pin.numpy()
         direct = len(tensors) <= 8 and all(t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() for t in tensors)
         if direct:
             # one kernel that stores straight into the pinned buffer (nbx_gather_to_host)
             flat[total] = 0.0
-            srcs = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
-            sizes = (ctypes.c_int64 * len(tensors))(*[int(t.numel()) for t in tensors])
+            # (argument arrays of the full eight entries, made once: ctypes builds a new array TYPE for every new length,
+            #  0.2-0.4 ms the first time -- which used to be behind the last cycle of the first SCF run of a process)
+            srcs, sizes = self._gather_args
+            for i, t in enumerate(tensors):
+                srcs[i] = t.data_ptr()
+                sizes[i] = int(t.numel())
             self._call("nbx_gather_to_host", len(tensors), srcs, sizes, self._p(pin), 1 if wait else 0)
         else:
             pin[:total].copy_(torch.cat([t.reshape(-1) for t in tensors]), non_blocking=True)
