@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--no-transform", action="store_true")
     ap.add_argument("--no-n2000", action="store_true", help="skip the bounded N_AO=2000 streamed sample")
     ap.add_argument("--no-tts", action="store_true", help="skip the cold-start time-to-solution run")
+    ap.add_argument("--no-mu", action="store_true", help="skip the mu-shift projector's SCF leg")
     ap.add_argument("--no-real", action="store_true", help="skip the real-molecule leg (octane / 6-31G*, nothing injected)")
     ap.add_argument("--no-small", action="store_true", help="skip the small-config legs (BASELINE configs[0], [1], [4] shape)")
     ap.add_argument("--no-scaling", action="store_true", help="skip the scaling workloads (N_AO = 256 packed, 384 symmetric)")
@@ -212,6 +213,94 @@ def timed_huzinaga_run(mf, emb_args, kw, warmup, steps, sync):
             "queue_pace_ms_first_cycles": [round(float(x) * 1e3, 3) for x in diffs[:12]],
             "scf_restarts": list(hist.info.get("restarts", [])), "one_call_per_cycle": bool(hist.info.get("cycle_call")),
             "energy_last_cycle": [float(x) for x in hist[-1][0]]}
+
+
+def cpu_baseline_mu_cycle(pr, eri_h, h3, ncycles):
+    """The CPU oracle's mu-shift cycle on the host cores: oracle.pyscf_like.ToyUHF.kernel() (scf.hf.kernel: CDIIS,
+    scipy generalised eigh, energy and gradient) with the C/OpenMP one-pass J/K behind get_veff, on the patched
+    hcore ``h3``; exactly ``ncycles`` cycles."""
+    cpu_baseline_cycle  # (the C library is loaded by the Huzinaga leg: same helper)
+    from oracle import cref
+    from oracle.pyscf_like import ToyMol, ToyUHF
+
+    lib = _CPU_LIB.get("lib")
+    if lib is None:
+        import tempfile
+
+        os.environ["OMP_NUM_THREADS"] = str(host_cores())
+        try:
+            lib = cref.load(cref.build(tempfile.mkdtemp(prefix="jkref_")))
+        except Exception:
+            lib = cref.load()
+        _CPU_LIB["lib"] = lib
+
+    class CUHF(ToyUHF):
+        def get_veff(self, mol=None, dm=None, dm_last=0, vhf_last=0):
+            jk = cref.jk(self._eri, np.asarray(dm), lib=lib)
+            return jk[0] - jk[1:]
+
+    mf = CUHF(ToyMol(pr["nao"], pr["nelec"]), pr["S"], pr["hcore"], eri_h)
+    mf.get_hcore = lambda *a: h3
+    mf.max_cycle, mf.conv_tol = ncycles, -1.0
+    t0 = time.perf_counter()
+    mf.kernel()
+    return ncycles / (time.perf_counter() - t0)
+
+
+def mu_shift_leg(be, mf_inputs, pr, args, sync, mu=1.0e6):
+    """The OTHER projector of north_star's sentence, the reference's default (nbed/config.py:110,128): the mu-shift
+    SCF of nbed/driver.py:500-538 -- PySCF's scf.hf.kernel on the hcore patched with mu S D_env S + V_emb -- on the
+    same inputs as ``value`` (configs[2] shape), by the same protocol: ONE kernel() run of warmup + steps cycles with
+    the stopping rule off, CDIIS on; the clock runs from the moment cycle ``warmup`` is about to be queued until the
+    run has returned its results.  One cycle = one nbx_mu_cycle call."""
+    from nbed_amd.scf import GpuUHF, Mole
+
+    N = int(pr["nao"])
+    S, hcore = np.asarray(pr["S"]), np.asarray(pr["hcore"])
+    h3 = hcore[None] + mu * (S @ np.asarray(pr["D_env"]) @ S) + np.asarray(pr["V_emb"])
+    eri, packed, shards = mf_inputs
+    steps, warmup = args.steps, args.warmup
+    res = {}
+    for attempt in ("first_call", "timed"):
+        mf = GpuUHF(Mole(N, pr["nelec"]), S, hcore, eri, backend=be, shards=shards, eri_packed=packed)
+        mf.get_hcore = lambda *a: h3
+        mf.conv_tol, mf.max_cycle = -1.0, warmup + steps
+        clock, stamps = {}, []
+
+        def on_cycle(i):
+            if i == 0:
+                del stamps[:]
+            stamps.append(time.perf_counter())
+            if i == warmup:
+                sync()
+                clock["t0"] = time.perf_counter()
+
+        mf.cycle_callback = on_cycle
+        mf.kernel()
+        sync()
+        dt = time.perf_counter() - clock["t0"]
+        diffs = np.diff(stamps)
+        res = {"cycles_per_sec": steps / dt, "ms_per_cycle": dt / steps * 1e3,
+               "ms_per_cycle_settled": float(np.median(diffs[-8:])) * 1e3 if len(diffs) else None,
+               "queue_pace_ms_first_cycles": [round(float(x) * 1e3, 3) for x in diffs[:12]],
+               "kernel_info": dict(mf.kernel_info), "e_tot": float(mf.e_tot)}
+    # time to solution with PySCF's stopping rule (conv_tol = Nbed's convergence 1e-6; conv_check cycle included)
+    mf = GpuUHF(Mole(N, pr["nelec"]), S, hcore, eri, backend=be, shards=shards, eri_packed=packed)
+    mf.get_hcore = lambda *a: h3
+    mf.conv_tol, mf.max_cycle = 1e-6, 50
+    sync()
+    t0 = time.perf_counter()
+    mf.kernel()
+    sync()
+    dts = time.perf_counter() - t0
+    res["time_to_solution"] = {"ms": dts * 1e3, "cycles": int(mf.cycles), "converged": bool(mf.converged),
+                               "stopping_rule": "|dE| < 1e-6 and |g_orb|/sqrt(size) < 1e-3 (scf.hf.kernel, conv_tol = nbed/config.py:110), "
+                                                "core-Hamiltonian guess, CDIIS, conv_check cycle included",
+                               "e_tot": float(mf.e_tot), "kernel_info": dict(mf.kernel_info)}
+    res["workload"] = (f"mu-shift SCF (nbed/driver.py:500-538), mu = {mu:g}, same N_AO={N} inputs as `value`: hcore + mu S D_env S "
+                       "+ V_emb, GpuUHF.kernel() = scf.hf.kernel control flow, one nbx_mu_cycle call per cycle")
+    res["steps"], res["warmup"] = steps, warmup
+    return res, h3
 
 
 def embedded_molecule_run(be, cfg, prov):
@@ -571,6 +660,19 @@ def main():
     e_last = [float(x) for x in hist[-1][0]]
     dm_change_last = float(hist[-1][1])
 
+    # ---------------- the mu-shift projector's SCF on the same inputs (the reference's default projector)
+    mu_leg, mu_h3 = None, None
+    if not args.no_mu:
+        try:
+            mu_leg, mu_h3 = mu_shift_leg(be, (eri, mf.eri_packed_device(), shards), pr, args, barrier)
+            if world > 1:
+                tmax = torch.tensor([mu_leg["ms_per_cycle"]], dtype=torch.float64, device=be.device)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                mu_leg["ms_per_cycle"] = float(tmax.item())
+                mu_leg["cycles_per_sec"] = 1e3 / mu_leg["ms_per_cycle"]
+        except Exception as exc:  # informative leg: it must not take the bench line down with it
+            mu_leg = {"error": f"{type(exc).__name__}: {exc}"}
+
     # ---------------- four-index transform (3 unique spin blocks), outer index sharded
     transform = None
     if not args.no_transform:
@@ -805,6 +907,12 @@ def main():
             "sample": f"{args.cpu_cycles} Huzinaga UHF cycles at N_AO={N}: oracle loop with C/OpenMP one-pass dense J/K "
                       "(oracle/c/jk_ref.c, -march=native) + numpy/LAPACK eigh, same inputs",
         }
+        if mu_leg is not None and "error" not in mu_leg:
+            mu_leg["cpu_baseline"] = {
+                "value": cpu_baseline_mu_cycle(pr, eri_h, mu_h3, args.cpu_cycles), "unit": "cycles/s", "cores": host_cores(),
+                "kind": "port",
+                "sample": f"{args.cpu_cycles} cycles of the oracle's scf.hf.kernel loop (oracle/pyscf_like.py: CDIIS, scipy "
+                          "generalised eigh, gradient) with the C/OpenMP one-pass dense J/K, same patched hcore"}
         if transform is not None:
             from oracle import hamiltonian
 
@@ -911,6 +1019,7 @@ def main():
             "check": {"energy_last_cycle": e_last, "dm_change_last_cycle": dm_change_last, "scf_restarts": scf_restarts,
                       "one_call_per_cycle": one_call},
             "time_to_solution": tts,
+            "mu_shift": mu_leg,
             "transform": transform,
             "n2000_streamed": n2000,
             "n2000_density_fitted_jk": df_leg,

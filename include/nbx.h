@@ -34,7 +34,14 @@
 extern "C" {
 #endif
 
-#define NBX_VERSION 1
+/* ABI version: bumped whenever the meaning or the size of a buffer behind an existing entry point changes (a caller
+ * built against an older header would otherwise get silent out-of-bounds writes, not an error).  Callers compare
+ * nbx_version() with the NBX_VERSION they were built against and refuse to run on a mismatch (nbed_amd/_nbx.py does).
+ *   2 (round 4): nbx_huz_cycle's h_out is 7 doubles (was 6); nbx_huz_cycle_scalars_dev/_dts write a ready word at
+ *     d_out[4 + tail_n]; nbx_diis_update*'s d_coef holds nbx_diis_coef_doubles(space) zeroed doubles; nbx_huz_state
+ *     gained jk_kind, jk_p0, jk_p1, d_eri and (jk_p0, jk_p1) = (0, 0) now means an EMPTY slab; nbx_xc_density /
+ *     nbx_xc_half are gone; nbx_mu_cycle* are new.                                                              */
+#define NBX_VERSION 2
 
 #define NBX_OK 0
 #define NBX_E_INVALID (-1)  /* bad argument (null pointer, negative size, shape mismatch) */
@@ -515,7 +522,8 @@ typedef struct nbx_huz_state {
     /* which J/K kernel builds the Fock matrix, and on which rows of (pq|rs) */
     int64_t jk_kind;        /* NBX_HUZ_JK_PACKED: d_packed (nbx_jk_packed[_fock]); NBX_HUZ_JK_SYM: d_eri, the dense
                                tensor / row slab (nbx_jk_dense_sym: every N, falls to nbx_jk_dense inside) */
-    int64_t jk_p0, jk_p1;   /* this rank's slab rows [p0, p1) of the first AO index; 0, 0 = the whole tensor */
+    int64_t jk_p0, jk_p1;   /* this rank's slab rows [p0, p1) of the first AO index: 0, nao = the whole tensor;
+                               p0 == p1 = an empty slab (contributes zero) */
     const double* d_eri;    /* NBX_HUZ_JK_SYM: slab rows [p0, p1) of the dense (N,N,N,N) tensor */
 } nbx_huz_state;
 #define NBX_HUZ_JK_PACKED 0
@@ -536,6 +544,45 @@ int nbx_huz_cycle_jk(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_i
 int nbx_huz_cycle_post(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, const double* d_c_in,
                        double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out, double* d_hz_out, int mode,
                        int refine_iters, int diis_mode, int diis_slot, int diis_nd, double* h_out, int* d_status_out);
+
+/* ------------------------------------------------------------------ fused mu-shift SCF cycle
+ * One cycle of the SCF the mu-shift embedding runs -- `embedded_scf.kernel()` at nbed/driver.py:533 on the hcore
+ * patched with mu S D_env S + V_emb (:500-538), i.e. PySCF's scf.hf.kernel: CDIIS from cycle 1, eig, aufbau
+ * density, get_veff, energy_tot, |dE| and orbital-gradient test -- queued by ONE call, nothing synchronises.
+ * Also the global mean field's kernel() (driver.py:112-191).  The state block is nbx_huz_state with
+ *   d_hv        = the kernel's h1e per spin (2,N,N)  (hcore + mu P + V_emb, or hcore twice);
+ *   d_sb, d_x, d_jk, d_tmp, d_fo, d_fock2 (scratch), the J/K, eigensolver and refinement workspaces as for
+ *   nbx_huz_cycle; d_ds, d_fock, d_vhf, d_dts unused (may be NULL);
+ *   the DIIS ring for CDIIS: diis_space = 8, d_diis_xs / d_diis_es (8, 2 N^2), d_diis_h (9 x 9, row/column 0 = 1),
+ *   d_diis_coef zeroed, d_diis_xprev (2 N^2) receives the extrapolated Fock matrix.
+ * Cycle:  [diis_on: err = F D S - S D F of (d_dm_in, d_fock_in) per spin, pyscf.lib.diis.DIIS.update(F, err) with the
+ *   caller's ring position (diis_slot, diis_nd)]  ->  F C = S C eps (mode 0 guarded: Loewdin step + nbx_eigh_warm_ex
+ *   warm-started from d_c_in = the previous cycle's d_v_out, NULL = cold; mode 1 tracked: nbx_geig_refine from
+ *   d_c_in = the previous cycle's d_c_out, status in d_status_out)  ->  d_dm_out = C_occ C_occ^T  ->  J/K of d_dm_out,
+ *   d_fock_out = d_hv + J - K[x], d_vhf_out = J - K[x]  ->  [want_grad: sum of squares of the virtual-occupied block of
+ *   C^T F_out C per spin]  ->  scalars.
+ * h_out (pinned, device-mapped host memory; the caller clears the last word and polls it):
+ *   tr[(h + vhf/2) D] alpha, beta (their sum + E_nuc = energy_tot), |D - D_in|_F alpha, beta, the eigensolver's two
+ *   status words (as nbx_huz_cycle), [want_grad: the two gradient sums], 1.0  -- 7 or 9 doubles.
+ * Same kernels, order and operands as issuing the steps one by one: bit-identical results.                        */
+int nbx_mu_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, const double* d_fock_in,
+                 const double* d_c_in, double* d_dm_out, double* d_fock_out, double* d_vhf_out, double* d_c_out,
+                 double* d_v_out, double* d_w_out, int mode, int refine_iters, int diis_on, int diis_slot, int diis_nd,
+                 int want_grad, double* h_out, int* d_status_out);
+/* The pieces.  nbx_mu_cycle_solve: CDIIS -> eigenproblem -> density (no J/K).  nbx_mu_cycle_fock: J/K + Fock matrix of
+ * d_dm on this rank's WHOLE tensor, gradient if d_c != NULL, scalars (mode: whose status words travel with them --
+ * 0 the guarded solver's, 1 d_status_tracked, -1 none: h_out is then 5 or 7 doubles) -- alone it is the build of the
+ * starting density and of the conv_check cycle.  Several ranks (SURVEY 8e, J/K row slabs): nbx_mu_cycle_solve,
+ * nbx_huz_cycle_jk on the new density, the caller's all-reduce of st->d_jk, nbx_mu_cycle_fock_post.              */
+int nbx_mu_cycle_solve(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm_in, const double* d_fock_in,
+                       const double* d_c_in, double* d_dm_out, double* d_c_out, double* d_v_out, double* d_w_out,
+                       int mode, int refine_iters, int diis_on, int diis_slot, int diis_nd, int* d_status_out);
+int nbx_mu_cycle_fock(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm, const double* d_dm_old,
+                      const double* d_c, double* d_fock_out, double* d_vhf_out, int mode, const int* d_status_tracked,
+                      double* h_out);
+int nbx_mu_cycle_fock_post(nbx_ctx* ctx, const nbx_huz_state* st, const double* d_dm, const double* d_dm_old,
+                           const double* d_c, double* d_fock_out, double* d_vhf_out, int mode,
+                           const int* d_status_tracked, double* h_out);
 
 /* ------------------------------------------------------------------ exchange-correlation evaluation
  * (E_xc, v_xc) of a two-spin density matrix on the stored grid arrays -- what the reference gets from PySCF's

@@ -15,6 +15,7 @@ from pathlib import Path
 LIB_NAME = "libnbx.so"
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
 
+NBX_VERSION = 2  # the include/nbx.h this table mirrors (buffer sizes behind the entry points: see the header)
 NBX_OK = 0
 NBX_E_INVALID = -1
 NBX_E_HIP = -2
@@ -171,6 +172,12 @@ SIGNATURES = {
     "nbx_huz_cycle": (c_int, [_P, POINTER(HuzState), _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                               c_int, _P, _P]),
     "nbx_huz_cycle_jk": (c_int, [_P, POINTER(HuzState), _P]),
+    "nbx_mu_cycle": (c_int, [_P, POINTER(HuzState), _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                             c_int, _P, _P]),
+    "nbx_mu_cycle_solve": (c_int, [_P, POINTER(HuzState), _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                   _P]),
+    "nbx_mu_cycle_fock": (c_int, [_P, POINTER(HuzState), _P, _P, _P, _P, _P, c_int, _P, _P]),
+    "nbx_mu_cycle_fock_post": (c_int, [_P, POINTER(HuzState), _P, _P, _P, _P, _P, c_int, _P, _P]),
     "nbx_huz_cycle_post": (c_int, [_P, POINTER(HuzState), _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                    _P, _P]),
 }
@@ -198,6 +205,12 @@ def load_library(path: os.PathLike | None = None) -> ctypes.CDLL:
     except Exception:  # pragma: no cover - torch-less FFI users get the system runtime
         pass
     lib = ctypes.CDLL(str(p), mode=ctypes.RTLD_GLOBAL)
+    lib.nbx_version.restype = c_int
+    if lib.nbx_version() != NBX_VERSION:
+        raise NbxUnavailableError(
+            f"{p} is ABI version {lib.nbx_version()}, this package binds version {NBX_VERSION} (include/nbx.h): "
+            "rebuild it (`make -C nbed_amd/csrc`) -- buffer sizes behind several entry points differ between versions"
+        )
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = restype

@@ -50,8 +50,9 @@ class _PendingScalars:
 
     _POLL_TIMEOUT_S = 120.0
 
-    def __init__(self, torch, d_vals, ntail=0, ncore=4, host=None):
+    def __init__(self, torch, d_vals, ntail=0, ncore=4, host=None, ndtail=0):
         self._ncore = ncore
+        self._ndtail = ndtail  # doubles behind the status words (the mu-shift cycle's gradient sums)
         self._torch = torch
         self._event = None
         self._queried = False
@@ -62,8 +63,8 @@ class _PendingScalars:
             self._event.record()
             self._flag = None
         else:
-            self._host = host  # (ncore + ntail + 1,): the caller cleared the last word before queueing the kernel
-            self._flag = host.numpy()[ncore + ntail:ncore + ntail + 1]
+            self._host = host  # (ncore + ntail + ndtail + 1,): the caller cleared the last word before queueing the kernel
+            self._flag = host.numpy()[ncore + ntail + ndtail:ncore + ntail + ndtail + 1]
         self._keep = d_vals  # the source must outlive the copy
         self._ntail = ntail
 
@@ -100,6 +101,14 @@ class _PendingScalars:
         if not self._ntail:
             return None
         return self._host.numpy()[self._ncore:self._ncore + self._ntail].astype(np.int64)
+
+    def get_dtail(self):
+        """The doubles stored behind the status words, or None."""
+        self._wait()
+        if not self._ndtail:
+            return None
+        o = self._ncore + self._ntail
+        return self._host.numpy()[o:o + self._ndtail].copy()
 
 
 class _Deferred:
@@ -721,6 +730,9 @@ class HipBackend:
         h.sets = [{"c": self.empty((2, n, n)), "v": self.empty((2, n, n)), "w": self.empty((2, n)),
                    "dm": self.empty((2, n, n)), "hz": self.empty((2, n, n)),
                    "status": torch.empty(2, dtype=torch.int32, device=self.device)} for _ in range(3)]
+        if ds is None:  # the mu-shift cycle (mu_cycle): a cycle's Fock matrix and vhf belong to its result set
+            for out in h.sets:
+                out["fock"], out["vhf"] = out.pop("hz"), self.empty((2, n, n))
         st = _nbx.HuzState()
         st.nao, st.nocc_a, st.nocc_b = n, h.nelec[0], h.nelec[1]
         for name, t in (("d_packed", packed), ("d_hv", hv), ("d_ds", ds), ("d_sb", s_b), ("d_x", x), ("d_dts", dts),
@@ -763,6 +775,59 @@ class HipBackend:
                        int(refine_iters), int(diis_mode), int(diis_slot), int(diis_nd), self._p(h_out),
                        self._p(out["status"]))
         return _PendingScalars(self.torch, None, 2, host=h_out)
+
+    # ------------------------------------------------------------------ fused mu-shift SCF cycle (one call per cycle)
+    def mu_cycle_state(self, nao, nelec, packed, h1e, s_b, x, eri=None, p0: int = 0, p1: int | None = None):
+        """The state block of ``nbx_mu_cycle`` (PySCF's scf.hf.kernel cycle behind nbed/driver.py:533): as
+        ``huz_cycle_state`` with ``h1e`` (2,N,N) for ``hv``, no Huzinaga operands, the DIIS ring sized for CDIIS
+        (space 8) and result sets that carry the cycle's Fock matrix and vhf."""
+        return self.huz_cycle_state(nao, nelec, packed, h1e, None, s_b, x, None, diis_space=8, eri=eri, p0=p0, p1=p1)
+
+    def _pin_slot(self, n: int):
+        h_out = self._pin_ring[self._pin_next][:n]
+        h_out[n - 1] = 0.0  # the kernel's "all stored" word
+        self._pin_next = (self._pin_next + 1) % self._PIN_SLOTS
+        return h_out
+
+    def mu_cycle(self, h, dm_in, fock_in, c_in, out, tracked: bool, refine_iters: int, diis_on: bool, diis_slot: int,
+                 diis_nd: int, want_grad: bool = True, reduce=None):
+        """Queue one cycle of the mu-shift SCF (nbx_mu_cycle) from the previous cycle's density and Fock matrix
+        into the result set ``out`` (dm, fock, vhf, c, v, w, status); returns the handle of its scalars
+        (``get()``: E_alpha, E_beta, |dD| per spin; ``get_extra()``: the eigensolver's status words;
+        ``get_dtail()``: the two orbital-gradient sums).  ``reduce``: as for ``huz_cycle`` -- the cycle is then
+        nbx_mu_cycle_solve, nbx_huz_cycle_jk, the collective, nbx_mu_cycle_fock_post."""
+        ndt = 2 if want_grad else 0
+        h_out = self._pin_slot(4 + 2 + ndt + 1)
+        mode = 1 if tracked else 0
+        if reduce is None:
+            self._call("nbx_mu_cycle", ctypes.byref(h.st), self._p(dm_in), self._p(fock_in), self._p(c_in),
+                       self._p(out["dm"]), self._p(out["fock"]), self._p(out["vhf"]), self._p(out["c"]), self._p(out["v"]),
+                       self._p(out["w"]), mode, int(refine_iters), 1 if diis_on else 0, int(diis_slot), int(diis_nd),
+                       1 if want_grad else 0, self._p(h_out), self._p(out["status"]))
+        else:
+            self._call("nbx_mu_cycle_solve", ctypes.byref(h.st), self._p(dm_in), self._p(fock_in), self._p(c_in),
+                       self._p(out["dm"]), self._p(out["c"]), self._p(out["v"]), self._p(out["w"]), mode,
+                       int(refine_iters), 1 if diis_on else 0, int(diis_slot), int(diis_nd), self._p(out["status"]))
+            self._call("nbx_huz_cycle_jk", ctypes.byref(h.st), self._p(out["dm"]))
+            reduce(h.jk)
+            self._call("nbx_mu_cycle_fock_post", ctypes.byref(h.st), self._p(out["dm"]), self._p(dm_in),
+                       self._p(out["c"]) if want_grad else None, self._p(out["fock"]), self._p(out["vhf"]), mode,
+                       self._p(out["status"]), self._p(h_out))
+        return _PendingScalars(self.torch, None, 2, host=h_out, ndtail=ndt)
+
+    def mu_cycle_fock(self, h, dm, out, reduce=None):
+        """Fock matrix, vhf and energy of a given density (the starting density of ``kernel()``) into ``out``:
+        nbx_mu_cycle_fock with no orbitals and no status words."""
+        h_out = self._pin_slot(4 + 1)
+        if reduce is None:
+            self._call("nbx_mu_cycle_fock", ctypes.byref(h.st), self._p(dm), self._p(dm), None, self._p(out["fock"]),
+                       self._p(out["vhf"]), -1, None, self._p(h_out))
+        else:
+            self._call("nbx_huz_cycle_jk", ctypes.byref(h.st), self._p(dm))
+            reduce(h.jk)
+            self._call("nbx_mu_cycle_fock_post", ctypes.byref(h.st), self._p(dm), self._p(dm), None,
+                       self._p(out["fock"]), self._p(out["vhf"]), -1, None, self._p(h_out))
+        return _PendingScalars(self.torch, None, 0, host=h_out)
 
     # ------------------------------------------------------------------ density-fitted J/K (an extra: SURVEY 7 step 5)
     def df_synth(self, nao: int, l0: int, l1: int, scale: float | None = None, seed: int | None = None):

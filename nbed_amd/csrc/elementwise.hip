@@ -191,6 +191,26 @@ __global__ void huzinaga_sym_kernel(const double* __restrict__ fds, int N, doubl
     }
 }
 
+// out = A^T - A per batch entry: the CDIIS error vector F D S - S D F from A = S D F (pyscf.scf.diis.CDIIS
+// behind scf.hf.kernel, nbed/driver.py:533) in one launch
+__global__ void antisym_kernel(const double* __restrict__ a, int N, double* __restrict__ out) {
+    __shared__ double t[TILE][TILE + 1];
+    const int b = blockIdx.z;
+    const int64_t n2 = (int64_t)N * N;
+    a += b * n2;
+    out += b * n2;
+    const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
+    load_tile(a, N, j0, i0, t);  // t[j][i] = A[j0+j][i0+i]
+    __syncthreads();
+    for (int r = threadIdx.y; r < TILE; r += blockDim.y) {
+        const int gi = i0 + r, gj = j0 + threadIdx.x;
+        if (gi < N && gj < N) {
+            const int64_t o = (int64_t)gi * N + gj;
+            out[o] = t[threadIdx.x][r] - a[o];
+        }
+    }
+}
+
 // partial[blk*4 + {0,1}] = sum (h + v + 0.5 vhf + hz)[x][i,j] * D[x][j,i];  [2,3] = sum (D-Dold)^2
 // With `out`: the workgroup that arrives last (device-scope counter, left at zero) also does the
 // second stage in the fixed order of final_reduce_kernel -- out[0,1] the sums, out[2,3] the square
@@ -203,7 +223,8 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
                                    double* __restrict__ partial, double* __restrict__ out_final = nullptr,
                                    const int* __restrict__ tail = nullptr, int tail_n = 0,
                                    int* __restrict__ counter = nullptr, double* __restrict__ dts = nullptr,
-                                   int s4_nb_ = 0, int s4_lpt_ = 0, int dts_m4 = 0) {
+                                   int s4_nb_ = 0, int s4_lpt_ = 0, int dts_m4 = 0,
+                                   const double* __restrict__ dtail = nullptr, int dtail_n = 0) {
     // A kernel on the SCF's critical path: everything it reads is requested in one trip to memory (both spins'
     // tiles at once), the sums travel by lane moves, and the workgroup that arrives last adds the four columns
     // of partials side by side -- three dependent round trips to L2 where there were nine.
@@ -231,7 +252,8 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
             const int gi = i0 + r, gj = j0 + threadIdx.x;
             const bool in = gi < N && gj < N;
             const int64_t o = in ? (int64_t)gi * N + gj : 0;
-            double hm = h[h3d ? x * n2 + o : o] + 0.5 * vhf[x * n2 + o] + hz[x * n2 + o];
+            double hm = h[h3d ? x * n2 + o : o] + 0.5 * vhf[x * n2 + o];
+            if (hz) hm += hz[x * n2 + o];  // (no Huzinaga operator: the mu-shift cycle of scf_cycle.hip)
             if (vemb) hm += vemb[x * n2 + o];
             ham[x][k] = in ? hm : 0.0;
             dv[x][k] = in ? dm[x * n2 + o] : 0.0;
@@ -300,6 +322,9 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
     }
     __threadfence();
     if (tid < tail_n) out_final[4 + tid] = (double)tail[tid];
+    // `dtail`: doubles an earlier kernel of the chain left on the device (the orbital-gradient sums of the mu-shift
+    // cycle), carried to the host behind the status words
+    if (tid < dtail_n) out_final[4 + tail_n + tid] = dtail[tid];
     double t4[4] = {0.0, 0.0, 0.0, 0.0};
     for (int b = tid; b < nblocks; b += nthr)
 #pragma unroll
@@ -322,7 +347,7 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
     // on the stream -- an event record between two cycles holds the next cycle's first kernel back by ~10 us
     if (tid == 0) {
         __threadfence_system();
-        __hip_atomic_store(out_final + 4 + tail_n, 1.0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(out_final + 4 + tail_n + dtail_n, 1.0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     store_dts();  // (this workgroup's part of the table, last of all)
 }
@@ -1195,7 +1220,20 @@ int nbx_huz_cycle_scalars_dts(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
                               const double* d_vemb, const double* d_vhf, const double* d_hz, const double* d_dm,
                               const double* d_dm_old, double* d_out, const int* d_tail, int64_t tail_n,
                               double* d_dts) {
-    NBX_CHECK_ARG(ctx && d_hcore && d_vhf && d_hz && d_dm && d_dm_old && d_out && nao > 0);
+    NBX_CHECK_ARG(d_hz != nullptr);
+    return nbx_cycle_scalars_launch(ctx, nao, d_hcore, hcore_ndim, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, d_out, d_tail,
+                                    tail_n, d_dts, nullptr, 0);
+}
+
+}  // extern "C"
+
+// The launch behind the nbx_huz_cycle_scalars_* entry points; also (d_hz == NULL, d_dtail: dtail_n device doubles
+// forwarded behind the status words) the scalars of the mu-shift cycle (scf_cycle.hip).
+int nbx_cycle_scalars_launch(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim, const double* d_vemb,
+                             const double* d_vhf, const double* d_hz, const double* d_dm, const double* d_dm_old,
+                             double* d_out, const int* d_tail, int64_t tail_n, double* d_dts, const double* d_dtail,
+                             int64_t dtail_n) {
+    NBX_CHECK_ARG(ctx && d_hcore && d_vhf && d_dm && d_dm_old && d_out && nao > 0);
     int m4 = 0, nb4 = d_dts ? s4_nb(nao) : 0, lpt4 = d_dts ? s4_lpt(nao) : 0;
     if (d_dts && nbx_jk_m4_covers(nao)) {  // (the table in jk_m4.hip's order: its layout parameters travel in these three)
         int wl[4];
@@ -1206,6 +1244,7 @@ int nbx_huz_cycle_scalars_dts(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
     }
     NBX_CHECK_ARG(d_dts == nullptr || lpt4 > 0);  // the table exists for sizes nbx_jk_packed covers
     NBX_CHECK_ARG(tail_n >= 0 && tail_n <= 64 && (tail_n == 0 || d_tail != nullptr));
+    NBX_CHECK_ARG(dtail_n >= 0 && dtail_n <= 64 && (dtail_n == 0 || d_dtail != nullptr));
     NBX_CHECK_ARG(hcore_ndim == 2 || hcore_ndim == 3);
     // 16 x 16 tiles while the partials fit the scratch (N <= 500): more workgroups for small N
     const bool fine = nbx_cdiv(nao, 16) * nbx_cdiv(nao, 16) * 4 <= NBX_SCRATCH_DOUBLES - 64;
@@ -1214,15 +1253,27 @@ int nbx_huz_cycle_scalars_dts(nbx_ctx* ctx, int64_t nao, const double* d_hcore, 
     if (fine)
         hipLaunchKernelGGL(huz_scalars_kernel<16>, dim3((unsigned)g, (unsigned)g), dim3(16, 8), 0, ctx->stream, d_hcore,
                            hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao, ctx->d_scratch,
-                           d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1, d_dts, nb4, lpt4, m4);
+                           d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1, d_dts, nb4, lpt4, m4, d_dtail,
+                           (int)dtail_n);
     else
         hipLaunchKernelGGL(huz_scalars_kernel<TILE>, dim3((unsigned)g, (unsigned)g), dim3(TILE, 8), 0, ctx->stream,
                            d_hcore, hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao,
                            ctx->d_scratch, d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1, d_dts, nb4,
-                           lpt4, m4);
+                           lpt4, m4, d_dtail, (int)dtail_n);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }
+
+// out[b] = A[b]^T - A[b] (antisym_kernel)
+int nbx_antisym(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_a, double* d_out) {
+    NBX_CHECK_ARG(ctx && d_a && d_out && d_a != d_out && nao > 0 && batch > 0 && batch < 65536);
+    const unsigned g = (unsigned)nbx_cdiv(nao, TILE);
+    hipLaunchKernelGGL(antisym_kernel, dim3(g, g, (unsigned)batch), dim3(TILE, 8), 0, ctx->stream, d_a, (int)nao, d_out);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+extern "C" {
 
 size_t nbx_diis_coef_doubles(int64_t space) { return space > 0 ? (size_t)(space + DIIS_STATE_DOUBLES) : 0; }
 

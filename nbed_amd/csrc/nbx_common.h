@@ -69,6 +69,16 @@ inline int64_t nbx_gemm_small_norm_doubles(int64_t m, int64_t n, int64_t batch) 
     return batch * 2 * ((m + 15) / 16) * ((n + 15) / 16) * 2;
 }
 
+// elementwise.hip
+// The launch behind nbx_huz_cycle_scalars_dev / _dts with two more options: d_hz == NULL (no Huzinaga operator in the
+// energy) and d_dtail (dtail_n <= 64 device doubles stored behind the status words, ahead of the ready word).
+int nbx_cycle_scalars_launch(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim, const double* d_vemb,
+                             const double* d_vhf, const double* d_hz, const double* d_dm, const double* d_dm_old,
+                             double* d_out, const int* d_tail, int64_t tail_n, double* d_dts, const double* d_dtail,
+                             int64_t dtail_n);
+// out[b] = A[b]^T - A[b], (batch, nao, nao), out of place
+int nbx_antisym(nbx_ctx* ctx, int64_t nao, int64_t batch, const double* d_a, double* d_out);
+
 // jk_sym.hip
 bool nbx_jk_sym_supported(int64_t nao);
 int nbx_jk_sym_reduce(nbx_ctx* ctx, const double* k1, const double* k2, double* d_k, int64_t N, int64_t p0, int64_t np,

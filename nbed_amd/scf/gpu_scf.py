@@ -17,11 +17,21 @@ The ERI may be sharded by its first AO index over the ranks of a process group
 
 from __future__ import annotations
 
+import logging
+import os
+
 import numpy as np
 
 from ..backend import get_backend
 from ..dist import Shards
 from .pyscf_compat import RHF, RKS, UHF, UKS
+
+
+logger = logging.getLogger(__name__)
+
+
+class _TrackedCycleRejected(RuntimeError):
+    """A cycle solved by unguarded refinement did not pass its acceptance test: kernel() is repeated guarded."""
 
 
 class Mole:
@@ -316,9 +326,11 @@ class GpuUHF(_GpuSCF, UHF):
 
         be = self.be
         patched = any(k in vars(self) for k in ("get_veff", "get_occ", "make_rdm1", "get_fock"))
-        if not patched and self._device_kernel_ok and all(hasattr(be, a) for a in ("huz_cycle_scalars_async", "density_occ", "vo_sumsq",
-                                                       "async_to_host")):
-            return self._kernel_device(dm0)
+        if not patched and self._device_kernel_ok:
+            if hasattr(be, "mu_cycle") and os.environ.get("NBED_CYCLE_CALL", "1") != "0":
+                return self._kernel_cycle_calls(dm0)
+            if all(hasattr(be, a) for a in ("huz_cycle_scalars_async", "density_occ", "vo_sumsq", "async_to_host")):
+                return self._kernel_device(dm0)
         h1e = np.asarray(self.get_hcore())  # possibly patched by the driver: evaluated once
         if h1e.ndim == 2:
             h1e = np.array((h1e, h1e))
@@ -362,6 +374,8 @@ class GpuUHF(_GpuSCF, UHF):
         return e_tot
 
     _device_kernel_ok = True  # the look-ahead loop below assumes veff = J - K[x] (Hartree-Fock)
+    cycle_callback = None  # callable(cycle) or None: called by the one-call-per-cycle kernel() loop
+    kernel_info = None  # how the last kernel() went: cycle_call, split, tracked_cycles, guarded_cycles, restarts
 
     def _fock_energy_device(self, h_d, dm_dev):
         """(fock, e1, e2) of a two-spin density on the device: F = h + J - K[x], e1 = tr(h D),
@@ -371,6 +385,155 @@ class GpuUHF(_GpuSCF, UHF):
         e1 = be.trace_prod(h_d, dm_dev).sum()
         e2 = 0.5 * be.trace_prod(vhf, dm_dev).sum()
         return fock, float(e1), float(e2)
+
+    def _kernel_cycle_calls(self, dm0=None):
+        """``scf.hf.kernel`` with ONE C call per cycle (nbx_mu_cycle: CDIIS -> eigensolve -> density -> J/K + Fock
+        -> orbital gradient -> scalars stored into pinned memory), cycle i judged after cycle i+1 has been queued.
+        The same kernels in the same order as ``_kernel_device`` issues one by one (``NBED_CYCLE_CALL=0``), so the
+        guarded form is bit-identical to it; as in ``huzinaga_scf`` the eigenproblem of a cycle is solved by
+        refining the previous cycle's pair on the pencil (F, S) with no fallback queued ("tracked") once a cycle has
+        shown that refinement is accepted within two iterations -- and a rejected tracked cycle makes the whole run
+        repeat with the guarded solver, the path the parity tests pin.  Over several ranks (J/K row slabs) the
+        cycle is three calls around the all-reduce of the J/K partials."""
+        tracked = os.environ.get("NBED_TRACKED_EIG", "1") != "0"
+        self.kernel_info = {"restarts": []}
+        for _ in range(2):
+            try:
+                return self._kernel_cycle_calls_once(dm0, tracked)
+            except _TrackedCycleRejected as exc:
+                logger.warning("tracked eigensolve rejected a cycle (%s): repeating kernel() with the guarded solver", exc)
+                tracked = False
+                self.kernel_info = {"restarts": self.kernel_info["restarts"] + [str(exc)]}
+        raise RuntimeError("kernel(): the guarded run cannot raise _TrackedCycleRejected")  # pragma: no cover
+
+    def _kernel_cycle_calls_once(self, dm0, allow_tracked):
+        be = self.be
+        h1e = np.asarray(self.get_hcore())  # possibly patched by the driver (mu P + V_emb): evaluated once
+        if h1e.ndim == 2:
+            h1e = np.array((h1e, h1e))
+        n = h1e.shape[-1]
+        nelec = tuple(int(x) for x in self.mol.nelec)
+        gsize = max(sum((n - k) * k for k in nelec), 1)
+        e_nuc = self.energy_nuc()
+        dm_h = np.ascontiguousarray(self.get_init_guess() if dm0 is None else np.asarray(dm0), dtype=np.float64)
+        sh = self.shards
+        split = sh.world > 1 or sh.force_collective
+        reduce = (lambda jk: sh.all_reduce(be, jk)) if split else None
+        if hasattr(be, "asarray_many"):
+            h_d, dm_d = be.asarray_many([h1e, dm_h])
+        else:
+            h_d, dm_d = be.asarray(h1e), be.asarray(dm_h)
+        s_b = be.torch.stack([self._s_d] * 2).contiguous() if hasattr(be, "torch") and isinstance(
+            self._s_d, be.torch.Tensor) else be.asarray(np.stack([self._s_h] * 2))
+        packed_d = self.eri_packed_device()
+        hstate = be.mu_cycle_state(n, nelec, packed_d, h_d, s_b, self.x_device(),
+                                   eri=None if packed_d is not None else self.eri_device(), p0=sh.lo, p1=sh.hi)
+        info = getattr(self, "kernel_info", None) or {}
+        info.update(cycle_call=True, split=bool(split), tracked_cycles=0, guarded_cycles=0)
+        self.kernel_info = info
+
+        def energy(handle):
+            return float(handle.get()[:2].sum() + e_nuc)
+
+        first = hstate.sets[2]
+        first["dm"] = dm_d  # (the starting density is the caller's: not a result buffer)
+        last_e = e_tot = energy(be.mu_cycle_fock(hstate, dm_d, first, reduce=reduce))
+        conv_tol_grad = np.sqrt(self.conv_tol)
+        self.converged = False
+        warm = {"v": None, "c": None, "iters": 3, "tracked": False}
+        can_track = bool(allow_tracked)
+
+        def judge(st):
+            nonlocal last_e, e_tot
+            handle = st["handle"]
+            e_now = energy(handle)
+            norm_gorb = float(np.sqrt(handle.get_dtail().sum()) / np.sqrt(gsize))
+            status = handle.get_extra()
+            if st["tracked"]:
+                if np.any(status <= 0):
+                    raise _TrackedCycleRejected(f"cycle {st['cycle']}: status {status.tolist()}")
+            # launch-count policy of the eigensolver (results do not depend on it), as in huzinaga_scf: every
+            # matrix accepted by refinement within two iterations -> refine without the guard from the next cycle
+            # queued on, one iteration in reserve while the energy still moves
+            accepted = bool(np.all(status >= 1001))
+            needed = int(np.max(status)) - 1000 if accepted else 99
+            warm["tracked"] = bool(can_track and needed <= 2)
+            if warm["tracked"]:
+                warm["iters"] = needed + (1 if abs(e_now - last_e) > 1e-9 else 0)
+            else:
+                warm["iters"] = 3
+            self.cycles = st["cycle"] + 1
+            ok = abs(e_now - last_e) < self.conv_tol and norm_gorb < conv_tol_grad
+            logger.debug("kernel() cycle %s E = %.12f dE = %.3e |g| = %.3e status %s", st["cycle"], e_now,
+                         e_now - last_e, norm_gorb, status.tolist())
+            last_e = e_tot = e_now
+            return ok
+
+        head = nd = 0  # pyscf.lib.diis ring position of CDIIS (space 8)
+        space = 8
+        prev, pending, final = first, None, None
+        for cycle in range(self.max_cycle):
+            if self.cycle_callback is not None:
+                self.cycle_callback(cycle)  # (host side, before cycle `cycle` is queued: bench.py separates warm-up cycles)
+            out = hstate.sets[cycle % 3]
+            diis_on = cycle >= 1
+            slot = 0
+            if diis_on:
+                slot = head % space
+                head += 1
+                nd = min(nd + 1, space)
+            tracked_now = bool(warm["tracked"] and warm["c"] is not None)
+            c_in = warm["c"] if tracked_now else warm["v"]
+            handle = be.mu_cycle(hstate, prev["dm"], prev["fock"], c_in, out, tracked_now, warm["iters"], diis_on, slot,
+                                 nd, want_grad=True, reduce=reduce)
+            info["tracked_cycles" if tracked_now else "guarded_cycles"] += 1
+            warm["c"] = out["c"]
+            if not tracked_now:
+                warm["v"] = out["v"]
+            cur = {"cycle": cycle, "set": out, "handle": handle, "tracked": tracked_now}
+            if pending is not None and judge(pending):
+                self.converged, final = True, pending
+                break
+            pending, prev = cur, out
+        if not self.converged and pending is not None:
+            self.converged = judge(pending)
+            final = pending
+        if final is None:  # max_cycle == 0
+            res = first
+            c_d = w_d = None
+        else:
+            res = final["set"]
+            c_d, w_d = res["c"], res["w"]
+        if self.converged:  # one DIIS-free cycle from the converged Fock matrix (conv_check)
+            k = final["cycle"]
+            out = hstate.sets[(k + 2) % 3]  # (k + 1 may be the look-ahead cycle still in flight: any set but k's is safe)
+            tracked_now = bool(warm["tracked"] and warm["c"] is not None)
+            # the warm start is whatever the LAST queued cycle left (the look-ahead cycle included): a start, not data
+            c_in = warm["c"] if tracked_now else warm["v"]
+            if c_in is not None and (c_in is out["c"] or c_in is out["v"]):
+                c_in = be.copy(c_in)
+            handle = be.mu_cycle(hstate, res["dm"], res["fock"], c_in, out, tracked_now, warm["iters"], False, 0, 0,
+                                 want_grad=False, reduce=reduce)
+            e_tot = energy(handle)
+            status = handle.get_extra()
+            if tracked_now and np.any(status <= 0):
+                raise _TrackedCycleRejected(f"conv_check: status {status.tolist()}")
+            res, c_d, w_d = out, out["c"], out["w"]
+        mo_occ = np.zeros((2, n))
+        mo_occ[0, : nelec[0]] = 1
+        mo_occ[1, : nelec[1]] = 1
+        if c_d is not None:
+            if hasattr(be, "to_host_many"):
+                c_h, w_h = be.to_host_many([c_d, w_d])
+            else:
+                c_h, w_h = be.to_host(c_d), be.to_host(w_d)
+            self.mo_coeff = np.array([_sign_fix(c_h[0]), _sign_fix(c_h[1])])
+            self.mo_energy = w_h
+        self.mo_occ = mo_occ
+        self.e_tot = e_tot
+        self.scf_summary["e1"] = float(be.trace_prod(h_d, res["dm"]).sum())
+        self.scf_summary["e2"] = float(0.5 * be.trace_prod(res["vhf"], res["dm"]).sum())
+        return e_tot
 
     def _kernel_device(self, dm0=None):
         """The same control flow with nothing in a cycle waiting for the host (HIP backend): CDIIS,

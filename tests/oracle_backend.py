@@ -265,9 +265,13 @@ class OracleBackend:
 class _Done:
     """Handle of a 'queued' cycle's scalars (the HIP backend's _PendingScalars, already complete here)."""
 
-    def __init__(self, vals, extra=None):
+    def __init__(self, vals, extra=None, dtail=None):
         self._vals = np.asarray(vals, dtype=np.float64)
         self._extra = None if extra is None else np.asarray(extra, dtype=np.int64)
+        self._dtail = None if dtail is None else np.asarray(dtail, dtype=np.float64)
+
+    def get_dtail(self):
+        return self._dtail
 
     def get(self):
         return self._vals.copy()
@@ -397,3 +401,67 @@ class OracleLookaheadBackend(OracleBackend):
         out["hz"].copy_(torch.from_numpy(hz))
         vals = self.huz_cycle_scalars(h.hv, None, vhf, out["hz"], out["dm"], dm_in)
         return _Done(vals, status)
+
+    # ---- the mu-shift cycle (csrc/scf_cycle.hip: nbx_mu_cycle / _solve / _fock / _fock_post), step for step
+    def mu_cycle_state(self, nao, nelec, packed, h1e, s_b, x, eri=None, p0=0, p1=None):
+        h = self.huz_cycle_state(nao, nelec, packed, h1e, None, s_b, x, None, diis_space=8, eri=eri, p0=p0, p1=p1)
+        n = h.n
+        for out in h.sets:
+            out["fock"], out["vhf"] = out.pop("hz"), self.empty((2, n, n))
+        return h
+
+    def _mu_fock_tail(self, h, dm, dm_old, c, out, reduce):
+        h.jk = self.jk_sym(h.eri, dm, h.p0, h.p1)
+        if reduce is not None:
+            reduce(h.jk)
+        fock, vhf = self.fock_uhf(h.hv, None, h.jk)
+        out["fock"].copy_(fock)
+        out["vhf"].copy_(vhf)
+        gsq = None
+        if c is not None:
+            cn, fn = self._np(c), self._np(fock)
+            gsq = []
+            for x in range(2):
+                fmo = cn[x].T @ fn[x] @ cn[x]
+                k = h.nelec[x]
+                gsq.append(float(np.sum(fmo[k:, :k] ** 2)))
+        vals = self.huz_cycle_scalars(h.hv, None, vhf, self.zeros((2, h.n, h.n)), dm, dm_old)
+        return vals, gsq
+
+    def mu_cycle_fock(self, h, dm, out, reduce=None):
+        self._count("mu_cycle_fock")
+        vals, _ = self._mu_fock_tail(h, dm, dm, None, out, reduce)
+        return _Done(vals)
+
+    def mu_cycle(self, h, dm_in, fock_in, c_in, out, tracked, refine_iters, diis_on, diis_slot, diis_nd,
+                 want_grad=True, reduce=None):
+        from nbed_amd.scf.diis import diis_coefficients
+
+        self._count("mu_cycle")
+        n = h.n
+        f_use = self._np(fock_in)
+        if diis_on:  # pyscf.scf.diis.CDIIS: error F D S - S D F, lib.diis ring position with the caller
+            s = self._np(h.s_b)[0]
+            sdf = s @ self._np(dm_in) @ f_use
+            err = np.swapaxes(sdf, -1, -2) - sdf
+            h.xs[diis_slot] = f_use.reshape(-1)
+            h.es[diis_slot] = err.reshape(-1)
+            row = h.es[:diis_nd] @ h.es[diis_slot]
+            h.H[diis_slot + 1, 1: diis_nd + 1] = row
+            h.H[1: diis_nd + 1, diis_slot + 1] = row
+            coef = diis_coefficients(h.H[: diis_nd + 1, : diis_nd + 1])
+            f_use = (coef[1:] @ h.xs[:diis_nd]).reshape(2, n, n)
+        xn = self._np(h.x)
+        if tracked:
+            w, c = self.geig_refine(self.asarray(f_use), h.s_b, c_in, refine_iters)
+            status = np.array([1001, 1001])
+        else:
+            w, v = OracleBackend.eigh(self, self.asarray(xn @ f_use @ xn))
+            out["v"].copy_(v)
+            c = self.asarray(xn @ self._np(v))
+            status = np.array([1, 1] if c_in is None else [1001, 1001])
+        out["w"].copy_(w)
+        out["c"].copy_(c)
+        out["dm"].copy_(self.density_occ(c, h.nelec))
+        vals, gsq = self._mu_fock_tail(h, out["dm"], dm_in, out["c"] if want_grad else None, out, reduce)
+        return _Done(vals, status, gsq)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = _nbx.load_library()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.nbx_version() == 1
+    assert lib.nbx_version() == _nbx.NBX_VERSION == 2
 
 
 def test_every_entry_point_cites_the_reference():

@@ -247,6 +247,82 @@ def test_gpu_uhf_kernel_vs_oracle(be):
     np.testing.assert_allclose(mf.get_veff(dm=ref.make_rdm1()), ref.get_veff(dm=ref.make_rdm1()), rtol=0, atol=1e-11)
 
 
+@pytest.mark.parametrize("n,nocc,n_env,mu", [(7, (3, 3), 1, 1e6), (24, (6, 5), 2, 1e6), (49, (9, 8), 3, 1e6),
+                                             (72, (12, 11), 5, 1e6), (102, (17, 17), 6, 1e6), (148, (33, 33), 20, 1e6),
+                                             (24, (6, 5), 0, 0.0)])
+def test_mu_cycle_call_equals_step_by_step(be, monkeypatch, n, nocc, n_env, mu):
+    """nbx_mu_cycle is kernel()'s loop at every size -- the mu-shift SCF of nbed/driver.py:500-538 (hcore patched
+    with mu S D_env S + V_emb) and the plain UHF of the global mean field (mu = 0) -- and queues the kernels the
+    step-by-step loop (NBED_CYCLE_CALL=0) launches one by one: with the guarded eigensolver in every cycle the
+    two are bit-identical; the tracked cycles of the default schedule change nothing beyond rounding."""
+    from nbed_amd.scf import GpuUHF, Mole
+
+    pr = synth.problem(n, nocc, n_env)
+    s = pr["S"]
+    h3 = pr["hcore"][None] + mu * (s @ pr["D_env"] @ s) + pr["V_emb"] if n_env else pr["hcore"]
+    eri = be.synth_eri(n)
+
+    def run():
+        mf = GpuUHF(Mole(n, pr["nelec"], e_nuc=0.25), s, pr["hcore"], eri, backend=be)
+        mf.get_hcore = lambda *a: h3
+        mf.max_cycle, mf.conv_tol = 100, 1e-10
+        return mf.kernel(), mf
+
+    e1, m1 = run()  # default: one call per cycle, tracked once refinement is accepted
+    monkeypatch.setenv("NBED_TRACKED_EIG", "0")
+    e2, m2 = run()
+    monkeypatch.setenv("NBED_CYCLE_CALL", "0")
+    e3, m3 = run()
+    assert m1.converged and m2.converged and m3.converged
+    assert m1.kernel_info["cycle_call"] and m2.kernel_info["cycle_call"] and m2.kernel_info["tracked_cycles"] == 0
+    assert m2.cycles == m3.cycles
+    assert e2 == e3
+    np.testing.assert_array_equal(m2.mo_energy, m3.mo_energy)
+    np.testing.assert_array_equal(m2.mo_coeff, m3.mo_coeff)
+    assert m2.scf_summary == m3.scf_summary
+    assert not m1.kernel_info.get("restarts")
+    assert abs(m1.cycles - m2.cycles) <= 1
+    # (mu = 1e6 puts eigenvalues of 1e6 into F: absolute accuracy of the others is ~1e6 x 2e-16 x N)
+    assert abs(e1 - e2) < 1e-8
+    np.testing.assert_allclose(m1.mo_energy[:, : n - n_env], m2.mo_energy[:, : n - n_env], rtol=0, atol=1e-7)
+    if n_env:  # the environment orbitals are pushed to ~mu: the last n_env levels (nbed/driver.py:758-766)
+        assert np.all(m1.mo_energy[:, n - n_env:] > 0.1 * mu)
+    if n >= 72 and m1.cycles >= 9:  # (tracking starts once a guarded cycle was accepted within two iterations)
+        assert m1.kernel_info["tracked_cycles"] >= 1
+
+
+def test_mu_cycle_tracked_rejection_reruns_guarded(be, monkeypatch):
+    """A tracked cycle whose refinement reports failure makes kernel() repeat the run guarded: same numbers."""
+    from nbed_amd.scf import GpuUHF, Mole
+
+    n, nocc = 72, (12, 11)
+    pr = synth.problem(n, nocc, 0)
+    eri = be.synth_eri(n)
+
+    def run():
+        mf = GpuUHF(Mole(n, pr["nelec"]), pr["S"], pr["hcore"], eri, backend=be)
+        mf.max_cycle, mf.conv_tol = 100, 1e-10
+        return mf.kernel(), mf
+
+    monkeypatch.setenv("NBED_TRACKED_EIG", "0")
+    e0, m0 = run()
+    monkeypatch.delenv("NBED_TRACKED_EIG")
+    real = be.mu_cycle
+
+    def failing(h, dm_in, fock_in, c_in, out, tracked, *a, **k):
+        handle = real(h, dm_in, fock_in, c_in, out, tracked, *a, **k)
+        if tracked:
+            orig = handle.get_extra
+            handle.get_extra = lambda: orig() * 0
+        return handle
+
+    monkeypatch.setattr(be, "mu_cycle", failing)
+    e1, m1 = run()
+    assert m1.converged and m1.kernel_info["restarts"] and m1.kernel_info["tracked_cycles"] == 0
+    assert e1 == e0
+    np.testing.assert_array_equal(m1.mo_coeff, m0.mo_coeff)
+
+
 def test_driver_end_to_end_on_device_hf_in_hf_exact(be):
     """NbedDriver.embed() with every O(N^4)/O(N^5) step on the GPU, including the global mean
     field (an exact-exchange 'functional', so that HF-in-HF embedding is exact): the Huzinaga

@@ -230,6 +230,62 @@ def test_gpu_uhf_protocol_matches_oracle_scf(be):
     assert mf.copy().get_hcore is not None and mf() is mf
 
 
+@pytest.mark.parametrize("n,nelec", [(12, (4, 3)), (16, (5, 5))])
+def test_kernel_one_call_per_cycle_loop_matches_oracle(n, nelec, monkeypatch):
+    """GpuUHF.kernel() -- PySCF's scf.hf.kernel behind the mu-shift embedding (nbed/driver.py:533) -- through the
+    one-call-per-cycle loop (nbx_mu_cycle restated by the look-ahead checker backend: CDIIS ring bookkeeping by the
+    loop, cycle i judged after cycle i+1 is queued, guarded then tracked eigensolves, conv_check cycle) against the
+    sequential loop on the plain checker backend and the oracle's ToyUHF.kernel(): same cycle count, same result."""
+    pr = synth.problem(n, nelec, 0)
+    eri = synth.eri_dense(n)
+    ref = ToyUHF(ToyMol(n, nelec, e_nuc=0.5), pr["S"], pr["hcore"], eri)
+    ref.conv_tol = 1e-10
+    e_ref = ref.kernel()
+    runs = {}
+    for name, backend in (("seq", OracleBackend()), ("ahead", OracleLookaheadBackend())):
+        mf = GpuUHF(Mole(n, nelec, e_nuc=0.5), pr["S"], pr["hcore"], eri, backend=backend)
+        mf.conv_tol = 1e-10
+        runs[name] = (mf.kernel(), mf, backend)
+    e_seq, mf_seq, _ = runs["seq"]
+    e_ahead, mf, be2 = runs["ahead"]
+    assert ref.converged and mf_seq.converged and mf.converged
+    assert mf.kernel_info["cycle_call"] and not mf.kernel_info["split"]
+    assert mf.kernel_info["tracked_cycles"] >= 1 and mf.kernel_info["guarded_cycles"] >= 2
+    assert mf.cycles == mf_seq.cycles
+    # one J/K build per queued cycle: the starting density, the judged cycles, (at most) one dropped look-ahead
+    # cycle and the conv_check cycle
+    assert mf.cycles + 2 <= be2.calls["jk"] <= mf.cycles + 3
+    np.testing.assert_allclose(e_ahead, e_ref, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(e_ahead, e_seq, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(mf.mo_energy, ref.mo_energy, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(mf.make_rdm1(), ref.make_rdm1(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(mf.scf_summary["e1"] + mf.scf_summary["e2"] + 0.5, e_ahead, rtol=0, atol=1e-10)
+
+
+def test_kernel_tracked_cycle_rejected_reruns_guarded(monkeypatch):
+    """A tracked (unguarded refinement) cycle that reports failure makes kernel() repeat the run with the guarded
+    solver only: same result as a run that never tracked."""
+    n, nelec = 12, (4, 3)
+    pr = synth.problem(n, nelec, 0)
+    eri = synth.eri_dense(n)
+
+    class Failing(OracleLookaheadBackend):
+        def mu_cycle(self, *a, **k):
+            res = super().mu_cycle(*a, **k)
+            if a[5]:  # tracked
+                res._extra = np.array([0, 1001])
+            return res
+
+    out = {}
+    for name, backend in (("plain", OracleLookaheadBackend()), ("failing", Failing())):
+        mf = GpuUHF(Mole(n, nelec, e_nuc=0.5), pr["S"], pr["hcore"], eri, backend=backend)
+        mf.conv_tol = 1e-10
+        out[name] = (mf.kernel(), mf)
+    assert out["failing"][1].converged and out["failing"][1].kernel_info["restarts"]
+    assert out["failing"][1].kernel_info["tracked_cycles"] == 0
+    np.testing.assert_allclose(out["failing"][0], out["plain"][0], rtol=0, atol=1e-10)
+
+
 def test_synthetic_df_factor_host_generators_agree():
     """The product's vectorised generator of the three-index factor (nbed_amd.synth.df_factor, what nbx_df_synth makes
     on the device) against the oracle's element-by-element one: the same doubles, symmetric, slabs of L consistent."""
