@@ -48,6 +48,19 @@ int nbx_ctx_create(int device, void* stream, int private_stream, nbx_ctx** out) 
         return NBX_E_INVALID;
     }
     NBX_HIP(hipSetDevice(device));
+    {
+        // jk_m4.hip masks the block rows a chunk does not hold by pointing their LDS reads BEYOND the LDS of a CU, where
+        // gfx9 returns zero (M4_LDS_OOB = 0x30000 bytes past the buffer): a hardware contract, not a language one -- it
+        // holds while a CU's LDS ends below that address.  Checked here, once per context: a device that fails it (not
+        // gfx950: 160 KB) is refused rather than given a J/K build that might read live memory.
+        int lds_per_cu = 0;
+        NBX_HIP(hipDeviceGetAttribute(&lds_per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device));
+        if (lds_per_cu <= 0 || lds_per_cu > 0x28000) {
+            nbx_set_error("nbx_ctx_create: device %d reports %d bytes of LDS per CU; libnbx is built for gfx950 (163840) and "
+                          "its packed J/K kernel relies on reads beyond 0x30000 returning zero", device, lds_per_cu);
+            return NBX_E_UNSUPPORTED;
+        }
+    }
     nbx_ctx* c = new nbx_ctx();
     c->device = device;
     c->own_stream = (private_stream != 0);

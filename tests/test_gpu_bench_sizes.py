@@ -48,8 +48,9 @@ def rnd(stream, *shape):
 
 # ---------------------------------------------------------------- J/K at the bench size
 def test_jk_packed_n148_vs_c_oracle(be, eri148):
-    """jk_s4_kernel's N = 148 instance (the bench's roofline kernel) against oracle/c/jk_ref.c on the
-    same tensor: J, K_alpha, K_beta, all rows.  Also the device generator against the C generator."""
+    """jk_m4_kernel's N = 148 instance (the bench's roofline kernel: the packed J/K walk on v_mfma_f64_4x4x4,
+    csrc/jk_m4.hip) against oracle/c/jk_ref.c on the same tensor: J, K_alpha, K_beta, all rows.  Also the device
+    generator against the C generator."""
     n = N_BENCH
     eri = be.synth_eri(n)
     np.testing.assert_array_equal(be.to_host(eri[7:9]), eri148[7:9])  # same inputs on both sides
@@ -65,10 +66,12 @@ def test_jk_packed_n148_vs_c_oracle(be, eri148):
     np.testing.assert_allclose(be.to_host(fock), hv + ref[0] - ref[1:], rtol=0, atol=2e-11)
 
 
-@pytest.mark.parametrize("n", [128, 192, 256])
-def test_jk_packed_large_instances_vs_c_oracle(be, n):
-    """The other kernel instances (NB = 2 at N = 128; NB = 4 long rows at 192, 256): three row slabs
-    (first, middle, last rows) of J and K against the C oracle on slabs of the generated tensor."""
+@pytest.mark.parametrize("n", list(range(100, 148, 4)) + list(range(152, 257, 8)) + [156, 188, 252])
+def test_jk_packed_every_instance_vs_c_oracle(be, n):
+    """EVERY instance of the packed J/K kernels -- each jk_m4 size is separately generated straight-line code (one
+    instance per multiple of four, N = 100 .. 148 and beyond; csrc/jk_m4.hip), jk_s4.hip's instances serve the rest up
+    to 256 -- on three row slabs (first, middle, last rows) of J and K against the C oracle (oracle/c/jk_ref.c) on
+    slabs of the generated tensor.  (N = 148 itself: all rows, above.)"""
     eri = be.synth_eri(n)
     dm = np.stack([symm(534, n), symm(535, n)])
     got = be.to_host(be.jk_packed(be.eri_pack(eri, n), be.asarray(dm)))

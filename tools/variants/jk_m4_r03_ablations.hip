@@ -33,8 +33,7 @@
 // crosses a row, both summed in a fixed order by jk_sym_reduce_kernel (with the Fock epilogue), as in jk_s4.hip.
 // This is the production kernel of the sizes nbx_jk_m4_covers() names (N = 100 .. 148 in steps of four, one instance each:
 // the tile has to fit the five-buffer ring in four chunks and its Dtot' table a loading wave's registers); DESIGN.md section 9 has the
-// measurements that led here and what is left (0.74 of the HBM roofline at N = 148 against jk_s4's 0.55; the ablation
-// switches those measurements were made with live in tools/variants/jk_m4_r03_ablations.hip, not in this file).
+// measurements that led here and what is left (0.64-0.67 of the HBM roofline against jk_s4's 0.55).
 #include <cstdlib>
 
 #include "jk_m4_layout.h"
@@ -63,6 +62,9 @@ __device__ __forceinline__ void m4_wait_three_chunks() {
 }
 
 typedef double m4_d2 __attribute__((ext_vector_type(2)));
+#ifndef NBX_M4_NO_HOLD  // (-DNBX_M4_NO_HOLD: every tile's row-q partial stored when it is complete, as before -- for A/B)
+#define NBX_M4_HOLD_ROWS
+#endif
 // Row-q partials that wait for the end of the range (see the kernel): tiles [M4_HOLD_FIRST, M4_HOLD_FIRST + M4_HOLD_TILES) of a
 // range in the loading waves' registers -- as many as fit next to the Dtot' table without a spill: check private_seg_size
 // after touching this --, the M4_HOLD_LDS tiles before them in what is left of LDS (2 KB each); the first few go out at once.
@@ -153,10 +155,7 @@ struct M4Lane {
     int col0, cbx;    // column part: 16 b + (a ^ c), c ^ b
     int xlane;        // 4 a + c
 };
-// (doubles) beyond the LDS of a CU, with room for the offsets: out-of-range LDS reads return zero on gfx9 -- a HARDWARE
-// contract, which nbx_ctx_create checks the premise of (LDS per CU <= 0x28000 bytes) and the LDS-poisoning test of
-// tests/test_gpu_kernels.py the consequence of
-constexpr int M4_LDS_OOB = 0x30000 / 8;
+constexpr int M4_LDS_OOB = 0x30000 / 8;  // (doubles) beyond any workgroup's allocation, with room for the offsets
 
 template <int NB, int K>
 __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, const double* __restrict__ xs, int w4,
@@ -184,7 +183,11 @@ __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, co
         // (a block column past the matrix -- 4 j + w4 >= NB, the last j of waves 1..3 -- has no X row: the read would land
         //  behind the X of this tile, in LDS that nothing has written yet when the first tile of a range starts, and a NaN
         //  left there by an earlier kernel times the zero of the masked operand is a NaN.  Zero, not whatever is there.)
+#ifdef NBX_M4_TEST_UNINIT_BX  // (negative control of tests' LDS-poisoning check: the read as it was)
+        if (K == 0) bx = xr[64 * j];
+#else
         if (K == 0) bx = (4 * j + w4 < NB) ? xr[64 * j] : 0.0;
+#endif
         if (!row_live(j)) return;
 #pragma unroll
         for (int G = 0; G < NG; ++G) {
@@ -240,6 +243,17 @@ __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, co
     // accumulator and wait for the last read first).
     constexpr int JR = (NJR + 1) / 2, JC = NJC / 2;
     double avr[NJR][NG], avc[NJC][NG], btc[NJC];
+#ifdef NBX_M4_ONE_BATCH
+#pragma unroll
+    for (int j = 0; j < NJR; ++j) load_row(j, avr[j], bxr[j]);
+#pragma unroll
+    for (int j = 0; j < NJC; ++j) load_col(j, avc[j], btc[j]);
+    __builtin_amdgcn_sched_barrier(0);  // (nothing crosses: without it the scheduler sinks the reads between the MFMAs)
+#pragma unroll
+    for (int j = 0; j < NJR; ++j) mma_row(j, avr[j], bxr[j]);
+#pragma unroll
+    for (int j = 0; j < NJC; ++j) mma_col(j, avc[j], btc[j]);
+#else
 #pragma unroll
     for (int j = 0; j < JR; ++j) load_row(j, avr[j], bxr[j]);
 #pragma unroll
@@ -262,6 +276,7 @@ __device__ __forceinline__ void m4_walk_chunk(const double* __restrict__ buf, co
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = JC; j < NJC; ++j) mma_col(j, avc[j], btc[j]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- the kernel
@@ -322,8 +337,12 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         const double* tile = tile0 + (real ? (int64_t)(g >> 2) * TILE : 0);
         const int begin = 16 * m4_tri(G_::row0(k)), end = 16 * m4_tri(G_::row0(k + 1));
         double* buf = buf0 + (g % M4_RING) * BUF;
+#ifdef NBX_M4_HOLD_ROWS
         int pt_ = ptid;  // (opaque per chunk: the 24 clamped offsets of a tile are recomputed, not kept in registers)
         asm volatile("" : "+v"(pt_));
+#else
+        const int pt_ = ptid;
+#endif
 #pragma unroll
         for (int s = 0; s < LPT; ++s) {
             int d = begin + (s * PT + pt_) * 2;
@@ -376,10 +395,17 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         for (int e = ptid; e < NG * 32; e += PT) {
             const int g = e >> 5, l = 2 * (e & 31) + parity;
             const int row = 16 * g + 4 * ((l >> 2) & 3) + (l >> 4), x = (l & 3) >> 1;
+#ifdef NBX_M4_ROWS_NOSTORE  // (ablation, wrong results: the sums without the stores)
+            if (red[e] != 1.2345e300) continue;
+#endif
+#ifdef NBX_M4_ROWS_FRACTION  // (ablation, wrong results: only the first 1 / NBX_M4_ROWS_FRACTION of the columns stored)
+            if (row > last / NBX_M4_ROWS_FRACTION) continue;
+#endif
             if (row <= last && x < NDM) dst[x * N + row] = (red[e] + red[NG * 32 + e]) + (red[2 * NG * 32 + e] + red[3 * NG * 32 + e]);
         }
     };
 
+#ifdef NBX_M4_HOLD_ROWS
     // Row-q partials held back until the range is done.  Thread ptid owns element e = ptid of a tile's row (row groups
     // 0..7: rows < 128; the few rows above are stored at once), one register pair per tile for M4_HOLD_TILES tiles of the
     // range -- as many as the registers of a loading wave take next to its Dtot' table without a spill (the first
@@ -445,6 +471,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                 dst[x * N + row] = (redq[e] + redq[NG * 32 + e]) + (redq[2 * NG * 32 + e] + redq[3 * NG * 32 + e]);
         }
     };
+#endif
 
     // ------------------------------------------------------------------ consumer state
     double acc[NG], bxr[NG];  // (bxr: the row part's X operands of the tile being walked, m4_walk_chunk)
@@ -496,6 +523,13 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
             qq = 0;
         }
     };
+#ifdef NBX_M4_CLOCKS
+    long long ck[4] = {0, 0, 0, 0}, c0 = 0, c1 = 0;
+#define M4_CK(i) do { c1 = __builtin_amdgcn_s_memtime(); ck[i] += c1 - c0; c0 = c1; } while (0)
+    c0 = __builtin_amdgcn_s_memtime();
+#else
+#define M4_CK(i) do {} while (0)
+#endif
     if (producer) {
         for (int t = 0; t < ntile; ++t) {
             const int64_t T = T0 + t;
@@ -506,7 +540,9 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                 const int g = M4_NCH * t + k;
                 // step g: the consumers walk chunk g; chunk g + 4 goes into the slot they left at the last barrier
                 // (chunk g - 1's), chunk g + 1 has landed and gives its J contribution
+#ifndef NBX_M4_NO_STAGE
                 issue(g + 4);  // (first: the stream is what the kernel is bound by)
+#endif
                 if (k == 0 && t > 0) {
                     // the consumers' rows of tile t - 1 (written at its last step, behind that step's barrier), and its J
                     int pp = p, qq = q - 1;
@@ -514,28 +550,48 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                         pp = p - 1;
                         qq = pp;
                     }
+#ifdef NBX_M4_ROWS_SAMEPLACE  // (ablation, wrong results: every tile's row-q partial to the same, cache-resident place)
+#ifndef NBX_M4_ROWS_PLACES
+#define NBX_M4_ROWS_PLACES 1
+#endif
+                    if (qq < pp) reduce_rows(redq, 1, kpart2 + (((int64_t)blockIdx.x * NBX_M4_ROWS_PLACES + t % NBX_M4_ROWS_PLACES) * NDM) * (int64_t)N, N - 1);
+#else
+#ifdef NBX_M4_ROWS_EVERY  // (ablation, wrong results: the row-q partial of one tile in NBX_M4_ROWS_EVERY only)
+                    if (qq < pp && t % NBX_M4_ROWS_EVERY == 0) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
+#elif defined(NBX_M4_HOLD_ROWS)
                     if (qq < pp) {
                         if (t - 1 >= M4_HOLD_FIRST - M4_HOLD_LDS && t - 1 < M4_HOLD_FIRST + M4_HOLD_TILES)
                             hold_rows(t - 1 - M4_HOLD_FIRST, qq, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N);
                         else
                             reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
                     }
+#else
+                    if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
+#endif
+#endif
                     if (pp != p) reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
                     if (ptid == 0) {  // (J of the tile: kept in LDS until the range is done -- two scattered stores less per tile)
                         const double* jr = jred + ((t - 1) & 1) * 4;
                         jstage[t - 1] = (jr[0] + jr[1]) + (jr[2] + jr[3]);
                     }
                 }
+#if !defined(NBX_M4_NO_STAGE) && !defined(NBX_M4_NO_J)
                 // the J contribution of chunk g -- the one the consumers are walking: it landed a step ago, so nothing
                 // but the wait for chunk g + 1 stands between this wave and the barrier once that chunk is there
                 jpass(g);
+#endif
                 if (k == 3) {  // this wave's share of tile t's J
                     jacc = nbx_wave_sum(jacc);
                     if (lane == 0) jred[(t & 1) * 4 + (wave - 4)] = jacc;
                     jacc = 0.0;
                 }
+                M4_CK(0);  // issue + rows + J
+#ifndef NBX_M4_NO_STAGE
                 m4_wait_three_chunks<LPT>();  // my part of chunk g + 1 (chunks g + 2 .. g + 4 may be in flight)
+#endif
+                M4_CK(1);  // wait for the chunk
                 __syncthreads();
+                M4_CK(2);  // wait for the others
             }
             p = pn;
             q = qn;
@@ -549,6 +605,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
         }
         if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T_end - 1 - t_begin) * NDM) * (int64_t)N, qq);
         reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
+#ifdef NBX_M4_HOLD_ROWS
         {  // the rows held back: tiles 0 .. ntile - 2 of the range, (p, q) walked from its start
             int pt = p_first, qt = (int)(T0 - (int64_t)pt * (pt + 1) / 2);
             int row, x;
@@ -601,6 +658,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
             M4_FLUSH_HELD(33);
 #undef M4_FLUSH_HELD
         }
+#endif
         if (wave == 4) {  // J of every tile of the range: lane i stores tile i's (one wave: its LDS operations are in order)
             if (lane == 0) {  // the last tile's J (its partial sums were stored before the last barrier)
                 const double* jr = jred + ((ntile - 1) & 1) * 4;
@@ -628,10 +686,13 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
             for (int k = 0; k < M4_NCH; ++k) {
                 const double* buf = buf0 + slot * BUF;
                 slot = slot + 1 == M4_RING ? 0 : slot + 1;
+#ifndef NBX_M4_NO_WALK
                 if (k == 0) m4_walk_chunk<NB, 0>(buf, xs, wave, ln, acc, bxr);
                 else if (k == 1) m4_walk_chunk<NB, 1>(buf, xs, wave, ln, acc, bxr);
                 else if (k == 2) m4_walk_chunk<NB, 2>(buf, xs, wave, ln, acc, bxr);
                 else m4_walk_chunk<NB, 3>(buf, xs, wave, ln, acc, bxr);
+#endif
+                M4_CK(0);  // the walk
                 if (k == 1 && more) store_x(xs0 + ((t + 1) & 1) * 4 * N, xv);
                 if (k == M4_NCH - 1) {
                     // end of tile: the row-q halves (odd columns: they used D[p][:]) leave the registers; the row-p halves
@@ -644,17 +705,26 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                         acc[g] = (odd || row_ends) ? 0.0 : acc[g];
                     }
                 }
+                M4_CK(1);  // X and row stores
+#ifndef NBX_M4_BARRIER_FLOATS
                 // (the MFMAs are register-only, so the scheduler is free to sink them below the barrier -- and does: every
                 // wave then waits for ALL its LDS reads, meets the others, and the four run their MFMAs at the same time
                 // with the LDS idle, then read at the same time with the matrix pipe idle.  Pinned here, a wave's MFMAs
                 // run as its operands arrive, under the other waves' reads)
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 __syncthreads();
+                M4_CK(2);  // wait for the others
             }
             p = pn;
             q = qn;
         }
     }
+#ifdef NBX_M4_CLOCKS
+    if ((blockIdx.x == 3 || blockIdx.x == 200) && lane == 0 && (wave == 0 || wave == 2 || wave == 4 || wave == 6))
+        printf("m4 clocks wg %d wave %d tiles %d: per tile  work %lld  wait/store %lld  barrier %lld\n", (int)blockIdx.x, wave,
+               ntile, ck[0] / ntile, ck[1] / ntile, ck[2] / ntile);
+#endif
 }
 
 size_t m4_align256(size_t x) { return (x + 255) & ~(size_t)255; }
