@@ -98,8 +98,15 @@ def test_bench_child_process_over_single_rank_rccl(tmp_path):
     init, the per-cycle all-reduce of the J/K partials inside the timed SCF (nbx_huz_cycle_jk | RCCL | _post), the
     all-gather of the transform slabs, the all-reduces of the scaling workloads, barrier, destroy -- and ONE JSON line
     that says so."""
+    import gc
     import json
 
+    import torch
+
+    # the child needs the card's memory for its N_AO = 384 dense tensor (162 GiB): hand back what this process's
+    # caching allocator still holds from the earlier tests
+    gc.collect()
+    torch.cuda.empty_cache()
     env = dict(os.environ, NBED_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0",
                WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, str(HERE.parent / "bench.py"), "--no-real", "--no-n2000", "--no-small", "--no-cpu-baseline",
