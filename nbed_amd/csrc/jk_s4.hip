@@ -45,6 +45,14 @@ size_t nbx_jk_m4_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm);
 int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
 int nbx_jk_m4(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
               double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt);
+// jk_mx.hip: the same walk for the sizes above (N = 152 .. 288, a tile in 4 .. 20 chunks), unless NBX_JK_MX=0
+bool nbx_jk_mx_covers(int64_t N);
+int64_t nbx_jk_mx_padded(int64_t N);
+size_t nbx_jk_mx_packed_bytes(int64_t N, int64_t p0, int64_t p1);
+size_t nbx_jk_mx_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm);
+int nbx_jk_mx_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
+int nbx_jk_mx(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
+              double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf);
 #ifdef NBX_EXPERIMENTAL
 // jk_p8.hip: the 8-fold form (truncated tiles) that serves whole tensors of the NB = 4 / six-loads sizes
 bool nbx_jk_p8_covers(int64_t N, int64_t p0, int64_t p1);
@@ -385,14 +393,20 @@ static int64_t m4_padded(int64_t nao) {
     return (nao > 0 && nbx_jk_m4_covers(n4)) ? n4 : 0;
 }
 
+// the size jk_mx.hip runs nao as (nao itself or the next instance, at most eight zero rows / columns more); 0: none
+static int64_t mx_padded(int64_t nao) { return (nao > 0 && !m4_padded(nao)) ? nbx_jk_mx_padded(nao) : 0; }
+
 // 1: a kernel instance serves N; 2: served as the next covered size with zero rows/columns; 0: no
 extern "C" int nbx_jk_packed_supported(int64_t nao) {
+    if (const int64_t nx = mx_padded(nao)) return nx == nao ? 1 : 2;
     return s4_supported(nao) ? 1 : (s4_padded(nao) > 0 ? 2 : 0);
 }
 
 extern "C" size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1) {
+    if (p0 < 0 || p1 < p0 || p1 > nao) return 0;
+    if (const int64_t nx = mx_padded(nao)) return nbx_jk_mx_packed_bytes(nx, p0, p1);
     const int64_t NP = s4_padded(nao);
-    if (NP == 0 || p0 < 0 || p1 < p0 || p1 > nao) return 0;
+    if (NP == 0) return 0;
     if (m4_padded(nao)) return nbx_jk_m4_packed_bytes(m4_padded(nao), p0, p1);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_packed_bytes(nao);
     const S4Geom g = s4_geom((int)NP, s4_nb(NP));
@@ -402,6 +416,11 @@ extern "C" size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1) {
 extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri, double* d_packed) {
     NBX_CHECK_ARG(ctx);
     NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
+    if (const int64_t nx = mx_padded(nao)) {
+        if (p0 == p1) return NBX_OK;
+        NBX_CHECK_ARG(d_eri && d_packed);
+        return nbx_jk_mx_pack(ctx, nx, nao, p0, p1, d_eri, d_packed);
+    }
     const int64_t NP = s4_padded(nao);  // the tiles (p, q) with p < nao of the padded tensor: the others are zero
     if (NP == 0) {
         nbx_set_error("nbx_eri_pack: N = %lld is not covered by the packed J/K kernel", (long long)nao);
@@ -421,8 +440,11 @@ extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
 }
 
 extern "C" size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm) {
+    if (p0 < 0 || p1 < p0 || p1 > nao || ndm <= 0) return 0;
+    if (const int64_t nx = mx_padded(nao))  // (+ the padded densities and J/K of a size that is not an instance)
+        return nbx_jk_mx_worksize(nx, p0, p1, ndm) + (nx != nao ? s4_align256((size_t)((1 + 2 * ndm) * nx * nx) * sizeof(double)) : 0);
     const int64_t NP = s4_padded(nao);
-    if (NP == 0 || p0 < 0 || p1 < p0 || p1 > nao || ndm <= 0) return 0;
+    if (NP == 0) return 0;
     if (const int64_t n4 = m4_padded(nao))  // (+ the padded densities and J/K of a size that is not a multiple of four)
         return nbx_jk_m4_worksize(n4, p0, p1, ndm) + (n4 != nao ? s4_align256((size_t)((1 + 2 * ndm) * n4 * n4) * sizeof(double)) : 0);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_worksize(nao, ndm);
@@ -439,6 +461,7 @@ static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const
                         double* d_fock, double* d_vhf, const double* d_dts);
 
 extern "C" size_t nbx_jk_dts_bytes(int64_t nao) {
+    if (mx_padded(nao)) return 0;  // (jk_mx.hip prepares its table itself: one small launch beside a build of 0.2 .. 2.4 ms)
     if (nbx_jk_m4_covers(nao)) return nbx_jk_m4_weights_bytes(nao);  // (the same table in jk_m4.hip's staging order)
     if (!s4_supported(nao)) return 0;  // (zero-padded sizes build their table themselves)
     const int NB = s4_nb(nao);
@@ -446,7 +469,7 @@ extern "C" size_t nbx_jk_dts_bytes(int64_t nao) {
 }
 
 extern "C" int nbx_jk_dts_init(nbx_ctx* ctx, int64_t nao, double* d_dts) {
-    NBX_CHECK_ARG(ctx && d_dts && s4_supported(nao));
+    NBX_CHECK_ARG(ctx && d_dts && s4_supported(nao) && !mx_padded(nao));
     return nbx_memset(ctx, d_dts, 0, nbx_jk_dts_bytes(nao));
 }
 
@@ -469,9 +492,10 @@ static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double
     NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
     NBX_CHECK_ARG(d_packed != nullptr || p0 == p1);
     NBX_CHECK_ARG(ndm == 1 || ndm == 2);
-    const int64_t NPAD = s4_padded(nao);
+    const int64_t NX = mx_padded(nao);
+    const int64_t NPAD = NX ? NX : s4_padded(nao);
     if (NPAD == 0) {
-        nbx_set_error("nbx_jk_packed: N = %lld is not covered (N <= 256 within %d of an even size the kernel has an "
+        nbx_set_error("nbx_jk_packed: N = %lld is not covered (N <= 288 within %d of a size the kernels have an "
                       "instance for)", (long long)nao, S4_MAX_PAD);
         return NBX_E_UNSUPPORTED;
     }
@@ -482,6 +506,24 @@ static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double
     }
     NBX_CHECK_ARG((reinterpret_cast<uintptr_t>(d_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0);
     if (p1 == p0) return nbx_memset(ctx, d_jk, 0, (size_t)((1 + ndm) * nao * nao) * sizeof(double));
+    if (NX == nao) return nbx_jk_mx(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf);
+    if (NX) {
+        // as the NX x NX problem whose extra rows and columns are zero (tiles with p >= nao are neither stored nor visited)
+        char* tail = static_cast<char*>(d_work) + nbx_jk_mx_worksize(NX, p0, p1, ndm);
+        double* dm_pad = reinterpret_cast<double*>(tail);
+        double* jk_pad = dm_pad + ndm * NX * NX;
+        const int64_t tin = ndm * NX * NX, tout = (1 + ndm) * nao * nao;
+        hipLaunchKernelGGL(s4_pad_square_kernel, dim3((unsigned)nbx_cdiv(tin, 256)), dim3(256), 0, ctx->stream, d_dm,
+                           dm_pad, (int)nao, (int)NX, (int)ndm);
+        NBX_LAUNCH_CHECK();
+        const int rc = nbx_jk_mx(ctx, NX, p0, p1, d_packed, dm_pad, ndm, jk_pad, d_work, nullptr, nullptr, nullptr);
+        if (rc != NBX_OK) return rc;
+        hipLaunchKernelGGL(s4_crop_square_kernel, dim3((unsigned)nbx_cdiv(tout, 256)), dim3(256), 0, ctx->stream,
+                           jk_pad, d_jk, (int)nao, (int)NX, (int)(1 + ndm));
+        NBX_LAUNCH_CHECK();
+        if (d_fock != nullptr) return nbx_fock_uhf(ctx, nao, d_hv, 3, nullptr, d_jk, d_fock, d_vhf);
+        return NBX_OK;
+    }
     if (nbx_jk_m4_covers(nao)) return nbx_jk_m4(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
     if (const int64_t n4 = m4_padded(nao)) {
         // as the n4 x n4 problem whose extra rows and columns are zero (tiles with p >= nao are neither stored nor visited):
