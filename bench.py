@@ -386,11 +386,20 @@ def small_configs_leg(be, args) -> list:
     return out
 
 
+def packed_kernel_name(n_ao: int) -> str:
+    """Which kernel nbx_jk_packed runs a size on (csrc/jk_s4.hip's dispatch)."""
+    if 97 <= n_ao <= 148 and os.environ.get("NBX_JK_M4", "1") != "0":
+        return "jk_m4_kernel (4-fold packed tiles, MFMA walk, four chunks per tile)"
+    if 148 < n_ao <= 400 and os.environ.get("NBX_JK_MX", "1") != "0":
+        return "jk_mx_kernel (4-fold packed tiles, MFMA walk, tile in whole-row / band-segment chunks)"
+    return "jk_s4_kernel (4-fold packed tiles)"
+
+
 def scaling_workload_leg(be, args, world, rank, distributed, barrier) -> list:
     """Sizes at which sharding the J/K build pays (it grows as N^4, the replicated rest of a cycle as N^3), for every
-    --gpus N: N = 256 (packed kernel, 8.6 GB of tiles) and N = 384 (symmetric kernel on the dense tensor, 87 GB read
-    per build), each rank holding its equal-work slab of (pq|rs) rows; cycles/s of the product loop and the
-    all-reduce of the (3,N,N) J/K partials timed on its own."""
+    --gpus N: N = 256 (8.7 GB of packed tiles per build) and N = 384 (43.7 GB), each rank holding its equal-work slab
+    of (pq|rs) rows in the packed form; cycles/s of the product loop and the all-reduce of the (3,N,N) J/K partials
+    timed on its own."""
     import torch
     import torch.distributed as dist
 
@@ -430,7 +439,7 @@ def scaling_workload_leg(be, args, world, rank, distributed, barrier) -> list:
                 dt = float(tmax.item())
             ntiles = (sh.hi * (sh.hi + 1) - sh.lo * (sh.lo + 1)) // 2
             slab_bytes = float(be.lib.nbx_eri_packed_bytes(n_ao, sh.lo, sh.hi)) if packed else 8.0 * n_ao * n_ao * ntiles
-            out.append({"nao": n_ao, "jk_kernel": "jk_s4_kernel (4-fold packed tiles)" if packed else "jk_sym_kernel (dense tensor, tiles q <= p)",
+            out.append({"nao": n_ao, "jk_kernel": packed_kernel_name(n_ao) if packed else "jk_sym_kernel (dense tensor, tiles q <= p)",
                         "cycles_per_sec": steps / dt, "ms_per_cycle": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                         "n_gpus": world, "slab_rows": [int(sh.lo), int(sh.hi)], "slab_bytes_read_per_build": slab_bytes,
                         "allreduce_ms_alone": ar_ms, "allreduce_bytes": 24 * n_ao * n_ao,

@@ -55,9 +55,11 @@ __device__ __forceinline__ void mx_wait_vm() {
 }
 
 // ---------------------------------------------------------------------------------------------- pack and weights
+// slab rows [p0, p0 + np) of the dense tensor -> tiles of 4 x 4 blocks in chunk order; one workgroup per tile
+// (nsrc <= N: the dense tensor's own size; the tiles p < nsrc exist, their elements beyond nsrc are stored as zeros)
 template <int NB>
 __global__ __launch_bounds__(256) void mx_pack_kernel(const double* __restrict__ eri, double* __restrict__ out, int p0,
-                                                      int64_t t_begin, int nsrc) {
+                                                      int64_t t_begin, int nsrc, MxChunks ch) {
     using G = MxGeom<NB>;
     const int64_t T = t_begin + blockIdx.x;
     const int p = mx_tri_row(T), q = (int)(T - (int64_t)p * (p + 1) / 2);
@@ -65,9 +67,12 @@ __global__ __launch_bounds__(256) void mx_pack_kernel(const double* __restrict__
     double* dst = out + (int64_t)blockIdx.x * G::TILE;
     for (int e = threadIdx.x; e < G::TILE; e += 256) {
         const int blk = e >> 4;
-        const int bt = mx_tri_row(blk), bc = blk - m4_tri(bt);
-        const int k = ((e >> 2) & 3) ^ ((bt ^ bc) & 3), i = (e & 3) ^ k;  // (the swizzle: jk_m4.hip)
-        const int row = 4 * bt + i, col = 4 * bc + k;
+        int k = 0;
+        while (k + 1 < ch.n && ch.c[k + 1].start <= blk) ++k;
+        int bt, bc;
+        mx_block_of(ch, k, blk - ch.c[k].start, bt, bc);
+        const int kk = ((e >> 2) & 3) ^ ((bt ^ bc) & 3), i = (e & 3) ^ kk;  // (the swizzle: jk_m4.hip)
+        const int row = 4 * bt + i, col = 4 * bc + kk;
         dst[e] = (col <= row && row < nsrc) ? src[(int64_t)row * nsrc + col] : 0.0;
     }
 }
@@ -77,19 +82,19 @@ __global__ __launch_bounds__(256) void mx_pack_kernel(const double* __restrict__
 // elsewhere (the zeros of the diagonal blocks, the clamped tail of a chunk, the slots a short chunk does not use)
 template <int NB>
 __global__ __launch_bounds__(256) void mx_weights_kernel(const double* __restrict__ dm, int ndm, double* __restrict__ wt,
-                                                         MxRows rows) {
+                                                         MxChunks ch) {
     using G = MxGeom<NB>;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= G::NCH * G::LPTM * M4_PROD_THREADS) return;
     const int tid = i % M4_PROD_THREADS, s = (i / M4_PROD_THREADS) % G::LPTM, k = (i / M4_PROD_THREADS) / G::LPTM;
-    const int d0 = 16 * m4_tri(rows.r[k]) + (s * M4_PROD_THREADS + tid) * 2, dend = 16 * m4_tri(rows.r[k + 1]);
+    const int d0 = (s * M4_PROD_THREADS + tid) * 2, dend = 16 * ch.c[k].blocks;
     const int64_t n2 = (int64_t)G::N * G::N;
     double out[2] = {0.0, 0.0};
     for (int e = 0; e < 2; ++e) {
         const int d = d0 + e;
         if (d >= dend) continue;
-        const int blk = d >> 4;
-        const int bt = mx_tri_row(blk), bc = blk - m4_tri(bt);
+        int bt, bc;
+        mx_block_of(ch, k, d >> 4, bt, bc);
         const int kk = ((d >> 2) & 3) ^ ((bt ^ bc) & 3), ii = (d & 3) ^ kk;
         const int row = 4 * bt + ii, col = 4 * bc + kk;
         if (col > row) continue;
@@ -101,6 +106,44 @@ __global__ __launch_bounds__(256) void mx_weights_kernel(const double* __restric
         out[e] = row == col ? v : v + vt;
     }
     *reinterpret_cast<double2*>(wt + 2 * (int64_t)i) = make_double2(out[0], out[1]);
+}
+
+// ---------------------------------------------------------------------------------------------- the walk of a BAND chunk
+// Chunk K = the column groups [J0, J1) of band G (block rows 4 G .. 4 G + 3), row after row in the buffer.  With
+// lane = 16 a + 4 b + c as in jk_m4_walk.h:
+//   row part    item j in [J0, J1):  A = block (4 G + b, 4 j + w4) element (c, a),  B = X[4 (4 j + w4) + a][c] (bxr[j])
+//               -> acc[G]: every lane's block row is in the chunk, and so is every block left of the diagonal group;
+//   column part item H in [J0, J1):  A = block (4 G + w4, 4 H + b) element (a, c),  B = X[4 (4 G + w4) + a][c]
+//               -> acc[H]: each walking wave has one of the band's four rows.
+// Only the segment that holds the diagonal (J1 = G + 1) has anything to mask: its last group.
+template <class G_, int K>
+__device__ __forceinline__ void mx_walk_band(const double* __restrict__ buf, const double* __restrict__ xs, int w4,
+                                             const M4Lane<G_::NG>& ln, double (&acc)[G_::NG], const double (&bxr)[G_::NG]) {
+    constexpr MxChunk ch = G_::CH.c[K];
+    constexpr int G = ch.ra / 4, J0 = ch.j0, J1 = ch.j1, NJ = J1 - J0;
+    constexpr bool DIAG = J1 == G + 1;
+    const int a = ln.a, b = ln.b, c = ln.c;
+    const int rs_b = DIAG ? b * 4 * (G - J0) + m4_tri(b) : b * 4 * NJ;     // first block of this lane's row in the segment
+    const int rs_w = DIAG ? w4 * 4 * (G - J0) + m4_tri(w4) : w4 * 4 * NJ;  // first block of this wave's row (uniform)
+    const double* rp = buf + 16 * (rs_b + w4) + 4 * (a ^ b ^ w4) + (c ^ a);
+    const double* cp = buf + 16 * rs_w + ln.col0 + 4 * (ln.cbx ^ w4);
+    const double bt = xs[16 * (4 * G + w4) + ln.xlane];
+    double avr[NJ], avc[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) avr[i] = rp[64 * i];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) avc[i] = cp[64 * i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        double vr = avr[i], vc = avc[i];
+        if (DIAG && J0 + i == G) {
+            vr = b >= w4 ? vr : 0.0;                          // C = 4 G + w4 <= T = 4 G + b
+            vc = (b < w4 || (b == w4 && c < a)) ? vc : 0.0;   // block column 4 G + b left of T = 4 G + w4, or the strict lower part
+        }
+        acc[G] = __builtin_amdgcn_mfma_f64_4x4x4f64(vr, bxr[J0 + i], acc[G], 0, 0, 0);
+        acc[J0 + i] = __builtin_amdgcn_mfma_f64_4x4x4f64(vc, bt, acc[J0 + i], 0, 0, 0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- the kernel
@@ -139,7 +182,7 @@ __global__ __launch_bounds__(MX_THREADS, 1) void jk_mx_kernel(const double* __re
     // never read).
     auto issue = [&](auto cc, int tt, int slot) {
         constexpr int c = decltype(cc)::value;
-        constexpr int begin = 16 * m4_tri(G_::row0(c)), end = 16 * m4_tri(G_::row0(c + 1)), LP = G_::lpt(c);
+        constexpr int begin = 16 * G_::CH.c[c].start, end = begin + 16 * G_::CH.c[c].blocks, LP = G_::lpt(c);
         const double* tile = tile0 + (tt < ntile ? (int64_t)tt * TILE : 0);
         double* buf = buf0 + slot * BUF;
         int pt_ = ptid;  // (opaque per chunk: the clamped offsets are recomputed, not kept in registers)
@@ -357,7 +400,8 @@ __global__ __launch_bounds__(MX_THREADS, 1) void jk_mx_kernel(const double* __re
                 constexpr int k = decltype(kc)::value;
                 const double* buf = buf0 + slot * BUF;
                 slot = slot + 1 == MX_RING ? 0 : slot + 1;
-                m4_walk_chunk<G_, k>(buf, xs, wave, ln, acc, bxr);
+                if constexpr (G_::CH.c[k].band) mx_walk_band<G_, k>(buf, xs, wave, ln, acc, bxr);
+                else m4_walk_chunk<G_, k>(buf, xs, wave, ln, acc, bxr);
                 if (k == 1 && more) store_x(xs0 + ((t + 1) & 1) * 4 * N, xv);
                 if (k == NCH - 1) {
                     // end of tile: the row-q halves (odd columns: they used D[p][:]) leave the registers; the row-p halves
@@ -425,7 +469,7 @@ int mx_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
         if (rc != NBX_OK) return rc;
     }
     hipLaunchKernelGGL(mx_weights_kernel<NB>, dim3((unsigned)nbx_cdiv(G::NCH * G::LPTM * M4_PROD_THREADS, 256)), dim3(256), 0,
-                       ctx->stream, d_dm, (int)ndm, wt, G::ROWS);
+                       ctx->stream, d_dm, (int)ndm, wt, G::CH);
     NBX_LAUNCH_CHECK();
     const int64_t t_begin = m4_tri((int)p0), t_end = m4_tri((int)p1);
     {
@@ -451,67 +495,90 @@ int mx_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
 
 }  // namespace
 
-// The sizes this kernel has an instance for (N = 4 NB): every multiple of eight from 152 to 256 (the sizes between
-// run as the next one, zero-padded -- at most 1.11 x the bytes), and 272, 288.  NBX_JK_MX=0 in the environment (read
-// once per process) hands them back to jk_s4.hip / jk_sym.hip.
+// The sizes this kernel has an instance for (N = 4 NB): every multiple of eight from 152 to 256, then 272 and every
+// multiple of sixteen up to 400 (the sizes between run as the next one within eight, zero-padded; dense + packed
+// tensor fit one GPU's HBM up to N = 400).  The instances are compiled in two translation units (this file for
+// N <= 256, jk_mx_hi.hip -- which includes this one with another list -- for the rest) so that they build side by side.
+// NBX_JK_MX=0 in the environment (read once per process) hands the sizes back to jk_s4.hip / jk_sym.hip.
 #ifndef NBX_MX_SIZES
 #define NBX_MX_SIZES(X) X(38) X(40) X(42) X(44) X(46) X(48) X(50) X(52) X(54) X(56) X(58) X(60) X(62) X(64)
+#define MX_FN(name) name
+#define MX_HAS_HI 1
 #endif
 #define MX_DISPATCH(N_, EXPR)            \
     switch ((int)((N_) / 4)) {           \
         NBX_MX_SIZES(MX_CASE_##EXPR)     \
         default: break;                  \
     }
-bool nbx_jk_mx_covers(int64_t N) {
+#ifdef MX_HAS_HI
+bool nbx_jk_mx_covers_hi(int64_t N);
+size_t nbx_jk_mx_packed_bytes_hi(int64_t N, int64_t p0, int64_t p1);
+size_t nbx_jk_mx_worksize_hi(int64_t N, int64_t p0, int64_t p1, int64_t ndm);
+int nbx_jk_mx_pack_hi(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
+int nbx_jk_mx_hi(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
+                 double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf);
+#define MX_ELSE_HI(call) return call;
+#else
+#define MX_ELSE_HI(call)
+#endif
+
+bool MX_FN(nbx_jk_mx_covers)(int64_t N) {
     static const bool on = getenv("NBX_JK_MX") == nullptr || atoi(getenv("NBX_JK_MX")) != 0;
     if (!on || N % 4 != 0) return false;
 #define MX_CASE_covers(NB_) case NB_: return true;
     MX_DISPATCH(N, covers)
 #undef MX_CASE_covers
+    MX_ELSE_HI(nbx_jk_mx_covers_hi(N))
     return false;
 }
 
+#ifdef MX_HAS_HI
 // the covered size that N runs as (N itself, or the next instance: extra rows and columns zero); 0: none
 int64_t nbx_jk_mx_padded(int64_t N) {
     for (int64_t n = (N + 3) / 4 * 4; n <= N + 8; n += 4)
         if (nbx_jk_mx_covers(n)) return n;
     return 0;
 }
+#endif
 
-size_t nbx_jk_mx_packed_bytes(int64_t N, int64_t p0, int64_t p1) {
+size_t MX_FN(nbx_jk_mx_packed_bytes)(int64_t N, int64_t p0, int64_t p1) {
     const int64_t ntiles = m4_tri((int)p1) - m4_tri((int)p0);
 #define MX_CASE_bytes(NB_) case NB_: return (size_t)(ntiles * MxGeom<NB_>::TILE) * sizeof(double) + 256;
     MX_DISPATCH(N, bytes)
 #undef MX_CASE_bytes
+    MX_ELSE_HI(nbx_jk_mx_packed_bytes_hi(N, p0, p1))
     return 0;
 }
 
-size_t nbx_jk_mx_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm) {
+size_t MX_FN(nbx_jk_mx_worksize)(int64_t N, int64_t p0, int64_t p1, int64_t ndm) {
 #define MX_CASE_work(NB_) case NB_: return mx_plan_nb<NB_>(p0, p1 - p0, ndm).total;
     MX_DISPATCH(N, work)
 #undef MX_CASE_work
+    MX_ELSE_HI(nbx_jk_mx_worksize_hi(N, p0, p1, ndm))
     return 0;
 }
 
-int nbx_jk_mx_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed) {
-    NBX_CHECK_ARG(nbx_jk_mx_covers(N) && d_eri && d_packed && nsrc <= N && nsrc > N - 12 && p1 <= nsrc);
+int MX_FN(nbx_jk_mx_pack)(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed) {
+    NBX_CHECK_ARG(MX_FN(nbx_jk_mx_covers)(N) && d_eri && d_packed && nsrc <= N && nsrc > N - 12 && p1 <= nsrc);
     const int64_t ntiles = m4_tri((int)p1) - m4_tri((int)p0);
 #define MX_CASE_pack(NB_)                                                                                                  \
     case NB_:                                                                                                              \
         hipLaunchKernelGGL(mx_pack_kernel<NB_>, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, d_eri, d_packed, (int)p0, \
-                           (int64_t)m4_tri((int)p0), (int)nsrc);                                                           \
-        break;
+                           (int64_t)m4_tri((int)p0), (int)nsrc, MxGeom<NB_>::CH);                                          \
+        NBX_LAUNCH_CHECK();                                                                                                \
+        return NBX_OK;
     MX_DISPATCH(N, pack)
 #undef MX_CASE_pack
-    NBX_LAUNCH_CHECK();
-    return NBX_OK;
+    MX_ELSE_HI(nbx_jk_mx_pack_hi(ctx, N, nsrc, p0, p1, d_eri, d_packed))
+    return NBX_E_UNSUPPORTED;
 }
 
-int nbx_jk_mx(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
-              double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf) {
-    NBX_CHECK_ARG(nbx_jk_mx_covers(N));
+int MX_FN(nbx_jk_mx)(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
+                     double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf) {
+    NBX_CHECK_ARG(MX_FN(nbx_jk_mx_covers)(N));
 #define MX_CASE_run(NB_) case NB_: return mx_run<NB_>(ctx, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf);
     MX_DISPATCH(N, run)
 #undef MX_CASE_run
+    MX_ELSE_HI(nbx_jk_mx_hi(ctx, N, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf))
     return NBX_E_UNSUPPORTED;
 }

@@ -54,11 +54,7 @@ def test_no_gpu_means_no_backend():
         HipBackend()
 
 
-def test_streaming_jk_kernels_have_no_scratch(tmp_path):
-    """jk_m4_kernel keeps the row partials of a range in the loading waves' registers, 254 of 256 of them: one register
-    more and the compiler spills -- and a scratch access in that loop waits behind the whole queue of chunk loads
-    (DESIGN.md section 9 (xiv)).  The cross-compiled ISA must say private_seg_size 0 for every instance (N = 100 .. 148, one or two densities)."""
-    import re
+def _cross_compile_isa(tmp_path, name):
     import shutil
     import subprocess
     from pathlib import Path
@@ -69,10 +65,79 @@ def test_streaming_jk_kernels_have_no_scratch(tmp_path):
 
         pytest.skip("no hipcc")
     root = Path(__file__).resolve().parent.parent
-    asm = tmp_path / "jk_m4.s"
+    asm = tmp_path / f"{name}.s"
     subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", f"-I{root / 'include'}", "-S", "--cuda-device-only",
-                    str(root / "nbed_amd" / "csrc" / "jk_m4.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=600)
-    text = asm.read_text()
-    sizes = re.findall(r"jk_m4_kernelILi(\d+)ELi([12])E\S*\.private_seg_size, (\d+)", text)
-    assert ("37", "1") in {(nb, k) for nb, k, _ in sizes} and ("37", "2") in {(nb, k) for nb, k, _ in sizes}, sizes
-    assert len(sizes) >= 2 and all(int(v) == 0 for _, _, v in sizes), f"jk_m4_kernel spills: {sizes}"
+                    str(root / "nbed_amd" / "csrc" / f"{name}.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=900)
+    return asm.read_text()
+
+
+def _asm_sgpr_hazards(text):
+    """Inline-asm memory instructions that read an SGPR a VALU instruction (v_readlane / v_readfirstlane / a VALU compare)
+    wrote fewer than five instructions earlier: the compiler's hazard recogniser does not look into asm statements, and a
+    vector-memory instruction that reads an SGPR within five wait states of a VALU write of it sees the OLD value
+    (that is how jk_mx.hip's first weights loads read the previous slot's base when their scalar bases were
+    spilled into VGPR lanes)."""
+    import re
+
+    lines = [ln.strip() for ln in text.splitlines()]
+    code = [(i, ln) for i, ln in enumerate(lines) if ln and not ln.startswith((";", ".", "//")) and not ln.endswith(":")]
+    in_asm, bad = False, []
+    asm_idx = set()
+    for i, ln in enumerate(lines):
+        if ln.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif ln.startswith(";;#ASMEND"):
+            in_asm = False
+        elif in_asm and ln and not ln.startswith(";"):
+            asm_idx.add(i)
+    pos = {i: k for k, (i, _) in enumerate(code)}
+    for i in sorted(asm_idx):
+        ln = lines[i]
+        if not ln.startswith(("global_load", "buffer_load", "s_mov_b32 m0")):
+            continue
+        used = set()
+        for a, b in re.findall(r"s\[(\d+):(\d+)\]", ln):
+            used.update(range(int(a), int(b) + 1))
+        used.update(int(a) for a in re.findall(r"(?<![\w\[])s(\d+)\b", ln))
+        k = pos[i]
+        for back in range(1, 6):
+            if k - back < 0:
+                break
+            prev = code[k - back][1]
+            m = re.match(r"(v_readlane_b32|v_readfirstlane_b32)\s+s(\d+)", prev)
+            if m and int(m.group(2)) in used:
+                bad.append((prev, ln))
+    return bad
+
+
+def test_streaming_jk_kernels_have_no_scratch_and_no_asm_sgpr_hazard(tmp_path):
+    """jk_m4_kernel keeps the row partials of a range in the loading waves' registers, 254 of 256 of them: one register
+    more and the compiler spills -- and a scratch access in that loop waits behind the whole queue of chunk loads
+    (DESIGN.md section 9 (xiv)).  The cross-compiled ISA must say private_seg_size 0 for every instance (N = 100 .. 148
+    in jk_m4.hip, N = 152 .. 288 in jk_mx.hip; one or two densities), and no inline-asm load may read a scalar register
+    that a v_readlane has just written."""
+    import re
+
+    for name, probe in (("jk_m4", "37"), ("jk_mx", "64")):
+        text = _cross_compile_isa(tmp_path, name)
+        sizes = re.findall(name + r"_kernelILi(\d+)ELi([12])E\S*\.private_seg_size, (\d+)", text)
+        assert (probe, "1") in {(nb, k) for nb, k, _ in sizes} and (probe, "2") in {(nb, k) for nb, k, _ in sizes}, sizes
+        assert len(sizes) >= 2 and all(int(v) == 0 for _, _, v in sizes), f"{name}_kernel spills: {sizes}"
+        hazards = _asm_sgpr_hazards(text)
+        assert not hazards, hazards[:5]
+
+
+def test_asm_sgpr_hazard_checker_sees_the_pattern():
+    text = """
+	v_readlane_b32 s12, v183, 24
+	v_readlane_b32 s13, v183, 25
+	;;#ASMSTART
+	global_load_dwordx4 v[134:137], v166, s[12:13]
+	;;#ASMEND
+	s_add_u32 s14, s60, 0x16000
+	;;#ASMSTART
+	global_load_dwordx4 v[122:125], v166, s[14:15]
+	;;#ASMEND
+"""
+    bad = _asm_sgpr_hazards(text)
+    assert len(bad) == 2 and all("s[12:13]" in b[1] for b in bad)

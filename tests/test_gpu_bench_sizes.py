@@ -66,16 +66,26 @@ def test_jk_packed_n148_vs_c_oracle(be, eri148):
     np.testing.assert_allclose(be.to_host(fock), hv + ref[0] - ref[1:], rtol=0, atol=2e-11)
 
 
-@pytest.mark.parametrize("n", list(range(100, 148, 4)) + list(range(152, 257, 8)) + [156, 188, 252])
+MX_SIZES = list(range(152, 257, 8)) + [272, 288, 304, 320, 336, 352, 368, 384]
+
+
+@pytest.mark.parametrize("n", list(range(100, 148, 4)) + MX_SIZES + [156, 188, 252, 300])
 def test_jk_packed_every_instance_vs_c_oracle(be, n):
-    """EVERY instance of the packed J/K kernels -- each jk_m4 size is separately generated straight-line code (one
-    instance per multiple of four, N = 100 .. 148 and beyond; csrc/jk_m4.hip), jk_s4.hip's instances serve the rest up
-    to 256 -- on three row slabs (first, middle, last rows) of J and K against the C oracle (oracle/c/jk_ref.c) on
-    slabs of the generated tensor.  (N = 148 itself: all rows, above.)"""
+    """EVERY instance of the packed J/K kernels -- each size of the MFMA walk is separately generated straight-line code
+    (csrc/jk_m4.hip: one instance per multiple of four, N = 100 .. 148; csrc/jk_mx.hip: every multiple of eight up to
+    256, whole block rows per chunk, and 272 .. 384 in steps of sixteen, from N = 304 with the lower bands cut into
+    column segments; 156, 188, 252, 300 run zero-padded as the next instance) -- on three row slabs (first, middle,
+    last rows) of J and K against the C oracle (oracle/c/jk_ref.c) on slabs of the generated tensor.  (N = 148 itself:
+    all rows, above.)"""
+    import torch
+
+    torch.cuda.empty_cache()  # (the dense tensor of N = 384 is 174 GB)
     eri = be.synth_eri(n)
     dm = np.stack([symm(534, n), symm(535, n)])
-    got = be.to_host(be.jk_packed(be.eri_pack(eri, n), be.asarray(dm)))
+    packed = be.eri_pack(eri, n)
     del eri
+    got = be.to_host(be.jk_packed(packed, be.asarray(dm)))
+    del packed
     for p0, p1 in [(0, 3), (n // 2 - 1, n // 2 + 2), (n - 3, n)]:
         ref = cref.jk(cref.synth_eri(n, p0, p1), dm, p0, p1)  # (3, rows, N): J rows, K rows
         np.testing.assert_allclose(got[:, p0:p1], ref, rtol=0, atol=1e-11 * (n / 148) ** 2)

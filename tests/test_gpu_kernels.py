@@ -798,7 +798,7 @@ def test_jk_packed_full_size(be, n):
     np.testing.assert_array_equal(a[0], a[0].T)
 
 
-@pytest.mark.parametrize("n", [24, 72, 104, 128, 136, 148, 192])
+@pytest.mark.parametrize("n", [24, 72, 104, 128, 136, 148])
 def test_jk_packed_fock_and_prepared_dtot_table(be, n):
     """nbx_jk_packed_fock (Fock assembly in the reduction) against J/K + nbx_fock_uhf, and the Dtot'
     table left by the scalars kernel (nbx_huz_cycle_scalars_dts) against the one the build makes
@@ -822,12 +822,30 @@ def test_jk_packed_fock_and_prepared_dtot_table(be, n):
         np.testing.assert_array_equal(be.to_host(vhf1), be.to_host(vhf0))
 
 
+@pytest.mark.parametrize("n", [152, 192, 250, 256])
+def test_jk_packed_fock_of_the_sizes_that_make_their_own_table(be, n):
+    """N > 148 (jk_mx.hip: the weights of a tile no longer fit the loading waves' registers and are streamed from a
+    table the build writes itself): no Dtot' table is handed over -- nbx_jk_dts_bytes is 0 -- and the fused Fock
+    assembly equals J/K + nbx_fock_uhf bit for bit."""
+    eri = be.synth_eri(n)
+    packed = be.eri_pack(eri, n)
+    hv = be.asarray(np.stack([symm(570, n), symm(571, n)]))
+    with pytest.raises(ValueError):
+        be.jk_dts_new(n)
+    for seed in (572, 574):
+        dm = be.asarray(np.stack([symm(seed, n), symm(seed + 1, n)]))
+        fock0, vhf0 = be.jk_packed_fock(packed, dm, hv)
+        f_ref, v_ref = be.fock_uhf(hv, None, be.jk_packed(packed, dm))
+        np.testing.assert_array_equal(be.to_host(fock0), be.to_host(f_ref))
+        np.testing.assert_array_equal(be.to_host(vhf0), be.to_host(v_ref))
+
+
 def test_jk_packed_unsupported_sizes(be):
     """Sizes outside the packed kernel's reach are refused loudly (the host then keeps the
-    symmetric / plain kernel): too small, above 256."""
+    symmetric / plain kernel): too small, between instances, above 400."""
     from nbed_amd._nbx import NbxError
 
-    for n in (3, 7, 13, 258, 300):
+    for n in (3, 7, 13, 258, 322, 402, 500):
         assert not be.jk_packed_supported(n)
     eri = be.synth_eri(7)
     with pytest.raises((ValueError, NbxError)):
