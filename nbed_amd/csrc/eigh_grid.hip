@@ -19,12 +19,15 @@
 // behind the workgroup barrier that lane then joins.  The launch is cooperative (all workgroups resident, one per CU)
 // and the poll gives up after ~seconds (status word set, every workgroup still reaches the end of the kernel).
 // Conventions of d, e, tau and the reflectors are LAPACK dsytd2's (UPLO = 'L'), as in eigh_tridiag.hip.
+#include <cstdlib>
+
 #include "nbx_common.h"
 
 namespace {
 
 constexpr int TDG_THREADS = 256;
 constexpr unsigned TDG_SPIN_LIMIT = 1u << 22;
+constexpr int TDG_XCH = 4 * 2048;  // doubles of hand-over vectors per matrix (y and pivot row, two of each, N <= 2048)
 
 __device__ __forceinline__ double tdg_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void tdg_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -47,211 +50,250 @@ __device__ __forceinline__ void tdg_grid_sync(unsigned* counter, unsigned target
     __syncthreads();
 }
 
-// NM: registers per lane and vector (N <= 64 NM); NBT: matrices reduced side by side by one launch.
+// NM: registers per lane and vector: a wave owns the columns [wq, wq + 1) NP / WPM of its matrix (NP = 64 NM WPM
+// >= N), lane l of it the columns c0 + l + 64 m; NBT: matrices reduced side by side by one launch -- with two, waves
+// 0-1 work on the first and waves 2-3 on the second.  Sums over a matrix's columns go through LDS (partials of its
+// waves added in wave order by every wave: the same bits everywhere).
 // a_in (NBT, N, N) lower triangle read; d, e, tau (NBT, N); Vg (NBT, N, N): row k = reflector k in the coordinates of
-// the matrix (zeros up to column k, 1 at column k + 1); xch: 4 NBT 64 NM doubles (y and pivot-row vectors, two of each);
+// the matrix (zeros up to column k, 1 at column k + 1); xch: 4 NBT NP doubles (y and pivot-row vectors, two of each);
 // counter: zero at launch.
 template <int NM, int NBT>
-__global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __restrict__ a_in, int N, int R, int clog,
+__global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __restrict__ a_in, int N, int R, int P64,
                                                              double* __restrict__ dg, double* __restrict__ eg,
                                                              double* __restrict__ taug, double* __restrict__ Vg,
                                                              double* __restrict__ xch, unsigned* __restrict__ counter,
                                                              int* __restrict__ status) {
-    constexpr int NP = 64 * NM;  // padded row length
+    constexpr int WPM = 4 / NBT;       // waves per matrix
+    constexpr int NP = 64 * NM * WPM;  // padded row length
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* rows = smem;                               // [NBT][R][NP]
-    double* mini = smem + (size_t)NBT * R * NP;        // [4 waves][NBT][3][8]: vp, wp, vn at this workgroup's rows
+    double* red = smem + (size_t)NBT * R * NP;         // [2 parities][4 waves][16] partial sums
+    double* mini = red + 2 * 4 * 16;                   // [NBT][2][8]: vp, wp at this workgroup's rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = wave / WPM, wq = wave % WPM;         // this wave's matrix, and its place among that matrix's waves
+    const int c0 = wq * 64 * NM;                       // first column of this wave
     const int g = blockIdx.x, P = gridDim.x;
-    const int gl = g & 63, g64 = g >> 6, cmask = (1 << clog) - 1;
     const int64_t n2 = (int64_t)N * N;
+    a_in += b * n2;
+    dg += (size_t)b * N;
+    eg += (size_t)b * N;
+    taug += (size_t)b * N;
+    Vg += b * n2;
 
     // ---- this workgroup's rows into LDS (full rows from the lower triangle), zero padded
-    for (int b = 0; b < NBT; ++b)
+    for (int bb = 0; bb < NBT; ++bb)
         for (int q = 0; q < R; ++q) {
             const int i = g + P * q;
+            const double* src = a_in + (bb - b) * n2;
             for (int k = tid; k < NP; k += TDG_THREADS) {
                 double v = 0.0;
-                if (i < N && k < N) v = (i >= k) ? a_in[b * n2 + (int64_t)i * N + k] : a_in[b * n2 + (int64_t)k * N + i];
-                rows[((size_t)b * R + q) * NP + k] = v;
+                if (i < N && k < N) v = (i >= k) ? src[(int64_t)i * N + k] : src[(int64_t)k * N + i];
+                rows[((size_t)bb * R + q) * NP + k] = v;
             }
         }
     __syncthreads();
 
-    double vp[NBT][NM], wp[NBT][NM], vn[NBT][NM];
-    double taup[NBT];
+    // sum of `nv` values over the waves of this wave's matrix (all four waves call this together)
+    int rpar = 0;
+    auto wsum = [&](double (&v)[8], int nv) {
+        double* rd = red + rpar * 64;
+        rpar ^= 1;
 #pragma unroll
-    for (int b = 0; b < NBT; ++b) {
-        taup[b] = 0.0;
+        for (int x = 0; x < 8; ++x)
+            if (x < nv) v[x] = nbx_wave_sum_dpp(v[x]);
+        if (lane == 0)
+            for (int x = 0; x < nv; ++x) rd[wave * 16 + x] = v[x];
+        __syncthreads();
 #pragma unroll
-        for (int m = 0; m < NM; ++m) vp[b][m] = wp[b][m] = vn[b][m] = 0.0;
-    }
+        for (int x = 0; x < 8; ++x)
+            if (x < nv) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < WPM; ++w) t += rd[(b * WPM + w) * 16 + x];
+                v[x] = t;
+            }
+    };
+
+    double vp[NM], wp[NM], vn[NM];
+    double taup = 0.0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) vp[m] = wp[m] = vn[m] = 0.0;
+    double* mn = mini + (size_t)b * 16;
 
     for (int j = 0; j < N - 1; ++j) {
-        double* ybuf_w = xch + (size_t)(j & 1) * 2 * NBT * NP;          // this phase's products and next pivot row
+        double* ybuf_w = xch + (size_t)(j & 1) * 2 * NBT * NP;              // this phase's products and next pivot row
         const double* ybuf_r = xch + (size_t)((j + 1) & 1) * 2 * NBT * NP;  // the phase before's
-#pragma unroll
-        for (int b = 0; b < NBT; ++b) {
-            // ---- the vectors, by every wave: w of the step before, the pivot row j, the reflector of this step
-            double row[NM];
-            if (j > 0) {
-                double yv[NM];
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const int k = lane + 64 * m;
-                    const bool in = k >= j && k < N;
-                    yv[m] = in ? tdg_ld(ybuf_r + (size_t)b * NP + k) : 0.0;
-                    row[m] = in ? tdg_ld(ybuf_r + (size_t)(NBT + b) * NP + k) : 0.0;
-                }
-                double dot = 0.0, yj = 0.0;
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const int k = lane + 64 * m;
-                    yv[m] *= taup[b];  // p = tau A22 v
-                    dot = fma(yv[m], vp[b][m], dot);
-                    yj += (k == j) ? yv[m] : 0.0;
-                }
-                dot = nbx_wave_sum(dot);
-                yj = nbx_wave_sum(yj);
-                const double alpha2 = -0.5 * taup[b] * dot;
-                const double wpj = yj + alpha2;  // (v of the step before is 1 at index j)
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    wp[b][m] = fma(alpha2, vp[b][m], yv[m]);
-                    row[m] = row[m] - wp[b][m] - wpj * vp[b][m];
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const int k = lane + 64 * m;
-                    row[m] = k < N ? a_in[b * n2 + (int64_t)k * N] : 0.0;  // row 0 = column 0 of the lower triangle
-                    wp[b][m] = 0.0;
-                }
-            }
-            double dj = 0.0, alpha = 0.0, ss = 0.0;
+        // ---- the vectors (each wave its columns): w of the step before, the pivot row j, the reflector of this step
+        double row[NM];
+        if (j > 0) {
+            double yv[NM];
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                const int k = lane + 64 * m;
-                dj += (k == j) ? row[m] : 0.0;
-                alpha += (k == j + 1) ? row[m] : 0.0;
-                ss = (k > j + 1) ? fma(row[m], row[m], ss) : ss;
+                const int k = c0 + lane + 64 * m;
+                const bool in = k >= j && k < N;
+                yv[m] = in ? tdg_ld(ybuf_r + (size_t)b * NP + k) : 0.0;
+                row[m] = in ? tdg_ld(ybuf_r + (size_t)(NBT + b) * NP + k) : 0.0;
             }
-            dj = nbx_wave_sum(dj);
-            alpha = nbx_wave_sum(alpha);
-            ss = nbx_wave_sum(ss);
-            double beta, tk, scale;
-            if (ss == 0.0) {
-                beta = alpha;
-                tk = 0.0;
-                scale = 0.0;
-            } else {
-                beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
-                tk = (beta - alpha) / beta;
-                scale = 1.0 / (alpha - beta);
-            }
+            double s1[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                const int k = lane + 64 * m;
-                vn[b][m] = (k == j + 1) ? 1.0 : ((k > j + 1 && k < N) ? row[m] * scale : 0.0);
+                const int k = c0 + lane + 64 * m;
+                yv[m] *= taup;  // p = tau A22 v
+                s1[0] = fma(yv[m], vp[m], s1[0]);
+                s1[1] += (k == j) ? yv[m] : 0.0;
             }
-            if (g == 0 && tid == 0) {
-                dg[(size_t)b * N + j] = dj;
-                eg[(size_t)b * N + j] = beta;
-                taug[(size_t)b * N + j] = tk;
-            }
-            if (g == j % P && wave == 0) {
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const int k = lane + 64 * m;
-                    if (k < N) Vg[b * n2 + (int64_t)j * N + k] = vn[b][m];
-                }
-            }
-            // the entries at this workgroup's rows (i = g + P q: lane g % 64, register g / 64 + (P / 64) q), for the row pass
-            double* mn = mini + ((size_t)(wave * NBT + b) * 3) * 8;
+            wsum(s1, 2);
+            const double alpha2 = -0.5 * taup * s1[0];
+            const double wpj = s1[1] + alpha2;  // (v of the step before is 1 at index j)
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                if (lane == gl && m >= g64 && ((m - g64) & cmask) == 0) {
-                    const int q = (m - g64) >> clog;
-                    if (q < 8) {
-                        mn[q] = vp[b][m];
-                        mn[8 + q] = wp[b][m];
-                        mn[16 + q] = vn[b][m];
-                    }
-                }
+                wp[m] = fma(alpha2, vp[m], yv[m]);
+                row[m] = row[m] - wp[m] - wpj * vp[m];
             }
-            // ---- this wave's rows: update with the reflector of the step before, product with the new one
-            for (int q = wave; q < R; q += 4) {
-                const int i = g + P * q;
-                if (i <= j || i >= N) continue;  // (uniform) the row has left the trailing block
-                const double vpi = mn[q], wpi = mn[8 + q];
-                double* rw = rows + ((size_t)b * R + q) * NP;
-                double* pub = ybuf_w + (size_t)(NBT + b) * NP;
-                const bool publish = i == j + 1;  // the next pivot row, as it is before this step's update
-                double ysum = 0.0;
+        } else {
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const int k = lane + 64 * m;
-                    double a = rw[k];
-                    a -= fma(vpi, wp[b][m], wpi * vp[b][m]);
-                    rw[k] = a;
-                    ysum = fma(a, vn[b][m], ysum);
-                    if (publish && k < N) tdg_st(pub + k, a);
-                }
-                ysum = nbx_wave_sum(ysum);
-                if (lane == 0) tdg_st(ybuf_w + (size_t)b * NP + i, ysum);
+            for (int m = 0; m < NM; ++m) {
+                const int k = c0 + lane + 64 * m;
+                row[m] = k < N ? a_in[(int64_t)k * N] : 0.0;  // row 0 = column 0 of the lower triangle
+                wp[m] = 0.0;
             }
-#pragma unroll
-            for (int m = 0; m < NM; ++m) vp[b][m] = vn[b][m];
-            taup[b] = tk;
         }
+        double s2[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int k = c0 + lane + 64 * m;
+            s2[0] += (k == j) ? row[m] : 0.0;
+            s2[1] += (k == j + 1) ? row[m] : 0.0;
+            s2[2] = (k > j + 1) ? fma(row[m], row[m], s2[2]) : s2[2];
+        }
+        wsum(s2, 3);
+        const double dj = s2[0], alpha = s2[1], ss = s2[2];
+        double beta, tk, scale;
+        if (ss == 0.0) {
+            beta = alpha;
+            tk = 0.0;
+            scale = 0.0;
+        } else {
+            beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
+            tk = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int k = c0 + lane + 64 * m;
+            vn[m] = (k == j + 1) ? 1.0 : ((k > j + 1 && k < N) ? row[m] * scale : 0.0);
+        }
+        if (g == 0 && wq == 0 && lane == 0) {
+            dg[j] = dj;
+            eg[j] = beta;
+            taug[j] = tk;
+        }
+        if (g == j % P) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int k = c0 + lane + 64 * m;
+                if (k < N) Vg[(int64_t)j * N + k] = vn[m];
+            }
+        }
+        // the entries of vp, wp at this workgroup's rows i = g + P q, for the row pass: written by whoever holds them
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int k = c0 + lane + 64 * m;
+            const int kq = k - g;
+            if (kq >= 0 && (kq & (P - 1)) == 0 && (kq / P) < 8) {  // (P is a power of two)
+                mn[kq / P] = vp[m];
+                mn[8 + kq / P] = wp[m];
+            }
+        }
+        __syncthreads();
+        // ---- the workgroup's rows (each wave its columns): update with the reflector of the step before, product with the new one
+        double ys[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = g + P * q;
+            if (q >= R || i <= j || i >= N) continue;  // (uniform) the row has left the trailing block
+            const double vpi = mn[q], wpi = mn[8 + q];
+            double* rw = rows + ((size_t)b * R + q) * NP;
+            double* pub = ybuf_w + (size_t)(NBT + b) * NP;
+            const bool publish = i == j + 1;  // the next pivot row, as it is before this step's update
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int k = c0 + lane + 64 * m;
+                double a = rw[k];
+                a -= fma(vpi, wp[m], wpi * vp[m]);
+                rw[k] = a;
+                ys[q] = fma(a, vn[m], ys[q]);
+                if (publish && k < N) tdg_st(pub + k, a);
+            }
+        }
+        wsum(ys, 8);
+        if (wq == 0 && lane < 8) {
+            const int i = g + P * lane;
+            if (lane < R && i > j && i < N) {
+                double yv_ = ys[0];
+#pragma unroll
+                for (int x = 1; x < 8; ++x) yv_ = lane == x ? ys[x] : yv_;
+                tdg_st(ybuf_w + (size_t)b * NP + i, yv_);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) vp[m] = vn[m];
+        taup = tk;
         tdg_grid_sync(counter, (unsigned)(j + 1) * (unsigned)P, status);
     }
     // the last diagonal element: its row has every update (the reflector of the last step has tau = 0)
     {
         const int i = N - 1;
-        if (g == i % P && tid == 0) {
-            for (int b = 0; b < NBT; ++b) {
-                dg[(size_t)b * N + i] = rows[((size_t)b * R + i / P) * NP + i];
-                eg[(size_t)b * N + i] = 0.0;
-                taug[(size_t)b * N + i] = 0.0;
-            }
+        if (g == i % P && wq == 0 && lane == 0) {
+            dg[i] = rows[((size_t)b * R + i / P) * NP + i];
+            eg[i] = 0.0;
+            taug[i] = 0.0;
         }
-        if (g == 0 && wave == 0)
-            for (int b = 0; b < NBT; ++b)
-                for (int k = lane; k < N; k += 64) Vg[b * n2 + (int64_t)i * N + k] = 0.0;
+        if (g == 0 && wq == 0)
+            for (int k = lane; k < N; k += 64) Vg[(int64_t)i * N + k] = 0.0;
     }
+    (void)P64;
 }
 
-// T of the compact-WY form of a block of nb reflectors (LAPACK dlarft, forward, columnwise): T[i][i] = tau_i,
-// T[0:i, i] = -tau_i T[0:i, 0:i] (Y^T Y)[0:i, i].  G = Y^T Y (nb x nb, ld nb); one workgroup per (block, matrix).
-__global__ __launch_bounds__(64) void wy_tfactor_kernel(const double* __restrict__ G, const double* __restrict__ tau, int nb,
-                                                        int nbk, double* __restrict__ T) {
-    __shared__ double t[64][65];
-    __shared__ double z[64];
-    const int i0 = threadIdx.x;
-    for (int c = 0; c < nb; ++c) t[i0][c] = 0.0;
-    __syncthreads();
-    for (int i = 0; i < nbk; ++i) {
-        const double ti = tau[i];
-        // z = T[0:i, 0:i] G[0:i, i]  (upper triangular T: row r uses columns r .. i - 1)
-        double s = 0.0;
-        if (i0 < i)
-            for (int c = i0; c < i; ++c) s = fma(t[i0][c], G[c * nb + i], s);
-        z[i0] = s;
-        __syncthreads();
-        if (i0 < i) t[i0][i] = -ti * z[i0];
-        if (i0 == i) t[i][i] = ti;
-        __syncthreads();
+// T of the compact-WY form of a block of 64 reflectors (LAPACK dlarft, forward, columnwise): T[i][i] = tau_i,
+// T[0:i, i] = -tau_i T[0:i, 0:i] (Y^T Y)[0:i, i].  G = Y^T Y (64 x 64); one wavefront per (block, matrix): lane r owns
+// row r of T (upper triangular: its entries left of the diagonal are zero, so the sum over c < i needs no mask), G
+// in LDS (column i read as broadcasts).  Rows >= nbk (a short last block) come out zero.
+__global__ __launch_bounds__(64) void wy_tfactor_kernel(const double* __restrict__ Gb, const double* __restrict__ taub,
+                                                        int nblk, int nref, int64_t n, double* __restrict__ Tb) {
+    __shared__ double gs[64][65];
+    __shared__ double tl[64][65];  // tl[c][r] = T[r][c]: column r is lane r's own (no other lane reads it)
+    const int r = threadIdx.x;
+    const int blk = blockIdx.x % nblk, mat = blockIdx.x / nblk;
+    const double* G = Gb + ((int64_t)mat * nblk + blk) * 4096;
+    const double* tau = taub + mat * n + blk * 64;
+    double* T = Tb + ((int64_t)mat * nblk + blk) * 4096;
+    const int nbk = nref - blk * 64 < 64 ? nref - blk * 64 : 64;
+    for (int c = 0; c < 64; ++c) {
+        gs[c][r] = G[c * 64 + r];
+        tl[c][r] = 0.0;
     }
-    for (int c = 0; c < nb; ++c) T[i0 * nb + c] = (i0 < nb) ? t[i0][c] : 0.0;
+    __syncthreads();
+    for (int i = 0; i < 64; ++i) {
+        const double ti = i < nbk ? tau[i] : 0.0;
+        double s0 = 0.0, s1 = 0.0;
+        int c = 0;
+        for (; c + 1 < i; c += 2) {
+            s0 = fma(tl[c][r], gs[c][i], s0);
+            s1 = fma(tl[c + 1][r], gs[c + 1][i], s1);
+        }
+        if (c < i) s0 = fma(tl[c][r], gs[c][i], s0);
+        tl[i][r] = r < i ? -ti * (s0 + s1) : (r == i ? ti : 0.0);
+    }
+    for (int c = 0; c < 64; ++c) T[r * 64 + c] = tl[c][r];
 }
 
 }  // namespace
 
 // doubles of workspace the two entry points below need beside the caller's matrices
 size_t nbx_tdg_work_doubles(int64_t n, int64_t batch) {
-    const int64_t np = (n + 63) / 64 * 64;
-    return (size_t)(4 * batch * np + 64 /* counter, status */ + batch * (2 * 64 * 64 + 2 * 64 * n));
+    const int64_t nblk = (n + 63) / 64;
+    return (size_t)(TDG_XCH * batch + 64 /* counter, status */ + batch * (2 * nblk * 4096 + 2 * 64 * n));
 }
 
 bool nbx_tdg_covers(int64_t n) {
@@ -264,35 +306,35 @@ bool nbx_tdg_covers(int64_t n) {
 int nbx_tdg_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d, double* e, double* tau, double* Vg,
                     double* work) {
     const int N = (int)n;
-    const int nm = (N + 63) / 64;
-    const int NMt = nm <= 8 ? 8 : (nm <= 16 ? 16 : 32);
-    const int NP = 64 * NMt;
-    int c = nm < 4 ? nm : 4;          // workgroups = 64 c: every one holds at least one row
-    if (c == 3) c = 2;                // (a power of two: the row of a register is found by a shift)
-    const int clog = c == 4 ? 2 : (c == 2 ? 1 : 0);
-    const int P = 64 * c;
+    NBX_CHECK_ARG(N > 64 && N <= 2048);
+    // workgroups: a power of two, at most 256, every one with a row; rows per workgroup at most eight
+    int P = 64;
+    while (P < 256 && 2 * P <= N) P *= 2;
     const int R = (N + P - 1) / P;
-    NBX_CHECK_ARG(R <= 8 && N <= 2048);
-    unsigned* counter = reinterpret_cast<unsigned*>(work + 4 * batch * (size_t)(64 * 32));
+    NBX_CHECK_ARG(R <= 8);
+    // matrices side by side in one launch (two waves each) while their rows fit the LDS, else one after the other
+    unsigned* counter = reinterpret_cast<unsigned*>(work + (size_t)TDG_XCH * batch);
     int* status = reinterpret_cast<int*>(counter + 8);
-    // matrices side by side in one launch while their vectors fit the registers (N <= 1024), else one after the other
-    const int per = (NMt <= 16 && batch >= 2) ? 2 : 1;
+    const int per = (batch >= 2 && N <= 1024) ? 2 : 1;
     for (int64_t b0 = 0; b0 < batch; b0 += per) {
         const int nbt = (int)((batch - b0) < per ? (batch - b0) : per);
+        const int wpm = 4 / nbt;
+        const int nm = (N + 64 * wpm - 1) / (64 * wpm);  // registers per lane and vector
+        const int NMt = nm <= 2 ? 2 : (nm <= 4 ? 4 : 8);
+        const int NP = 64 * NMt * wpm;
         int rc = nbx_memset(ctx, counter, 0, 64);
         if (rc != NBX_OK) return rc;
-        const size_t lds = ((size_t)nbt * R * NP + 4 * nbt * 3 * 8) * sizeof(double);
+        const size_t lds = ((size_t)nbt * R * NP + 2 * 4 * 16 + 2 * 16) * sizeof(double);
+        NBX_CHECK_ARG(lds <= 160 * 1024 && NP >= N && 4 * nbt * NP <= TDG_XCH * nbt);
         const double* a_ = d_a + b0 * n * n;
         double *d_ = d + b0 * n, *e_ = e + b0 * n, *t_ = tau + b0 * n, *v_ = Vg + b0 * n * n, *x_ = work;
-        int N_ = N, R_ = R, cl_ = clog;
-        void* args[] = {(void*)&a_, (void*)&N_, (void*)&R_, (void*)&cl_, (void*)&d_, (void*)&e_, (void*)&t_, (void*)&v_,
+        int N_ = N, R_ = R, p64 = P / 64;
+        void* args[] = {(void*)&a_, (void*)&N_, (void*)&R_, (void*)&p64, (void*)&d_, (void*)&e_, (void*)&t_, (void*)&v_,
                         (void*)&x_, (void*)&counter, (void*)&status};
         const void* fn = nullptr;
-        if (NMt == 8) fn = nbt == 2 ? (const void*)&tdg_kernel<8, 2> : (const void*)&tdg_kernel<8, 1>;
-        else if (NMt == 16) fn = nbt == 2 ? (const void*)&tdg_kernel<16, 2> : (const void*)&tdg_kernel<16, 1>;
-        else fn = (const void*)&tdg_kernel<32, 1>;
+        if (nbt == 2) fn = NMt == 2 ? (const void*)&tdg_kernel<2, 2> : (NMt == 4 ? (const void*)&tdg_kernel<4, 2> : (const void*)&tdg_kernel<8, 2>);
+        else fn = NMt == 2 ? (const void*)&tdg_kernel<2, 1> : (NMt == 4 ? (const void*)&tdg_kernel<4, 1> : (const void*)&tdg_kernel<8, 1>);
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        NBX_CHECK_ARG(lds <= 160 * 1024);
         const hipError_t err = hipLaunchCooperativeKernel(fn, dim3((unsigned)P), dim3(TDG_THREADS), args, lds, ctx->stream);
         if (err != hipSuccess) {
             nbx_set_error("nbx_tdg_tridiag: cooperative launch of %d workgroups failed: %s", P, hipGetErrorString(err));
@@ -303,30 +345,41 @@ int nbx_tdg_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, d
 }
 
 // Z (batch, n, n) <- Q Z with Q = H_0 H_1 ... H_{n-2} from Vg / tau of nbx_tdg_tridiag, in compact-WY blocks of 64
-// reflectors, last block first.  work: the same workspace (its tail).
+// reflectors (Q_b = I - Y T Y^T), last block first.  work: the same workspace (its tail).
 int nbx_tdg_backtransform(nbx_ctx* ctx, int64_t n, int64_t batch, const double* Vg, const double* tau, double* Z, double* work) {
     const int64_t nb = 64, n2 = n * n;
-    const int64_t np = (n + 63) / 64 * 64;
-    double* base = work + 4 * batch * np + 64;
-    double* G = base;                       // (batch, nb, nb)
-    double* T = G + batch * nb * nb;        // (batch, nb, nb)
-    double* W1 = T + batch * nb * nb;       // (batch, nb, n)
-    double* W2 = W1 + batch * nb * n;       // (batch, nb, n)
     const int64_t nref = n - 1;
     const int64_t nblk = (nref + nb - 1) / nb;
+    double* base = work + (size_t)TDG_XCH * batch + 64;
+    double* G = base;                            // (batch, nblk, nb, nb)
+    double* T = G + batch * nblk * nb * nb;      // (batch, nblk, nb, nb)
+    double* W1 = T + batch * nblk * nb * nb;     // (batch, nb, n)
+    double* W2 = W1 + batch * nb * n;            // (batch, nb, n)
+    // G_b = Y_b Y_b^T of every block (rows beyond the last reflector are zero: Vg's row n - 1), then every T_b
+    int rc = nbx_memset(ctx, G, 0, (size_t)(batch * nblk * nb * nb) * sizeof(double));
+    if (rc != NBX_OK) return rc;
+    for (int64_t b = 0; b < batch; ++b) {
+        const int64_t full = nref / nb;  // blocks of nb whole reflectors
+        if (full > 0) {
+            rc = nbx_gemm(ctx, 'N', 'T', nb, nb, n, 1.0, Vg + b * n2, n, nb * n, Vg + b * n2, n, nb * n, 0.0,
+                          G + b * nblk * nb * nb, nb, nb * nb, full);
+            if (rc != NBX_OK) return rc;
+        }
+        if (full < nblk) {
+            const int64_t k0 = full * nb, nbk = nref - k0;
+            rc = nbx_gemm(ctx, 'N', 'T', nbk, nbk, n, 1.0, Vg + b * n2 + k0 * n, n, 0, Vg + b * n2 + k0 * n, n, 0, 0.0,
+                          G + (b * nblk + full) * nb * nb, nb, 0, 1);
+            if (rc != NBX_OK) return rc;
+        }
+    }
+    hipLaunchKernelGGL(wy_tfactor_kernel, dim3((unsigned)(batch * nblk)), dim3(64), 0, ctx->stream, G, tau, (int)nblk, (int)nref, n, T);
+    NBX_LAUNCH_CHECK();
     for (int64_t blk = nblk - 1; blk >= 0; --blk) {
         const int64_t k0 = blk * nb, nbk = (nref - k0) < nb ? (nref - k0) : nb;
         const double* Y = Vg + k0 * n;  // (nbk, n) rows of reflectors, ld n
-        int rc = nbx_gemm(ctx, 'N', 'T', nbk, nbk, n, 1.0, Y, n, n2, Y, n, n2, 0.0, G, nb, nb * nb, batch);
-        if (rc != NBX_OK) return rc;
-        for (int64_t b = 0; b < batch; ++b) {
-            hipLaunchKernelGGL(wy_tfactor_kernel, dim3(1), dim3(64), 0, ctx->stream, G + b * nb * nb, tau + b * n + k0, (int)nb,
-                               (int)nbk, T + b * nb * nb);
-            NBX_LAUNCH_CHECK();
-        }
         rc = nbx_gemm(ctx, 'N', 'N', nbk, n, n, 1.0, Y, n, n2, Z, n, n2, 0.0, W1, n, nb * n, batch);
         if (rc != NBX_OK) return rc;
-        rc = nbx_gemm(ctx, 'N', 'N', nbk, n, nbk, 1.0, T, nb, nb * nb, W1, n, nb * n, 0.0, W2, n, nb * n, batch);
+        rc = nbx_gemm(ctx, 'N', 'N', nbk, n, nbk, 1.0, T + blk * nb * nb, nb, nblk * nb * nb, W1, n, nb * n, 0.0, W2, n, nb * n, batch);
         if (rc != NBX_OK) return rc;
         rc = nbx_gemm(ctx, 'T', 'N', n, n, nbk, -1.0, Y, n, n2, W2, n, nb * n, 1.0, Z, n, n2, batch);
         if (rc != NBX_OK) return rc;

@@ -17,6 +17,13 @@
 #include "nbx_common.h"
 #include "synth_device.h"
 
+// eigh_grid.hip: tridiagonalisation on the whole chip and blocked back-transformation (N > 198)
+bool nbx_tdg_covers(int64_t n);
+size_t nbx_tdg_work_doubles(int64_t n, int64_t batch);
+int nbx_tdg_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d, double* e, double* tau, double* Vg,
+                    double* work);
+int nbx_tdg_backtransform(nbx_ctx* ctx, int64_t n, int64_t batch, const double* Vg, const double* tau, double* Z, double* work);
+
 namespace {
 
 constexpr int TD_THREADS = 1024;
@@ -830,7 +837,14 @@ static int td_pipeline(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a
     double* scr = reinterpret_cast<double*>(base + L.scr_off);
     const int N = (int)n;
     static const bool in_memory = getenv("NBX_TRIDIAG_IN_MEMORY") != nullptr;  // A/B switch
-    if (in_memory || !tridiag_reg_launch(ctx, N, batch, d_a, d, e, tau, Vh))
+    // N > 198 (beyond one workgroup's registers): the reduction on the whole chip, the matrix in the LDS of up to 256
+    // workgroups, and the back-transformation in compact-WY blocks on the GEMM (eigh_grid.hip; NBX_TRIDIAG_GRID=0: off)
+    const bool grid = !in_memory && N > 198 && nbx_tdg_covers(n) &&
+                      nbx_tdg_work_doubles(n, batch) <= (size_t)(batch * 6 * n * n);
+    if (grid) {
+        const int rc = nbx_tdg_tridiag(ctx, n, batch, d_a, d, e, tau, Vh, scr);
+        if (rc != NBX_OK) return rc;
+    } else if (in_memory || !tridiag_reg_launch(ctx, N, batch, d_a, d, e, tau, Vh))
         hipLaunchKernelGGL(tridiag_kernel, dim3((unsigned)batch), dim3(TD_THREADS),
                            (size_t)(3 * N + TD_THREADS + 20) * sizeof(double), ctx->stream, d_a, N, W, d, e, tau, Vh);
     NBX_LAUNCH_CHECK();
@@ -841,7 +855,10 @@ static int td_pipeline(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a
         hipLaunchKernelGGL(invit_kernel, dim3((unsigned)nbx_cdiv(N, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d,
                            e, d_w, N, scr, Z);
     NBX_LAUNCH_CHECK();
-    if (in_memory || !backtransform_reg_launch(ctx, N, batch, Vh, tau, Z))
+    if (grid) {
+        const int rc = nbx_tdg_backtransform(ctx, n, batch, Vh, tau, Z, scr);
+        if (rc != NBX_OK) return rc;
+    } else if (in_memory || !backtransform_reg_launch(ctx, N, batch, Vh, tau, Z))
         hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)nbx_cdiv(N, BT_COLS), (unsigned)batch), dim3(BT_THREADS),
                            (size_t)(N + BT_GROUPS * BT_COLS) * sizeof(double), ctx->stream, Vh, tau, N, Z);
     NBX_LAUNCH_CHECK();

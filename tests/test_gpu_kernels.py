@@ -467,6 +467,42 @@ def test_eigh_tridiagonal_path_hard_cases(be):
     check_eigh(be, np.stack([symm(86, n), symm(87, n) + np.eye(n)]))  # batched
 
 
+@pytest.mark.parametrize("n,batch", [(199, 2), (257, 2), (300, 1), (384, 2), (520, 2), (700, 1), (1000, 2), (1100, 2), (2000, 1)])
+def test_eigh_whole_chip_reduction_every_instance(be, n, batch):
+    """csrc/eigh_grid.hip (N > 198): the Householder reduction with the matrix in the LDS of up to 256 workgroups, one
+    grid-wide hand-over per step, and the compact-WY back-transformation -- every instance of the kernel (2, 4 or 8
+    registers per lane and vector; two matrices side by side up to N = 1024, one after the other above; sizes that
+    are not multiples of 64; workgroups with a different number of rows) against numpy's eigenvalues, with residual
+    and orthonormality at rounding level.  NBX_TRIDIAG_GRID=0 would select the one-workgroup kernel instead."""
+    a = np.stack([symm(90 + x, n) for x in range(batch)])
+    a = a[0] if batch == 1 else a
+    w, v = be.eigh(be.asarray(a), check=True)
+    w, v = be.to_host(w), be.to_host(v)
+    scale = np.linalg.norm(a, axis=(-2, -1)).max()
+    np.testing.assert_allclose(w, np.linalg.eigvalsh(a), rtol=0, atol=1e-12 * scale)
+    np.testing.assert_allclose(a @ v, v * w[..., None, :], rtol=0, atol=1e-12 * scale)
+    np.testing.assert_allclose(np.swapaxes(v, -1, -2) @ v, np.broadcast_to(np.eye(n), a.shape), rtol=0, atol=1e-12)
+
+
+def test_eigh_whole_chip_reduction_hard_cases(be):
+    """The same path on spectra that break naive reductions: an (n-1)-fold degenerate eigenvalue (reflectors with
+    tau = 0 almost everywhere after the first), a matrix that is already diagonal, a 1e6 block beside O(1) entries
+    (the mu-shifted Fock matrix of nbed/driver.py:518), and zero rows."""
+    n = 520
+    u = rnd(83, n)
+    check_eigh(be, np.eye(n) + np.outer(u, u))
+    check_eigh(be, np.diag(np.arange(float(n))))
+    g = symm(84, n)
+    p = np.zeros((n, n))
+    p[:7, :7] = 1e6 * (np.eye(7) + 0.1 * symm(85, 7))
+    w, v = check_eigh(be, g + p)
+    np.testing.assert_allclose(w[: n - 7], np.linalg.eigvalsh(g + p)[: n - 7], rtol=0, atol=1e-8)
+    z = symm(86, n)
+    z[100:140] = 0.0
+    z[:, 100:140] = 0.0
+    check_eigh(be, z)
+
+
 @pytest.mark.parametrize("p", [-0.5, 0.5, -1.0])
 def test_sym_pow(be, p):
     n = 37
