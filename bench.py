@@ -467,6 +467,17 @@ def small_configs_leg(be, args) -> list:
     return out
 
 
+def gather_per_rank(entry: dict, world: int, distributed: bool) -> list:
+    """One small dict per rank, gathered on every rank (rank order)."""
+    if not distributed or world == 1:
+        return [entry]
+    import torch.distributed as dist
+
+    rows = [None] * world
+    dist.all_gather_object(rows, entry)
+    return rows
+
+
 def packed_kernel_name(n_ao: int) -> str:
     """Which kernel nbx_jk_packed runs a size on (csrc/jk_s4.hip's dispatch)."""
     if 97 <= n_ao <= 148 and os.environ.get("NBX_JK_M4", "1") != "0":
@@ -501,7 +512,14 @@ def scaling_workload_leg(be, args, world, rank, distributed, barrier) -> list:
                 mf._eri_d = None  # (the packed tiles are what the loop reads: the dense slab can go)
                 del eri
             steps, warmup = 10, 3
+            from nbed_amd import _nbx
+
+            be.profile(True, slots=[_nbx.PROF_JK_DENSE], every=2)  # (HIP events around every other J/K launch)
+            be.profile_reset()
             run = timed_huzinaga_run(mf, (pr["V_emb"], pr["D_env"]), {}, warmup, steps, barrier)
+            be.profile(False)
+            jk_ms_tot, jk_n = be.profile_read(_nbx.PROF_JK_DENSE)
+            jk_ms = jk_ms_tot / jk_n if jk_n else None
             dt = steps / run["cycles_per_sec"]
             ar_ms = None
             if distributed:
@@ -520,7 +538,17 @@ def scaling_workload_leg(be, args, world, rank, distributed, barrier) -> list:
                 dt = float(tmax.item())
             ntiles = (sh.hi * (sh.hi + 1) - sh.lo * (sh.lo + 1)) // 2
             slab_bytes = float(be.lib.nbx_eri_packed_bytes(n_ao, sh.lo, sh.hi)) if packed else 8.0 * n_ao * n_ao * ntiles
+            per_rank = gather_per_rank({"rank": rank, "slab_rows": [int(sh.lo), int(sh.hi)], "slab_bytes_read_per_build": slab_bytes,
+                                        "jk_kernel_ms": jk_ms}, world, distributed)
+            ms_cycle = dt / steps * 1e3
             out.append({"nao": n_ao, "jk_kernel": packed_kernel_name(n_ao) if packed else "jk_sym_kernel (dense tensor, tiles q <= p)",
+                        "jk_kernel_ms_this_rank": jk_ms,
+                        "jk_frac_of_hbm_peak_this_rank": (slab_bytes / (jk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if jk_ms else None,
+                        "per_rank": per_rank,
+                        "replicated_part_ms": (ms_cycle - max(r["jk_kernel_ms"] or 0.0 for r in per_rank) - (ar_ms or 0.0))
+                        if jk_ms else None,
+                        "replicated_part_note": "ms_per_cycle - the slowest rank's J/K kernel - the all-reduce timed alone: Fock assembly, "
+                                                "Huzinaga operator, DIIS, eigensolve, density, scalars (N^3, identical on every rank)",
                         "cycles_per_sec": steps / dt, "ms_per_cycle": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                         "n_gpus": world, "slab_rows": [int(sh.lo), int(sh.hi)], "slab_bytes_read_per_build": slab_bytes,
                         "allreduce_ms_alone": ar_ms, "allreduce_bytes": 24 * n_ao * n_ao,
@@ -1041,6 +1069,54 @@ def main():
             }
         del eri_h
 
+    # ---------------- what a scaling curve needs to be read (every rank takes part: collectives): per-rank slab bytes
+    # and J/K kernel time, the two collectives of the path timed on their own, the replicated remainder of a cycle
+    multi = None
+    if distributed:
+        from nbed_amd.dist import Shards as _Shards
+
+        per_rank = gather_per_rank({"rank": rank, "slab_rows": [int(shards.lo), int(shards.hi)],
+                                    "slab_bytes_read_per_build": packed_bytes if packed else 8.0 * N * N * (
+                                        (shards.hi * (shards.hi + 1) - shards.lo * (shards.lo + 1)) // 2),
+                                    "jk_kernel_ms": jk_ms / max(jk_cnt, 1) if jk_cnt else None}, world, distributed)
+        buf = be.zeros((3, N, N))
+        for _ in range(3):
+            dist.all_reduce(buf)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        barrier()
+        ar_ms = (time.perf_counter() - t0) / 20 * 1e3
+        ish2 = _Shards(n_act, world, rank, force_collective=True)
+        slab = be.zeros((ish2.chunk, n_act, n_act, n_act))
+        full = be.empty((ish2.chunk * world, n_act, n_act, n_act))
+        be.all_gather_stack(slab, None, out=full)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            be.all_gather_stack(slab, None, out=full)
+        barrier()
+        ag_ms = (time.perf_counter() - t0) / 3 * 1e3
+        part = be.zeros((ish2.chunk * world, n_act, n_act, n_act))
+        ish2.reduce_scatter_all_gather(be, part)
+        barrier()
+        t0 = time.perf_counter()
+        ish2.reduce_scatter_all_gather(be, part)
+        barrier()
+        rsag_ms = (time.perf_counter() - t0) * 1e3
+        del slab, full, part, buf
+        ms_cycle = dt / args.steps * 1e3
+        slowest = max((r["jk_kernel_ms"] or 0.0) for r in per_rank)
+        multi = {"nao": N, "per_rank": per_rank, "jk_allreduce_ms_alone": ar_ms, "jk_allreduce_bytes": 24 * N * N,
+                 "replicated_part_ms": ms_cycle - slowest - ar_ms,
+                 "replicated_part_note": "ms_per_step - the slowest rank's J/K kernel - the all-reduce timed alone: Fock assembly, "
+                                         "Huzinaga operator, DIIS, eigensolve, density, scalars (N^3, identical on every rank)",
+                 "transform_allgather_ms_alone_per_block": ag_ms, "transform_allgather_bytes_per_block": 8.0 * n_act**4,
+                 "streamed_transform_reduce_scatter_all_gather_ms_per_block": rsag_ms,
+                 "backend": "gloo rehearsal" if os.environ.get("NBED_BENCH_REHEARSE") == "1" else "RCCL"}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         cycles_per_s = args.steps / dt
         jk_avg_ms = jk_ms / max(jk_cnt, 1)
@@ -1142,6 +1218,7 @@ def main():
             "real_molecule": real,
             "small_configs": small,
             "scaling_workload": scaling,
+            "multi_gpu": multi,
         }
         print(json.dumps(out))
     if distributed:

@@ -172,9 +172,16 @@ int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const do
  * zeros above the diagonal of the diagonal blocks; NBX_JK_M4=0 in the environment keeps the layout above.  Either way the
  * packed buffer is opaque to the caller: nbx_eri_packed_bytes / nbx_eri_pack / nbx_jk_packed agree on it per process.
  * That kernel uses K = K^T (d_dm symmetric, as the interface asks): its per-slab outputs are symmetrised partials.
- *   nbx_jk_packed_supported : 1 = a kernel instance serves N (even N <= 256 with N % NB == 0);
- *            2 = N <= 256 is served as the next such size (at most 8 more) with the extra rows and
- *            columns zero -- odd N, N = 102, 150, ...: the same entry points, the padding is internal
+ * N = 149 .. 400 run the same walk with a tile in more chunks (csrc/jk_mx.hip: instances at every multiple of eight from
+ * 152 to 256, then 272, 288 and every multiple of sixteen from 304 to 400; the same 4 x 4 blocks, stored chunk after
+ * chunk -- whole block rows at the top of the triangle, from N = 304 the lower bands of four block rows in segments of
+ * column groups; a size between two instances runs as the next one within eight, zero-padded as above;
+ * NBX_JK_MX=0 hands N <= 256 back to the layout above and the sizes beyond it to nbx_jk_dense_sym).  These sizes make
+ * their Dtot' table themselves (nbx_jk_dts_bytes = 0: nothing to hand over).  Dense + packed tensor must both be
+ * resident while nbx_eri_pack runs, which ends at N = 400 on one 288 GB device.
+ *   nbx_jk_packed_supported : 1 = a kernel instance serves N (even N <= 256 with N % NB == 0; the sizes above);
+ *            2 = N is served as the next such size (at most 8 more) with the extra rows and
+ *            columns zero -- odd N, N = 102, 150, 300, ...: the same entry points, the padding is internal
  *            (tiles with p >= N are neither stored nor visited, D is padded on the way in, J/K cropped
  *            on the way out); 0 = not covered (use nbx_jk_dense_sym)
  *   d_jk   : out, ((1+ndm), N, N): ADDITIVE over slabs exactly as nbx_jk_dense_sym
@@ -316,7 +323,12 @@ int nbx_scale_cols(nbx_ctx* ctx, int64_t rows, int64_t cols, int64_t batch, cons
  * Replaces np.linalg.eigh (LAPACK dsyevd) at nbed/scf/huzinaga_scf.py:145,168 and the
  * eigensolve inside fractional_matrix_power at :128 / spade.py:99.
  * d_a: (batch,N,N) symmetric, preserved.  d_w: (batch,N) ascending.  d_v: (batch,N,N),
- * columns = eigenvectors.  Cyclic two-sided Jacobi (parallel ordering).
+ * columns = eigenvectors.  Cyclic two-sided Jacobi (parallel ordering) for N < 64; Householder reduction,
+ * Sturm multisection, inverse iteration and back-transformation above (csrc/eigh_tridiag.hip: the matrix in one
+ * workgroup's registers up to N = 198; csrc/eigh_grid.hip beyond: the matrix in the LDS of up to 256 workgroups,
+ * one grid-wide hand-over per Householder step -- a COOPERATIVE launch, so the call needs the device's CUs to itself
+ * for its duration -- and the back-transformation in compact-WY blocks on the GEMM; N <= 2048), Jacobi as the
+ * polisher when a cluster defeats inverse iteration.
  * d_work: nbx_eigh_worksize() bytes.  Returns NBX_E_NOCONV if max sweeps hit.             */
 size_t nbx_eigh_worksize(int64_t n, int64_t batch);
 int nbx_eigh(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d_w, double* d_v,

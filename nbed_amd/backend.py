@@ -465,6 +465,16 @@ class HipBackend:
         dist.all_reduce(a, op=dist.ReduceOp.SUM, group=group)
         return a
 
+    def reduce_scatter_sum(self, a, group=None):
+        """RCCL reduce-scatter (sum) of ``a`` (world * chunk, ...) over its leading axis: this rank's (chunk, ...) piece."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group)
+        a = a.contiguous()
+        out = self.empty((a.shape[0] // world,) + tuple(a.shape[1:]))
+        dist.reduce_scatter_tensor(out, a, op=dist.ReduceOp.SUM, group=group)
+        return out
+
     def unstack_concat(self, stacked, axis: int, n: int):
         """(world, ..., chunk, ...) -> (..., world*chunk, ...)[:n] along ``axis``."""
         world = stacked.shape[0]

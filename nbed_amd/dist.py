@@ -14,10 +14,10 @@ One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).
 * streamed four-index transform (N_AO = 2000: the integrals are generated in registers and never
   stored): the AO index r of (pq|rs) is partitioned instead -- rank g generates and half-transforms
   only the pairs (r in R_g, s <= r), so the hash evaluations and quarters 1-2 (94 % of the work)
-  divide by G -- and the ranks' partial (ij|kl) tensors are summed by one all-reduce of n^4 doubles
-  (``streamed_transform``).  north_star's outer-MO-index shards + all-gather would make every rank
-  generate ALL N^4/2 integrals and leave the quarter-1 GEMM n/G = 16 rows tall; an all-reduce is
-  a reduce-scatter over the outer MO index followed by exactly that all-gather.
+  divide by G -- and the ranks' partial (ij|kl) tensors are summed by a reduce-scatter over the outer MO
+  index followed by north_star's all-gather of the n^4/G shards (``streamed_transform``).  Sharding the
+  outer MO index of the WORK as well would make every rank generate ALL N^4/2 integrals and leave the
+  quarter-1 GEMM n/G = 16 rows tall.
 
 Everything else in a cycle (Huzinaga products, DIIS, eigensolve) is N^3 and replicated:
 it is deterministic, so every rank holds identical matrices.
@@ -91,6 +91,24 @@ class Shards:
             return partial
         return be.all_reduce_sum(partial, self.group)
 
+    def reduce_scatter_all_gather(self, be, partial, keep_shard: bool = False):
+        """Sum every rank's full-size ``partial`` over the ranks as north_star's collective: a reduce-scatter over the
+        LEADING index (the outer MO index i of (ij|kl): rank g receives the sum of the rows i in its uniform shard),
+        then the all-gather of those n/G-row shards -- the bytes of an all-reduce, with the summed tensor sharded until
+        the last step.  ``keep_shard``: return ``(full, shard, (i0, i1))`` so a caller that goes on with its own rows
+        (the spin-orbital scatter of ham_builder.py:158-216 shards the same way) need not slice them out again."""
+        if self.world == 1 and not self.force_collective:
+            return (partial, partial, (0, int(partial.shape[0]))) if keep_shard else partial
+        n0 = int(partial.shape[0])
+        rows = Shards(n0, self.world, self.rank, self.group)  # uniform shards of the leading index
+        padded = be.pad_axis(partial, 0, rows.chunk * self.world)
+        mine = be.reduce_scatter_sum(padded, self.group)  # (chunk, ...): this rank's rows, summed over the ranks
+        gathered = be.all_gather_stack(mine, self.group)  # (world, chunk, ...)
+        full = be.unstack_concat(gathered, 0, n0)
+        if keep_shard:
+            return full, mine[: rows.size], (rows.lo, rows.hi)
+        return full
+
     def all_gather(self, be, slab, axis: int = 0, out=None):
         """Concatenate every rank's ``slab`` (its ``lo:hi`` piece along ``axis``) into the
         full-length array.  ``slab`` may be shorter than ``chunk`` on the last ranks.  ``out``: a
@@ -115,8 +133,10 @@ def streamed_transform(be, nao: int, ca, cb=None, shards: Shards | None = None, 
 
     ``shards``: a ``Shards(nao, world, rank, balance="triangular")`` over the AO index r -- a range
     costs ~sum (r + 1), so equal-work ranges are not equal-length.  Each rank transforms its range
-    (``nbx_ao2mo_synth[_pair]``), then one all-reduce per tensor sums the partial results; every
-    rank returns the full tensors (the same bits on every rank)."""
+    (``nbx_ao2mo_synth[_pair]``); the partial tensors are then summed by north_star's collective: a
+    reduce-scatter over the outer MO index i followed by the all-gather of the n^4/G shards
+    (``Shards.reduce_scatter_all_gather``: the bytes of an all-reduce, the summed tensor sharded until the
+    last step); every rank returns the full tensors (the same bits on every rank)."""
     sh = shards if shards is not None else Shards(nao, balance="triangular")
     if sh.n != nao:
         raise ValueError(f"shards partition range({sh.n}), the AO index has {nao} values")
@@ -126,5 +146,5 @@ def streamed_transform(be, nao: int, ca, cb=None, shards: Shards | None = None, 
         aa, ab = be.ao2mo_synth_pair(nao, ca, ca, ca, ca, cb, cb, r0=sh.lo, r1=sh.hi, seed=seed)
         bb = be.ao2mo_synth(nao, cb, cb, cb, cb, r0=sh.lo, r1=sh.hi, seed=seed)
         parts = (aa, ab, bb)
-    parts = tuple(sh.all_reduce(be, t) for t in parts)
+    parts = tuple(sh.reduce_scatter_all_gather(be, t) for t in parts)
     return parts[0] if cb is None else parts

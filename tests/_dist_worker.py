@@ -50,13 +50,15 @@ def main():
     full.mo_coeff, full.mo_occ = c[:, :, :nmo], mf.get_occ(e, c)[:, :nmo]
     ish = Shards.from_env(nmo)
     const, h1, h2 = HamiltonianBuilder(full, 0.25, backend=be, shards=ish).build()
-    # streamed (generated-integral) transform, the N_AO = 2000 path: r-sharded at equal work, all-reduce
+    # streamed (generated-integral) transform, the N_AO = 2000 path: r-sharded at equal work; the partial tensors
+    # summed by a reduce-scatter over the outer MO index + the all-gather of the shards (north_star's collective)
     rsh = Shards(n, world, rank, balance="triangular")
     ca_d, cb_d = be.asarray(c[0][:, :nmo]), be.asarray(c[1][:, :nmo])
     s_aa, s_ab, s_bb = (be.to_host(t) for t in streamed_transform(be, n, ca_d, cb_d, shards=rsh))
     np.savez(out_dir / f"rank{rank}.npz", c=c, e=e, d=d, hz=hz, conv=conv, h1=h1, h2=h2, lo=sh.lo, hi=sh.hi,
              jk_calls=be.calls.get("jk", 0), cycle_call=bool(hist.info.get("cycle_call")),
-             split=bool(hist.info.get("split")), ncycles=len(hist), restarts=len(hist.info["restarts"]), s_aa=s_aa, s_ab=s_ab, s_bb=s_bb, r_lo=rsh.lo, r_hi=rsh.hi)
+             split=bool(hist.info.get("split")), ncycles=len(hist), restarts=len(hist.info["restarts"]), s_aa=s_aa, s_ab=s_ab, s_bb=s_bb, r_lo=rsh.lo, r_hi=rsh.hi,
+             reduce_scatters=be.calls.get("reduce_scatter", 0))
     dist.barrier()
     dist.destroy_process_group()
 

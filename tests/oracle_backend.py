@@ -83,6 +83,22 @@ class OracleBackend:
         dist.all_reduce(a, op=dist.ReduceOp.SUM, group=group)
         return a
 
+    def reduce_scatter_sum(self, a, group=None):
+        """(world * chunk, ...) -> this rank's (chunk, ...) piece of the sum.  gloo has no reduce-scatter: one reduce per
+        destination rank (what a reduce-scatter is), each rank keeping the piece it is the destination of."""
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        chunk = a.shape[0] // world
+        self._count("reduce_scatter")
+        mine = None
+        for dst in range(world):
+            piece = a[dst * chunk:(dst + 1) * chunk].clone().contiguous()
+            dist.reduce(piece, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            if dst == rank:
+                mine = piece
+        return mine
+
     def unstack_concat(self, stacked, axis, n):
         world = stacked.shape[0]
         moved = stacked.movedim(0, axis)

@@ -107,7 +107,9 @@ def test_sharded_scf_and_transform_match_single_rank(tmp_path, world):
         for key in ("e", "d", "hz", "h1", "h2"):
             np.testing.assert_allclose(r[key], single[key], rtol=0, atol=1e-10, err_msg=key)
         assert int(r["jk_calls"]) == int(single["jk_calls"])  # same cycle count on every rank
-        # r-sharded streamed transform + all-reduce == the single-rank transform == the einsum oracle
+        # r-sharded streamed transform + reduce-scatter over the outer MO index + all-gather of the shards (one of each
+        # per spin block) == the single-rank transform == the einsum oracle
+        assert int(r["reduce_scatters"]) == 3
         for key in ("s_aa", "s_ab", "s_bb"):
             np.testing.assert_allclose(r[key], single[key], rtol=0, atol=1e-12, err_msg=key)
     from oracle import hamiltonian, synth
