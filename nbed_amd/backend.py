@@ -116,9 +116,14 @@ class _Deferred:
 
     def __init__(self, fn):
         self._fn = fn
+        self._done = False
+        self._value = None
 
     def get(self):
-        return self._fn()
+        if not self._done:  # (collected once: a later transfer may reuse the buffer the value came through)
+            self._value = self._fn()
+            self._done = True
+        return self._value
 
 
 class HipBackend:
@@ -285,6 +290,13 @@ class HipBackend:
         ``get()`` polls that word and hands out the arrays: host work in between overlaps the transfer."""
         torch = self.torch
         total = sum(int(t.numel()) for t in tensors)
+        # a deferred transfer still in flight owns the landing buffer: finish it first (its arrays are then held by its
+        # handle), so that a second call -- from a callback, a logging hook -- can neither clear its ready word nor
+        # overwrite data the first gather is still storing
+        pending = getattr(self, "_pin_pending", None)
+        if pending is not None:
+            self._pin_pending = None
+            pending.get()
         pin = getattr(self, "_pin_results", None)  # (a pageable destination costs a staging copy per call)
         if pin is None or pin.numel() < total + 1:
             pin = self._pin_results = torch.empty(max(total + 1, 1 << 19), dtype=torch.float64, pin_memory=True)
@@ -324,7 +336,9 @@ class HipBackend:
 
         if wait:
             return collect()
-        return _Deferred(collect)
+        handle = _Deferred(collect)
+        self._pin_pending = handle
+        return handle
 
     def to_host(self, a) -> np.ndarray:
         if isinstance(a, self.torch.Tensor):
@@ -471,7 +485,17 @@ class HipBackend:
 
         world = dist.get_world_size(group)
         a = a.contiguous()
-        out = self.empty((a.shape[0] // world,) + tuple(a.shape[1:]))
+        chunk = a.shape[0] // world
+        if dist.get_backend(group) == "gloo":  # (the one-GPU rehearsal of bench.py: gloo has no reduce-scatter --
+            rank = dist.get_rank(group)        #  one reduce per destination rank, which is what a reduce-scatter is)
+            mine = None
+            for dst in range(world):
+                piece = a[dst * chunk:(dst + 1) * chunk].clone()
+                dist.reduce(piece, dst=dst, op=dist.ReduceOp.SUM, group=group)
+                if dst == rank:
+                    mine = piece
+            return mine
+        out = self.empty((chunk,) + tuple(a.shape[1:]))
         dist.reduce_scatter_tensor(out, a, op=dist.ReduceOp.SUM, group=group)
         return out
 

@@ -133,7 +133,8 @@ class BuiltinHFProvider:
     def __init__(self, backend=None, xc_grid: tuple[int, int] | None = None):
         """``xc_grid``: (radial points per heavy atom, polar angles) of the exchange-correlation quadrature, or
         ("lebedev", level) for the Treutler-Ahlrichs x pruned-Lebedev construction PySCF documents as its default
-        (``nbed_amd.xc.build_grid``; None = the product grid's defaults, which converge energies to ~1e-7 Ha).  Matrix elements of
+        (``nbed_amd.xc.build_grid``; None = that construction at its default level 3, which needs SciPy >= 1.15 for
+        ``scipy.integrate.lebedev_rule`` -- pass (n_rad, n_theta) for the product grid on an older SciPy).  Matrix elements of
         v_xc[D_act] between VIRTUAL orbitals converge much more slowly -- the active density of a SPADE partition
         has near-nodal surfaces where the GGA potential is singular -- and need a finer grid."""
         self._be = backend
@@ -369,7 +370,7 @@ class NbedDriver:
             # after the environment is deleted / the virtuals are re-ordered the occupied MOs need not lead
             mo_occ = np.asarray(scf_obj.mo_occ)
             if mo_occ.ndim == 1:
-                mo_occ = np.array((mo_occ > 1, mo_occ > 0), dtype=float)
+                mo_occ = np.array((mo_occ > 0, mo_occ > 1), dtype=float)  # (alpha holds the singly occupied orbitals)
             occupied = ([2 * int(i) for i in np.flatnonzero(mo_occ[0] > 0)]
                         + [2 * int(i) + 1 for i in np.flatnonzero(mo_occ[1] > 0)])
             na, nb = scf_obj.mol.nelec

@@ -103,7 +103,11 @@ _LEBEDEV_DEGREES = (3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 35, 
 
 def _lebedev(degree: int):
     """(unit vectors (n, 3), weights summing to 4 pi) of the Lebedev rule of the given degree."""
-    from scipy.integrate import lebedev_rule
+    try:
+        from scipy.integrate import lebedev_rule
+    except ImportError as exc:  # SciPy < 1.15
+        raise ImportError("the 'lebedev' grid scheme needs scipy.integrate.lebedev_rule (SciPy >= 1.15); pass "
+                          "xc_grid={'scheme': 'product', ...} (n_rad, n_theta) to use the product grid instead") from exc
 
     x, w = lebedev_rule(int(degree))
     return np.ascontiguousarray(x.T), np.asarray(w)
