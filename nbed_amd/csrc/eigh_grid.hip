@@ -13,11 +13,16 @@
 //     then updates its rows with the previous reflector and takes their products with the new one in one pass over LDS;
 //   * the back-transformation V = Q Z as compact-WY blocks of 64 reflectors on the MFMA GEMM (Q_b = I - Y T Y^T:
 //     three products per block) instead of one reflector at a time on column tiles (62 ms -> a few ms at N = 2000).
-// Hand-off discipline (MI355X: private L2 per XCD, L1 never refreshed by other CUs' stores): every handed-over double
-// is stored and loaded with agent-scope relaxed atomics (global_store/load ... sc1), every storing wave drains its
-// stores, the workgroup meets at its barrier, ONE lane adds to the arrival counter and polls it; the other waves load
-// behind the workgroup barrier that lane then joins.  The launch is cooperative (all workgroups resident, one per CU)
-// and the poll gives up after ~seconds (status word set, every workgroup still reaches the end of the kernel).
+// Hand-off discipline (MI355X: private L2 per XCD, L1 never refreshed by other CUs' stores): a handed-over double
+// travels as a 16-byte word (value, tag) -- one sc1 store, one sc1 load -- whose tag mixes (launch nonce, step) with the
+// bits of the value; a reader polls the words it needs until each verifies (tdg_put / tdg_verified below).  There is
+// no grid-wide barrier: what orders two workgroups is only the data one needs of the other, a workgroup whose rows
+// have all left the trailing block leaves the kernel, and the two parities of the hand-over buffers cannot be
+// overwritten early (a word of step j + 1 can only be written after every word of step j was read, which was written
+// after its writer had read step j - 1).  The launch is cooperative (every workgroup resident, one per CU: a poll must
+// not wait for a workgroup that has no CU) and a poll gives up after ~seconds (status word set, every workgroup then
+// ends the same way).  First form of this kernel: sc1 vectors + drain + arrival counter + poll per step, 9-12 us a
+// step; with the tagged words 5.5-8 us (N = 2000: 23.9 -> 16.1 ms per matrix).
 // Conventions of d, e, tau and the reflectors are LAPACK dsytd2's (UPLO = 'L'), as in eigh_tridiag.hip.
 #include <cstdlib>
 
@@ -27,27 +32,31 @@ namespace {
 
 constexpr int TDG_THREADS = 256;
 constexpr unsigned TDG_SPIN_LIMIT = 1u << 22;
-constexpr int TDG_XCH = 4 * 2048;  // doubles of hand-over vectors per matrix (y and pivot row, two of each, N <= 2048)
+constexpr int TDG_XCH = 8 * 2048;  // doubles of hand-over words per matrix (y and pivot row, two of each, 16 bytes a word, N <= 2048)
 
-__device__ __forceinline__ double tdg_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void tdg_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A hand-over word: 16 bytes = (value, tag), written by ONE 16-byte sc1 store and read by one 16-byte sc1 load, with
+// tag = (launch nonce, step) mixed with the bits of the value -- a reader polls the word itself until the tag fits the
+// value it came with: no drain of the writer's stores, no counter, no grid-wide barrier between a product and its
+// readers (two trips to memory instead of five), and a torn or a stale word (an older step of this launch, another
+// launch on the same workspace) simply does not verify.  (16-byte sc1 accesses are observed untorn on gfx950 --
+// MI355X_MICROARCH.md, visibility -- but nothing here relies on that.)
+typedef double tdg_d2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long tdg_u64;
+constexpr tdg_u64 TDG_MIX = 0x9E3779B97F4A7C15ull;
 
-// all workgroups of the grid have passed here `target / gridDim.x` times
-__device__ __forceinline__ void tdg_grid_sync(unsigned* counter, unsigned target, int* status) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > TDG_SPIN_LIMIT) {  // (a workgroup that never came: give up, say so; every workgroup ends)
-                __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
+__device__ __forceinline__ void tdg_put(tdg_d2* p, double v, tdg_u64 key) {
+    tdg_d2 w;
+    w.x = v;
+    w.y = __longlong_as_double((long long)(key ^ (tdg_u64)__double_as_longlong(v)));
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ tdg_d2 tdg_get_issue(const tdg_d2* p) {
+    tdg_d2 w;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w) : "v"(p) : "memory");
+    return w;
+}
+__device__ __forceinline__ bool tdg_verified(const tdg_d2& w, tdg_u64 key) {
+    return (tdg_u64)__double_as_longlong(w.y) == (key ^ (tdg_u64)__double_as_longlong(w.x));
 }
 
 // NM: registers per lane and vector: a wave owns the columns [wq, wq + 1) NP / WPM of its matrix (NP = 64 NM WPM
@@ -55,13 +64,13 @@ __device__ __forceinline__ void tdg_grid_sync(unsigned* counter, unsigned target
 // 0-1 work on the first and waves 2-3 on the second.  Sums over a matrix's columns go through LDS (partials of its
 // waves added in wave order by every wave: the same bits everywhere).
 // a_in (NBT, N, N) lower triangle read; d, e, tau (NBT, N); Vg (NBT, N, N): row k = reflector k in the coordinates of
-// the matrix (zeros up to column k, 1 at column k + 1); xch: 4 NBT NP doubles (y and pivot-row vectors, two of each);
-// counter: zero at launch.
+// the matrix (zeros up to column k, 1 at column k + 1); xch: 4 NBT NP hand-over words (y and pivot-row vectors, two
+// of each); nonce: a number no earlier launch on this workspace has used.
 template <int NM, int NBT>
 __global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __restrict__ a_in, int N, int R, int P64,
                                                              double* __restrict__ dg, double* __restrict__ eg,
                                                              double* __restrict__ taug, double* __restrict__ Vg,
-                                                             double* __restrict__ xch, unsigned* __restrict__ counter,
+                                                             double* __restrict__ xch_, unsigned nonce,
                                                              int* __restrict__ status) {
     constexpr int WPM = 4 / NBT;       // waves per matrix
     constexpr int NP = 64 * NM * WPM;  // padded row length
@@ -69,6 +78,7 @@ __global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __res
     double* rows = smem;                               // [NBT][R][NP]
     double* red = smem + (size_t)NBT * R * NP;         // [2 parities][4 waves][16] partial sums
     double* mini = red + 2 * 4 * 16;                   // [NBT][2][8]: vp, wp at this workgroup's rows
+    int* gflag = reinterpret_cast<int*>(mini + 2 * 16); // "a wave of this workgroup gave up waiting"
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = wave / WPM, wq = wave % WPM;         // this wave's matrix, and its place among that matrix's waves
     const int c0 = wq * 64 * NM;                       // first column of this wave
@@ -79,6 +89,12 @@ __global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __res
     eg += (size_t)b * N;
     taug += (size_t)b * N;
     Vg += b * n2;
+    tdg_d2* xch = reinterpret_cast<tdg_d2*>(xch_);
+    // the last row this workgroup holds: once the reduction has passed it the workgroup has nothing left to give
+    int i_max = g + P * (R - 1);
+    while (i_max >= N) i_max -= P;
+    if (g == 0 && wq == 0)  // (reflector N - 1 does not exist: its row of Vg is zero)
+        for (int k = lane; k < N; k += 64) Vg[(int64_t)(N - 1) * N + k] = 0.0;
 
     // ---- this workgroup's rows into LDS (full rows from the lower triangle), zero padded
     for (int bb = 0; bb < NBT; ++bb)
@@ -91,6 +107,7 @@ __global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __res
                 rows[((size_t)bb * R + q) * NP + k] = v;
             }
         }
+    if (tid == 0) *gflag = 0;
     __syncthreads();
 
     // sum of `nv` values over the waves of this wave's matrix (all four waves call this together)
@@ -120,20 +137,58 @@ __global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __res
     for (int m = 0; m < NM; ++m) vp[m] = wp[m] = vn[m] = 0.0;
     double* mn = mini + (size_t)b * 16;
 
+    bool gave_up = false;
     for (int j = 0; j < N - 1; ++j) {
-        double* ybuf_w = xch + (size_t)(j & 1) * 2 * NBT * NP;              // this phase's products and next pivot row
-        const double* ybuf_r = xch + (size_t)((j + 1) & 1) * 2 * NBT * NP;  // the phase before's
+        if (i_max <= j || gave_up) break;  // (uniform over the workgroup)
+        tdg_d2* ybuf_w = xch + (size_t)(j & 1) * 2 * NBT * NP;              // this step's products and next pivot row
+        const tdg_d2* ybuf_r = xch + (size_t)((j + 1) & 1) * 2 * NBT * NP;  // the step before's
+        const tdg_u64 key_r = (((tdg_u64)nonce << 32) | (tdg_u64)j) * TDG_MIX;        // words written in step j - 1
+        const tdg_u64 key_w = (((tdg_u64)nonce << 32) | (tdg_u64)(j + 1)) * TDG_MIX;  // words written in this step
         // ---- the vectors (each wave its columns): w of the step before, the pivot row j, the reflector of this step
         double row[NM];
         if (j > 0) {
             double yv[NM];
+            // poll the 2 NM words of this lane until every one verifies
+            unsigned need = 0;
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const int k = c0 + lane + 64 * m;
-                const bool in = k >= j && k < N;
-                yv[m] = in ? tdg_ld(ybuf_r + (size_t)b * NP + k) : 0.0;
-                row[m] = in ? tdg_ld(ybuf_r + (size_t)(NBT + b) * NP + k) : 0.0;
+                yv[m] = row[m] = 0.0;
+                if (k >= j && k < N) need |= 3u << (2 * m);
             }
+            for (unsigned spins = 0;; ++spins) {
+                tdg_d2 wy[NM], wr[NM];
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const int k = c0 + lane + 64 * m;
+                    if (need & (1u << (2 * m))) wy[m] = tdg_get_issue(ybuf_r + (size_t)b * NP + k);
+                    if (need & (2u << (2 * m))) wr[m] = tdg_get_issue(ybuf_r + (size_t)(NBT + b) * NP + k);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    asm volatile("" : "+v"(wy[m]), "+v"(wr[m]));
+                    if ((need & (1u << (2 * m))) && tdg_verified(wy[m], key_r)) {
+                        yv[m] = wy[m].x;
+                        need &= ~(1u << (2 * m));
+                    }
+                    if ((need & (2u << (2 * m))) && tdg_verified(wr[m], key_r)) {
+                        row[m] = wr[m].x;
+                        need &= ~(2u << (2 * m));
+                    }
+                }
+                if (!__any(need != 0)) break;
+                if (spins > TDG_SPIN_LIMIT) {  // (a word that never came: say so; every workgroup ends the same way)
+                    __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (gave_up) *gflag = 1;
+            __syncthreads();
+            gave_up = *gflag != 0;
+            if (gave_up) break;
             double s1[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
@@ -183,12 +238,12 @@ __global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __res
             const int k = c0 + lane + 64 * m;
             vn[m] = (k == j + 1) ? 1.0 : ((k > j + 1 && k < N) ? row[m] * scale : 0.0);
         }
-        if (g == 0 && wq == 0 && lane == 0) {
+        if (g == (j + 1) % P && wq == 0 && lane == 0) {  // (the owner of row j + 1: a workgroup that is still in the loop)
             dg[j] = dj;
             eg[j] = beta;
             taug[j] = tk;
         }
-        if (g == j % P) {
+        if (g == (j + 1) % P) {
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const int k = c0 + lane + 64 * m;
@@ -214,7 +269,7 @@ __global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __res
             if (q >= R || i <= j || i >= N) continue;  // (uniform) the row has left the trailing block
             const double vpi = mn[q], wpi = mn[8 + q];
             double* rw = rows + ((size_t)b * R + q) * NP;
-            double* pub = ybuf_w + (size_t)(NBT + b) * NP;
+            tdg_d2* pub = ybuf_w + (size_t)(NBT + b) * NP;
             const bool publish = i == j + 1;  // the next pivot row, as it is before this step's update
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
@@ -223,7 +278,7 @@ __global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __res
                 a -= fma(vpi, wp[m], wpi * vp[m]);
                 rw[k] = a;
                 ys[q] = fma(a, vn[m], ys[q]);
-                if (publish && k < N) tdg_st(pub + k, a);
+                if (publish && k < N) tdg_put(pub + k, a, key_w);
             }
         }
         wsum(ys, 8);
@@ -233,13 +288,12 @@ __global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __res
                 double yv_ = ys[0];
 #pragma unroll
                 for (int x = 1; x < 8; ++x) yv_ = lane == x ? ys[x] : yv_;
-                tdg_st(ybuf_w + (size_t)b * NP + i, yv_);
+                tdg_put(ybuf_w + (size_t)b * NP + i, yv_, key_w);
             }
         }
 #pragma unroll
         for (int m = 0; m < NM; ++m) vp[m] = vn[m];
         taup = tk;
-        tdg_grid_sync(counter, (unsigned)(j + 1) * (unsigned)P, status);
     }
     // the last diagonal element: its row has every update (the reflector of the last step has tau = 0)
     {
@@ -249,8 +303,6 @@ __global__ __launch_bounds__(TDG_THREADS, 1) void tdg_kernel(const double* __res
             eg[i] = 0.0;
             taug[i] = 0.0;
         }
-        if (g == 0 && wq == 0)
-            for (int k = lane; k < N; k += 64) Vg[(int64_t)i * N + k] = 0.0;
     }
     (void)P64;
 }
@@ -293,7 +345,7 @@ __global__ __launch_bounds__(64) void wy_tfactor_kernel(const double* __restrict
 // doubles of workspace the two entry points below need beside the caller's matrices
 size_t nbx_tdg_work_doubles(int64_t n, int64_t batch) {
     const int64_t nblk = (n + 63) / 64;
-    return (size_t)(TDG_XCH * batch + 64 /* counter, status */ + batch * (2 * nblk * 4096 + 2 * 64 * n));
+    return (size_t)(TDG_XCH * batch + 64 /* status */ + batch * (2 * nblk * 4096 + 2 * 64 * n));
 }
 
 bool nbx_tdg_covers(int64_t n) {
@@ -313,8 +365,7 @@ int nbx_tdg_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, d
     const int R = (N + P - 1) / P;
     NBX_CHECK_ARG(R <= 8);
     // matrices side by side in one launch (two waves each) while their rows fit the LDS, else one after the other
-    unsigned* counter = reinterpret_cast<unsigned*>(work + (size_t)TDG_XCH * batch);
-    int* status = reinterpret_cast<int*>(counter + 8);
+    int* status = reinterpret_cast<int*>(work + (size_t)TDG_XCH * batch);
     const int per = (batch >= 2 && N <= 1024) ? 2 : 1;
     for (int64_t b0 = 0; b0 < batch; b0 += per) {
         const int nbt = (int)((batch - b0) < per ? (batch - b0) : per);
@@ -322,19 +373,27 @@ int nbx_tdg_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, d
         const int nm = (N + 64 * wpm - 1) / (64 * wpm);  // registers per lane and vector
         const int NMt = nm <= 2 ? 2 : (nm <= 4 ? 4 : 8);
         const int NP = 64 * NMt * wpm;
-        int rc = nbx_memset(ctx, counter, 0, 64);
-        if (rc != NBX_OK) return rc;
-        const size_t lds = ((size_t)nbt * R * NP + 2 * 4 * 16 + 2 * 16) * sizeof(double);
-        NBX_CHECK_ARG(lds <= 160 * 1024 && NP >= N && 4 * nbt * NP <= TDG_XCH * nbt);
+        static unsigned launch_nonce = 0;
+        unsigned nonce = ++launch_nonce;
+        if (nonce == 1) {  // (first use of a workspace in this process: no word may verify by accident of old bytes)
+            const int rc = nbx_memset(ctx, work, 0, (size_t)TDG_XCH * batch * sizeof(double) + 256);
+            if (rc != NBX_OK) return rc;
+        }
+        const size_t lds = ((size_t)nbt * R * NP + 2 * 4 * 16 + 2 * 16 + 2) * sizeof(double);
+        NBX_CHECK_ARG(lds <= 160 * 1024 && NP >= N && 8 * nbt * NP <= TDG_XCH * nbt);
         const double* a_ = d_a + b0 * n * n;
         double *d_ = d + b0 * n, *e_ = e + b0 * n, *t_ = tau + b0 * n, *v_ = Vg + b0 * n * n, *x_ = work;
         int N_ = N, R_ = R, p64 = P / 64;
         void* args[] = {(void*)&a_, (void*)&N_, (void*)&R_, (void*)&p64, (void*)&d_, (void*)&e_, (void*)&t_, (void*)&v_,
-                        (void*)&x_, (void*)&counter, (void*)&status};
+                        (void*)&x_, (void*)&nonce, (void*)&status};
         const void* fn = nullptr;
         if (nbt == 2) fn = NMt == 2 ? (const void*)&tdg_kernel<2, 2> : (NMt == 4 ? (const void*)&tdg_kernel<4, 2> : (const void*)&tdg_kernel<8, 2>);
         else fn = NMt == 2 ? (const void*)&tdg_kernel<2, 1> : (NMt == 4 ? (const void*)&tdg_kernel<4, 1> : (const void*)&tdg_kernel<8, 1>);
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            nbx_set_error("nbx_tdg_tridiag: the kernel cannot have 160 KB of dynamic LDS (static LDS in it?)");
+            return NBX_E_HIP;
+        }
         const hipError_t err = hipLaunchCooperativeKernel(fn, dim3((unsigned)P), dim3(TDG_THREADS), args, lds, ctx->stream);
         if (err != hipSuccess) {
             nbx_set_error("nbx_tdg_tridiag: cooperative launch of %d workgroups failed: %s", P, hipGetErrorString(err));

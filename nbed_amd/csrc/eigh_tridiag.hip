@@ -769,7 +769,9 @@ __global__ __launch_bounds__(1024) void offdiag_diag_max_kernel(const double* __
     const double* m = M + (int64_t)b * N * N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double mo = 0.0, md = 0.0;
-    for (int i = wave; i < N; i += 16) {
+    // (gridDim.y > 1: the rows are dealt to gridDim.y workgroups, whose partial maxima offdiag_max_combine_kernel joins
+    //  -- a matrix of 2000 rows took 1.45 ms on one workgroup)
+    for (int i = wave + 16 * blockIdx.y; i < N; i += 16 * gridDim.y) {
         const double* row = m + (int64_t)i * N;
         for (int j = lane; j < N; j += 64) {
             const double x = row[j];
@@ -794,9 +796,38 @@ __global__ __launch_bounds__(1024) void offdiag_diag_max_kernel(const double* __
             o = td_nanmax(o, red_o[w]);
             d = td_nanmax(d, red_d[w]);
         }
-        out[2 * b] = o;
-        out[2 * b + 1] = d;
+        out[2 * (b * gridDim.y + blockIdx.y)] = o;
+        out[2 * (b * gridDim.y + blockIdx.y) + 1] = d;
     }
+}
+
+__global__ void offdiag_max_combine_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (int)gridDim.x * (int)blockDim.x) return;
+    double o = part[2 * b * nblk], d = part[2 * b * nblk + 1];
+    for (int k = 1; k < nblk; ++k) {
+        o = td_nanmax(o, part[2 * (b * nblk + k)]);
+        d = td_nanmax(d, part[2 * (b * nblk + k) + 1]);
+    }
+    out[2 * b] = o;
+    out[2 * b + 1] = d;
+}
+
+// max |off-diagonal| and max |diagonal - DIAG_SHIFT| of `batch` matrices into out[2 b + {0, 1}]
+template <int DIAG_SHIFT>
+static int offdiag_diag_max(nbx_ctx* ctx, const double* M, int N, int64_t batch, double* out) {
+    const int nblk = N > 512 ? 32 : 1;
+    double* part = ctx->d_scratch + NBX_SCRATCH_DOUBLES / 2;  // (the callers' results live in the first half)
+    if (nblk == 1 || 2 * nblk * batch > NBX_SCRATCH_DOUBLES / 2) {
+        hipLaunchKernelGGL(offdiag_diag_max_kernel<DIAG_SHIFT>, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, M, N, out);
+        NBX_LAUNCH_CHECK();
+        return NBX_OK;
+    }
+    hipLaunchKernelGGL(offdiag_diag_max_kernel<DIAG_SHIFT>, dim3((unsigned)batch, (unsigned)nblk), dim3(1024), 0, ctx->stream, M, N, part);
+    NBX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(offdiag_max_combine_kernel, dim3(1), dim3((unsigned)batch), 0, ctx->stream, part, nblk, out);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
 }
 
 struct TdLayout {
@@ -865,9 +896,7 @@ static int td_pipeline(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a
     int rc = nbx_gemm(ctx, 'T', 'N', n, n, n, 1.0, Z, n, n * n, Z, n, n * n, 0.0, W, n, n * n, batch);
     if (rc != NBX_OK) return rc;
     NBX_CHECK_ARG(2 * batch <= NBX_SCRATCH_DOUBLES);
-    hipLaunchKernelGGL(offdiag_diag_max_kernel<1>, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, W, N, ctx->d_scratch);
-    NBX_LAUNCH_CHECK();
-    return NBX_OK;
+    return offdiag_diag_max<1>(ctx, W, N, batch, ctx->d_scratch);
 }
 
 static int td_check(int64_t n, int64_t batch, const void* d_work, size_t work_bytes, const TdLayout& L) {
@@ -959,8 +988,8 @@ int nbx_eigh_tridiag_dev(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d
     rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, W, n, n * n, d_v, n, n * n, 0.0, Z, n, n * n, batch);
     if (rc != NBX_OK) return rc;
     double* rq = ctx->d_scratch + 2 * batch;
-    hipLaunchKernelGGL(offdiag_diag_max_kernel<0>, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, Z, N, rq);
-    NBX_LAUNCH_CHECK();
+    rc = offdiag_diag_max<0>(ctx, Z, N, batch, rq);
+    if (rc != NBX_OK) return rc;
     hipLaunchKernelGGL(quality_status_kernel, dim3((unsigned)nbx_cdiv(batch, 64)), dim3(64), 0, ctx->stream,
                        ctx->d_scratch, rq, (int)batch, d_status, d_skip);
     NBX_LAUNCH_CHECK();
@@ -1012,8 +1041,8 @@ int nbx_eigh_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, 
     rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, W, n, n * n, d_v, n, n * n, 0.0, Z, n, n * n, batch);
     if (rc != NBX_OK) return rc;
     NBX_CHECK_ARG(2 * batch <= NBX_SCRATCH_DOUBLES);
-    hipLaunchKernelGGL(offdiag_diag_max_kernel<0>, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, Z, N, ctx->d_scratch);
-    NBX_LAUNCH_CHECK();
+    rc = offdiag_diag_max<0>(ctx, Z, N, batch, ctx->d_scratch);
+    if (rc != NBX_OK) return rc;
     NBX_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch, (size_t)(2 * batch) * sizeof(double), hipMemcpyDeviceToHost,
                            ctx->stream));
     NBX_HIP(hipStreamSynchronize(ctx->stream));

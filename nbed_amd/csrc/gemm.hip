@@ -816,7 +816,9 @@ int nbx_gemm_gated(nbx_ctx* ctx, char trans_a, char trans_b, int64_t m, int64_t 
         } else if (tiles128 >= 512 && m > 64 && n > 64) {
             launch<128, 128, 2, 4>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
                              beta, C, ldc, stride_c, nb, vec_a, vec_b, d_gate, gate_a, gate_b);
-        } else if (m <= 32 || n <= 32) {
+        } else if (m <= 32 || n <= 32 || nbx_cdiv(m, 64) * nbx_cdiv(n, 64) * nb < 128) {
+            // (also where 64 x 64 tiles would leave half the chip idle -- the 64-row panels of the blocked
+            //  back-transformation, csrc/eigh_grid.hip, batched matrices of a few hundred rows: four times the workgroups)
             launch<32, 32, 2, 2>(ctx, a_kc, b_kc, (int)m, (int)n, (int)k, alpha, A, lda, stride_a, B, ldb, stride_b,
                            beta, C, ldc, stride_c, nb, vec_a, vec_b, d_gate, gate_a, gate_b);
         } else {
