@@ -216,7 +216,12 @@ __global__ void antisym_kernel(const double* __restrict__ a, int N, double* __re
 // second stage in the fixed order of final_reduce_kernel -- out[0,1] the sums, out[2,3] the square
 // roots, then `tail_n` status words as doubles, then 1.0 (stored last, system scope) -- so the cycle's
 // scalars cost one launch.  `out` may be pinned host memory: the values then need no copy.
-template <int T>  // tile edge: 16 x 16 tiles give N = 148 a hundred workgroups instead of 25
+// DENS (T = 16, 128 threads): the density is not read but MADE here -- D[x] = C[x][:, :nocc_x] C[x][:, :nocc_x]^T, the
+// tile of spin x on the matrix cores by wavefront x with the k-slot order of gemm_small_kernel (gemm.hip: bitwise the
+// density nbx_gemm would have written), stored to `dm_w` and used from LDS; D is symmetric to the bit (the products of
+// (i, j) and (j, i) are the same numbers added in the same order), so the transposed tile the energy needs is this one.
+// One launch instead of the density product + this kernel on the SCF's critical path.
+template <int T, bool DENS = false>  // tile edge: 16 x 16 tiles give N = 148 a hundred workgroups instead of 25
 __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const double* __restrict__ vemb,
                                    const double* __restrict__ vhf, const double* __restrict__ hz,
                                    const double* __restrict__ dm, const double* __restrict__ dm_old, int N,
@@ -224,7 +229,9 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
                                    const int* __restrict__ tail = nullptr, int tail_n = 0,
                                    int* __restrict__ counter = nullptr, double* __restrict__ dts = nullptr,
                                    int s4_nb_ = 0, int s4_lpt_ = 0, int dts_m4 = 0,
-                                   const double* __restrict__ dtail = nullptr, int dtail_n = 0) {
+                                   const double* __restrict__ dtail = nullptr, int dtail_n = 0,
+                                   const double* __restrict__ cmo = nullptr, int nocc_a = 0, int nocc_b = 0,
+                                   double* __restrict__ dm_w = nullptr) {
     // A kernel on the SCF's critical path: everything it reads is requested in one trip to memory (both spins'
     // tiles at once), the sums travel by lane moves, and the workgroup that arrives last adds the four columns
     // of partials side by side -- three dependent round trips to L2 where there were nine.
@@ -242,13 +249,29 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
     // -- which saves that build its preparation launch.  Tiles on or below the diagonal write.
     double dsum[R], tsum[R];
     double ham[2][R], dv[2][R], dold[2][R];
+    constexpr int DSTEPS = 16;  // MFMA steps of four k: nocc <= 64 (the caller checks)
+    double ca[DENS ? DSTEPS : 1], cb[DENS ? DSTEPS : 1];
+    if (DENS) {
+        // wavefront x: operands of the whole k range of spin x requested in one trip (A: row i0 + fr, B: row j0 + fr of C)
+        const int x = tid >> 6, lane = tid & 63, fr = lane & 15, fk = lane >> 4;
+        const int K = x == 0 ? nocc_a : nocc_b;
+        const int ra = i0 + fr, rb = j0 + fr;
+        const double* pa = cmo + x * n2 + (int64_t)(ra < N ? ra : 0) * N;
+        const double* pb = cmo + x * n2 + (int64_t)(rb < N ? rb : 0) * N;
+#pragma unroll
+        for (int j = 0; j < DSTEPS; ++j) {
+            const int k = 4 * j + fk;
+            ca[j] = (k < K && ra < N) ? pa[k] : 0.0;
+            cb[j] = (k < K && rb < N) ? pb[k] : 0.0;
+        }
+    }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int r = threadIdx.y + 8 * k;
             const int gr = j0 + r, gc = i0 + threadIdx.x;  // dt[x][j][i] = D[x][j0+j][i0+i]
-            dt[x][r][threadIdx.x] = (gr < N && gc < N) ? dm[x * n2 + (int64_t)gr * N + gc] : 0.0;
+            if (!DENS) dt[x][r][threadIdx.x] = (gr < N && gc < N) ? dm[x * n2 + (int64_t)gr * N + gc] : 0.0;
             const int gi = i0 + r, gj = j0 + threadIdx.x;
             const bool in = gi < N && gj < N;
             const int64_t o = in ? (int64_t)gi * N + gj : 0;
@@ -256,10 +279,31 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
             if (hz) hm += hz[x * n2 + o];  // (no Huzinaga operator: the mu-shift cycle of scf_cycle.hip)
             if (vemb) hm += vemb[x * n2 + o];
             ham[x][k] = in ? hm : 0.0;
-            dv[x][k] = in ? dm[x * n2 + o] : 0.0;
+            if (!DENS) dv[x][k] = in ? dm[x * n2 + o] : 0.0;
             dold[x][k] = in ? dm_old[x * n2 + o] : 0.0;
         }
+    if (DENS) {
+        const int x = tid >> 6, lane = tid & 63, fr = lane & 15, fk = lane >> 4;
+        const int K = x == 0 ? nocc_a : nocc_b;
+        ew_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < DSTEPS; ++j)
+            if (4 * j < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[j], cb[j], acc, 0, 0, 0);  // (uniform)
+        // accumulator element r of a lane: tile row fk + 4 r, tile column fr; dt[x][i][j] = D[x][i0+i][j0+j] here
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = fk + 4 * r;
+            dt[x][row][fr] = acc[r];
+            if (i0 + row < N && j0 + fr < N) dm_w[x * n2 + (int64_t)(i0 + row) * N + j0 + fr] = acc[r];
+        }
+    }
     __syncthreads();
+    if (DENS) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int k = 0; k < R; ++k) dv[x][k] = dt[x][threadIdx.y + 8 * k][threadIdx.x];  // (zero outside the matrix)
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) dsum[k] = tsum[k] = 0.0;
 #pragma unroll
@@ -267,7 +311,7 @@ __global__ void huz_scalars_kernel(const double* __restrict__ h, int h3d, const 
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int r = threadIdx.y + 8 * k;
-            const double t = dt[x][threadIdx.x][r];
+            const double t = DENS ? dv[x][k] : dt[x][threadIdx.x][r];  // D[j][i] (DENS: = D[i][j], bit for bit)
             out[x] = fma(ham[x][k], t, out[x]);
             const double dd = dv[x][k] - dold[x][k];
             out[2 + x] = fma(dd, dd, out[2 + x]);
@@ -1260,6 +1304,37 @@ int nbx_cycle_scalars_launch(nbx_ctx* ctx, int64_t nao, const double* d_hcore, i
                            d_hcore, hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm, d_dm_old, (int)nao,
                            ctx->d_scratch, d_out, d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1, d_dts, nb4,
                            lpt4, m4, d_dtail, (int)dtail_n);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+// The aufbau density D[x] = C[x][:, :nocc_x] C[x][:, :nocc_x]^T AND the scalars of the cycle that judge it, in one
+// launch (huz_scalars_kernel<16, true>): what nbx_gemm('N','T') + nbx_huz_cycle_scalars_dts give, bit for bit.
+// Returns NBX_E_UNSUPPORTED (nothing launched) where the fused form does not apply -- more than 64 occupied orbitals,
+// an empty spin, N > 500 -- and the caller takes the two launches.
+int nbx_density_scalars_launch(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim, const double* d_vemb,
+                               const double* d_vhf, const double* d_hz, const double* d_c, int64_t nocc_a, int64_t nocc_b,
+                               double* d_dm_out, const double* d_dm_old, double* d_out, const int* d_tail, int64_t tail_n,
+                               double* d_dts) {
+    NBX_CHECK_ARG(ctx && d_hcore && d_vhf && d_c && d_dm_out && d_dm_old && d_out && nao > 0);
+    const bool fine = nbx_cdiv(nao, 16) * nbx_cdiv(nao, 16) * 4 <= NBX_SCRATCH_DOUBLES - 64;
+    if (!fine || nocc_a <= 0 || nocc_b <= 0 || nocc_a > 64 || nocc_b > 64) return NBX_E_UNSUPPORTED;
+    int m4 = 0, nb4 = d_dts ? s4_nb(nao) : 0, lpt4 = d_dts ? s4_lpt(nao) : 0;
+    if (d_dts && nbx_jk_m4_covers(nao)) {
+        int wl[4];
+        nbx_jk_m4_weight_layout(nao, wl);
+        nb4 = wl[0];
+        lpt4 = wl[1];
+        m4 = (wl[2] << 8) | wl[3];
+    }
+    NBX_CHECK_ARG(d_dts == nullptr || lpt4 > 0);
+    NBX_CHECK_ARG(tail_n >= 0 && tail_n <= 64 && (tail_n == 0 || d_tail != nullptr));
+    NBX_CHECK_ARG(hcore_ndim == 2 || hcore_ndim == 3);
+    const int64_t g = nbx_cdiv(nao, 16);
+    hipLaunchKernelGGL((huz_scalars_kernel<16, true>), dim3((unsigned)g, (unsigned)g), dim3(16, 8), 0, ctx->stream, d_hcore,
+                       hcore_ndim == 3 ? 1 : 0, d_vemb, d_vhf, d_hz, d_dm_out, d_dm_old, (int)nao, ctx->d_scratch, d_out,
+                       d_tail, (int)tail_n, ctx->d_counters + NBX_COUNTERS - 1, d_dts, nb4, lpt4, m4, nullptr, 0, d_c,
+                       (int)nocc_a, (int)nocc_b, d_dm_out);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

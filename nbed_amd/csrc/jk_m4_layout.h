@@ -80,8 +80,8 @@ template <int NB_>
 struct MxGeom {
     static constexpr int NB = NB_, N = 4 * NB, NG = (NB + 3) / 4, NBLK = m4_tri(NB), TILE = 16 * NBLK;
     static constexpr int LMAX = (m4_tri(N) + MX_CUS - 1) / MX_CUS + 1;  // tiles of a workgroup's range, at most
-    // doubles of LDS besides the ring: X of two tiles, the consumers' row-q / row-p partials, J partials, J of the range
-    static constexpr int FIXED = 2 * 4 * N + 2 * 4 * NG * 32 + 16 + LMAX;
+    // doubles of LDS besides the ring: X of two tiles, the consumers' partial rows (one buffer), J partials, J of the range
+    static constexpr int FIXED = 2 * 4 * N + 4 * NG * 32 + 16 + LMAX;
     static constexpr int lptm_room() {
         int l = (MX_LDS_BYTES - 8 * FIXED) / (MX_RING * 4096);
         return l > 6 ? 6 : l;

@@ -160,9 +160,13 @@ __global__ __launch_bounds__(MX_THREADS, 1) void jk_mx_kernel(const double* __re
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* buf0 = smem;                     // [MX_RING][BUF] chunk buffers
     double* xs0 = smem + MX_RING * BUF;      // [2][N][4] X of the current / next tile
-    double* redq = xs0 + 2 * 4 * N;          // [4][NG][32] consumers' row-q halves (odd columns) of the tile just walked
-    double* redp = redq + 4 * NG * 32;       // [4][NG][32] consumers' row-p halves (even columns) when the row ends
-    double* jred = redp + 4 * NG * 32;       // [2][4] producers' J partials per tile parity
+    // ONE buffer for the consumers' partial rows: the row-q halves (odd columns) of the tile just walked are written at the
+    // tile's last step and summed by the producers during step 0 of the next tile; the row-p halves (even columns) of a row
+    // that has ended wait in the consumers' registers until the end of that step 1 and are summed during step 2.  (Two
+    // buffers were 32 KB at N = 256 -- the difference between five and six 4 KB loads per chunk.)
+    double* redq = xs0 + 2 * 4 * N;          // [4][NG][32]
+    double* redp = redq;
+    double* jred = redq + 4 * NG * 32;       // [2][4] producers' J partials per tile parity
     double* jstage = jred + 16;              // [L] J of the tiles done, stored at the end of the range
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave >= 4;
@@ -274,11 +278,14 @@ __global__ __launch_bounds__(MX_THREADS, 1) void jk_mx_kernel(const double* __re
                         qq = pp;
                     }
                     if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, qq);
-                    if (pp != p) reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
                     if (ptid == 0) {
                         const double* jr = jred + ((t - 1) & 1) * 4;
                         jstage[t - 1] = (jr[0] + jr[1]) + (jr[2] + jr[3]);
                     }
+                }
+                if (k == 2 && t > 0) {  // the row-p halves of a row that ended with tile t - 1 (in the buffer since step 1)
+                    const int pp = q == 0 ? p - 1 : p;
+                    if (pp != p) reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
                 }
                 // the J contribution of chunk k (the one being walked: it landed a step ago)
                 {
@@ -348,6 +355,8 @@ __global__ __launch_bounds__(MX_THREADS, 1) void jk_mx_kernel(const double* __re
             qq = pp;
         }
         if (qq < pp) reduce_rows(redq, 1, kpart2 + ((T_end - 1 - t_begin) * NDM) * (int64_t)N, qq);
+        __syncthreads();  // (the consumers now put the last row's row-p halves into the buffer)
+        __syncthreads();
         reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
         if (wave == 4) {  // J of every tile of the range: lane i stores tile i's (one wave: its LDS operations are in order)
             if (lane == 0) {
@@ -388,6 +397,10 @@ __global__ __launch_bounds__(MX_THREADS, 1) void jk_mx_kernel(const double* __re
         }
         __syncthreads();
         int slot = 0;  // ring slot of the chunk being walked
+        double accsave[NG];  // row-p halves of a row that has ended, on their way to the buffer
+        bool pend_p = false;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) accsave[g] = 0.0;
         for (int t = 0; t < ntile; ++t) {
             int pn = p, qn = q;
             next_pq(pn, qn);
@@ -403,16 +416,24 @@ __global__ __launch_bounds__(MX_THREADS, 1) void jk_mx_kernel(const double* __re
                 if constexpr (G_::CH.c[k].band) mx_walk_band<G_, k>(buf, xs, wave, ln, acc, bxr);
                 else m4_walk_chunk<G_, k>(buf, xs, wave, ln, acc, bxr);
                 if (k == 1 && more) store_x(xs0 + ((t + 1) & 1) * 4 * N, xv);
+                if (k == 1 && pend_p) {  // (uniform) the producers are done with the row-q halves that were in the buffer
+                    if (!(lane & 1)) {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) redp[(wave * NG + g) * 32 + (lane >> 1)] = accsave[g];
+                    }
+                    pend_p = false;
+                }
                 if (k == NCH - 1) {
                     // end of tile: the row-q halves (odd columns: they used D[p][:]) leave the registers; the row-p halves
-                    // (even columns) stay until the row changes.  The producers sum them up during the next step.
+                    // (even columns) stay until the row changes, then wait in accsave for the buffer to be free.
                     const bool odd = lane & 1;
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         if (odd) redq[(wave * NG + g) * 32 + (lane >> 1)] = acc[g];
-                        else if (row_ends) redp[(wave * NG + g) * 32 + (lane >> 1)] = acc[g];
+                        else if (row_ends) accsave[g] = acc[g];
                         acc[g] = (odd || row_ends) ? 0.0 : acc[g];
                     }
+                    pend_p = row_ends;
                 }
                 __builtin_amdgcn_sched_barrier(0);  // (the MFMAs stay above the barrier: jk_m4.hip)
                 __syncthreads();
@@ -420,6 +441,13 @@ __global__ __launch_bounds__(MX_THREADS, 1) void jk_mx_kernel(const double* __re
             p = pn;
             q = qn;
         }
+        // the last tile always ends its row: its row-p halves go into the buffer when the producers have read the row-q ones
+        __syncthreads();
+        if (!(lane & 1)) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) redp[(wave * NG + g) * 32 + (lane >> 1)] = accsave[g];
+        }
+        __syncthreads();
     }
 }
 
@@ -440,7 +468,7 @@ MxPlan mx_plan_nb(int64_t p0, int64_t np, int64_t ndm) {
     pl.L = (int)L;
     pl.wgs = (int)nbx_cdiv(ntiles, L);
     pl.S = (int)sqrt(2.0 * (double)L) + 3;
-    pl.lds_bytes = (size_t)(MX_RING * G::BUF + 2 * 4 * G::N + 2 * 4 * G::NG * 32 + 16 + pl.L) * sizeof(double);
+    pl.lds_bytes = (size_t)(MX_RING * G::BUF + 2 * 4 * G::N + 4 * G::NG * 32 + 16 + pl.L) * sizeof(double);
     size_t off = 0;
     pl.wt_off = off; off += mx_align256((size_t)(G::NCH * G::LPTM * M4_PROD_THREADS * 2) * sizeof(double));
     pl.k1_off = off; off += mx_align256((size_t)((int64_t)pl.wgs * pl.S * ndm * G::N) * sizeof(double));

@@ -72,6 +72,10 @@ inline int64_t nbx_gemm_small_norm_doubles(int64_t m, int64_t n, int64_t batch) 
 // elementwise.hip
 // The launch behind nbx_huz_cycle_scalars_dev / _dts with two more options: d_hz == NULL (no Huzinaga operator in the
 // energy) and d_dtail (dtail_n <= 64 device doubles stored behind the status words, ahead of the ready word).
+int nbx_density_scalars_launch(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim, const double* d_vemb,
+                               const double* d_vhf, const double* d_hz, const double* d_c, int64_t nocc_a, int64_t nocc_b,
+                               double* d_dm_out, const double* d_dm_old, double* d_out, const int* d_tail, int64_t tail_n,
+                               double* d_dts);
 int nbx_cycle_scalars_launch(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim, const double* d_vemb,
                              const double* d_vhf, const double* d_hz, const double* d_dm, const double* d_dm_old,
                              double* d_out, const int* d_tail, int64_t tail_n, double* d_dts, const double* d_dtail,

@@ -8,6 +8,8 @@
 // (tools/trace_cycle.py).  Here the chain is queued by one C call from a state block the host fills
 // once per SCF; all arithmetic stays in the kernels the step-by-step path uses (same entry points,
 // same order, same operands): results are bit-identical to that path.
+#include <cstdlib>
+
 #include "nbx_common.h"
 
 // This rank's J/K contribution from the density d_dm_in into st->d_jk: the whole tensor or the slab rows
@@ -178,12 +180,18 @@ static int huz_cycle_rest(nbx_ctx* ctx, const nbx_huz_state* st, const double* d
                                                 nbx_eigh_status_offset(N, 2));
     }
 
-    // ---- density of the aufbau occupation (:170-174)
+    // ---- density of the aufbau occupation (:170-174) and the energy and convergence scalars (:181-194) with the
+    // eigensolver's status words, stored by the kernel into (pinned) host memory; it also leaves the Dtot' table of the
+    // new density for the next build.  One launch where the occupied block is at most 64 orbitals wide (the same bits
+    // as the two launches it stands for: elementwise.hip), else the product and the scalars kernel.
+    static const bool fused_density = getenv("NBX_FUSED_DENSITY") == nullptr || atoi(getenv("NBX_FUSED_DENSITY")) != 0;
+    if (fused_density) {
+        rc = nbx_density_scalars_launch(ctx, N, st->d_hv, 3, nullptr, st->d_vhf, d_hz_out, d_c_out, st->nocc_a, st->nocc_b,
+                                        d_dm_out, d_dm_in, h_out, d_status, 2, st->d_dts);
+        if (rc != NBX_E_UNSUPPORTED) return rc;
+    }
     rc = cycle_density(ctx, N, st->nocc_a, st->nocc_b, d_c_out, d_dm_out);
     if (rc != NBX_OK) return rc;
-
-    // ---- energy and convergence scalars (:181-194) + the eigensolver's status words, stored by the kernel
-    // into (pinned) host memory; it also leaves the Dtot' table of the new density for the next build
     return nbx_huz_cycle_scalars_dts(ctx, N, st->d_hv, 3, nullptr, st->d_vhf, d_hz_out, d_dm_out, d_dm_in, h_out,
                                      d_status, 2, st->d_dts);
 }

@@ -54,7 +54,7 @@ def test_no_gpu_means_no_backend():
         HipBackend()
 
 
-def _cross_compile_isa(tmp_path, name):
+def _cross_compile_isa(tmp_path, name, extra=()):
     import shutil
     import subprocess
     from pathlib import Path
@@ -66,7 +66,7 @@ def _cross_compile_isa(tmp_path, name):
         pytest.skip("no hipcc")
     root = Path(__file__).resolve().parent.parent
     asm = tmp_path / f"{name}.s"
-    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", f"-I{root / 'include'}", "-S", "--cuda-device-only",
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", f"-I{root / 'include'}", *extra, "-S", "--cuda-device-only",
                     str(root / "nbed_amd" / "csrc" / f"{name}.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=900)
     return asm.read_text()
 
@@ -118,9 +118,11 @@ def test_streaming_jk_kernels_have_no_scratch_and_no_asm_sgpr_hazard(tmp_path):
     that a v_readlane has just written."""
     import re
 
-    for name, probe in (("jk_m4", "37"), ("jk_mx", "64")):
-        text = _cross_compile_isa(tmp_path, name)
-        sizes = re.findall(name + r"_kernelILi(\d+)ELi([12])E\S*\.private_seg_size, (\d+)", text)
+    # (jk_mx.hip a second time with two of the instances of jk_mx_hi.hip: band-segment chunks, N = 304 and 384)
+    for name, kernel, probe, extra in (("jk_m4", "jk_m4", "37", ()), ("jk_mx", "jk_mx", "64", ()),
+                                       ("jk_mx", "jk_mx", "96", ("-DNBX_MX_SIZES(X)=X(76) X(96)", "-DMX_FN(name)=name##_hi"))):
+        text = _cross_compile_isa(tmp_path, name, extra)
+        sizes = re.findall(kernel + r"_kernelILi(\d+)ELi([12])E\S*\.private_seg_size, (\d+)", text)
         assert (probe, "1") in {(nb, k) for nb, k, _ in sizes} and (probe, "2") in {(nb, k) for nb, k, _ in sizes}, sizes
         assert len(sizes) >= 2 and all(int(v) == 0 for _, _, v in sizes), f"{name}_kernel spills: {sizes}"
         hazards = _asm_sgpr_hazards(text)
