@@ -209,7 +209,9 @@ def n2000_cycle(be, b, N, nocc, sync):
     n2 = N * N
     space = 6
     xs, es = be.zeros((space, 2 * n2)), be.zeros((space, 2 * n2))
-    hmat, coef = be.zeros((space + 1, space + 1)), be.diis_coef_buffer(space)
+    hm = np.zeros((space + 1, space + 1))
+    hm[0, 1:] = hm[1:, 0] = 1  # (the border of the Pulay matrix: pyscf.lib.diis)
+    hmat, coef = be.asarray(hm), be.diis_coef_buffer(space)
     xprev = be.zeros((2, N, N))
     x2 = torch.stack([x_d, x_d]).contiguous()
     # core guess: orbitals of X (h + V_emb) X
