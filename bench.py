@@ -260,8 +260,9 @@ def n2000_cycle(be, b, N, nocc, sync):
         phases.append({"jk_df_ms": t_jk * 1e3, "eigensolve_ms": t_eig * 1e3, "rest_ms": (dt - t_jk - t_eig) * 1e3})
         e_hist.append([float(sc[0]), float(sc[1]), dd])
         dm, v_prev = dm_new, v
-    res = float((torch.bmm(fo, v) - v * w[:, None, :]).abs().max() / fo.abs().max())
-    orth = float((torch.bmm(v.transpose(1, 2), v) - torch.eye(N, dtype=v.dtype, device=v.device)).abs().max())
+    # (the checks too on libnbx's GEMM: no kernel of another library in this process's profile)
+    res = float((be.gemm(fo, v) - v * w[:, None, :]).abs().max() / fo.abs().max())
+    orth = float((be.gemm(v, v, "T", "N") - torch.eye(N, dtype=v.dtype, device=v.device)).abs().max())
     return {"workload": f"one Huzinaga UHF cycle at N_AO={N}, n_occ={nocc}: density-fitted J/K on the resident factor + Fock + "
                         "Huzinaga operator + DIIS + X F X + batched eigensolve + density + energy, libnbx calls step by step",
             "cold_cycle_ms": times[0] * 1e3, "warm_cycle_ms": times[-1] * 1e3, "cycles_ms": [t * 1e3 for t in times],
@@ -540,12 +541,20 @@ def scaling_workload_leg(be, args, world, rank, distributed, barrier) -> list:
                 dt = float(tmax.item())
             ntiles = (sh.hi * (sh.hi + 1) - sh.lo * (sh.lo + 1)) // 2
             slab_bytes = float(be.lib.nbx_eri_packed_bytes(n_ao, sh.lo, sh.hi)) if packed else 8.0 * n_ao * n_ao * ntiles
+            traffic = None
+            tfile = REPO / "profiles" / "r04" / f"jk_mx_traffic_n{n_ao}.json"
+            if packed and world == 1 and tfile.exists():
+                try:
+                    traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
             per_rank = gather_per_rank({"rank": rank, "slab_rows": [int(sh.lo), int(sh.hi)], "slab_bytes_read_per_build": slab_bytes,
                                         "jk_kernel_ms": jk_ms}, world, distributed)
             ms_cycle = dt / steps * 1e3
             out.append({"nao": n_ao, "jk_kernel": packed_kernel_name(n_ao) if packed else "jk_sym_kernel (dense tensor, tiles q <= p)",
                         "jk_kernel_ms_this_rank": jk_ms,
                         "jk_frac_of_hbm_peak_this_rank": (slab_bytes / (jk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if jk_ms else None,
+                        "jk_hbm_traffic_bytes_per_launch_pmc": traffic,
                         "per_rank": per_rank,
                         "replicated_part_ms": (ms_cycle - max(r["jk_kernel_ms"] or 0.0 for r in per_rank) - (ar_ms or 0.0))
                         if jk_ms else None,
@@ -1138,7 +1147,9 @@ def main():
         jk_kernel = ("jk_m4_kernel" if m4 else "jk_s4_kernel") if packed else ("jk_sym_kernel" if sym else "jk_dense_kernel")
         achieved = alg_bytes / (jk_avg_ms * 1e-3) / 1e9 if jk_cnt else None
         traffic = None
-        tfile = REPO / "profiles" / ("r03/jk_m4_traffic.json" if m4 else "jk_traffic.json")
+        tfile = REPO / "profiles" / ("r04/jk_m4_traffic_n148.json" if m4 else "jk_traffic.json")
+        if m4 and not tfile.exists():
+            tfile = REPO / "profiles" / "r03" / "jk_m4_traffic.json"
         if tfile.exists() and world == 1 and N == 148:
             try:
                 tj = json.loads(tfile.read_text())
