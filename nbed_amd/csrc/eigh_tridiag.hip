@@ -383,13 +383,17 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ d, const d
     return cnt;
 }
 
-// grid (N, batch), 64 threads: eigenvalue index blockIdx.x (ascending)
-__global__ __launch_bounds__(64) void bisect_kernel(const double* __restrict__ db, const double* __restrict__ eb, int N,
-                                                    double* __restrict__ wb) {
+// grid (ceil(N / W), batch), 64 W threads: wavefront w of a workgroup finds eigenvalue W blockIdx.x + w (ascending).  The
+// W wavefronts share ONE copy of d and e^2 in LDS (every one of them writes it, with the same values, and forms the
+// Gershgorin bounds over all of it as the one-wavefront form did: same bits): at N = 2000 the 32 KB copy per 64 threads
+// left five wavefronts on a CU and the kernel took 4.4 ms; W = 8 fills it.
+__global__ __launch_bounds__(512) void bisect_kernel(const double* __restrict__ db, const double* __restrict__ eb, int N,
+                                                     double* __restrict__ wb) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* d = smem;        // [N]
     double* e2 = d + N;      // [N]
-    const int b = blockIdx.y, j = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const double* dg = db + (int64_t)b * N;
     const double* eg = eb + (int64_t)b * N;
     double gl = 1.0e300, gu = -1.0e300, emax = 0.0, tnorm = 0.0;
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(64) void bisect_kernel(const double* __restrict__ d
         lo = xlo;
         hi = xhi;
     }
-    if (lane == 0) wb[(int64_t)b * N + j] = 0.5 * (lo + hi);
+    if (lane == 0 && j < N) wb[(int64_t)b * N + j] = 0.5 * (lo + hi);
 }
 
 // ---------------------------------------------------------------- K3: eigenvectors of T (inverse iteration)
@@ -449,7 +453,7 @@ __device__ __forceinline__ void invit_solve(const double* __restrict__ d, const 
     // LU with partial pivoting of T - lam I  (LAPACK dlagtf restated); the pivots are kept as reciprocals
     double ai = d[0] - lam;
     double bi = N > 1 ? e[0] : 0.0;  // super-diagonal entry of the current row
-#pragma unroll 4
+#pragma unroll 16
     for (int i = 0; i < N - 1; ++i) {
         const double ci = e[i];                        // sub-diagonal entry (row i+1, col i)
         double anext = d[i + 1] - lam;                 // diagonal of row i+1
@@ -489,7 +493,7 @@ __device__ __forceinline__ void invit_solve(const double* __restrict__ d, const 
     for (int it = 0; it < 3; ++it) {
         // forward: apply the row operations of the factorisation to the right-hand side
         double yi = x[0];
-#pragma unroll 4
+#pragma unroll 16
         for (int i = 0; i < N - 1; ++i) {
             double yn = x[(int64_t)(i + 1) * NT];
             if (sw[(int64_t)i * NT] != 0.0) {
@@ -504,7 +508,7 @@ __device__ __forceinline__ void invit_solve(const double* __restrict__ d, const 
         x[(int64_t)(N - 1) * NT] = yi;
         // backward substitution with the three diagonals of U
         double x1 = 0.0, x2 = 0.0, amax = 0.0;
-#pragma unroll 4
+#pragma unroll 16
         for (int i = N - 1; i >= 0; --i) {
             const double t = x[(int64_t)i * NT] - ub[(int64_t)i * NT] * x1 - uc[(int64_t)i * NT] * x2;
             const double xi = t * ua[(int64_t)i * NT];
@@ -879,8 +883,9 @@ static int td_pipeline(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a
         hipLaunchKernelGGL(tridiag_kernel, dim3((unsigned)batch), dim3(TD_THREADS),
                            (size_t)(3 * N + TD_THREADS + 20) * sizeof(double), ctx->stream, d_a, N, W, d, e, tau, Vh);
     NBX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bisect_kernel, dim3((unsigned)N, (unsigned)batch), dim3(64), (size_t)(2 * N) * sizeof(double),
-                       ctx->stream, d, e, N, d_w);
+    const int bw = N > 512 ? 8 : 1;  // wavefronts (eigenvalues) per workgroup
+    hipLaunchKernelGGL(bisect_kernel, dim3((unsigned)nbx_cdiv(N, bw), (unsigned)batch), dim3(64 * bw),
+                       (size_t)(2 * N) * sizeof(double), ctx->stream, d, e, N, d_w);
     NBX_LAUNCH_CHECK();
     if (in_memory || !invit_lds_launch(ctx, N, batch, d, e, d_w, Z))
         hipLaunchKernelGGL(invit_kernel, dim3((unsigned)nbx_cdiv(N, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d,
