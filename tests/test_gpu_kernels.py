@@ -896,6 +896,30 @@ def test_jk_packed_fock_of_the_sizes_that_make_their_own_table(be, n):
         np.testing.assert_array_equal(be.to_host(vhf0), be.to_host(v_ref))
 
 
+@pytest.mark.parametrize("n", [160, 250, 304])
+def test_jk_mx_slabs_add_up_and_single_density(be, n):
+    """csrc/jk_mx.hip through the slab interface that the multi-GPU split uses (three row slabs cut at equal triangular
+    work, packed separately, partial J/K added: the whole-tensor result to rounding) and with ONE density (the NDM = 1
+    instances), at a size with whole-row chunks, a zero-padded one and one with band-segment chunks; against the
+    symmetric kernel on the dense tensor."""
+    import torch
+
+    torch.cuda.empty_cache()
+    eri = be.synth_eri(n)
+    dm = be.asarray(np.stack([symm(560, n), symm(561, n)]))
+    ref = be.to_host(be.jk_sym(eri, dm))
+    whole = be.to_host(be.jk_packed(be.eri_pack(eri, n), dm))
+    np.testing.assert_allclose(whole, ref, rtol=0, atol=1e-11 * (n / 148) ** 2)
+    cuts = [0] + [int(round(n * np.sqrt(g / 3.0))) for g in (1, 2)] + [n]
+    acc = np.zeros_like(ref)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        acc += be.to_host(be.jk_packed(be.eri_pack(eri[lo:hi], n, lo, hi), dm, lo, hi))
+    np.testing.assert_allclose(acc, ref, rtol=0, atol=1e-11 * (n / 148) ** 2)
+    one = be.to_host(be.jk_packed(be.eri_pack(eri, n), dm[:1]))
+    ref1 = be.to_host(be.jk_sym(eri, dm[:1]))
+    np.testing.assert_allclose(one, ref1, rtol=0, atol=1e-11 * (n / 148) ** 2)
+
+
 def test_jk_packed_unsupported_sizes(be):
     """Sizes outside the packed kernel's reach are refused loudly (the host then keeps the
     symmetric / plain kernel): too small, between instances, above 400."""
