@@ -24,6 +24,7 @@
 // ends the same way).  First form of this kernel: sc1 vectors + drain + arrival counter + poll per step, 9-12 us a
 // step; with the tagged words 5.5-8 us (N = 2000: 23.9 -> 16.1 ms per matrix).
 // Conventions of d, e, tau and the reflectors are LAPACK dsytd2's (UPLO = 'L'), as in eigh_tridiag.hip.
+#include <atomic>
 #include <cstdlib>
 
 #include "nbx_common.h"
@@ -373,7 +374,7 @@ int nbx_tdg_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, d
         const int nm = (N + 64 * wpm - 1) / (64 * wpm);  // registers per lane and vector
         const int NMt = nm <= 2 ? 2 : (nm <= 4 ? 4 : 8);
         const int NP = 64 * NMt * wpm;
-        static unsigned launch_nonce = 0;
+        static std::atomic<unsigned> launch_nonce{0};  // (one sequence per process: contexts of several threads draw from it)
         unsigned nonce = ++launch_nonce;
         if (nonce == 1) {  // (first use of a workspace in this process: no word may verify by accident of old bytes)
             const int rc = nbx_memset(ctx, work, 0, (size_t)TDG_XCH * batch * sizeof(double) + 256);
