@@ -441,11 +441,13 @@ constexpr int DIIS_STATE_DOUBLES = 2 * DIIS_STATE_HALF;
 constexpr long long DIIS_STATE_MAGIC = 0x4e42585f44494953ll;
 
 // xs[slot] = x, es[slot] = e = (err given ? err : x - xprev), partial[blk*nd + k] = sum_i e[i] * es[k][i]
+// (anti_n > 0: err points at matrices A of order anti_n and the error vector is A^T - A, formed on the fly -- the CDIIS
+//  error F D S - S D F from A = S D F without a launch of its own)
 __global__ __launch_bounds__(256) void diis_push_kernel(int64_t n, int nd, int slot, const double* __restrict__ x,
                                                         const double* __restrict__ xprev,
                                                         const double* __restrict__ err, double* __restrict__ xs,
                                                         double* __restrict__ es, double* __restrict__ partial,
-                                                        double* __restrict__ state) {
+                                                        double* __restrict__ state, int anti_n = 0) {
     __shared__ double red[4][DIIS_MAX_SPACE];
     // the solver's basis of the previous update becomes the one this update starts from (see
     // diis_solve8_lincomb_kernel: its workgroups read one copy while workgroup 0 writes the other)
@@ -455,7 +457,14 @@ __global__ __launch_bounds__(256) void diis_push_kernel(int64_t n, int nd, int s
     for (int k = 0; k < DIIS_MAX_SPACE; ++k) acc[k] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double xv = x[i];
-        const double e = (err != nullptr) ? err[i] : xv - xprev[i];
+        double e;
+        if (anti_n > 0) {
+            const int64_t a2 = (int64_t)anti_n * anti_n, bb = i / a2, rc = i - bb * a2;
+            const int64_t r = rc / anti_n, c = rc - r * anti_n;
+            e = err[bb * a2 + c * anti_n + r] - err[i];
+        } else {
+            e = (err != nullptr) ? err[i] : xv - xprev[i];
+        }
         xs[(int64_t)slot * n + i] = xv;
         es[(int64_t)slot * n + i] = e;
 #pragma unroll
@@ -1360,13 +1369,24 @@ int nbx_diis_update(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_
 int nbx_diis_update_err(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_t nd, const double* d_x,
                         const double* d_err, double* d_xprev, double* d_xs, double* d_es, double* d_h,
                         double* d_coef) {
+    return nbx_diis_update_anti(ctx, n, space, slot, nd, d_x, d_err, 0, d_xprev, d_xs, d_es, d_h, d_coef);
+}
+
+}  // extern "C"
+
+// nbx_diis_update_err with the error vector given as the matrices A (order anti_n > 0; n = batch anti_n^2) whose
+// antisymmetric part A^T - A it is (scf_cycle.hip: the CDIIS step of the mu-shift cycle); anti_n = 0: d_err as it is
+int nbx_diis_update_anti(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_t nd, const double* d_x,
+                         const double* d_err, int64_t anti_n, double* d_xprev, double* d_xs, double* d_es, double* d_h,
+                         double* d_coef) {
     NBX_CHECK_ARG(ctx && d_x && d_xprev && d_xs && d_es && d_h && d_coef && n > 0);
+    NBX_CHECK_ARG(anti_n == 0 || (d_err != nullptr && anti_n > 0 && n % (anti_n * anti_n) == 0));
     NBX_CHECK_ARG(space >= 1 && space <= DIIS_MAX_SPACE && slot >= 0 && slot < space && nd >= 1 && nd <= space &&
                   slot < nd);
     const unsigned blocks = grid1d(n, 256, 128);
     NBX_CHECK_ARG((int64_t)blocks * nd <= NBX_SCRATCH_DOUBLES - 64);
     hipLaunchKernelGGL(diis_push_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, (int)nd, (int)slot, d_x,
-                       d_xprev, d_err, d_xs, d_es, ctx->d_scratch, d_coef + space);
+                       d_xprev, d_err, d_xs, d_es, ctx->d_scratch, d_coef + space, (int)anti_n);
     NBX_LAUNCH_CHECK();
     if (nd <= 7 && nbx_cdiv(n, 64 * DIIS8_PER_LANE) <= 65535) {  // the usual case: solve and extrapolation in one launch
         hipLaunchKernelGGL(diis_solve8_lincomb_kernel, dim3((unsigned)nbx_cdiv(n, 64 * DIIS8_PER_LANE)), dim3(64), 0,
@@ -1384,8 +1404,18 @@ int nbx_diis_update_err(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, in
     return NBX_OK;
 }
 
+extern "C" {
+
 int nbx_vo_sumsq(nbx_ctx* ctx, int64_t nao, const double* d_fmo, int64_t nocc_a, int64_t nocc_b, double* d_out) {
     NBX_CHECK_ARG(ctx && d_fmo && d_out && nao > 0 && nocc_a >= 0 && nocc_a <= nao && nocc_b >= 0 && nocc_b <= nao);
+    // (the orbital gradient of a cycle at N ~ 150 is 2 x 3800 numbers: one workgroup per spin writes its sum itself)
+    const int64_t na = (nao - nocc_a) * nocc_a, nb = (nao - nocc_b) * nocc_b;
+    if ((na > nb ? na : nb) <= 16384) {
+        hipLaunchKernelGGL(vo_sumsq_kernel, dim3(1, 2), dim3(256), 0, ctx->stream, d_fmo, (int)nao, (int)nocc_a, (int)nocc_b,
+                           d_out);
+        NBX_LAUNCH_CHECK();
+        return NBX_OK;
+    }
     const int blocks = 32;
     hipLaunchKernelGGL(vo_sumsq_kernel, dim3(blocks, 2), dim3(256), 0, ctx->stream, d_fmo, (int)nao, (int)nocc_a,
                        (int)nocc_b, ctx->d_scratch);

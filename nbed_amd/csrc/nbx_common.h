@@ -76,6 +76,9 @@ int nbx_density_scalars_launch(nbx_ctx* ctx, int64_t nao, const double* d_hcore,
                                const double* d_vhf, const double* d_hz, const double* d_c, int64_t nocc_a, int64_t nocc_b,
                                double* d_dm_out, const double* d_dm_old, double* d_out, const int* d_tail, int64_t tail_n,
                                double* d_dts);
+int nbx_diis_update_anti(nbx_ctx* ctx, int64_t n, int64_t space, int64_t slot, int64_t nd, const double* d_x,
+                         const double* d_err, int64_t anti_n, double* d_xprev, double* d_xs, double* d_es, double* d_h,
+                         double* d_coef);
 int nbx_cycle_scalars_launch(nbx_ctx* ctx, int64_t nao, const double* d_hcore, int hcore_ndim, const double* d_vemb,
                              const double* d_vhf, const double* d_hz, const double* d_dm, const double* d_dm_old,
                              double* d_out, const int* d_tail, int64_t tail_n, double* d_dts, const double* d_dtail,

@@ -223,10 +223,9 @@ extern "C" int nbx_mu_cycle_solve(nbx_ctx* ctx, const nbx_huz_state* st, const d
         if (rc != NBX_OK) return rc;
         rc = nbx_gemm(ctx, 'N', 'N', N, N, N, 1.0, st->d_tmp, N, n2, d_fock_in, N, n2, 0.0, st->d_fo, N, n2, 2);
         if (rc != NBX_OK) return rc;
-        rc = nbx_antisym(ctx, N, 2, st->d_fo, st->d_fock2);
-        if (rc != NBX_OK) return rc;
-        rc = nbx_diis_update_err(ctx, 2 * n2, st->diis_space, diis_slot, diis_nd, d_fock_in, st->d_fock2,
-                                 st->d_diis_xprev, st->d_diis_xs, st->d_diis_es, st->d_diis_h, st->d_diis_coef);
+        // (the error vector A^T - A of A = S D F is formed inside the push kernel: the same numbers as nbx_antisym's)
+        rc = nbx_diis_update_anti(ctx, 2 * n2, st->diis_space, diis_slot, diis_nd, d_fock_in, st->d_fo, N,
+                                  st->d_diis_xprev, st->d_diis_xs, st->d_diis_es, st->d_diis_h, st->d_diis_coef);
         if (rc != NBX_OK) return rc;
         f_use = st->d_diis_xprev;
     }
