@@ -40,7 +40,8 @@ __global__ __launch_bounds__(PUR_THREADS) void pur_init_kernel(int N, const doub
         // consecutive threads read consecutive addresses, where the row sums were a stride-N walk per thread
         double r = 0.0;
         const double d = F[(int64_t)i * N + i];
-#pragma unroll 4
+        // (sixteen loads in flight: unrolled by four this loop was the 59 us of the kernel -- 148 trips to L2 in 37 rounds)
+#pragma unroll 16
         for (int j = 0; j < N; ++j) r += (j == i) ? 0.0 : fabs(F[(int64_t)j * N + i]);
         mn = fmin(mn, d - r);
         mx = fmax(mx, d + r);
@@ -57,12 +58,14 @@ __global__ __launch_bounds__(PUR_THREADS) void pur_init_kernel(int N, const doub
     }
     const double lmin = lo[0], lmax = hi[0];
     const double inv = 1.0 / (lmax - lmin);
-    for (int i = threadIdx.x >> 6; i < N; i += PUR_THREADS >> 6)  // a wave per row: no index division
-        for (int j = threadIdx.x & 63; j < N; j += 64) {
+    // (gridDim.y workgroups per matrix: each finds the same bounds -- that is eight rounds of loads -- and writes every
+    //  gridDim.y-th group of four rows of P0; with one workgroup the 37 rounds of this loop were 50 us of the kernel)
+    for (int i = (threadIdx.x >> 6) + (PUR_THREADS >> 6) * blockIdx.y; i < N; i += (PUR_THREADS >> 6) * gridDim.y)
+        for (int j = threadIdx.x & 63; j < N; j += 64) {  // a wave per row: no index division
             const int64_t e = (int64_t)i * N + j;
             P[e] = ((i == j ? lmax : 0.0) - F[e]) * inv;
         }
-    if (threadIdx.x == 0) status[b] = (lmax > lmin && isfinite(inv)) ? 0 : -2;
+    if (threadIdx.x == 0 && blockIdx.y == 0) status[b] = (lmax > lmin && isfinite(inv)) ? 0 : -2;
 }
 
 typedef double pur_v4 __attribute__((ext_vector_type(4)));
@@ -196,8 +199,8 @@ extern "C" int nbx_purify(nbx_ctx* ctx, int64_t n, int64_t batch, const double* 
     const int64_t n2 = n * n;
     double* pb = static_cast<double*>(d_work);
     double* traces = pb + n2 * batch;
-    hipLaunchKernelGGL(pur_init_kernel, dim3((unsigned)batch), dim3(PUR_THREADS), 0, ctx->stream, (int)n, d_f, d_p,
-                       d_status);
+    hipLaunchKernelGGL(pur_init_kernel, dim3((unsigned)batch, (unsigned)(n >= 64 ? 8 : 1)), dim3(PUR_THREADS), 0, ctx->stream,
+                       (int)n, d_f, d_p, d_status);
     NBX_LAUNCH_CHECK();
     const unsigned tiles = (unsigned)nbx_cdiv(n, 16);
     for (int it = 0; it < max_iter; ++it) {
