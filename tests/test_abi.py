@@ -143,3 +143,26 @@ def test_asm_sgpr_hazard_checker_sees_the_pattern():
 """
     bad = _asm_sgpr_hazards(text)
     assert len(bad) == 2 and all("s[12:13]" in b[1] for b in bad)
+
+
+def test_jk_mx_chunk_tables(tmp_path):
+    """The compile-time chunk tables of csrc/jk_mx.hip (whole block rows at the top of a tile's triangle, band segments
+    below) for every instantiated size, checked on the host: exact cover in order, ring-buffer and LDS budgets,
+    block <-> (chunk, offset) round trip (tests/native/mx_geometry_check.hip)."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        import pytest
+
+        pytest.skip("no hipcc")
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "mx_geometry_check"
+    subprocess.run([hipcc, "-std=c++17", "-O1", "--offload-arch=gfx950", f"-I{root / 'nbed_amd' / 'csrc'}",
+                    str(root / "tests" / "native" / "mx_geometry_check.hip"), "-o", str(exe)], check=True, capture_output=True,
+                   timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count("bad=0") == 23, r.stdout
