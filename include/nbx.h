@@ -369,6 +369,14 @@ int nbx_eigh_approx(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, d
  * nbed/localizers/occupied/spade.py:99; np.linalg.inv(S_AA) at
  * nbed/localizers/virtual/concentric.py:147 (p = -1).                                      */
 size_t nbx_sym_pow_worksize(int64_t n);
+/* The same power, p in {-1/2, +1/2, -1}, of a symmetric POSITIVE DEFINITE S by the coupled Newton-Schulz iteration
+ * (three GEMMs per step, ~0.2 ms at N = 148 where the eigen route takes ~1-3 ms): c = a bound of the spectrum (the
+ * caller's ||S||_inf), convergence (||I - Z Y||_F) read back every `check_every` steps.  *h_iters = steps taken, or -1
+ * when it did not converge within max_iter (not positive definite, condition number beyond ~1e6): d_out is then
+ * untouched and the caller takes nbx_sym_pow.  Agrees with fractional_matrix_power to ~cond(S) 1e-16.  Synchronises. */
+size_t nbx_sym_pow_ns_worksize(int64_t n);
+int nbx_sym_pow_ns(nbx_ctx* ctx, int64_t n, const double* d_s, double p, double c, double* d_out, void* d_work,
+                   size_t work_bytes, int max_iter, int check_every, int* h_iters);
 int nbx_sym_pow(nbx_ctx* ctx, int64_t n, const double* d_s, double p, double* d_out,
                 void* d_work, size_t work_bytes);
 

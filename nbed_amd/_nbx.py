@@ -130,6 +130,8 @@ SIGNATURES = {
     "nbx_eigh_status": (c_int, [_P, c_int64, c_int64, _P, POINTER(c_int)]),
     "nbx_sym_pow_worksize": (c_size_t, [c_int64]),
     "nbx_sym_pow": (c_int, [_P, c_int64, _P, c_double, _P, _P, c_size_t]),
+    "nbx_sym_pow_ns_worksize": (c_size_t, [c_int64]),
+    "nbx_sym_pow_ns": (c_int, [_P, c_int64, _P, c_double, c_double, _P, _P, c_size_t, c_int, c_int, POINTER(c_int)]),
     "nbx_svd_worksize": (c_size_t, [c_int64, c_int64]),
     "nbx_svd_right": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, c_size_t]),
     "nbx_svd_status": (c_int, [_P, c_int64, c_int64, _P, POINTER(c_int)]),

@@ -1124,6 +1124,14 @@ class HipBackend:
             c = float(np.abs(self.to_host(s)).sum(axis=1).max())
         if not np.isfinite(c) or c <= 0.0:
             return None
+        if hasattr(self.lib, "nbx_sym_pow_ns"):  # the whole iteration queued by one C call (csrc/eigh.hip)
+            nbytes = int(self.lib.nbx_sym_pow_ns_worksize(n))
+            work = self._workspace("sym_pow_ns", nbytes)
+            out = torch.empty_like(s)
+            iters = c_int(-1)
+            self._call("nbx_sym_pow_ns", n, self._p(s), float(p), c, self._p(out), self._p(work), work.numel(), int(max_iter),
+                       int(check_every), ctypes.byref(iters))
+            return out if iters.value > 0 else None
         eye = torch.eye(n, dtype=torch.float64, device=self.device)
         eye3 = self.empty((n, n))
         self.axpby(3.0, eye, 0.0, eye3)

@@ -441,3 +441,113 @@ extern "C" int nbx_sym_pow(nbx_ctx* ctx, int64_t n, const double* d_s, double p,
     // out = (U diag(w^p)) U^T
     return nbx_gemm(ctx, 'N', 'T', n, n, n, 1.0, us, n, 0, u, n, 0, 0.0, d_out, n, 0, 1);
 }
+
+// ------------------------------------------------------------------ S^p by the coupled Newton-Schulz iteration, in one call
+// (fractional_matrix_power(S, -1/2) of nbed/scf/huzinaga_scf.py:128, (S, 1/2) of spade.py:99, inv of concentric.py:147 for
+// a symmetric positive definite S: Higham, Functions of Matrices, eq. 6.35.)  With A = S / c, c >= ||S||_inf:
+//     Y_0 = A, Z_0 = I;   T = 3 I - Z Y;   Y <- Y T / 2 -> A^1/2,   Z <- T Z / 2 -> A^-1/2
+// -- three products and one element-wise kernel per step, queued from here (from Python a step was four ctypes calls and
+// a device copy, ~50 us of host time against ~25 us of kernels: half a millisecond of every SCF set-up at N = 148).  The
+// residual ||I - Z Y||_F is read back every `check_every` steps as the host version did, with its stopping rule.
+namespace {
+
+__global__ void ns_init_kernel(int64_t n, const double* __restrict__ s, double inv_c, double* __restrict__ y, double* __restrict__ z) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * n) return;
+    y[i] = s[i] * inv_c;
+    z[i] = (i / n == i % n) ? 1.0 : 0.0;
+}
+
+// t = 3 I - p in place; partial[blockIdx.x] = this block's share of ||I - p||_F^2
+__global__ __launch_bounds__(256) void ns_t_kernel(int64_t n, double* __restrict__ p, double* __restrict__ partial) {
+    __shared__ double red[17];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double d = (i / n == i % n) ? 1.0 : 0.0;
+        const double v = p[i];
+        const double r = d - v;
+        acc = fma(r, r, acc);
+        p[i] = 3.0 * d - v;
+    }
+    acc = nbx_block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// out = scale (a + a^T) / 2
+__global__ void ns_finish_kernel(int64_t n, const double* __restrict__ a, double scale, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * n) return;
+    const int64_t r = i / n, c = i % n;
+    out[i] = 0.5 * scale * (a[i] + a[c * n + r]);
+}
+
+}  // namespace
+
+extern "C" size_t nbx_sym_pow_ns_worksize(int64_t n) { return n <= 0 ? 0 : align256((size_t)(5 * n * n + 1024) * sizeof(double)); }
+
+// p in {-1/2, +1/2, -1}; c: a bound of the spectrum (the caller's ||S||_inf).  *h_iters: steps taken, or -1 when the
+// iteration did not converge within max_iter (S not positive definite, condition number beyond ~1e6) or met a NaN -- the
+// caller then takes nbx_sym_pow (the eigendecomposition); d_out is only written on success.  Synchronises.
+extern "C" int nbx_sym_pow_ns(nbx_ctx* ctx, int64_t n, const double* d_s, double p, double c, double* d_out, void* d_work,
+                              size_t work_bytes, int max_iter, int check_every, int* h_iters) {
+    NBX_CHECK_ARG(ctx && d_s && d_out && h_iters && n > 0 && c > 0.0 && max_iter > 0 && check_every > 0);
+    NBX_CHECK_ARG(p == -0.5 || p == 0.5 || p == -1.0);
+    if (d_work == nullptr || work_bytes < nbx_sym_pow_ns_worksize(n)) {
+        nbx_set_error("nbx_sym_pow_ns: workspace %zu < %zu bytes", work_bytes, nbx_sym_pow_ns_worksize(n));
+        return NBX_E_NOMEM;
+    }
+    const int64_t n2 = n * n;
+    double* y[2] = {static_cast<double*>(d_work), static_cast<double*>(d_work) + n2};
+    double* z[2] = {y[1] + n2, y[1] + 2 * n2};
+    double* t = z[1] + n2;
+    double* partial = t + n2;
+    const unsigned eb = (unsigned)nbx_cdiv(n2, 256);
+    const int tb = (int)(eb < 128 ? eb : 128);
+    *h_iters = -1;
+    hipLaunchKernelGGL(ns_init_kernel, dim3(eb), dim3(256), 0, ctx->stream, n, d_s, 1.0 / c, y[0], z[0]);
+    NBX_LAUNCH_CHECK();
+    int cur = 0;
+    double prev = -1.0;
+    bool done = false, converged = false;
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        int rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, z[cur], n, 0, y[cur], n, 0, 0.0, t, n, 0, 1);  // Z Y
+        if (rc != NBX_OK) return rc;
+        hipLaunchKernelGGL(ns_t_kernel, dim3((unsigned)tb), dim3(256), 0, ctx->stream, n, t, partial);  // T = 3 I - Z Y
+        NBX_LAUNCH_CHECK();
+        if (it % check_every == check_every - 1 || done) {
+            double hp[128];
+            rc = nbx_memcpy_d2h(ctx, hp, partial, (size_t)tb * sizeof(double));
+            if (rc != NBX_OK) return rc;
+            double ss = 0.0;
+            for (int b = 0; b < tb; ++b) ss += hp[b];
+            const double res = sqrt(ss);
+            if (!(res == res) || res > 1.0e300) return NBX_OK;  // NaN / inf: not converged (*h_iters stays -1)
+            if (done || res < 1.0e-14 * (double)n) {
+                converged = true;
+                break;
+            }
+            // quadratic phase reached: one more step takes the residual to rounding level
+            if (res < 1.0e-6 || (prev >= 0.0 && res > 0.5 * prev && res < 1.0e-9)) done = true;
+            prev = res;
+        }
+        rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 0.5, y[cur], n, 0, t, n, 0, 0.0, y[cur ^ 1], n, 0, 1);  // Y T / 2
+        if (rc != NBX_OK) return rc;
+        rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 0.5, t, n, 0, z[cur], n, 0, 0.0, z[cur ^ 1], n, 0, 1);  // T Z / 2
+        if (rc != NBX_OK) return rc;
+        cur ^= 1;
+    }
+    if (!converged) return NBX_OK;
+    const double* src = p == 0.5 ? y[cur] : z[cur];
+    double scale = p == 0.5 ? sqrt(c) : 1.0 / sqrt(c);
+    if (p == -1.0) {  // A^-1 = Z Z
+        const int rc = nbx_gemm(ctx, 'N', 'N', n, n, n, 1.0, z[cur], n, 0, z[cur], n, 0, 0.0, t, n, 0, 1);
+        if (rc != NBX_OK) return rc;
+        src = t;
+        scale = 1.0 / c;
+    }
+    hipLaunchKernelGGL(ns_finish_kernel, dim3(eb), dim3(256), 0, ctx->stream, n, src, scale, d_out);
+    NBX_LAUNCH_CHECK();
+    *h_iters = it + 1;
+    return NBX_OK;
+}
