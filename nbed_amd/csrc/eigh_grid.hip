@@ -355,9 +355,10 @@ bool nbx_tdg_covers(int64_t n) {
 }
 
 // Householder reduction of `batch` symmetric matrices (lower triangles of d_a): d, e, tau (batch, n), Vg (batch, n, n)
-// with row k = reflector k in matrix coordinates.  work: nbx_tdg_work_doubles(n, batch) doubles.
+// with row k = reflector k in matrix coordinates.  work: nbx_tdg_work_doubles(n, batch) doubles.  status: a device
+// word of the caller's (64 bytes), zeroed here and set to 1 by a launch in which a hand-over never arrived.
 int nbx_tdg_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d, double* e, double* tau, double* Vg,
-                    double* work) {
+                    double* work, int* status) {
     const int N = (int)n;
     NBX_CHECK_ARG(N > 64 && N <= 2048);
     // workgroups: a power of two, at most 256, every one with a row; rows per workgroup at most eight
@@ -366,7 +367,10 @@ int nbx_tdg_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, d
     const int R = (N + P - 1) / P;
     NBX_CHECK_ARG(R <= 8);
     // matrices side by side in one launch (two waves each) while their rows fit the LDS, else one after the other
-    int* status = reinterpret_cast<int*>(work + (size_t)TDG_XCH * batch);
+    {
+        const int rc = nbx_memset(ctx, status, 0, 64);
+        if (rc != NBX_OK) return rc;
+    }
     const int per = (batch >= 2 && N <= 1024) ? 2 : 1;
     for (int64_t b0 = 0; b0 < batch; b0 += per) {
         const int nbt = (int)((batch - b0) < per ? (batch - b0) : per);

@@ -21,7 +21,7 @@
 bool nbx_tdg_covers(int64_t n);
 size_t nbx_tdg_work_doubles(int64_t n, int64_t batch);
 int nbx_tdg_tridiag(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a, double* d, double* e, double* tau, double* Vg,
-                    double* work);
+                    double* work, int* status);
 int nbx_tdg_backtransform(nbx_ctx* ctx, int64_t n, int64_t batch, const double* Vg, const double* tau, double* Z, double* work);
 
 namespace {
@@ -835,7 +835,7 @@ static int offdiag_diag_max(nbx_ctx* ctx, const double* M, int N, int64_t batch,
 }
 
 struct TdLayout {
-    size_t w_off, d_off, e_off, tau_off, vh_off, z_off, zt_off, scr_off, total;
+    size_t w_off, d_off, e_off, tau_off, vh_off, z_off, zt_off, scr_off, flag_off, total;
 };
 TdLayout layout(int64_t n, int64_t batch) {
     TdLayout L;
@@ -850,6 +850,7 @@ TdLayout layout(int64_t n, int64_t batch) {
     L.z_off = off; off += mat;
     L.zt_off = off; off += mat;
     L.scr_off = off; off += align256((size_t)(batch * 6 * n * n) * sizeof(double));
+    L.flag_off = off; off += 256;  // the whole-chip reduction's status word (scr is reused by the stages after it)
     L.total = off;
     return L;
 }
@@ -877,7 +878,7 @@ static int td_pipeline(nbx_ctx* ctx, int64_t n, int64_t batch, const double* d_a
     const bool grid = !in_memory && N > 198 && nbx_tdg_covers(n) &&
                       nbx_tdg_work_doubles(n, batch) <= (size_t)(batch * 6 * n * n);
     if (grid) {
-        const int rc = nbx_tdg_tridiag(ctx, n, batch, d_a, d, e, tau, Vh, scr);
+        const int rc = nbx_tdg_tridiag(ctx, n, batch, d_a, d, e, tau, Vh, scr, reinterpret_cast<int*>(base + L.flag_off));
         if (rc != NBX_OK) return rc;
     } else if (in_memory || !tridiag_reg_launch(ctx, N, batch, d_a, d, e, tau, Vh))
         hipLaunchKernelGGL(tridiag_kernel, dim3((unsigned)batch), dim3(TD_THREADS),
@@ -917,9 +918,13 @@ static int td_check(int64_t n, int64_t batch, const void* d_work, size_t work_by
     return NBX_OK;
 }
 
-__global__ void approx_status_kernel(const double* __restrict__ defect, int batch, int* __restrict__ status) {
+// (tdg: NULL, or the word the whole-chip reduction sets when a hand-over between its workgroups never arrived -- the
+//  tridiagonal matrix is then garbage, and orthonormal eigenvectors of garbage would pass the Gram test)
+__global__ void approx_status_kernel(const double* __restrict__ defect, int batch, int* __restrict__ status,
+                                     const int* __restrict__ tdg) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < batch) status[b] = (defect[2 * b] <= 1.0e-6 && defect[2 * b + 1] <= 1.0e-6) ? 1 : -1;  // NaN: -1
+    const bool reduced = tdg == nullptr || *tdg == 0;
+    if (b < batch) status[b] = (reduced && defect[2 * b] <= 1.0e-6 && defect[2 * b + 1] <= 1.0e-6) ? 1 : -1;  // NaN: -1
 }
 
 // include/nbx.h: eigenpairs to inverse-iteration accuracy with NOTHING read back -- a start for a warm solver
@@ -940,8 +945,11 @@ extern "C" int nbx_eigh_approx(nbx_ctx* ctx, int64_t n, int64_t batch, const dou
     nbx_prof_scope prof(ctx, NBX_PROF_EIGH);
     rc = td_pipeline(ctx, n, batch, d_a, d_w, L, base);
     if (rc != NBX_OK) return rc;
+    const bool grid = getenv("NBX_TRIDIAG_IN_MEMORY") == nullptr && n > 198 && nbx_tdg_covers(n) &&
+                      nbx_tdg_work_doubles(n, batch) <= (size_t)(batch * 6 * n * n);  // (td_pipeline's own test)
+    const int* tdg = grid ? reinterpret_cast<const int*>(base + L.flag_off) : nullptr;
     hipLaunchKernelGGL(approx_status_kernel, dim3((unsigned)nbx_cdiv(batch, 64)), dim3(64), 0, ctx->stream,
-                       ctx->d_scratch, (int)batch, d_status);
+                       ctx->d_scratch, (int)batch, d_status, tdg);
     NBX_LAUNCH_CHECK();
     // one Newton-Schulz step V = Z (3I - Z^T Z)/2: squares a defect below 1e-6 (status 1); vectors that
     // clusters left nearly dependent stay so, and status says it (-1)
