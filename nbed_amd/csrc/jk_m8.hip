@@ -1,0 +1,752 @@
+// libnbx: the J/K contraction on the 8-FOLD packed (pq|rs) -- every integral read once per build (what stands behind
+// get_veff of nbed/scf/huzinaga_scf.py:156; PySCF's own mf._eri is 8-fold packed too).
+//
+// jk_m4.hip streams the tiles T(p,q), q <= p, each the whole (r, s <= r) triangle: every (pq|rs) with (pq) != (rs) is in
+// HBM twice, as element (rs) of tile (pq) and as element (pq) of tile (rs).  Here a tile keeps the elements (rs) <= (pq)
+// only (jk_m8_layout.h: the block rows up to p / 4, in chunks), the element (rs) = (pq) halved, and each element does
+// the work of both its copies:
+//   K   the walk of jk_m4_walk.h gives Kp[p][r] += (pq|rs) D[q][s], Kp[p][s] += .. D[q][r], Kp[q][r] += .. D[p][s],
+//       Kp[q][s] += .. D[p][r] as before (now r <= p: the row-q partial of a tile has columns up to p, not q); the four
+//       terms of the mirrored copy are the transposes of these (symmetric D), so K = Kp + Kp^T -- no extra arithmetic;
+//   J   J[pq] += (pq|rs) D'[rs] is the flat dot product of the tile with the Dtot' table in the loading waves' registers
+//       as before; the mirrored copy's J[rs] += (pq|rs) D'[pq] is an AXPY of the tile into an accumulator of tile size in
+//       the same registers (one more FMA per element, on the value the dot product has read back anyway), kept for the
+//       whole range of the workgroup and summed over the workgroups in a fixed order by the reduction kernel.
+// Tiles are of different lengths now, so (a) the chunk sequence of a range is produced by run-time iterators (which chunk
+// of which tile goes into the ring next) while every chunk is the same number of LDS-DMA instructions -- the s_waitcnt
+// immediates stay static --, (b) the code of a step is still specialised per chunk: the steps of a tile are unrolled
+// over k with a uniform exit at k = nk(p), (c) the ranges of the persistent workgroups are cut at equal COST
+// (m8_first_tile), not at equal tile counts.
+// Roles, ring, LDS-DMA, X operands, fixed-order partial rows: jk_m4.hip / jk_mx.hip.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "jk_m8_layout.h"
+#include "jk_m4_walk.h"
+#include "nbx_common.h"
+
+#pragma clang diagnostic ignored "-Winline-asm"
+
+namespace {
+
+constexpr int M8_THREADS = 512;
+#ifndef NBX_M8_ABL
+#define NBX_M8_ABL 0
+#endif
+#ifndef NBX_M8_DBG_WG
+#define NBX_M8_DBG_WG 255
+#endif
+constexpr int M8_ABL = NBX_M8_ABL;  // TEMPORARY ablation bits: 1 no row stores, 2 no row reductions, 4 no X refresh, 8 no J2, 16 no walk, 32 no J dot
+typedef __attribute__((address_space(3))) void* m8_lds_vp;
+typedef double m8_d2 __attribute__((ext_vector_type(2)));
+
+__host__ __device__ __forceinline__ int m8_tri_row(int64_t T) {
+    int64_t p = (int64_t)((sqrt(8.0 * (double)T + 1.0) - 1.0) * 0.5);
+    while (p * (p + 1) / 2 > T) --p;
+    while ((p + 1) * (p + 2) / 2 <= T) ++p;
+    return (int)p;
+}
+
+template <int K0, int K1, class F>
+__device__ __forceinline__ void m8_for(F&& f) {
+    if constexpr (K0 < K1) {
+        f(std::integral_constant<int, K0>{});
+        m8_for<K0 + 1, K1>(f);
+    }
+}
+
+template <int CNT>
+__device__ __forceinline__ void m8_wait_vm() {
+    static_assert(CNT >= 0 && CNT <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------- pack and weights
+// slab rows [p0, p0 + np) of the dense tensor -> 8-fold tiles; one workgroup per tile
+// (nsrc <= N: the dense tensor's own size; the tiles p < nsrc exist, their elements beyond nsrc are stored as zeros)
+template <class G>
+__global__ __launch_bounds__(256) void m8_pack_kernel(const double* __restrict__ eri, double* __restrict__ out, int p0,
+                                                      int64_t t_begin, int nsrc) {
+    const int64_t T = t_begin + blockIdx.x;
+    const int p = m8_tri_row(T), q = (int)(T - (int64_t)p * (p + 1) / 2);
+    const double* src = eri + ((int64_t)(p - p0) * nsrc + q) * nsrc * nsrc;
+    double* dst = out + (m8_tile_offset<G>(T) - m8_tile_offset<G>(t_begin));
+    const int len = G::len(m8_nk<G>(p));
+    for (int e = threadIdx.x; e < len; e += 256) {
+        const int blk = e >> 4;
+        const int bt = m8_tri_row(blk), bc = blk - m4_tri(bt);
+        const int k = ((e >> 2) & 3) ^ ((bt ^ bc) & 3), i = (e & 3) ^ k;  // (the swizzle: jk_m4.hip)
+        const int row = 4 * bt + i, col = 4 * bc + k;
+        const bool keep = col <= row && (row < p || (row == p && col <= q));  // (rs) <= (pq); row <= p < nsrc
+        const double v = keep ? src[(int64_t)row * nsrc + col] : 0.0;
+        dst[e] = (row == p && col == q) ? 0.5 * v : v;
+    }
+}
+
+// Dtot' in the staging order (m8_stage_index): Dtot[r][c] + Dtot[c][r] below the diagonal, Dtot[r][r] on it, 0 elsewhere
+template <class G>
+__global__ __launch_bounds__(256) void m8_weights_kernel(const double* __restrict__ dm, int ndm, double* __restrict__ wt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G::NCH * G::LP * M4_PROD_THREADS) return;
+    const int tid = i % M4_PROD_THREADS, s = (i / M4_PROD_THREADS) % G::LP, k = (i / M4_PROD_THREADS) / G::LP;
+    const int d0 = (s * M4_PROD_THREADS + tid) * 2, dend = 16 * G::blocks(k);
+    const int64_t n2 = (int64_t)G::N * G::N;
+    double out[2] = {0.0, 0.0};
+    for (int e = 0; e < 2; ++e) {
+        const int d = d0 + e;
+        if (d >= dend) continue;
+        const int blk = G::start(k) + (d >> 4);
+        const int bt = m8_tri_row(blk), bc = blk - m4_tri(bt);
+        const int kk = ((d >> 2) & 3) ^ ((bt ^ bc) & 3), ii = (d & 3) ^ kk;
+        const int row = 4 * bt + ii, col = 4 * bc + kk;
+        if (col > row) continue;
+        double v = 0.0, vt = 0.0;
+        for (int x = 0; x < ndm; ++x) {
+            v += dm[x * n2 + (int64_t)row * G::N + col];
+            vt += dm[x * n2 + (int64_t)col * G::N + row];
+        }
+        out[e] = row == col ? v : v + vt;
+    }
+    *reinterpret_cast<double2*>(wt + 2 * (int64_t)i) = make_double2(out[0], out[1]);
+}
+
+// ---------------------------------------------------------------------------------------------- the kernel
+// kpart1[(w S + slot) NDM + x][N]: row-p partial of workgroup w for the slot-th row of its range (columns <= p);
+// kpart2[(T - t_begin) NDM + x][N]: row-q partial of tile T (q < p; columns <= p);
+// jfull (N, N): J[p][q] = J[q][p] = the dot-product half of J for the tiles visited;
+// jpart[w][NCH LP 512]: workgroup w's AXPY half of J, in the staging order
+template <int NB, int NDM, int LP>
+__global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __restrict__ packed, const double* __restrict__ dm,
+                                                              const double* __restrict__ wtab, double* __restrict__ jfull,
+                                                              double* __restrict__ kpart1, double* __restrict__ kpart2,
+                                                              double* __restrict__ jpart, int64_t t_begin, int64_t t_end, int S, double* __restrict__ dbg) {
+    using G_ = M8Geom<NB, LP>;
+    constexpr int N = G_::N, NG = G_::NG, NCH = G_::NCH, BUF = G_::BUF, PT = M4_PROD_THREADS, RING = G_::RING, AHEAD = RING - 1;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* buf0 = smem;                     // [RING][BUF] chunk buffers
+    double* xs0 = smem + RING * BUF;         // [2][N][4] X of the current / next tile
+    double* redq0 = xs0 + 2 * 4 * N;         // [2][4][NG][32] consumers' row-q halves (odd columns), by tile parity
+    double* redp = redq0 + 2 * 4 * NG * 32;  // [4][NG][32] consumers' row-p halves (even columns) of a row that has ended
+    double* jred = redp + 4 * NG * 32;       // [2][4] producers' J partials per tile parity
+    double* jstage = jred + 16;              // [tiles of the range] J of the tiles done, stored at the end of the range
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
+    const int ptid = tid - 256;  // producers: 0 .. 255
+
+    const int W = (int)gridDim.x;
+    const int64_t T0 = m8_first_tile<G_>(t_begin, t_end, W, (int)blockIdx.x);
+    const int64_t T_end = m8_first_tile<G_>(t_begin, t_end, W, (int)blockIdx.x + 1);
+    if (T0 >= T_end) return;  // uniform for the whole workgroup
+    const int p_first = m8_tri_row(T0);
+    const int ntile = (int)(T_end - T0);
+    const double* tile0 = packed + (m8_tile_offset<G_>(T0) - m8_tile_offset<G_>(t_begin));
+    const uint64_t dbg_t0 = (M8_ABL & 64) ? __builtin_readcyclecounter() : 0;
+    const uint64_t dbg_r0 = (M8_ABL & 64) ? wall_clock64() : 0;
+    double* dbgl = jstage + 512;  // (variant builds only: [2 roles][64 steps][8 stamps])
+    const bool dbg_on = (M8_ABL & 128) && (int)blockIdx.x == NBX_M8_DBG_WG;
+    if ((M8_ABL & 128) && dbg_on) {
+        for (int i = tid; i < 1024; i += M8_THREADS) dbgl[i] = 0.0;
+        __syncthreads();
+    }
+
+    // X of a tile: xs[n][c] = D^{c / 2}[c & 1 ? p : q][n]  (NDM = 1: columns 2, 3 are zero); by the CONSUMER waves
+    constexpr int XU = (4 * N + PT - 1) / PT;
+    auto fetch_x = [&](int pp, int qq, double (&v)[XU]) {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int e = tid + PT * u;  // element e = 4 n + c
+            const int n = e >> 2, cc = e & 3, x = cc >> 1;
+            const int off = x * N * N + ((cc & 1) ? pp : qq) * N + n;
+            v[u] = (e < 4 * N && x < NDM) ? dm[off] : 0.0;
+        }
+    };
+    auto store_x = [&](double* xs, const double (&v)[XU]) {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int e = tid + PT * u;
+            if (e < 4 * N) xs[e] = v[u];
+        }
+    };
+    // the consumers' partial rows of a finished tile: summed over the four consumer waves, in wave order; `last`: the
+    // last column that is stored
+    auto reduce_rows = [&](const double* red, int parity, double* dst, int last) {  // dst[x N + row]
+        for (int e = ptid; e < NG * 32; e += PT) {
+            const int g = e >> 5, l = 2 * (e & 31) + parity;
+            const int row = 16 * g + 4 * ((l >> 2) & 3) + (l >> 4), x = (l & 3) >> 1;
+            if (M8_ABL & 2) continue;
+            const double v = (red[e] + red[NG * 32 + e]) + (red[2 * NG * 32 + e] + red[3 * NG * 32 + e]);
+            if (M8_ABL & 1) {
+                if (v == 1.2345e300) dst[0] = v;
+                continue;
+            }
+            if (row <= last && x < NDM) dst[x * N + row] = v;
+        }
+    };
+    auto next_pq = [](int& pp, int& qq) {
+        if (++qq > pp) {
+            ++pp;
+            qq = 0;
+        }
+    };
+
+    int p = p_first, q = (int)(T0 - (int64_t)p * (p + 1) / 2);
+    if (producer) {
+        // ------------------------------------------------------------------ the loading waves
+        m8_d2 wres[NCH][LP];  // Dtot' of the whole tile (the same for every tile)
+        double j2x[NCH][LP], j2y[NCH][LP];  // J[rs] += (pq|rs) D'[pq], summed over the tiles of the range
+        double jacc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int s = 0; s < LP; ++s) {
+                wres[k][s] = *reinterpret_cast<const m8_d2*>(wtab + 2 * ((k * LP + s) * PT + ptid));
+                j2x[k][s] = j2y[k][s] = 0.0;
+            }
+        if (ptid < 8) jred[ptid] = 0.0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the table: nothing of the compiler's in the counter from here)
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int s = 0; s < LP; ++s) asm volatile("" : "+v"(wres[k][s]));  // (the compiler's own wait for the table: here, not behind the first chunk loads)
+        // the chunk that goes into the ring next: chunk ik of tile it = (ip, iq), which has ink chunks and starts at itile
+        int it = 0, ik = 0, ip = p, iq = q, ink = m8_nk<G_>(p);
+        const double* itile = tile0;
+        int islot = 0;
+        // Chunk -> ring slot: global_load_lds_dwordx4, lane l of a wave lands its 16 bytes at the instruction's LDS base +
+        // 16 l; slot s of the chunk is one instruction per producer wave (thread ptid's two doubles of slot s at
+        // (s PT + ptid) 2).  Every chunk is LP instructions per wave (the tail re-reads the chunk's last 16 bytes; a chunk
+        // past the last tile re-reads the first tile's first: landed in a free slot, never read).
+        auto issue_next = [&]() {
+            const bool real = it < ntile;
+            const double* tile = real ? itile : tile0;
+            const int kk = real ? ik : 0;
+            int begin = 0, end = 16 * G_::blocks(0);
+            m8_for<1, NCH>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                begin = kk == k ? 16 * G_::start(k) : begin;
+                end = kk == k ? 16 * (G_::start(k) + G_::blocks(k)) : end;
+            });
+            double* buf = buf0 + islot * BUF;
+            islot = islot + 1 == RING ? 0 : islot + 1;
+            int pt_ = ptid;  // (opaque per chunk: the clamped offsets are recomputed, not kept in registers)
+            asm volatile("" : "+v"(pt_));
+#pragma unroll
+            for (int s = 0; s < LP; ++s) {
+                int d = begin + (s * PT + pt_) * 2;
+                d = min(d, end - 2);
+                const unsigned off = 8u * (unsigned)d;
+                const unsigned lds_a = (unsigned)(size_t)(m8_lds_vp)(buf + (s * PT + (wave - 4) * 64) * 2);
+                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(off), "s"(tile), "s"(lds_a) : "memory", "m0");
+            }
+            if (real && ++ik == ink) {
+                int ln = G_::len(1);
+                m8_for<2, NCH + 1>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    ln = ink == k ? G_::len(k) : ln;
+                });
+                itile += ln;
+                ik = 0;
+                ++it;
+                next_pq(ip, iq);
+                ink = m8_nk<G_>(ip);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < AHEAD; ++c) issue_next();
+        m8_wait_vm<(AHEAD - 1) * LP>();  // my part of the first chunk
+        __syncthreads();
+        int jslot = 0;  // ring slot of the chunk the consumers walk at this step
+        int dbg_n = 0;
+#define STAMP(slot_) if ((M8_ABL & 128) && dbg_on && dbg_n < 64 && (tid & 255) == 0) dbgl[((tid >> 8) * 64 + dbg_n) * 8 + (slot_)] = (double)(wall_clock64() - dbg_r0)
+        for (int t = 0; t < ntile; ++t) {
+            const int64_t T = T0 + t;
+            const int nk = m8_nk<G_>(p);
+            int pn = p, qn = q;
+            next_pq(pn, qn);
+            // D'[pq] of this tile from its X (xs[n][c] = D^{c / 2}[c & 1 ? p : q][n])
+            double dpq;
+            {
+                const double* xs = xs0 + (t & 1) * 4 * N;
+                const double dp = xs[4 * q + 1] + xs[4 * q + 3];  // sum over spins of D[p][q]
+                const double dq = xs[4 * p + 0] + xs[4 * p + 2];  //                    D[q][p]
+                dpq = q < p ? dp + dq : dp;
+            }
+            m8_for<0, NCH>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (k < nk) {
+                    // step (t, k): the consumers walk chunk k; the chunk AHEAD steps on goes into the slot they left at the
+                    // last barrier; the next chunk has landed when this step ends
+                    STAMP(0);
+                    issue_next();  // (first: the stream is what the kernel is bound by)
+                    STAMP(1);
+                    if (k == 0 && t > 0) {
+                        // the consumers' rows of tile t - 1 (written at its last step, behind that step's barrier), and its J
+                        int pp = p, qq = q - 1;
+                        if (qq < 0) {
+                            pp = p - 1;
+                            qq = pp;
+                        }
+                        if (qq < pp) reduce_rows(redq0 + ((t - 1) & 1) * 4 * NG * 32, 1, kpart2 + ((T - 1 - t_begin) * NDM) * (int64_t)N, pp);
+                        if (pp != p) reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
+                        if (ptid == 0) {
+                            const double* jr = jred + ((t - 1) & 1) * 4;
+                            jstage[t - 1] = (jr[0] + jr[1]) + (jr[2] + jr[3]);
+                        }
+                        // (the one case in which the consumers write the row-p buffer in the step in which it is read: the
+                        //  range ends with a single-step tile that opens a row -- the last tile always hands its row over)
+                        if (pp != p && nk == 1 && t + 1 == ntile) __syncthreads();
+                    }
+                    STAMP(2);
+                    {  // the two J contributions of chunk k (the one being walked: it landed a step ago)
+                        const double* buf = buf0 + jslot * BUF;
+                        jslot = jslot + 1 == RING ? 0 : jslot + 1;
+#pragma unroll
+                        for (int s = 0; s < LP; ++s) {
+                            const double2 v = *reinterpret_cast<const double2*>(buf + (s * PT + ptid) * 2);
+                            if (!(M8_ABL & 32)) jacc = fma(v.y, wres[k][s].y, fma(v.x, wres[k][s].x, jacc));
+                            if (!(M8_ABL & 8)) j2x[k][s] = fma(v.x, dpq, j2x[k][s]);
+                            if (!(M8_ABL & 8)) j2y[k][s] = fma(v.y, dpq, j2y[k][s]);
+                            asm volatile("" : "+v"(j2x[k][s]), "+v"(j2y[k][s]));  // (here: left alone, the compiler sinks the FMAs of every
+                                                                                    //  step to the tile's end and keeps each chunk's read-back alive)
+                        }
+                        asm volatile("" : "+v"(jacc));
+                    }
+                    STAMP(3);
+                    if (k == nk - 1) {  // this wave's share of tile t's J[pq]
+                        jacc = nbx_wave_sum_dpp(jacc);  // (every lane active; not the LDS butterfly: six ds_bpermute round trips, 0.4 us, at every tile end)
+                        if (lane == 0) jred[(t & 1) * 4 + (wave - 4)] = jacc;
+                        jacc = 0.0;
+                    }
+                    STAMP(4);
+                    m8_wait_vm<(AHEAD - 1) * LP>();  // my part of the next chunk
+                    STAMP(5);
+                    ++dbg_n;
+                    __syncthreads();
+                }
+            });
+            p = pn;
+            q = qn;
+        }
+        if ((M8_ABL & 128) && dbg_on) {
+            __syncthreads();
+            for (int i = ptid; i < 1024; i += PT) dbg[4 * M8_CUS + i] = dbgl[i];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the padding chunks: nothing may land after the workgroup has gone)
+        // the last tile's rows ((p, q) has moved one past it)
+        int pp = p, qq = q - 1;
+        if (qq < 0) {
+            pp = p - 1;
+            qq = pp;
+        }
+        if (qq < pp) reduce_rows(redq0 + ((ntile - 1) & 1) * 4 * NG * 32, 1, kpart2 + ((T_end - 1 - t_begin) * NDM) * (int64_t)N, pp);
+        reduce_rows(redp, 0, kpart1 + (((int64_t)blockIdx.x * S + (pp - p_first)) * NDM) * N, pp);
+        // the AXPY half of J of this range
+        {
+            double* dst = jpart + (int64_t)blockIdx.x * (NCH * LP * PT * 2) + 2 * ptid;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+#pragma unroll
+                for (int s = 0; s < LP; ++s)
+                    *reinterpret_cast<double2*>(dst + (k * LP + s) * PT * 2) = make_double2(j2x[k][s], j2y[k][s]);
+        }
+        if (wave == 4) {  // J of every tile of the range: lane i stores tile i's (one wave: its LDS operations are in order)
+            if (lane == 0) {
+                const double* jr = jred + ((ntile - 1) & 1) * 4;
+                jstage[ntile - 1] = (jr[0] + jr[1]) + (jr[2] + jr[3]);
+            }
+            for (int i = lane; i < ntile; i += 64) {
+                const int64_t Ti = T0 + i;
+                const int pi = m8_tri_row(Ti), qi = (int)(Ti - (int64_t)pi * (pi + 1) / 2);
+                const double j = jstage[i];
+                jfull[(int64_t)pi * N + qi] = j;
+                jfull[(int64_t)qi * N + pi] = j;
+            }
+            if ((M8_ABL & 64) && lane == 0) {
+                dbg[4 * blockIdx.x + 0] = (double)(__builtin_readcyclecounter() - dbg_t0);
+                dbg[4 * blockIdx.x + 1] = (double)(wall_clock64() - dbg_r0);
+                dbg[4 * blockIdx.x + 2] = (double)ntile;
+                dbg[4 * blockIdx.x + 3] = (double)p_first;
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ the walking waves
+        double acc[NG], bxr[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = bxr[g] = 0.0;
+        M4Lane<NG> ln;
+        ln.a = lane >> 4;
+        ln.b = (lane >> 2) & 3;
+        ln.c = lane & 3;
+        {
+            const int w4 = wave & 3;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                ln.rowg[g] = 64 * g * ln.b + 16 * (m4_tri(ln.b) + w4) + 4 * (ln.a ^ ln.b ^ w4) + (ln.c ^ ln.a);
+            ln.xlane = 4 * ln.a + ln.c;
+            ln.xrow = ln.xlane + 16 * w4;
+            ln.col0 = 16 * ln.b + (ln.a ^ ln.c);
+            ln.cbx = ln.c ^ ln.b;
+        }
+        // X two tiles ahead: the X of tile t + 1 is stored at the first step of tile t (into the buffer tile t - 1 has left),
+        // from registers that were loaded at the first step of tile t - 1 -- a tile may be a single step
+        double xv[XU];
+        int px = p, qx = q;  // the tile whose X is fetched next
+        fetch_x(px, qx, xv);
+        store_x(xs0, xv);
+        if (ntile > 1) next_pq(px, qx);
+        fetch_x(px, qx, xv);  // X of tile 1
+        __syncthreads();
+        int slot = 0;  // ring slot of the chunk being walked
+        int dbg_n = 0;
+        for (int t = 0; t < ntile; ++t) {
+            const int nk = m8_nk<G_>(p);
+            int pn = p, qn = q;
+            next_pq(pn, qn);
+            const bool more = t + 1 < ntile;
+            const bool row_ends = pn != p || !more;
+            const double* xs = xs0 + (t & 1) * 4 * N;
+            m8_for<0, NCH>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (k < nk) {
+                    const double* buf = buf0 + slot * BUF;
+                    slot = slot + 1 == RING ? 0 : slot + 1;
+                    STAMP(0);
+                    if (!(M8_ABL & 16)) m4_walk_chunk<G_, k>(buf, xs, wave, ln, acc, bxr);
+                    __builtin_amdgcn_sched_barrier(0);
+                    STAMP(1);
+                    if (k == 0 && !(M8_ABL & 4)) {
+                        if (more) store_x(xs0 + ((t + 1) & 1) * 4 * N, xv);
+                        STAMP(2);
+                        if (t + 2 < ntile) next_pq(px, qx);
+                        fetch_x(px, qx, xv);
+                    }
+                    STAMP(3);
+                    if (k == nk - 1) {
+                        // end of tile: the row-q halves (odd columns: they used D[p][:]) leave the registers; the row-p halves
+                        // (even columns) stay until the row changes.  The producers sum them up during the next step.
+                        const bool odd = lane & 1;
+                        double* redq = redq0 + (t & 1) * 4 * NG * 32;
+                        if (t > 0 && q == 0 && nk == 1 && !more) __syncthreads();  // (see the loading waves: the row-p buffer is still being read)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            if (odd) redq[(wave * NG + g) * 32 + (lane >> 1)] = acc[g];
+                            else if (row_ends) redp[(wave * NG + g) * 32 + (lane >> 1)] = acc[g];
+                            acc[g] = (odd || row_ends) ? 0.0 : acc[g];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // (the MFMAs stay above the barrier: jk_m4.hip)
+                    STAMP(5);
+                    ++dbg_n;
+                    __syncthreads();
+                }
+            });
+            p = pn;
+            q = qn;
+        }
+        if ((M8_ABL & 128) && dbg_on) __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- the reductions
+// (1) kpf[x][r][c] = Kp[r][c], every column: the row-p partials of the workgroups whose range has tiles of row r (c <= r)
+//     + the row-q partials of the tiles (P, r), P > r, P >= c.   N NDM ceil(N / 64) blocks, 256 threads = 4 interleaved
+//     partial sums over P x 64 columns; fixed summation order.
+// (2) (the blocks behind those, same launch) j2sum[e] = sum over the workgroups of jpart[w][e], e in the staging order
+template <class G>
+__global__ __launch_bounds__(256) void m8_reduce_kernel(const double* __restrict__ kpart1, const double* __restrict__ kpart2,
+                                                        const double* __restrict__ jpart, double* __restrict__ kpf,
+                                                        double* __restrict__ j2sum, int p0, int np, int ndm, int64_t t_begin,
+                                                        int64_t t_end, int W, int S) {
+    constexpr int N = G::N, JLEN = G::NCH * G::LP * M4_PROD_THREADS * 2, CZ = (N + 63) / 64;
+    __shared__ double part[8][64];
+    const int nkb = N * ndm * CZ;  // blocks of the first kind
+    if ((int)blockIdx.x >= nkb) {
+        // 32 double pairs per block, the workgroups in eight interleaved groups
+        const int blk = (int)blockIdx.x - nkb;
+        const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+        const int e = (blk * 32 + l) * 2;
+        double sx = 0.0, sy = 0.0;
+        if (e < JLEN) {
+            int w = grp;
+            for (; w + 24 < W; w += 32) {
+                double2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const double2*>(jpart + (int64_t)(w + 8 * u) * JLEN + e);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    sx += v[u].x;
+                    sy += v[u].y;
+                }
+            }
+            for (; w < W; w += 8) {
+                const double2 v = *reinterpret_cast<const double2*>(jpart + (int64_t)w * JLEN + e);
+                sx += v.x;
+                sy += v.y;
+            }
+        }
+        part[grp][l] = sx;
+        part[grp][32 + l] = sy;
+        __syncthreads();
+        if (grp == 0 && e < JLEN) {
+            double tx = part[0][l], ty = part[0][32 + l];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) {
+                tx += part[g][l];
+                ty += part[g][32 + l];
+            }
+            *reinterpret_cast<double2*>(j2sum + e) = make_double2(tx, ty);
+        }
+        return;
+    }
+    const int row = (int)blockIdx.x % N, x = ((int)blockIdx.x / N) % ndm, bz = (int)blockIdx.x / (N * ndm);
+    const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+    const int c = bz * 64 + lane;
+    double t = 0.0;
+    if (c < N) {
+        const double* src = kpart2 + (int64_t)x * N + c;
+        const int64_t stride = (int64_t)ndm * N;
+        const int first = max(max(row + 1, c), p0);  // first global P
+        auto at = [&](int P) { return src[((int64_t)P * (P + 1) / 2 + row - t_begin) * stride]; };
+        int P = first + chunk;
+        for (; P + 7 * 4 < p0 + np; P += 8 * 4) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = at(P + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; P < p0 + np; P += 4) t += at(P);
+    }
+    part[chunk][lane] = t;
+    __syncthreads();
+    if (chunk == 0 && c < N) {
+        double tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (row >= p0 && row < p0 + np && c <= row) {
+            const int w_lo = m8_wg_of<G>(t_begin, t_end, W, m4_tri(row)), w_hi = m8_wg_of<G>(t_begin, t_end, W, m4_tri(row) + row);
+            for (int w = w_lo; w <= w_hi; ++w) {
+                const int slot = row - m8_tri_row(m8_first_tile<G>(t_begin, t_end, W, w));
+                tot += kpart1[(((int64_t)w * S + slot) * ndm + x) * N + c];
+            }
+        }
+        kpf[((int64_t)x * N + row) * N + c] = tot;
+    }
+}
+
+// K = Kp + Kp^T, J = the dot-product half + the AXPY half (J[r][c] = J[c][r]), and the Fock epilogue F = hv + J - K
+template <class G>
+__global__ __launch_bounds__(256) void m8_finish_kernel(const double* __restrict__ kpf, const double* __restrict__ j2sum,
+                                                        double* __restrict__ jout, double* __restrict__ kout, int ndm,
+                                                        const double* __restrict__ hv, double* __restrict__ fock,
+                                                        double* __restrict__ vhf) {
+    constexpr int N = G::N;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * N) return;
+    const int r = i / N, c = i - r * N;
+    const int hi = r > c ? r : c, lo = r > c ? c : r;
+    const double j = jout[i] + j2sum[m8_stage_index<G>(hi, lo)];
+    for (int x = 0; x < ndm; ++x) {
+        const double k = kpf[((int64_t)x * N + r) * N + c] + kpf[((int64_t)x * N + c) * N + r];
+        const int64_t o = (int64_t)x * N * N + i;
+        kout[o] = k;
+        if (fock != nullptr) {
+            const double v = j - k;
+            fock[o] = hv[o] + v;
+            if (vhf != nullptr) vhf[o] = v;
+        }
+    }
+    jout[i] = j;
+}
+
+size_t m8_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct M8Plan {
+    int wgs, S, lmax;
+    size_t wt_off, k1_off, k2_off, jp_off, js_off, kpf_off, dbg_off, total, lds_bytes;
+};
+
+template <class G>
+M8Plan m8_plan(int64_t p0, int64_t np, int64_t ndm) {
+    M8Plan pl;
+    const int64_t t_begin = m4_tri((int)p0), t_end = m4_tri((int)(p0 + np));
+    const int64_t ntiles = t_end - t_begin;
+    pl.wgs = (int)(ntiles < M8_CUS ? (ntiles > 0 ? ntiles : 1) : M8_CUS);
+    int S = 1, lmax = 1;
+    for (int w = 0; w < pl.wgs; ++w) {
+        const int64_t a = m8_first_tile<G>(t_begin, t_end, pl.wgs, w), b = m8_first_tile<G>(t_begin, t_end, pl.wgs, w + 1);
+        if (b <= a) continue;
+        const int rows = m8_tri_row(b - 1) - m8_tri_row(a) + 1;
+        S = rows > S ? rows : S;
+        lmax = (int)(b - a) > lmax ? (int)(b - a) : lmax;
+    }
+    pl.S = S;
+    pl.lmax = lmax;
+    pl.lds_bytes = (size_t)(G::RING * G::BUF + G::FIXED + ((M8_ABL & 128) ? 512 + 1024 : lmax)) * sizeof(double);
+    const size_t jlen = (size_t)G::NCH * G::LP * M4_PROD_THREADS * 2;
+    size_t off = 0;
+    pl.wt_off = off; off += m8_align256(jlen * sizeof(double));
+    pl.k1_off = off; off += m8_align256((size_t)((int64_t)pl.wgs * pl.S * ndm * G::N) * sizeof(double));
+    pl.k2_off = off; off += m8_align256((size_t)(ntiles * ndm * G::N) * sizeof(double));
+    pl.jp_off = off; off += m8_align256((size_t)pl.wgs * jlen * sizeof(double));
+    pl.js_off = off; off += m8_align256(jlen * sizeof(double));
+    pl.kpf_off = off; off += m8_align256((size_t)(ndm * G::N * G::N) * sizeof(double));
+    pl.dbg_off = off; off += (M8_ABL & 64) ? (4 * M8_CUS + 1024) * sizeof(double) : 0;
+    pl.total = off;
+    return pl;
+}
+
+template <int NB, int LP>
+int m8_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm, double* d_jk,
+           void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt_in) {
+    using G = M8Geom<NB, LP>;
+    const int64_t np = p1 - p0, N = G::N, n2 = N * N;
+    const M8Plan pl = m8_plan<G>(p0, np, ndm);
+    if (pl.lds_bytes > (size_t)M8_LDS_BYTES) {
+        nbx_set_error("nbx_jk_m8: %zu bytes of LDS for N = %lld", pl.lds_bytes, (long long)N);
+        return NBX_E_UNSUPPORTED;
+    }
+    char* base = static_cast<char*>(d_work);
+    double* wt = reinterpret_cast<double*>(base + pl.wt_off);
+    double* k1 = reinterpret_cast<double*>(base + pl.k1_off);
+    double* k2 = reinterpret_cast<double*>(base + pl.k2_off);
+    double* jp = reinterpret_cast<double*>(base + pl.jp_off);
+    double* js = reinterpret_cast<double*>(base + pl.js_off);
+    double* kpf = reinterpret_cast<double*>(base + pl.kpf_off);
+    if (np < N) {  // J entries this slab does not own must read as zero
+        const int rc = nbx_memset(ctx, d_jk, 0, (size_t)n2 * sizeof(double));
+        if (rc != NBX_OK) return rc;
+    }
+    constexpr int JSLOTS = G::NCH * G::LP * M4_PROD_THREADS;
+    if (d_wt_in != nullptr) {
+        wt = const_cast<double*>(d_wt_in);
+    } else {
+        hipLaunchKernelGGL(m8_weights_kernel<G>, dim3((unsigned)nbx_cdiv(JSLOTS, 256)), dim3(256), 0, ctx->stream, d_dm, (int)ndm, wt);
+        NBX_LAUNCH_CHECK();
+    }
+    const int64_t t_begin = m4_tri((int)p0), t_end = m4_tri((int)p1);
+    {
+        nbx_prof_scope prof(ctx, NBX_PROF_JK_DENSE);
+        static bool attr_set = false;
+        if (!attr_set) {
+            const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&jk_m8_kernel<NB, 1, LP>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, M8_LDS_BYTES);
+            const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&jk_m8_kernel<NB, 2, LP>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, M8_LDS_BYTES);
+            if (e1 != hipSuccess || e2 != hipSuccess) {
+                nbx_set_error("nbx_jk_m8: hipFuncSetAttribute(%d bytes of LDS): %s", M8_LDS_BYTES,
+                              hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+                return NBX_E_HIP;
+            }
+            attr_set = true;
+        }
+        if (ndm == 2)
+            hipLaunchKernelGGL((jk_m8_kernel<NB, 2, LP>), dim3((unsigned)pl.wgs), dim3(M8_THREADS), pl.lds_bytes, ctx->stream,
+                               d_packed, d_dm, wt, d_jk, k1, k2, jp, t_begin, t_end, pl.S, reinterpret_cast<double*>(base + pl.dbg_off));
+        else
+            hipLaunchKernelGGL((jk_m8_kernel<NB, 1, LP>), dim3((unsigned)pl.wgs), dim3(M8_THREADS), pl.lds_bytes, ctx->stream,
+                               d_packed, d_dm, wt, d_jk, k1, k2, jp, t_begin, t_end, pl.S, reinterpret_cast<double*>(base + pl.dbg_off));
+    }
+    NBX_LAUNCH_CHECK();
+    if (M8_ABL & 64) {
+        static int calls = 0;
+        if (++calls == 20) {
+            static double h[4 * M8_CUS + 1024];
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(h, base + pl.dbg_off, sizeof(h), hipMemcpyDeviceToHost);
+            for (int w = 0; w < pl.wgs; ++w)
+                fprintf(stderr, "m8dbg wg %d cycles %.0f wall %.0f ntile %.0f p_first %.0f\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
+            if (M8_ABL & 128)
+                for (int r = 0; r < 2; ++r)
+                    for (int i = 0; i < 64; ++i) {
+                        const double* o = h + 4 * M8_CUS + (r * 64 + i) * 8;
+                        fprintf(stderr, "m8step %s step %d stamps %.0f %.0f %.0f %.0f %.0f %.0f\n", r ? "producer" : "consumer", i, o[0], o[1], o[2], o[3], o[4], o[5]);
+                    }
+        }
+    }
+    {  // the two reductions in one launch
+        const int jblocks = (int)nbx_cdiv(JSLOTS, 32);
+        const int nkb = (int)(N * ndm * nbx_cdiv(N, 64));
+        hipLaunchKernelGGL(m8_reduce_kernel<G>, dim3((unsigned)(nkb + jblocks)), dim3(256), 0, ctx->stream, k1, k2, jp, kpf, js,
+                           (int)p0, (int)np, (int)ndm, t_begin, t_end, pl.wgs, pl.S);
+        NBX_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(m8_finish_kernel<G>, dim3((unsigned)nbx_cdiv(n2, 256)), dim3(256), 0, ctx->stream, kpf, js, d_jk, d_jk + n2,
+                       (int)ndm, d_hv, d_fock, d_vhf);
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+}  // namespace
+
+// The sizes this kernel has an instance for (N = 4 NB).  NBX_JK_M8=0 in the environment (read once per process) hands
+// them back to jk_m4.hip's 4-fold form.
+#ifndef NBX_M8_SIZES
+#define NBX_M8_SIZES(X) X(37)
+#endif
+#ifndef NBX_M8_LP
+#define NBX_M8_LP 6  // LDS-DMA instructions per loading wave and chunk (a chunk = 32 NBX_M8_LP blocks at most; measured: 3 .. 7)
+#endif
+#define M8_DISPATCH(N_, EXPR)            \
+    switch ((int)((N_) / 4)) {           \
+        NBX_M8_SIZES(M8_CASE_##EXPR)     \
+        default: break;                  \
+    }
+bool nbx_jk_m8_covers(int64_t N) {
+    static const bool on = getenv("NBX_JK_M8") != nullptr && atoi(getenv("NBX_JK_M8")) != 0;
+    if (!on || N % 4 != 0) return false;
+#define M8_CASE_covers(NB_) case NB_: return true;
+    M8_DISPATCH(N, covers)
+#undef M8_CASE_covers
+    return false;
+}
+
+size_t nbx_jk_m8_packed_bytes(int64_t N, int64_t p0, int64_t p1) {
+    const int64_t t0 = m4_tri((int)p0), t1 = m4_tri((int)p1);
+    // (+ slack: a chunk past the last tile of a range re-reads the range's first tile, nothing beyond the array)
+#define M8_CASE_bytes(NB_) \
+    case NB_: return (size_t)(m8_tile_offset<M8Geom<NB_, NBX_M8_LP>>(t1) - m8_tile_offset<M8Geom<NB_, NBX_M8_LP>>(t0)) * sizeof(double) + 256;
+    M8_DISPATCH(N, bytes)
+#undef M8_CASE_bytes
+    return 0;
+}
+
+size_t nbx_jk_m8_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm) {
+#define M8_CASE_work(NB_) case NB_: return m8_plan<M8Geom<NB_, NBX_M8_LP>>(p0, p1 - p0, ndm).total;
+    M8_DISPATCH(N, work)
+#undef M8_CASE_work
+    return 0;
+}
+
+int nbx_jk_m8_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed) {
+    NBX_CHECK_ARG(nbx_jk_m8_covers(N) && d_eri && d_packed && nsrc <= N && nsrc > N - 4 && p1 <= nsrc);
+    const int64_t ntiles = m4_tri((int)p1) - m4_tri((int)p0);
+#define M8_CASE_pack(NB_)                                                                                                  \
+    case NB_:                                                                                                              \
+        hipLaunchKernelGGL((m8_pack_kernel<M8Geom<NB_, NBX_M8_LP>>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, d_eri, \
+                           d_packed, (int)p0, (int64_t)m4_tri((int)p0), (int)nsrc);                                        \
+        break;
+    M8_DISPATCH(N, pack)
+#undef M8_CASE_pack
+    NBX_LAUNCH_CHECK();
+    return NBX_OK;
+}
+
+// the Dtot' weights table of a density (m8_stage_index order; the entries nothing writes are zero weights)
+size_t nbx_jk_m8_weights_bytes(int64_t N) {
+#define M8_CASE_wbytes(NB_) \
+    case NB_: return (size_t)(M8Geom<NB_, NBX_M8_LP>::NCH * NBX_M8_LP * M4_PROD_THREADS * 2) * sizeof(double);
+    M8_DISPATCH(N, wbytes)
+#undef M8_CASE_wbytes
+    return 0;
+}
+
+// d_wt: NULL, or that table for d_dm: saves the preparation launch
+int nbx_jk_m8(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
+              double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt) {
+    NBX_CHECK_ARG(nbx_jk_m8_covers(N));
+#define M8_CASE_run(NB_) \
+    case NB_: return m8_run<NB_, NBX_M8_LP>(ctx, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_wt);
+    M8_DISPATCH(N, run)
+#undef M8_CASE_run
+    return NBX_E_UNSUPPORTED;
+}

@@ -45,6 +45,13 @@ size_t nbx_jk_m4_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm);
 int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
 int nbx_jk_m4(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
               double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt);
+// jk_m8.hip: the 8-fold packed form (every integral once) for the sizes it has an instance for, under NBX_JK_M8=1
+bool nbx_jk_m8_covers(int64_t N);
+size_t nbx_jk_m8_packed_bytes(int64_t N, int64_t p0, int64_t p1);
+size_t nbx_jk_m8_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm);
+int nbx_jk_m8_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
+int nbx_jk_m8(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
+              double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt);
 // jk_mx.hip: the same walk for the sizes above (N = 152 .. 288, a tile in 4 .. 20 chunks), unless NBX_JK_MX=0
 bool nbx_jk_mx_covers(int64_t N);
 int64_t nbx_jk_mx_padded(int64_t N);
@@ -407,6 +414,7 @@ extern "C" size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1) {
     if (const int64_t nx = mx_padded(nao)) return nbx_jk_mx_packed_bytes(nx, p0, p1);
     const int64_t NP = s4_padded(nao);
     if (NP == 0) return 0;
+    if (nbx_jk_m8_covers(nao)) return nbx_jk_m8_packed_bytes(nao, p0, p1);
     if (m4_padded(nao)) return nbx_jk_m4_packed_bytes(m4_padded(nao), p0, p1);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_packed_bytes(nao);
     const S4Geom g = s4_geom((int)NP, s4_nb(NP));
@@ -428,6 +436,7 @@ extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
     }
     if (p0 == p1) return NBX_OK;
     NBX_CHECK_ARG(d_eri && d_packed);
+    if (nbx_jk_m8_covers(nao)) return nbx_jk_m8_pack(ctx, nao, nao, p0, p1, d_eri, d_packed);
     if (m4_padded(nao)) return nbx_jk_m4_pack(ctx, m4_padded(nao), nao, p0, p1, d_eri, d_packed);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_pack(ctx, nao, d_eri, d_packed);
     const int64_t ntiles = s4_tri(p1) - s4_tri(p0);
@@ -445,6 +454,7 @@ extern "C" size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, in
         return nbx_jk_mx_worksize(nx, p0, p1, ndm) + (nx != nao ? s4_align256((size_t)((1 + 2 * ndm) * nx * nx) * sizeof(double)) : 0);
     const int64_t NP = s4_padded(nao);
     if (NP == 0) return 0;
+    if (nbx_jk_m8_covers(nao)) return nbx_jk_m8_worksize(nao, p0, p1, ndm);
     if (const int64_t n4 = m4_padded(nao))  // (+ the padded densities and J/K of a size that is not a multiple of four)
         return nbx_jk_m4_worksize(n4, p0, p1, ndm) + (n4 != nao ? s4_align256((size_t)((1 + 2 * ndm) * n4 * n4) * sizeof(double)) : 0);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_worksize(nao, ndm);
@@ -462,6 +472,7 @@ static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const
 
 extern "C" size_t nbx_jk_dts_bytes(int64_t nao) {
     if (mx_padded(nao)) return 0;  // (jk_mx.hip prepares its table itself: one small launch beside a build of 0.2 .. 2.4 ms)
+    if (nbx_jk_m8_covers(nao)) return 0;  // (jk_m8.hip: its own table, its own launch)
     if (nbx_jk_m4_covers(nao)) return nbx_jk_m4_weights_bytes(nao);  // (the same table in jk_m4.hip's staging order)
     if (!s4_supported(nao)) return 0;  // (zero-padded sizes build their table themselves)
     const int NB = s4_nb(nao);
@@ -524,6 +535,7 @@ static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double
         if (d_fock != nullptr) return nbx_fock_uhf(ctx, nao, d_hv, 3, nullptr, d_jk, d_fock, d_vhf);
         return NBX_OK;
     }
+    if (nbx_jk_m8_covers(nao)) return nbx_jk_m8(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, nullptr);
     if (nbx_jk_m4_covers(nao)) return nbx_jk_m4(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
     if (const int64_t n4 = m4_padded(nao)) {
         // as the n4 x n4 problem whose extra rows and columns are zero (tiles with p >= nao are neither stored nor visited):
