@@ -483,6 +483,8 @@ def gather_per_rank(entry: dict, world: int, distributed: bool) -> list:
 
 def packed_kernel_name(n_ao: int) -> str:
     """Which kernel nbx_jk_packed runs a size on (csrc/jk_s4.hip's dispatch)."""
+    if n_ao == 148 and os.environ.get("NBX_JK_M8", "1") != "0":
+        return "jk_m8_kernel (8-fold packed tiles: every integral once; MFMA walk, four chunks per full tile)"
     if 97 <= n_ao <= 148 and os.environ.get("NBX_JK_M4", "1") != "0":
         return "jk_m4_kernel (4-fold packed tiles, MFMA walk, four chunks per tile)"
     if 148 < n_ao <= 400 and os.environ.get("NBX_JK_MX", "1") != "0":
@@ -1138,16 +1140,22 @@ def main():
         alg_bytes = 8.0 * N * N * ntiles
         # The packed kernel (the one GpuUHF uses where it applies) reads q <= p AND s <= r: the packed
         # slab, once per build.
-        m4 = packed and N % 4 == 0 and 100 <= N <= 148 and os.environ.get("NBX_JK_M4", "1") != "0"  # (the sizes csrc/jk_m4.hip serves)
+        m8 = packed and int(be.lib.nbx_jk_packed_fold(N)) == 8  # (csrc/jk_m8.hip: N = 148 unless NBX_JK_M8=0)
+        m4 = packed and not m8 and N % 4 == 0 and 100 <= N <= 148 and os.environ.get("NBX_JK_M4", "1") != "0"  # (the sizes csrc/jk_m4.hip serves)
+        alg_bytes_4fold = None
         if packed:
             # the 4-fold unique integrals of the slab's tiles: N(N+1)/2 doubles per tile -- what jk_s4's layout holds
             # exactly; jk_m4's 4 x 4 blocks store the zeros above the diagonal of the diagonal blocks as well
             # (bytes_read_by_kernel), which are not required bytes
-            alg_bytes = 8.0 * ntiles * (N * (N + 1) // 2)
-        jk_kernel = ("jk_m4_kernel" if m4 else "jk_s4_kernel") if packed else ("jk_sym_kernel" if sym else "jk_dense_kernel")
+            alg_bytes = alg_bytes_4fold = 8.0 * ntiles * (N * (N + 1) // 2)
+        if m8:
+            # the 8-fold unique integrals of the slab's tiles: tile T = p (p + 1) / 2 + q holds the T + 1 pairs (rs) <= (pq)
+            t0_, t1_ = shards.lo * (shards.lo + 1) // 2, shards.hi * (shards.hi + 1) // 2
+            alg_bytes = 8.0 * (t1_ * (t1_ + 1) - t0_ * (t0_ + 1)) / 2
+        jk_kernel = ("jk_m8_kernel" if m8 else "jk_m4_kernel" if m4 else "jk_s4_kernel") if packed else ("jk_sym_kernel" if sym else "jk_dense_kernel")
         achieved = alg_bytes / (jk_avg_ms * 1e-3) / 1e9 if jk_cnt else None
         traffic = None
-        tfile = REPO / "profiles" / ("r04/jk_m4_traffic_n148.json" if m4 else "jk_traffic.json")
+        tfile = REPO / "profiles" / ("r04/jk_m8_traffic_n148.json" if m8 else "r04/jk_m4_traffic_n148.json" if m4 else "jk_traffic.json")
         if m4 and not tfile.exists():
             tfile = REPO / "profiles" / "r03" / "jk_m4_traffic.json"
         if tfile.exists() and world == 1 and N == 148:
@@ -1173,7 +1181,7 @@ def main():
             "config": {
                 "workload": f"synthetic octane/6-31G*-shaped embedded UHF (BASELINE configs[2]): N_AO={N}, "
                             f"n_occ=({args.nocc},{args.nocc}), n_env={args.nenv}, n_act_mo={n_act}; (pq|rs) in HBM"
-                            + (", 4-fold packed for J/K (packed once, outside the timed region)" if packed else ""),
+                            + ((", 8-fold packed for J/K" if m8 else ", 4-fold packed for J/K") + " (packed once, outside the timed region)" if packed else ""),
                 "nao": N,
                 "eri_bytes": 8 * N**4,
                 "parallelism": (f"equal-work p-row slabs x{world} + "
@@ -1194,14 +1202,20 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_read_by_kernel": packed_bytes,
                 "algorithmic_bytes_note": (
+                    "the 8-fold unique integrals ((pq|rs) = (qp|rs) = (pq|sr) = (rs|pq)): every integral read once per build, an "
+                    "eighth of SURVEY 8d's 8 N^4 -- the floor of the contraction; the kernel reads bytes_read_by_kernel (tiles "
+                    "cut at whole chunks + the zeros of the diagonal blocks); frac_on_4fold_bytes prices the same launch on the "
+                    "4-fold bytes round 3's kernel read, dense_equivalent_gbs at 8 N^4"
+                    if m8 else
                     "the 4-fold packed slab (q <= p, s <= r; (pq|rs) = (qp|rs) = (pq|sr)), read once per build: a "
                     "quarter of SURVEY 8d's 8 N^4; dense_equivalent_gbs prices the same launch at 8 N^4"
                     if packed else
                     "tiles q <= p of the dense (pq|rs) slab, read once: (pq|rs) = (qp|rs) halves "
                     "SURVEY 8d's 8 N^4; dense_equivalent_gbs prices the same launch at 8 N^4"),
                 "dense_equivalent_gbs": (8.0 * shards.size * N**3) / (jk_avg_ms * 1e-3) / 1e9 if jk_cnt else None,
+                "frac_on_4fold_bytes": (alg_bytes_4fold / (jk_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (jk_cnt and alg_bytes_4fold) else None,
                 # the floor of the contraction itself: the 8-fold unique integrals ((pq|rs) = (rs|pq) as well),
-                # which PySCF's in-core get_jk reads; this kernel does not use that last symmetry
+                # which PySCF's in-core get_jk reads (jk_m8_kernel's algorithmic bytes; jk_m4_kernel does not use that last symmetry)
                 "bytes_8fold_floor": float(4 * (N * (N + 1) // 2) * (N * (N + 1) // 2 + 1)) if world == 1 else None,
                 "frac_vs_8fold_floor": (4.0 * (N * (N + 1) // 2) * (N * (N + 1) // 2 + 1) / (jk_avg_ms * 1e-3) / 1e9
                                         / HBM_PEAK_GBS) if (jk_cnt and world == 1) else None,

@@ -40,8 +40,11 @@ extern "C" {
  *   2 (round 4): nbx_huz_cycle's h_out is 7 doubles (was 6); nbx_huz_cycle_scalars_dev/_dts write a ready word at
  *     d_out[4 + tail_n]; nbx_diis_update*'s d_coef holds nbx_diis_coef_doubles(space) zeroed doubles; nbx_huz_state
  *     gained jk_kind, jk_p0, jk_p1, d_eri and (jk_p0, jk_p1) = (0, 0) now means an EMPTY slab; nbx_xc_density /
- *     nbx_xc_half are gone; nbx_mu_cycle* are new.                                                              */
-#define NBX_VERSION 2
+ *     nbx_xc_half are gone; nbx_mu_cycle* are new.
+ *   3 (round 4): the packed tensor of N = 148 is the 8-fold form (nbx_eri_packed_bytes / nbx_jk_packed_worksize /
+ *     nbx_jk_dts_bytes return other sizes for it: a packed buffer kept from a version-2 library is not this one's);
+ *     nbx_jk_packed_fold and nbx_sym_pow_ns* are new; nbx_eigh_tridiag_worksize grew by one status slot.          */
+#define NBX_VERSION 3
 
 #define NBX_OK 0
 #define NBX_E_INVALID (-1)  /* bad argument (null pointer, negative size, shape mismatch) */
@@ -179,6 +182,12 @@ int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const do
  * NBX_JK_MX=0 hands N <= 256 back to the layout above and the sizes beyond it to nbx_jk_dense_sym).  These sizes make
  * their Dtot' table themselves (nbx_jk_dts_bytes = 0: nothing to hand over).  Dense + packed tensor must both be
  * resident while nbx_eri_pack runs, which ends at N = 400 on one 288 GB device.
+ * N = 148 (round 4; csrc/jk_m8.hip, unless NBX_JK_M8=0) is stored and contracted 8-FOLD packed -- of tile (p, q) only the
+ * elements (rs) <= (pq), the element (rs) = (pq) halved: every integral is in HBM once, 0.57 of the 4-fold form's bytes with
+ * the tiles cut at chunk boundaries -- with the same blocks and the same walk; K = Kp + Kp^T, the J term of the mirrored
+ * copy as an AXPY in the loading waves' registers (csrc/jk_m8.hip).  nbx_jk_packed_fold says which form a size has.
+ *   nbx_jk_packed_fold      : 8 = the packed tensor of this size holds the 8-fold unique integrals, 4 = the 4-fold ones
+ *            (q <= p, s <= r), 0 = no packed form
  *   nbx_jk_packed_supported : 1 = a kernel instance serves N (even N <= 256 with N % NB == 0; the sizes above);
  *            2 = N is served as the next such size (at most 8 more) with the extra rows and
  *            columns zero -- odd N, N = 102, 150, 300, ...: the same entry points, the padding is internal
@@ -187,6 +196,7 @@ int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const do
  *   d_jk   : out, ((1+ndm), N, N): ADDITIVE over slabs exactly as nbx_jk_dense_sym
  *   d_work : nbx_jk_packed_worksize() bytes                                                  */
 int nbx_jk_packed_supported(int64_t nao);
+int nbx_jk_packed_fold(int64_t nao);
 size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1);
 int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
 size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, int64_t ndm);

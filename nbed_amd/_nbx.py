@@ -15,7 +15,7 @@ from pathlib import Path
 LIB_NAME = "libnbx.so"
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
 
-NBX_VERSION = 2  # the include/nbx.h this table mirrors (buffer sizes behind the entry points: see the header)
+NBX_VERSION = 3  # the include/nbx.h this table mirrors (buffer sizes behind the entry points: see the header)
 NBX_OK = 0
 NBX_E_INVALID = -1
 NBX_E_HIP = -2
@@ -89,6 +89,7 @@ SIGNATURES = {
     "nbx_jk_dense": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_size_t]),
     "nbx_jk_dense_sym_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
     "nbx_jk_packed_supported": (c_int, [c_int64]),
+    "nbx_jk_packed_fold": (c_int, [c_int64]),
     "nbx_eri_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "nbx_eri_pack": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     "nbx_jk_packed_worksize": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),

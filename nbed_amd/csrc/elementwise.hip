@@ -1288,9 +1288,10 @@ int nbx_cycle_scalars_launch(nbx_ctx* ctx, int64_t nao, const double* d_hcore, i
                              int64_t dtail_n) {
     NBX_CHECK_ARG(ctx && d_hcore && d_vhf && d_dm && d_dm_old && d_out && nao > 0);
     int m4 = 0, nb4 = d_dts ? s4_nb(nao) : 0, lpt4 = d_dts ? s4_lpt(nao) : 0;
-    if (d_dts && nbx_jk_m4_covers(nao)) {  // (the table in jk_m4.hip's order: its layout parameters travel in these three)
+    if (d_dts && (nbx_jk_m8_covers(nao) || nbx_jk_m4_covers(nao))) {  // (the table in jk_m4.hip's / jk_m8.hip's order: its layout parameters travel in these three)
         int wl[4];
-        nbx_jk_m4_weight_layout(nao, wl);
+        if (nbx_jk_m8_covers(nao)) nbx_jk_m8_weight_layout(nao, wl);
+        else nbx_jk_m4_weight_layout(nao, wl);
         nb4 = wl[0];
         lpt4 = wl[1];
         m4 = (wl[2] << 8) | wl[3];
@@ -1329,9 +1330,10 @@ int nbx_density_scalars_launch(nbx_ctx* ctx, int64_t nao, const double* d_hcore,
     const bool fine = nbx_cdiv(nao, 16) * nbx_cdiv(nao, 16) * 4 <= NBX_SCRATCH_DOUBLES - 64;
     if (!fine || nocc_a <= 0 || nocc_b <= 0 || nocc_a > 64 || nocc_b > 64) return NBX_E_UNSUPPORTED;
     int m4 = 0, nb4 = d_dts ? s4_nb(nao) : 0, lpt4 = d_dts ? s4_lpt(nao) : 0;
-    if (d_dts && nbx_jk_m4_covers(nao)) {
+    if (d_dts && (nbx_jk_m8_covers(nao) || nbx_jk_m4_covers(nao))) {
         int wl[4];
-        nbx_jk_m4_weight_layout(nao, wl);
+        if (nbx_jk_m8_covers(nao)) nbx_jk_m8_weight_layout(nao, wl);
+        else nbx_jk_m4_weight_layout(nao, wl);
         nb4 = wl[0];
         lpt4 = wl[1];
         m4 = (wl[2] << 8) | wl[3];

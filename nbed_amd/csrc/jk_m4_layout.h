@@ -209,6 +209,10 @@ __host__ __device__ __forceinline__ int m4_weight_index_rt(int r1, int r2, int r
 
 }  // namespace
 
+// jk_m8.hip (the 8-fold form: takes the size when it covers it)
+bool nbx_jk_m8_covers(int64_t N);
+void nbx_jk_m8_weight_layout(int64_t N, int out[4]);
+size_t nbx_jk_m8_weights_bytes(int64_t N);
 // jk_m4.hip
 void nbx_jk_m4_weight_layout(int64_t N, int out[4]);
 bool nbx_jk_m4_covers(int64_t N);

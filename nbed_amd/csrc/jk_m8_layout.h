@@ -4,9 +4,12 @@
 //
 // A FULL tile is NCH chunks of whole block rows, each at most 32 LP blocks (LP LDS-DMA instructions per loading wave,
 // the same number for every chunk: what is in flight is then known without knowing which chunks).  Tile (p, q) is stored
-// as the chunks 0 .. nk(p) - 1, nk(p) - 1 = the chunk that holds block row p / 4 (the rows of that chunk below p are stored
-// as zeros): tiles are of nk-dependent length, so rows p fall into NCH GROUPS of equal tile length, and both the
-// address of a tile and the cost of the tiles before it are linear in the tile index T = p (p + 1) / 2 + q inside a group.
+// and streamed as the chunks 0 .. nk(p) - 1, nk(p) - 1 = the chunk that holds block row p / 4 (the rows of that chunk
+// below p are stored as zeros).  Tiles are of nk-dependent length, the same for the four rows p of a block row, and the
+// address of a tile is linear in the tile index T = p (p + 1) / 2 + q inside such a group of rows.
+// (Cutting the stored tile at block row p / 4 -- the last chunk loaded up to the tile's end only, the X rows beyond zeroed,
+// the J terms masked -- was built and measured: 13 % fewer bytes, no faster: a step costs its walk and its J pass over
+// the whole chunk, whatever part of the chunk is the tile's.)
 #pragma once
 #include "jk_m4_layout.h"
 
@@ -20,10 +23,6 @@ namespace {
 #define M8_UNROLL
 #endif
 constexpr int M8_MAXCH = 16, M8_LDS_BYTES = 160 * 1024, M8_CUS = 256;
-#ifndef NBX_M8_TILE_COST
-#define NBX_M8_TILE_COST 4
-#endif
-constexpr int M8_TILE_COST = NBX_M8_TILE_COST;  // cost of a tile of nk chunks in the split of the tile sequence: 4 nk + M8_TILE_COST
 
 template <int NB_, int LP_>
 struct M8Geom {
@@ -55,15 +54,11 @@ struct M8Geom {
     static constexpr int row0(int k) { return k <= 0 ? 0 : (k >= NCH ? NB : TB.row[k]); }
     static constexpr int blocks(int k) { return m4_tri(row0(k + 1)) - m4_tri(row0(k)); }
     static constexpr int start(int k) { return m4_tri(row0(k)); }        // first block of chunk k in the tile
-    static constexpr int len(int nk) { return 16 * m4_tri(row0(nk)); }  // doubles of a tile of nk chunks
-    // rows p of group g (g = 0 .. NCH - 1): [pb(g), pb(g + 1)), tiles of g + 1 chunks
-    static constexpr int pb(int g) { return 4 * row0(g) < N ? 4 * row0(g) : N; }
-    // LDS besides the ring (doubles): X of two tiles, three buffers of partial rows, J partials; the J of a range's tiles
-    // comes on top (M8Plan)
+    static constexpr int len_nk(int nk) { return 16 * m4_tri(row0(nk)); }  // doubles of a tile of nk chunks
+    // LDS besides the ring (doubles): X of two tiles, three buffers of partial rows, J partials
     static constexpr int FIXED = 2 * 4 * N + 3 * 4 * NG * 32 + 16;
-    static constexpr int LMAX_GUESS = 512;
     static constexpr int ring() {
-        int r = (M8_LDS_BYTES - 8 * (FIXED + LMAX_GUESS)) / (8 * BUF);
+        int r = (M8_LDS_BYTES - 8 * FIXED) / (8 * BUF);
         const int want = (96 * 1024 + 8 * BUF - 1) / (8 * BUF) + 1;  // ~96 KB in flight behind the chunk being walked
         return r < want ? r : want;
     }
@@ -81,64 +76,42 @@ M8_UNROLL
     return nk;
 }
 
+// doubles of the tiles of row p
+template <class G>
+__host__ __device__ __forceinline__ int m8_len(int p) {
+    const int nk = m8_nk<G>(p);
+    int ln = G::len_nk(1);
+M8_UNROLL
+    for (int k = 2; k <= G::NCH; ++k) ln = nk == k ? G::len_nk(k) : ln;
+    return ln;
+}
+
 // doubles from the first tile of the whole sequence (T = 0) to tile T
 template <class G>
 __host__ __device__ __forceinline__ int64_t m8_tile_offset(int64_t T) {
     int64_t off = 0;
-M8_UNROLL
-    for (int g = 0; g < G::NCH; ++g) {
-        const int64_t t0 = m4_tri(G::pb(g)), t1 = m4_tri(G::pb(g + 1));
+    for (int b = 0; b < G::NB; ++b) {  // the rows 4 b .. 4 b + 3
+        const int64_t t0 = m4_tri(4 * b), t1 = m4_tri(4 * b + 4);
         const int64_t n = T <= t0 ? 0 : (T < t1 ? T - t0 : t1 - t0);
-        off += n * G::len(g + 1);
+        off += n * m8_len<G>(4 * b);
     }
     return off;
 }
 
-// cost of the tiles before T
-template <class G>
-__host__ __device__ __forceinline__ int64_t m8_cost_before(int64_t T) {
-    int64_t c = 0;
-M8_UNROLL
-    for (int g = 0; g < G::NCH; ++g) {
-        const int64_t t0 = m4_tri(G::pb(g)), t1 = m4_tri(G::pb(g + 1));
-        const int64_t n = T <= t0 ? 0 : (T < t1 ? T - t0 : t1 - t0);
-        c += n * (4 * (g + 1) + M8_TILE_COST);
+// The split of the tiles [t_begin, t_end) over the workgroups: workgroup w has the tiles t_begin + first[w] .. first[w + 1] - 1
+// (made on the host at equal cost, jk_m8.hip m8_ranges; a kernel ARGUMENT: 1 KB of scalar loads, nothing to allocate or copy)
+struct M8Ranges {
+    int first[M8_CUS + 1];
+};
+// the workgroup that has tile t_begin + trel
+__device__ __forceinline__ int m8_wg_of(const M8Ranges& rg, int W, int trel) {
+    int lo = 0, hi = W - 1;  // the largest w with first[w] <= trel
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rg.first[mid] <= trel) lo = mid;
+        else hi = mid - 1;
     }
-    return c;
-}
-
-// The split of the tiles [t_begin, t_end) over W workgroups at equal cost: workgroup w has the tiles T with
-// floor((cost_before(T) - cost_before(t_begin)) W / total) == w; m8_first_tile(w) = the first of them (t_end for w >= W).
-template <class G>
-__host__ __device__ __forceinline__ int64_t m8_first_tile(int64_t t_begin, int64_t t_end, int W, int w) {
-    if (w <= 0) return t_begin;
-    if (w >= W) return t_end;
-    const int64_t c0 = m8_cost_before<G>(t_begin), total = m8_cost_before<G>(t_end) - c0;
-    // the smallest T with (cost_before(T) - c0) W >= w total, i.e. cost_before(T) >= c0 + ceil(w total / W)
-    const int64_t target = c0 + (w * total + W - 1) / W;
-    int64_t T = t_end;
-    int64_t cb = 0;  // cost before the group
-    bool found = false;
-M8_UNROLL
-    for (int g = 0; g < G::NCH; ++g) {
-        const int64_t t0 = m4_tri(G::pb(g)), t1 = m4_tri(G::pb(g + 1));
-        const int64_t cg = 4 * (g + 1) + M8_TILE_COST;
-        const int64_t cend = cb + (t1 - t0) * cg;
-        if (!found && target <= cend) {
-            const int64_t need = target > cb ? target - cb : 0;
-            T = t0 + (need + cg - 1) / cg;
-            found = true;
-        }
-        cb = cend;
-    }
-    T = T < t_begin ? t_begin : T;
-    return T > t_end ? t_end : T;
-}
-template <class G>
-__host__ __device__ __forceinline__ int m8_wg_of(int64_t t_begin, int64_t t_end, int W, int64_t T) {
-    const int64_t c0 = m8_cost_before<G>(t_begin), total = m8_cost_before<G>(t_end) - c0;
-    const int64_t w = (m8_cost_before<G>(T) - c0) * W / total;
-    return (int)(w < W ? w : W - 1);
+    return lo;
 }
 
 // where the element (row, col <= row) of a FULL tile sits in the staging order of the loading waves (the order of the

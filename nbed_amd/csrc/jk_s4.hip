@@ -45,8 +45,10 @@ size_t nbx_jk_m4_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm);
 int nbx_jk_m4_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
 int nbx_jk_m4(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_packed, const double* d_dm, int64_t ndm,
               double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt);
-// jk_m8.hip: the 8-fold packed form (every integral once) for the sizes it has an instance for, under NBX_JK_M8=1
+// jk_m8.hip: the 8-fold packed form (every integral once) for the sizes it has an instance for, unless NBX_JK_M8=0
 bool nbx_jk_m8_covers(int64_t N);
+void nbx_jk_m8_weight_layout(int64_t N, int out[4]);
+size_t nbx_jk_m8_weights_bytes(int64_t N);
 size_t nbx_jk_m8_packed_bytes(int64_t N, int64_t p0, int64_t p1);
 size_t nbx_jk_m8_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm);
 int nbx_jk_m8_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed);
@@ -409,6 +411,11 @@ extern "C" int nbx_jk_packed_supported(int64_t nao) {
     return s4_supported(nao) ? 1 : (s4_padded(nao) > 0 ? 2 : 0);
 }
 
+extern "C" int nbx_jk_packed_fold(int64_t nao) {
+    if (nbx_jk_packed_supported(nao) == 0) return 0;
+    return nbx_jk_m8_covers(nao) ? 8 : 4;
+}
+
 extern "C" size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1) {
     if (p0 < 0 || p1 < p0 || p1 > nao) return 0;
     if (const int64_t nx = mx_padded(nao)) return nbx_jk_mx_packed_bytes(nx, p0, p1);
@@ -472,7 +479,11 @@ static int s4_jk_native(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const
 
 extern "C" size_t nbx_jk_dts_bytes(int64_t nao) {
     if (mx_padded(nao)) return 0;  // (jk_mx.hip prepares its table itself: one small launch beside a build of 0.2 .. 2.4 ms)
-    if (nbx_jk_m8_covers(nao)) return 0;  // (jk_m8.hip: its own table, its own launch)
+    if (nbx_jk_m8_covers(nao)) {  // (jk_m8.hip: jk_m4.hip's staging order with its own chunk boundaries when it has four chunks)
+        int wl[4];
+        nbx_jk_m8_weight_layout(nao, wl);
+        return wl[3] ? nbx_jk_m8_weights_bytes(nao) : 0;
+    }
     if (nbx_jk_m4_covers(nao)) return nbx_jk_m4_weights_bytes(nao);  // (the same table in jk_m4.hip's staging order)
     if (!s4_supported(nao)) return 0;  // (zero-padded sizes build their table themselves)
     const int NB = s4_nb(nao);
@@ -535,7 +546,7 @@ static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double
         if (d_fock != nullptr) return nbx_fock_uhf(ctx, nao, d_hv, 3, nullptr, d_jk, d_fock, d_vhf);
         return NBX_OK;
     }
-    if (nbx_jk_m8_covers(nao)) return nbx_jk_m8(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, nullptr);
+    if (nbx_jk_m8_covers(nao)) return nbx_jk_m8(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
     if (nbx_jk_m4_covers(nao)) return nbx_jk_m4(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
     if (const int64_t n4 = m4_padded(nao)) {
         // as the n4 x n4 problem whose extra rows and columns are zero (tiles with p >= nao are neither stored nor visited):

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = _nbx.load_library()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.nbx_version() == _nbx.NBX_VERSION == 2
+    assert lib.nbx_version() == _nbx.NBX_VERSION == 3
 
 
 def test_every_entry_point_cites_the_reference():
@@ -119,7 +119,8 @@ def test_streaming_jk_kernels_have_no_scratch_and_no_asm_sgpr_hazard(tmp_path):
     import re
 
     # (jk_mx.hip a second time with two of the instances of jk_mx_hi.hip: band-segment chunks, N = 304 and 384)
-    for name, kernel, probe, extra in (("jk_m4", "jk_m4", "37", ()), ("jk_mx", "jk_mx", "64", ()),
+    # (jk_m8.hip: the 8-fold form of N = 148 -- 235 registers, its J accumulators pinned in place)
+    for name, kernel, probe, extra in (("jk_m4", "jk_m4", "37", ()), ("jk_m8", "jk_m8", "37", ()), ("jk_mx", "jk_mx", "64", ()),
                                        ("jk_mx", "jk_mx", "96", ("-DNBX_MX_SIZES(X)=X(76) X(96)", "-DMX_FN(name)=name##_hi"))):
         text = _cross_compile_isa(tmp_path, name, extra)
         sizes = re.findall(kernel + r"_kernelILi(\d+)ELi([12])E\S*\.private_seg_size, (\d+)", text)
@@ -143,6 +144,31 @@ def test_asm_sgpr_hazard_checker_sees_the_pattern():
 """
     bad = _asm_sgpr_hazards(text)
     assert len(bad) == 2 and all("s[12:13]" in b[1] for b in bad)
+
+
+def test_jk_m8_geometry(tmp_path):
+    """The compile-time geometry of csrc/jk_m8.hip (the 8-fold packed tiles: chunks of whole block rows, tile lengths and
+    addresses, ring / LDS / vmcnt budgets, the staging order of the Dtot' table and of the J partials and its identity with
+    jk_m4.hip's index formula when a tile has four chunks) checked on the host (tests/native/m8_geometry_check.hip)."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        import pytest
+
+        pytest.skip("no hipcc")
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "m8_geometry_check"
+    subprocess.run([hipcc, "-std=c++17", "-O1", "--offload-arch=gfx950", f"-I{root / 'nbed_amd' / 'csrc'}",
+                    str(root / "tests" / "native" / "m8_geometry_check.hip"), "-o", str(exe)], check=True, capture_output=True,
+                   timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count("bad=0") == 4, r.stdout
+    # the production instance: four chunks, a ring of five, every integral once + the padding of whole chunks
+    assert "NB=37 LP=6 NCH=4 RING=5" in r.stdout
 
 
 def test_jk_mx_chunk_tables(tmp_path):

@@ -281,7 +281,9 @@ def test_mu_cycle_call_equals_step_by_step(be, monkeypatch, n, nocc, n_env, mu):
     np.testing.assert_array_equal(m2.mo_coeff, m3.mo_coeff)
     assert m2.scf_summary == m3.scf_summary
     assert not m1.kernel_info.get("restarts")
-    assert abs(m1.cycles - m2.cycles) <= 1
+    # (the stopping rule sits at the rounding level of a mu = 1e6 Fock matrix: which cycle crosses it moves with the
+    #  summation order of the J/K kernel -- two apart at N = 148 since the 8-fold kernel, one apart before)
+    assert abs(m1.cycles - m2.cycles) <= 2
     # (mu = 1e6 puts eigenvalues of 1e6 into F: absolute accuracy of the others is ~1e6 x 2e-16 x N)
     assert abs(e1 - e2) < 1e-8
     np.testing.assert_allclose(m1.mo_energy[:, : n - n_env], m2.mo_energy[:, : n - n_env], rtol=0, atol=1e-7)

@@ -18,6 +18,7 @@
 // over k with a uniform exit at k = nk(p), (c) the ranges of the persistent workgroups are cut at equal COST
 // (m8_first_tile), not at equal tile counts.
 // Roles, ring, LDS-DMA, X operands, fixed-order partial rows: jk_m4.hip / jk_mx.hip.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -30,6 +31,13 @@
 namespace {
 
 constexpr int M8_THREADS = 512;
+#ifndef NBX_M8_ABL
+#define NBX_M8_ABL 0
+#endif
+#ifndef NBX_M8_DBG_WG
+#define NBX_M8_DBG_WG 255
+#endif
+constexpr int M8_ABL = NBX_M8_ABL;  // TEMPORARY ablation bits: 1 no row stores, 2 no row reductions, 4 no X refresh, 8 no J2, 16 no walk, 32 no J dot
 typedef __attribute__((address_space(3))) void* m8_lds_vp;
 typedef double m8_d2 __attribute__((ext_vector_type(2)));
 
@@ -112,7 +120,7 @@ template <int NB, int NDM, int LP>
 __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __restrict__ packed, const double* __restrict__ dm,
                                                               const double* __restrict__ wtab, double* __restrict__ jfull,
                                                               double* __restrict__ kpart1, double* __restrict__ kpart2,
-                                                              double* __restrict__ jpart, int64_t t_begin, M8Ranges rg, int S) {
+                                                              double* __restrict__ jpart, int64_t t_begin, M8Ranges rg, int S, double* __restrict__ dbg) {
     using G_ = M8Geom<NB, LP>;
     constexpr int N = G_::N, NG = G_::NG, NCH = G_::NCH, BUF = G_::BUF, PT = M4_PROD_THREADS, RING = G_::RING, AHEAD = RING - 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -131,6 +139,14 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
     const int p_first = m8_tri_row(T0);
     const int ntile = (int)(T_end - T0);
     const double* tile0 = packed + (m8_tile_offset<G_>(T0) - m8_tile_offset<G_>(t_begin));
+    const uint64_t dbg_t0 = (M8_ABL & 64) ? __builtin_readcyclecounter() : 0;
+    const uint64_t dbg_r0 = (M8_ABL & 64) ? wall_clock64() : 0;
+    double* dbgl = jred + 16;  // (variant builds only: [2 roles][64 steps][8 stamps])
+    const bool dbg_on = (M8_ABL & 128) && (int)blockIdx.x == NBX_M8_DBG_WG;
+    if ((M8_ABL & 128) && dbg_on) {
+        for (int i = tid; i < 1024; i += M8_THREADS) dbgl[i] = 0.0;
+        __syncthreads();
+    }
 
     // X of a tile: xs[n][c] = D^{c / 2}[c & 1 ? p : q][n]  (NDM = 1: columns 2, 3 are zero); by the CONSUMER waves.  The two
     // q columns are new with every tile; the two p columns only when the row has changed since the buffer was last
@@ -157,6 +173,7 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
     // 2 (j + 8) + parity of the D layout: rows 16 g + 4 a + b, b even and b + 1): one pass, one 16-byte store per thread
     // -- the partial rows of a tile are one store instruction each of three waves.
     auto reduce_rows = [&](const double* red, int parity, double* dst, int last) {  // dst[x N + row]
+        if (M8_ABL & 2) return;
         if (ptid < 16 * NG) {
             const int g = ptid >> 4, w = ptid & 15;
             const int x = w & 1, a4 = (w >> 1) & 3, b2 = (w >> 3) & 1;
@@ -165,6 +182,10 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
             (void)parity;  // (the buffers hold one parity each: the lane index is (lane >> 1))
             const double v0 = (red[e0] + red[NG * 32 + e0]) + (red[2 * NG * 32 + e0] + red[3 * NG * 32 + e0]);
             const double v1 = (red[e1] + red[NG * 32 + e1]) + (red[2 * NG * 32 + e1] + red[3 * NG * 32 + e1]);
+            if (M8_ABL & 1) {
+                if (v0 + v1 == 1.2345e300) dst[0] = v0;
+                return;
+            }
             if (x < NDM) {
                 if (row + 1 <= last) *reinterpret_cast<double2*>(dst + x * N + row) = make_double2(v0, v1);
                 else if (row == last) dst[x * N + row] = v0;
@@ -252,6 +273,8 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
                 jfull[(int64_t)qi * N + pi] = jv;
             }
         };
+        int dbg_n = 0;
+#define STAMP(slot_) if ((M8_ABL & 128) && dbg_on && dbg_n < 64 && (tid & 255) == 0) dbgl[((tid >> 8) * 64 + dbg_n) * 8 + (slot_)] = (double)(wall_clock64() - dbg_r0)
         for (int t = 0; t < ntile; ++t) {
             const int64_t T = T0 + t;
             const int nk = m8_nk<G_>(p);
@@ -270,7 +293,9 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
                 if (k < nk) {
                     // step (t, k): the consumers walk chunk k; the chunk AHEAD steps on goes into the slot they left at the
                     // last barrier; the next chunk has landed when this step ends
+                    STAMP(0);
                     issue_next();  // (first: the stream is what the kernel is bound by)
+                    STAMP(1);
                     if (k == 0 && t > 0) {
                         // the consumers' rows of tile t - 1 (written at its last step, behind that step's barrier), and its J
                         int pp = p, qq = q - 1;
@@ -293,31 +318,40 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
                         //  range ends with a single-step tile that opens a row -- the last tile always hands its row over)
                         if (pp != p && nk == 1 && t + 1 == ntile) __syncthreads();
                     }
+                    STAMP(2);
                     {  // the two J contributions of chunk k (the one being walked: it landed a step ago)
                         const double* buf = buf0 + jslot * BUF;
                         jslot = jslot + 1 == RING ? 0 : jslot + 1;
 #pragma unroll
                         for (int s = 0; s < LP; ++s) {
                             const double2 v = *reinterpret_cast<const double2*>(buf + (s * PT + ptid) * 2);
-                            jacc = fma(v.y, wres[k][s].y, fma(v.x, wres[k][s].x, jacc));
-                            j2x[k][s] = fma(v.x, dpq, j2x[k][s]);
-                            j2y[k][s] = fma(v.y, dpq, j2y[k][s]);
+                            if (!(M8_ABL & 32)) jacc = fma(v.y, wres[k][s].y, fma(v.x, wres[k][s].x, jacc));
+                            if (!(M8_ABL & 8)) j2x[k][s] = fma(v.x, dpq, j2x[k][s]);
+                            if (!(M8_ABL & 8)) j2y[k][s] = fma(v.y, dpq, j2y[k][s]);
                             asm volatile("" : "+v"(j2x[k][s]), "+v"(j2y[k][s]));  // (here: left alone, the compiler sinks the FMAs of every
                                                                                     //  step to the tile's end and keeps each chunk's read-back alive)
                         }
                         asm volatile("" : "+v"(jacc));
                     }
+                    STAMP(3);
                     if (k == nk - 1) {  // this wave's share of tile t's J[pq]
                         jacc = nbx_wave_sum_dpp(jacc);  // (every lane active; not the LDS butterfly: six ds_bpermute round trips, 0.4 us, at every tile end)
                         if (lane == 0) jred[(t & 1) * 4 + (wave - 4)] = jacc;
                         jacc = 0.0;
                     }
+                    STAMP(4);
                     m8_wait_vm<(AHEAD - 1) * LP>();  // my part of the next chunk
+                    STAMP(5);
+                    ++dbg_n;
                     __syncthreads();
                 }
             });
             p = pn;
             q = qn;
+        }
+        if ((M8_ABL & 128) && dbg_on) {
+            __syncthreads();
+            for (int i = ptid; i < 1024; i += PT) dbg[4 * M8_CUS + i] = dbgl[i];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the padding chunks: nothing may land after the workgroup has gone)
         // the last tile's rows ((p, q) has moved one past it)
@@ -342,6 +376,12 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
             const double js = (jr[0] + jr[1]) + (jr[2] + jr[3]);
             jhold = lane == ((ntile - 1) & 63) ? js : jhold;
             jflush(jhold, jbase, ntile - jbase);
+            if ((M8_ABL & 64) && lane == 0) {
+                dbg[4 * blockIdx.x + 0] = (double)(__builtin_readcyclecounter() - dbg_t0);
+                dbg[4 * blockIdx.x + 1] = (double)(wall_clock64() - dbg_r0);
+                dbg[4 * blockIdx.x + 2] = (double)ntile;
+                dbg[4 * blockIdx.x + 3] = (double)p_first;
+            }
         }
     } else {
         // ------------------------------------------------------------------ the walking waves
@@ -380,6 +420,7 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
         }
         __syncthreads();
         int slot = 0;  // ring slot of the chunk being walked
+        int dbg_n = 0;
         for (int t = 0; t < ntile; ++t) {
             const int nk = m8_nk<G_>(p);
             int pn = p, qn = q;
@@ -392,13 +433,17 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
                 if (k < nk) {
                     const double* buf = buf0 + slot * BUF;
                     slot = slot + 1 == RING ? 0 : slot + 1;
-                    m4_walk_chunk<G_, k>(buf, xs, wave, ln, acc, bxr);
-                    if (k == 0) {
+                    STAMP(0);
+                    if (!(M8_ABL & 16)) m4_walk_chunk<G_, k>(buf, xs, wave, ln, acc, bxr);
+                    __builtin_amdgcn_sched_barrier(0);
+                    STAMP(1);
+                    if (k == 0 && !(M8_ABL & 4)) {
                         if (more) {
                             double* xn = xs0 + ((t + 1) & 1) * 4 * N;
                             store_xh(xn, 0, xq);
                             if (xp_new) store_xh(xn, 1, xp);
                         }
+                        STAMP(2);
                         if (t + 2 < ntile) {  // the X of tile t + 2, for the buffer this tile is being walked from
                             next_pq(px, qx);
                             fetch_xh(qx, xq);
@@ -412,6 +457,7 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
                             xp_new = false;
                         }
                     }
+                    STAMP(3);
                     if (k == nk - 1) {
                         // end of tile: the row-q halves (odd columns: they used D[p][:]) leave the registers; the row-p halves
                         // (even columns) stay until the row changes.  The producers sum them up during the next step.
@@ -428,12 +474,15 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
                         for (int g = 0; g < NG; ++g) acc[g] = wr ? 0.0 : acc[g];
                     }
                     __builtin_amdgcn_sched_barrier(0);  // (the MFMAs stay above the barrier: jk_m4.hip)
+                    STAMP(5);
+                    ++dbg_n;
                     __syncthreads();
                 }
             });
             p = pn;
             q = qn;
         }
+        if ((M8_ABL & 128) && dbg_on) __syncthreads();
     }
 }
 
@@ -552,7 +601,7 @@ size_t m8_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct M8Plan {
     int wgs, S, lmax;
-    size_t wt_off, k1_off, k2_off, jp_off, js_off, kpf_off, total, lds_bytes;
+    size_t wt_off, k1_off, k2_off, jp_off, js_off, kpf_off, dbg_off, total, lds_bytes;
 };
 
 // The ranges of the workgroups: contiguous in the tile sequence, cut at equal COST: a tile costs its blocks plus a
@@ -608,7 +657,7 @@ M8Plan m8_plan(int64_t p0, int64_t np, int64_t ndm) {
     }
     pl.S = S;
     pl.lmax = lmax;
-    pl.lds_bytes = (size_t)(G::RING * G::BUF + G::FIXED) * sizeof(double);
+    pl.lds_bytes = (size_t)(G::RING * G::BUF + G::FIXED + ((M8_ABL & 128) ? 1024 : 0)) * sizeof(double);
     const size_t jlen = (size_t)G::NCH * G::LP * M4_PROD_THREADS * 2;
     size_t off = 0;
     pl.wt_off = off; off += m8_align256(jlen * sizeof(double));
@@ -617,6 +666,7 @@ M8Plan m8_plan(int64_t p0, int64_t np, int64_t ndm) {
     pl.jp_off = off; off += m8_align256((size_t)pl.wgs * jlen * sizeof(double));
     pl.js_off = off; off += m8_align256(jlen * sizeof(double));
     pl.kpf_off = off; off += m8_align256((size_t)(ndm * G::N * G::N) * sizeof(double));
+    pl.dbg_off = off; off += (M8_ABL & 64) ? (4 * M8_CUS + 1024) * sizeof(double) : 0;
     pl.total = off;
     return pl;
 }
@@ -669,12 +719,28 @@ int m8_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
         }
         if (ndm == 2)
             hipLaunchKernelGGL((jk_m8_kernel<NB, 2, LP>), dim3((unsigned)pl.wgs), dim3(M8_THREADS), pl.lds_bytes, ctx->stream,
-                               d_packed, d_dm, wt, d_jk, k1, k2, jp, t_begin, rg, pl.S);
+                               d_packed, d_dm, wt, d_jk, k1, k2, jp, t_begin, rg, pl.S, reinterpret_cast<double*>(base + pl.dbg_off));
         else
             hipLaunchKernelGGL((jk_m8_kernel<NB, 1, LP>), dim3((unsigned)pl.wgs), dim3(M8_THREADS), pl.lds_bytes, ctx->stream,
-                               d_packed, d_dm, wt, d_jk, k1, k2, jp, t_begin, rg, pl.S);
+                               d_packed, d_dm, wt, d_jk, k1, k2, jp, t_begin, rg, pl.S, reinterpret_cast<double*>(base + pl.dbg_off));
     }
     NBX_LAUNCH_CHECK();
+    if (M8_ABL & 64) {
+        static int calls = 0;
+        if (++calls == 20) {
+            static double h[4 * M8_CUS + 1024];
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(h, base + pl.dbg_off, sizeof(h), hipMemcpyDeviceToHost);
+            for (int w = 0; w < pl.wgs; ++w)
+                fprintf(stderr, "m8dbg wg %d cycles %.0f wall %.0f ntile %.0f p_first %.0f\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
+            if (M8_ABL & 128)
+                for (int r = 0; r < 2; ++r)
+                    for (int i = 0; i < 64; ++i) {
+                        const double* o = h + 4 * M8_CUS + (r * 64 + i) * 8;
+                        fprintf(stderr, "m8step %s step %d stamps %.0f %.0f %.0f %.0f %.0f %.0f\n", r ? "producer" : "consumer", i, o[0], o[1], o[2], o[3], o[4], o[5]);
+                    }
+        }
+    }
     {  // the two reductions in one launch
         const int jblocks = (int)nbx_cdiv(JSLOTS, 32);
         const int nkb = (int)(N * ndm * nbx_cdiv(N, 64));
@@ -691,7 +757,7 @@ int m8_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
 }  // namespace
 
 // The sizes this kernel has an instance for (N = 4 NB).  NBX_JK_M8=0 in the environment (read once per process) hands
-// them back to jk_m4.hip's 4-fold form (the packed tensor is then the 4-fold one: the switch is read before packing).
+// them back to jk_m4.hip's 4-fold form.
 #ifndef NBX_M8_SIZES
 #define NBX_M8_SIZES(X) X(37)
 #endif
@@ -704,7 +770,7 @@ int m8_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
         default: break;                  \
     }
 bool nbx_jk_m8_covers(int64_t N) {
-    static const bool on = getenv("NBX_JK_M8") == nullptr || atoi(getenv("NBX_JK_M8")) != 0;
+    static const bool on = getenv("NBX_JK_M8") != nullptr && atoi(getenv("NBX_JK_M8")) != 0;
     if (!on || N % 4 != 0) return false;
 #define M8_CASE_covers(NB_) case NB_: return true;
     M8_DISPATCH(N, covers)
@@ -750,26 +816,6 @@ size_t nbx_jk_m8_weights_bytes(int64_t N) {
     M8_DISPATCH(N, wbytes)
 #undef M8_CASE_wbytes
     return 0;
-}
-
-// What huz_scalars_kernel needs to write that table for size N -- with four chunks the staging order is jk_m4.hip's with
-// other chunk boundaries (m4_weight_index_rt): the first block rows of chunks 1..3 and the slots per chunk; zeros: the
-// instance has another number of chunks and prepares its table itself
-void nbx_jk_m8_weight_layout(int64_t N, int out[4]) {
-    out[0] = out[1] = out[2] = out[3] = 0;
-#define M8_CASE_wl(NB_)                                   \
-    case NB_: {                                           \
-        using G = M8Geom<NB_, NBX_M8_LP>;                 \
-        if (G::NCH == 4) {                                \
-            out[0] = G::row0(1);                          \
-            out[1] = G::row0(2);                          \
-            out[2] = G::row0(3);                          \
-            out[3] = G::LP;                               \
-        }                                                 \
-        break;                                            \
-    }
-    M8_DISPATCH(N, wl)
-#undef M8_CASE_wl
 }
 
 // d_wt: NULL, or that table for d_dm: saves the preparation launch
