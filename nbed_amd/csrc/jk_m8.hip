@@ -204,7 +204,8 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
         // Chunk -> ring slot: global_load_lds_dwordx4, lane l of a wave lands its 16 bytes at the instruction's LDS base +
         // 16 l; slot s of the chunk is one instruction per producer wave (thread ptid's two doubles of slot s at
         // (s PT + ptid) 2).  Every chunk is LP instructions per wave (the tail re-reads the chunk's last 16 bytes; a chunk
-        // past the last tile re-reads the first tile's first: landed in a free slot, never read).
+        // past the last tile re-reads the first tile's first: landed in a free slot, never read -- leaving those loads out,
+        // with a wait that counts what is really in flight, was measured 5 us SLOWER: the count costs every step).
         auto issue_next = [&]() {
             const bool real = it < ntile;
             const double* tile = real ? itile : tile0;
@@ -331,11 +332,14 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
         // the AXPY half of J of this range
         {
             double* dst = jpart + (int64_t)blockIdx.x * (NCH * LP * PT * 2) + 2 * ptid;
+            const int nkmax = m8_nk<G_>(pp);  // (the last tile's: rows only grow along a range)
 #pragma unroll
             for (int k = 0; k < NCH; ++k)
+                if (k < nkmax) {
 #pragma unroll
-                for (int s = 0; s < LP; ++s)
-                    *reinterpret_cast<double2*>(dst + (k * LP + s) * PT * 2) = make_double2(j2x[k][s], j2y[k][s]);
+                    for (int s = 0; s < LP; ++s)
+                        *reinterpret_cast<double2*>(dst + (k * LP + s) * PT * 2) = make_double2(j2x[k][s], j2y[k][s]);
+                }
         }
         if (wave == 4) {  // J of the tiles not stored yet
             const double* jr = jred + ((ntile - 1) & 1) * 4;
@@ -443,44 +447,48 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
 //     partial sums over P x 64 columns; fixed summation order.
 // (2) (the blocks behind those, same launch) j2sum[e] = sum over the workgroups of jpart[w][e], e in the staging order
 template <class G>
-__global__ __launch_bounds__(256) void m8_reduce_kernel(const double* __restrict__ kpart1, const double* __restrict__ kpart2,
+__global__ __launch_bounds__(512) void m8_reduce_kernel(const double* __restrict__ kpart1, const double* __restrict__ kpart2,
                                                         const double* __restrict__ jpart, double* __restrict__ kpf,
                                                         double* __restrict__ j2sum, int p0, int np, int ndm, int64_t t_begin,
                                                         M8Ranges rg, int W, int S) {
-    constexpr int N = G::N, JLEN = G::NCH * G::LP * M4_PROD_THREADS * 2, CZ = (N + 63) / 64;
-    __shared__ double part[8][64];
+    constexpr int N = G::N, JCH = G::LP * M4_PROD_THREADS * 2, JLEN = G::NCH * JCH, CZ = (N + 63) / 64;
+    static_assert(JCH % 64 == 0, "a block's 32 pairs lie in one chunk");
+    __shared__ double part[16][64];
     const int nkb = N * ndm * CZ;  // blocks of the first kind
     if ((int)blockIdx.x >= nkb) {
-        // 32 double pairs per block, the workgroups in eight interleaved groups
+        // 32 double pairs per block, the workgroups that have this chunk in sixteen interleaved groups
         const int blk = (int)blockIdx.x - nkb;
         const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
         const int e = (blk * 32 + l) * 2;
+        const int w0 = rg.wmin[(blk * 64) / JCH];
         double sx = 0.0, sy = 0.0;
-        if (e < JLEN) {
-            int w = grp;
-            for (; w + 24 < W; w += 32) {
-                double2 v[4];
+        int w = w0 + grp;
+        // (a workgroup without tiles -- a tile dearer than a workgroup's share of a small slab -- has written nothing)
+        auto at = [&](int v) {
+            return rg.first[v + 1] > rg.first[v] ? *reinterpret_cast<const double2*>(jpart + (int64_t)v * JLEN + e) : make_double2(0.0, 0.0);
+        };
+        for (; w + 7 * 16 < W; w += 8 * 16) {
+            double2 v[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const double2*>(jpart + (int64_t)(w + 8 * u) * JLEN + e);
+            for (int u = 0; u < 8; ++u) v[u] = at(w + 16 * u);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    sx += v[u].x;
-                    sy += v[u].y;
-                }
+            for (int u = 0; u < 8; ++u) {
+                sx += v[u].x;
+                sy += v[u].y;
             }
-            for (; w < W; w += 8) {
-                const double2 v = *reinterpret_cast<const double2*>(jpart + (int64_t)w * JLEN + e);
-                sx += v.x;
-                sy += v.y;
-            }
+        }
+        for (; w < W; w += 16) {
+            const double2 v = at(w);
+            sx += v.x;
+            sy += v.y;
         }
         part[grp][l] = sx;
         part[grp][32 + l] = sy;
         __syncthreads();
-        if (grp == 0 && e < JLEN) {
+        if (grp == 0) {
             double tx = part[0][l], ty = part[0][32 + l];
 #pragma unroll
-            for (int g = 1; g < 8; ++g) {
+            for (int g = 1; g < 16; ++g) {
                 tx += part[g][l];
                 ty += part[g][32 + l];
             }
@@ -498,23 +506,25 @@ __global__ __launch_bounds__(256) void m8_reduce_kernel(const double* __restrict
         const int first = max(max(row + 1, c), p0);  // first global P
         auto at = [&](int P) { return src[((int64_t)P * (P + 1) / 2 + row - t_begin) * stride]; };
         int P = first + chunk;
-        for (; P + 7 * 4 < p0 + np; P += 8 * 4) {
+        for (; P + 7 * 8 < p0 + np; P += 8 * 8) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = at(P + 4 * u);
+            for (int u = 0; u < 8; ++u) v[u] = at(P + 8 * u);
 #pragma unroll
             for (int u = 0; u < 8; ++u) t += v[u];
         }
-        for (; P < p0 + np; P += 4) t += at(P);
+        for (; P < p0 + np; P += 8) t += at(P);
     }
     part[chunk][lane] = t;
     __syncthreads();
     if (chunk == 0 && c < N) {
-        double tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        double tot = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
+                     ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
         if (row >= p0 && row < p0 + np && c <= row) {
             const int trow = (int)(m4_tri(row) - t_begin);  // (first tile of the row, relative)
             const int w_lo = m8_wg_of(rg, W, trow), w_hi = m8_wg_of(rg, W, trow + row);
             for (int w = w_lo; w <= w_hi; ++w) {
+                if (rg.first[w + 1] <= rg.first[w]) continue;  // (no tiles: nothing written)
                 const int slot = row - m8_tri_row(t_begin + rg.first[w]);
                 tot += kpart1[(((int64_t)w * S + slot) * ndm + x) * N + c];
             }
@@ -585,6 +595,12 @@ const M8Ranges& m8_ranges(int64_t p0, int64_t np, int* wgs_out) {
             }
         }
         while (w <= M8_CUS) rg.first[w++] = (int)ntiles;
+        for (int k = 0; k < M8_MAXCH; ++k) rg.wmin[k] = wgs;
+        for (int v = wgs - 1; v >= 0; --v) {
+            if (rg.first[v + 1] <= rg.first[v]) continue;
+            const int nkmax = m8_nk<G>(m8_tri_row(t_begin + rg.first[v + 1] - 1));
+            for (int k = 0; k < nkmax && k < M8_MAXCH; ++k) rg.wmin[k] = v;
+        }
         key_p0 = p0;
         key_np = np;
     }
@@ -678,7 +694,7 @@ int m8_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
     {  // the two reductions in one launch
         const int jblocks = (int)nbx_cdiv(JSLOTS, 32);
         const int nkb = (int)(N * ndm * nbx_cdiv(N, 64));
-        hipLaunchKernelGGL(m8_reduce_kernel<G>, dim3((unsigned)(nkb + jblocks)), dim3(256), 0, ctx->stream, k1, k2, jp, kpf, js,
+        hipLaunchKernelGGL(m8_reduce_kernel<G>, dim3((unsigned)(nkb + jblocks)), dim3(512), 0, ctx->stream, k1, k2, jp, kpf, js,
                            (int)p0, (int)np, (int)ndm, t_begin, rg, pl.wgs, pl.S);
         NBX_LAUNCH_CHECK();
     }

@@ -102,6 +102,7 @@ __host__ __device__ __forceinline__ int64_t m8_tile_offset(int64_t T) {
 // (made on the host at equal cost, jk_m8.hip m8_ranges; a kernel ARGUMENT: 1 KB of scalar loads, nothing to allocate or copy)
 struct M8Ranges {
     int first[M8_CUS + 1];
+    int wmin[M8_MAXCH];  // the first workgroup whose range has a tile with chunk k (the J partials of chunk k exist from there on)
 };
 // the workgroup that has tile t_begin + trel
 __device__ __forceinline__ int m8_wg_of(const M8Ranges& rg, int W, int trel) {

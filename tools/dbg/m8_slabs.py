@@ -17,7 +17,7 @@ eri = be.synth_eri(n)
 dm = be.asarray(dm_h)
 whole = be.to_host(be.jk_packed(be.eri_pack(eri, n), dm))
 print("whole", np.abs(whole - ref).max(axis=(1, 2)), flush=True)
-for cutsname, cuts in (("3 slabs", [0] + [int(round(n * np.sqrt(g / 3.0))) for g in (1, 2)] + [n]), ("5 slabs", [0, 1, 5, 60, 147, 148])):
+for cutsname, cuts in (("3 slabs", [0] + [int(round(n * np.sqrt(g / 3.0))) for g in (1, 2)] + [n]), ("5 slabs", [0, 1, 5, 60, 147, 148]), ("awkward", [0, 22, 23, 74, 78, 107, 110, 131, 134, 148])):
     acc = np.zeros_like(ref)
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         acc += be.to_host(be.jk_packed(be.eri_pack(eri[lo:hi], n, lo, hi), dm, lo, hi))
