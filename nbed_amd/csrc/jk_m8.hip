@@ -166,6 +166,7 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
             const double v0 = (red[e0] + red[NG * 32 + e0]) + (red[2 * NG * 32 + e0] + red[3 * NG * 32 + e0]);
             const double v1 = (red[e1] + red[NG * 32 + e1]) + (red[2 * NG * 32 + e1] + red[3 * NG * 32 + e1]);
             if (x < NDM) {
+                // (non-temporal stores, here and for the J partials: -2 us in this kernel, within the noise of the build)
                 if (row + 1 <= last) *reinterpret_cast<double2*>(dst + x * N + row) = make_double2(v0, v1);
                 else if (row == last) dst[x * N + row] = v0;
             }
@@ -709,10 +710,12 @@ int m8_run(nbx_ctx* ctx, int64_t p0, int64_t p1, const double* d_packed, const d
 // The sizes this kernel has an instance for (N = 4 NB).  NBX_JK_M8=0 in the environment (read once per process) hands
 // them back to jk_m4.hip's 4-fold form (the packed tensor is then the 4-fold one: the switch is read before packing).
 #ifndef NBX_M8_SIZES
-#define NBX_M8_SIZES(X) X(37)
+#define NBX_M8_SIZES(X) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37)  // N = 100 .. 148
 #endif
-#ifndef NBX_M8_LP
-#define NBX_M8_LP 6  // LDS-DMA instructions per loading wave and chunk (a chunk = 32 NBX_M8_LP blocks at most; measured: 3 .. 7)
+#ifdef NBX_M8_LP  // (measurements: one chunk size for every instance)
+#define M8_LP(NB_) NBX_M8_LP
+#else
+#define M8_LP(NB_) m8_lp(NB_)
 #endif
 #define M8_DISPATCH(N_, EXPR)            \
     switch ((int)((N_) / 4)) {           \
@@ -732,25 +735,25 @@ size_t nbx_jk_m8_packed_bytes(int64_t N, int64_t p0, int64_t p1) {
     const int64_t t0 = m4_tri((int)p0), t1 = m4_tri((int)p1);
     // (+ slack: a chunk past the last tile of a range re-reads the range's first tile, nothing beyond the array)
 #define M8_CASE_bytes(NB_) \
-    case NB_: return (size_t)(m8_tile_offset<M8Geom<NB_, NBX_M8_LP>>(t1) - m8_tile_offset<M8Geom<NB_, NBX_M8_LP>>(t0)) * sizeof(double) + 256;
+    case NB_: return (size_t)(m8_tile_offset<M8Geom<NB_, M8_LP(NB_)>>(t1) - m8_tile_offset<M8Geom<NB_, M8_LP(NB_)>>(t0)) * sizeof(double) + 256;
     M8_DISPATCH(N, bytes)
 #undef M8_CASE_bytes
     return 0;
 }
 
 size_t nbx_jk_m8_worksize(int64_t N, int64_t p0, int64_t p1, int64_t ndm) {
-#define M8_CASE_work(NB_) case NB_: return m8_plan<M8Geom<NB_, NBX_M8_LP>>(p0, p1 - p0, ndm).total;
+#define M8_CASE_work(NB_) case NB_: return m8_plan<M8Geom<NB_, M8_LP(NB_)>>(p0, p1 - p0, ndm).total;
     M8_DISPATCH(N, work)
 #undef M8_CASE_work
     return 0;
 }
 
 int nbx_jk_m8_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1, const double* d_eri, double* d_packed) {
-    NBX_CHECK_ARG(nbx_jk_m8_covers(N) && d_eri && d_packed && nsrc <= N && nsrc > N - 4 && p1 <= nsrc);
+    NBX_CHECK_ARG(nbx_jk_m8_covers(N) && d_eri && d_packed && nsrc <= N && nsrc > N - 4 && p1 <= nsrc);  // (nsrc < N: zero rows and columns beyond)
     const int64_t ntiles = m4_tri((int)p1) - m4_tri((int)p0);
 #define M8_CASE_pack(NB_)                                                                                                  \
     case NB_:                                                                                                              \
-        hipLaunchKernelGGL((m8_pack_kernel<M8Geom<NB_, NBX_M8_LP>>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, d_eri, \
+        hipLaunchKernelGGL((m8_pack_kernel<M8Geom<NB_, M8_LP(NB_)>>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, d_eri, \
                            d_packed, (int)p0, (int64_t)m4_tri((int)p0), (int)nsrc);                                        \
         break;
     M8_DISPATCH(N, pack)
@@ -762,21 +765,21 @@ int nbx_jk_m8_pack(nbx_ctx* ctx, int64_t N, int64_t nsrc, int64_t p0, int64_t p1
 // the Dtot' weights table of a density (m8_stage_index order; the entries nothing writes are zero weights)
 size_t nbx_jk_m8_weights_bytes(int64_t N) {
 #define M8_CASE_wbytes(NB_) \
-    case NB_: return (size_t)(M8Geom<NB_, NBX_M8_LP>::NCH * NBX_M8_LP * M4_PROD_THREADS * 2) * sizeof(double);
+    case NB_: return (size_t)(M8Geom<NB_, M8_LP(NB_)>::NCH * M8_LP(NB_) * M4_PROD_THREADS * 2) * sizeof(double);
     M8_DISPATCH(N, wbytes)
 #undef M8_CASE_wbytes
     return 0;
 }
 
-// What huz_scalars_kernel needs to write that table for size N -- with four chunks the staging order is jk_m4.hip's with
-// other chunk boundaries (m4_weight_index_rt): the first block rows of chunks 1..3 and the slots per chunk; zeros: the
-// instance has another number of chunks and prepares its table itself
+// What huz_scalars_kernel needs to write that table for size N -- with at most four chunks the staging order is
+// jk_m4.hip's with other chunk boundaries (m4_weight_index_rt; a chunk that does not exist begins at block row NB): the
+// first block rows of chunks 1..3 and the slots per chunk; zeros: the instance has more chunks and prepares its table itself
 void nbx_jk_m8_weight_layout(int64_t N, int out[4]) {
     out[0] = out[1] = out[2] = out[3] = 0;
 #define M8_CASE_wl(NB_)                                   \
     case NB_: {                                           \
-        using G = M8Geom<NB_, NBX_M8_LP>;                 \
-        if (G::NCH == 4) {                                \
+        using G = M8Geom<NB_, M8_LP(NB_)>;                 \
+        if (G::NCH <= 4) {                                \
             out[0] = G::row0(1);                          \
             out[1] = G::row0(2);                          \
             out[2] = G::row0(3);                          \
@@ -793,7 +796,7 @@ int nbx_jk_m8(nbx_ctx* ctx, int64_t N, int64_t p0, int64_t p1, const double* d_p
               double* d_jk, void* d_work, const double* d_hv, double* d_fock, double* d_vhf, const double* d_wt) {
     NBX_CHECK_ARG(nbx_jk_m8_covers(N));
 #define M8_CASE_run(NB_) \
-    case NB_: return m8_run<NB_, NBX_M8_LP>(ctx, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_wt);
+    case NB_: return m8_run<NB_, M8_LP(NB_)>(ctx, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_wt);
     M8_DISPATCH(N, run)
 #undef M8_CASE_run
     return NBX_E_UNSUPPORTED;

@@ -24,6 +24,25 @@ namespace {
 #endif
 constexpr int M8_MAXCH = 16, M8_LDS_BYTES = 160 * 1024, M8_CUS = 256;
 
+// chunks of a full tile of NB block rows at LP LDS-DMA instructions per loading wave and chunk (M8Geom::build's count)
+constexpr int m8_nch(int NB, int LP) {
+    int r = 0, k = 0;
+    while (r < NB) {
+        int blk = 0;
+        while (r < NB && blk + r + 1 <= 32 * LP) blk += ++r;
+        ++k;
+    }
+    return k;
+}
+// The chunk size of an instance: the smallest with at most four chunks per full tile -- a step then lasts as long as
+// jk_m4.hip's (what a tile's hand-over costs is spread over steps of that length: measured at N = 148 with LP = 3 .. 7),
+// and with exactly four chunks the Dtot' table has jk_m4.hip's order (nbx_jk_m8_weight_layout).
+constexpr int m8_lp(int NB) {
+    int lp = (NB + 1 + 31) / 32;
+    while (m8_nch(NB, lp) > 4) ++lp;
+    return lp;
+}
+
 template <int NB_, int LP_>
 struct M8Geom {
     static constexpr int NB = NB_, LP = LP_, N = 4 * NB, NG = (NB + 3) / 4, NBLK = m4_tri(NB), TILE = 16 * NBLK;

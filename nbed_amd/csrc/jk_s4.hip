@@ -402,6 +402,12 @@ static int64_t m4_padded(int64_t nao) {
     return (nao > 0 && nbx_jk_m4_covers(n4)) ? n4 : 0;
 }
 
+// the same for jk_m8.hip (the 8-fold form of these sizes; it takes them when it has the instance)
+static int64_t m8_padded(int64_t nao) {
+    const int64_t n4 = (nao + 3) / 4 * 4;
+    return (nao > 0 && nbx_jk_m8_covers(n4)) ? n4 : 0;
+}
+
 // the size jk_mx.hip runs nao as (nao itself or the next instance, at most eight zero rows / columns more); 0: none
 static int64_t mx_padded(int64_t nao) { return (nao > 0 && !m4_padded(nao)) ? nbx_jk_mx_padded(nao) : 0; }
 
@@ -413,7 +419,7 @@ extern "C" int nbx_jk_packed_supported(int64_t nao) {
 
 extern "C" int nbx_jk_packed_fold(int64_t nao) {
     if (nbx_jk_packed_supported(nao) == 0) return 0;
-    return nbx_jk_m8_covers(nao) ? 8 : 4;
+    return m8_padded(nao) ? 8 : 4;
 }
 
 extern "C" size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1) {
@@ -421,7 +427,7 @@ extern "C" size_t nbx_eri_packed_bytes(int64_t nao, int64_t p0, int64_t p1) {
     if (const int64_t nx = mx_padded(nao)) return nbx_jk_mx_packed_bytes(nx, p0, p1);
     const int64_t NP = s4_padded(nao);
     if (NP == 0) return 0;
-    if (nbx_jk_m8_covers(nao)) return nbx_jk_m8_packed_bytes(nao, p0, p1);
+    if (const int64_t n8 = m8_padded(nao)) return nbx_jk_m8_packed_bytes(n8, p0, p1);
     if (m4_padded(nao)) return nbx_jk_m4_packed_bytes(m4_padded(nao), p0, p1);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_packed_bytes(nao);
     const S4Geom g = s4_geom((int)NP, s4_nb(NP));
@@ -443,7 +449,7 @@ extern "C" int nbx_eri_pack(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, c
     }
     if (p0 == p1) return NBX_OK;
     NBX_CHECK_ARG(d_eri && d_packed);
-    if (nbx_jk_m8_covers(nao)) return nbx_jk_m8_pack(ctx, nao, nao, p0, p1, d_eri, d_packed);
+    if (const int64_t n8 = m8_padded(nao)) return nbx_jk_m8_pack(ctx, n8, nao, p0, p1, d_eri, d_packed);
     if (m4_padded(nao)) return nbx_jk_m4_pack(ctx, m4_padded(nao), nao, p0, p1, d_eri, d_packed);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_pack(ctx, nao, d_eri, d_packed);
     const int64_t ntiles = s4_tri(p1) - s4_tri(p0);
@@ -461,7 +467,8 @@ extern "C" size_t nbx_jk_packed_worksize(int64_t nao, int64_t p0, int64_t p1, in
         return nbx_jk_mx_worksize(nx, p0, p1, ndm) + (nx != nao ? s4_align256((size_t)((1 + 2 * ndm) * nx * nx) * sizeof(double)) : 0);
     const int64_t NP = s4_padded(nao);
     if (NP == 0) return 0;
-    if (nbx_jk_m8_covers(nao)) return nbx_jk_m8_worksize(nao, p0, p1, ndm);
+    if (const int64_t n8 = m8_padded(nao))  // (+ the padded densities and J/K of a size that is not a multiple of four)
+        return nbx_jk_m8_worksize(n8, p0, p1, ndm) + (n8 != nao ? s4_align256((size_t)((1 + 2 * ndm) * n8 * n8) * sizeof(double)) : 0);
     if (const int64_t n4 = m4_padded(nao))  // (+ the padded densities and J/K of a size that is not a multiple of four)
         return nbx_jk_m4_worksize(n4, p0, p1, ndm) + (n4 != nao ? s4_align256((size_t)((1 + 2 * ndm) * n4 * n4) * sizeof(double)) : 0);
     if (nbx_jk_p8_covers(nao, p0, p1)) return nbx_jk_p8_worksize(nao, ndm);
@@ -547,6 +554,23 @@ static int s4_jk(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double
         return NBX_OK;
     }
     if (nbx_jk_m8_covers(nao)) return nbx_jk_m8(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
+    if (const int64_t n8 = m8_padded(nao)) {
+        // (n8 > nao: as the n8 x n8 problem whose extra rows and columns are zero, like the jk_m4.hip branch below)
+        char* tail = static_cast<char*>(d_work) + nbx_jk_m8_worksize(n8, p0, p1, ndm);
+        double* dm_pad = reinterpret_cast<double*>(tail);
+        double* jk_pad = dm_pad + ndm * n8 * n8;
+        const int64_t tin = ndm * n8 * n8, tout = (1 + ndm) * nao * nao;
+        hipLaunchKernelGGL(s4_pad_square_kernel, dim3((unsigned)nbx_cdiv(tin, 256)), dim3(256), 0, ctx->stream, d_dm,
+                           dm_pad, (int)nao, (int)n8, (int)ndm);
+        NBX_LAUNCH_CHECK();
+        const int rc = nbx_jk_m8(ctx, n8, p0, p1, d_packed, dm_pad, ndm, jk_pad, d_work, nullptr, nullptr, nullptr, nullptr);
+        if (rc != NBX_OK) return rc;
+        hipLaunchKernelGGL(s4_crop_square_kernel, dim3((unsigned)nbx_cdiv(tout, 256)), dim3(256), 0, ctx->stream,
+                           jk_pad, d_jk, (int)nao, (int)n8, (int)(1 + ndm));
+        NBX_LAUNCH_CHECK();
+        if (d_fock != nullptr) return nbx_fock_uhf(ctx, nao, d_hv, 3, nullptr, d_jk, d_fock, d_vhf);
+        return NBX_OK;
+    }
     if (nbx_jk_m4_covers(nao)) return nbx_jk_m4(ctx, nao, p0, p1, d_packed, d_dm, ndm, d_jk, d_work, d_hv, d_fock, d_vhf, d_dts);
     if (const int64_t n4 = m4_padded(nao)) {
         // as the n4 x n4 problem whose extra rows and columns are zero (tiles with p >= nao are neither stored nor visited):

@@ -166,8 +166,8 @@ def test_jk_m8_geometry(tmp_path):
                    timeout=600)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.count("bad=0") == 4, r.stdout
-    # the production instance: four chunks, a ring of five, every integral once + the padding of whole chunks
+    assert r.stdout.count("bad=0") == 16, r.stdout
+    # the bench's instance: four chunks, a ring of five, every integral once + the padding of whole chunks
     assert "NB=37 LP=6 NCH=4 RING=5" in r.stdout
 
 

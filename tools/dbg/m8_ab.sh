@@ -6,7 +6,7 @@ for round in 1 2 3; do
   for v in "" $@ m4; do
     unset NBX_LIB; export NBX_JK_M8=1
     if [ "$v" = "m4" ]; then export NBX_JK_M8=0; elif [ -n "$v" ]; then export NBX_LIB=$PWD/build/variants/libnbx_$v.so; fi
-    r=$(timeout -k 10 240 python tools/dbg/m8_time.py 148 40 2>&1 | tail -1)
+    r=$(timeout -k 10 240 python tools/dbg/m8_time.py ${M8N:-148} 40 2>&1 | tail -1)
     echo "round $round variant '$v': $r"
   done
 done
