@@ -3,7 +3,7 @@ rows=[]
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 rows.sort(key=lambda r:r[1])
-idx=[i for i,r in enumerate(rows) if re.search(r"jk_(s4|m4|sym|dense)_kernel",r[0])]
+idx=[i for i,r in enumerate(rows) if re.search(r"jk_(s4|m4|m8|sym|dense)_kernel",r[0])]
 def short(n):
     return n.replace("(anonymous namespace)::","").replace("void ","")[:50]
 c=len(idx)-3

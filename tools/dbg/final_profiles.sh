@@ -15,12 +15,12 @@ rm -rf $O/trace
 echo "rocprof done"
 # 3. PMC traffic of the J/K kernels
 for N in 148 256 384; do
-  K=jk_mx_kernel; if [ $N = 148 ]; then K=jk_m4_kernel; fi
+  K=jk_mx_kernel; if [ $N = 148 ]; then K=jk_m8_kernel; fi
   python $R/tools/time_jk_kernel.py $N > $O/time_jk_kernel_$N.txt 2>&1
   tail -1 $O/time_jk_kernel_$N.txt
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/f$N -- python $R/tools/time_jk_kernel.py $N > $O/pmc_f$N.log 2>&1 || true
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/w$N -- python $R/tools/time_jk_kernel.py $N > $O/pmc_w$N.log 2>&1 || true
-  B=$(python -c "n=$N; print(8*(n*(n+1)//2)**2)")
+  B=$(python -c "n=$N; m=n*(n+1)//2; print(4*m*(m+1) if n == 148 else 8*m*m)")  # (8-fold unique integrals at N = 148, the 4-fold ones above)
   python $R/tools/pmc_traffic.py $O/f$N $O/w$N $K $B $O/jk_traffic_n$N.json "N_AO=$N whole tensor, two densities, tools/time_jk_kernel.py $N, final code of round 4" | cut -c1-200
   rm -rf $O/f$N $O/w$N $O/pmc_f$N.log $O/pmc_w$N.log
 done

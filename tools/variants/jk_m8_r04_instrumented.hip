@@ -1,3 +1,8 @@
+// A COPY of csrc/jk_m8.hip of mid round 4 with its measurement switches left in (NBX_M8_ABL bits: 1 no row stores, 2 no row
+// reductions, 4 no X refresh, 8 no J AXPY, 16 no walk, 32 no J dot, 64 per-workgroup wall time printed at the 20th call,
+// 128 per-step time stamps of workgroup NBX_M8_DBG_WG).  Built by tools/build_m8_variant.sh with
+// M8_SRC=tools/variants/jk_m8_r04_instrumented.hip "-DNBX_M8_SIZES(X)=X(37)" -DNBX_M8_LP=6 against the headers of csrc/
+// (it built at the end of round 4); what it measured: profiles/r04/jk_m8_measurements.txt.  Not part of libnbx.
 // libnbx: the J/K contraction on the 8-FOLD packed (pq|rs) -- every integral read once per build (what stands behind
 // get_veff of nbed/scf/huzinaga_scf.py:156; PySCF's own mf._eri is 8-fold packed too).
 //
