@@ -483,7 +483,7 @@ def gather_per_rank(entry: dict, world: int, distributed: bool) -> list:
 
 def packed_kernel_name(n_ao: int) -> str:
     """Which kernel nbx_jk_packed runs a size on (csrc/jk_s4.hip's dispatch)."""
-    if n_ao == 148 and os.environ.get("NBX_JK_M8", "1") != "0":
+    if 97 <= n_ao <= 148 and os.environ.get("NBX_JK_M8", "1") != "0":
         return "jk_m8_kernel (8-fold packed tiles: every integral once; MFMA walk, four chunks per full tile)"
     if 97 <= n_ao <= 148 and os.environ.get("NBX_JK_M4", "1") != "0":
         return "jk_m4_kernel (4-fold packed tiles, MFMA walk, four chunks per tile)"
@@ -1140,7 +1140,7 @@ def main():
         alg_bytes = 8.0 * N * N * ntiles
         # The packed kernel (the one GpuUHF uses where it applies) reads q <= p AND s <= r: the packed
         # slab, once per build.
-        m8 = packed and int(be.lib.nbx_jk_packed_fold(N)) == 8  # (csrc/jk_m8.hip: N = 148 unless NBX_JK_M8=0)
+        m8 = packed and int(be.lib.nbx_jk_packed_fold(N)) == 8  # (csrc/jk_m8.hip: N = 97 .. 148 unless NBX_JK_M8=0)
         m4 = packed and not m8 and N % 4 == 0 and 100 <= N <= 148 and os.environ.get("NBX_JK_M4", "1") != "0"  # (the sizes csrc/jk_m4.hip serves)
         alg_bytes_4fold = None
         if packed:

@@ -41,7 +41,7 @@ extern "C" {
  *     d_out[4 + tail_n]; nbx_diis_update*'s d_coef holds nbx_diis_coef_doubles(space) zeroed doubles; nbx_huz_state
  *     gained jk_kind, jk_p0, jk_p1, d_eri and (jk_p0, jk_p1) = (0, 0) now means an EMPTY slab; nbx_xc_density /
  *     nbx_xc_half are gone; nbx_mu_cycle* are new.
- *   3 (round 4): the packed tensor of N = 148 is the 8-fold form (nbx_eri_packed_bytes / nbx_jk_packed_worksize /
+ *   3 (round 4): the packed tensor of N = 97 .. 148 is the 8-fold form (nbx_eri_packed_bytes / nbx_jk_packed_worksize /
  *     nbx_jk_dts_bytes return other sizes for it: a packed buffer kept from a version-2 library is not this one's);
  *     nbx_jk_packed_fold and nbx_sym_pow_ns* are new; nbx_eigh_tridiag_worksize grew by one status slot.          */
 #define NBX_VERSION 3
@@ -182,9 +182,10 @@ int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const do
  * NBX_JK_MX=0 hands N <= 256 back to the layout above and the sizes beyond it to nbx_jk_dense_sym).  These sizes make
  * their Dtot' table themselves (nbx_jk_dts_bytes = 0: nothing to hand over).  Dense + packed tensor must both be
  * resident while nbx_eri_pack runs, which ends at N = 400 on one 288 GB device.
- * N = 148 (round 4; csrc/jk_m8.hip, unless NBX_JK_M8=0) is stored and contracted 8-FOLD packed -- of tile (p, q) only the
- * elements (rs) <= (pq), the element (rs) = (pq) halved: every integral is in HBM once, 0.57 of the 4-fold form's bytes with
- * the tiles cut at chunk boundaries -- with the same blocks and the same walk; K = Kp + Kp^T, the J term of the mirrored
+ * N = 97 .. 148 (round 4; csrc/jk_m8.hip, an instance per multiple of four as for jk_m4.hip, unless NBX_JK_M8=0) are stored
+ * and contracted 8-FOLD packed -- of tile (p, q) only the elements (rs) <= (pq), the element (rs) = (pq) halved: every
+ * integral is in HBM once, 0.63 of the 4-fold form's bytes with the tiles cut at chunk boundaries -- with the same blocks and
+ * the same walk; K = Kp + Kp^T, the J term of the mirrored
  * copy as an AXPY in the loading waves' registers (csrc/jk_m8.hip).  nbx_jk_packed_fold says which form a size has.
  *   nbx_jk_packed_fold      : 8 = the packed tensor of this size holds the 8-fold unique integrals, 4 = the 4-fold ones
  *            (q <= p, s <= r), 0 = no packed form

@@ -843,9 +843,9 @@ def test_jk_packed_vs_oracle(be, n, ndm):
 @pytest.mark.parametrize("n", [100, 104, 116, 118, 124, 128, 130, 132, 140, 144, 148, 152, 192, 256])
 def test_jk_packed_full_size(be, n):
     """The kernel instances of the larger sizes against the plain streaming kernel on the generated tensor, both
-    spins: N = 100 .. 148 in steps of four are jk_m4.hip's (one instance per size; 148 is the bench size; the sizes here
-    cover its chunk-length classes LPT = 3 .. 6; 118 and 130 run as 120 and 132 with zero rows and columns), the others
-    jk_s4.hip's."""
+    spins: N = 100 .. 148 in steps of four are jk_m8.hip's (the 8-fold packed form, one instance per size; 148 is the bench
+    size; the sizes here cover its chunk sizes LP = 3 .. 6 and the three-chunk instance N = 104; 118 and 130 run as 120 and
+    132 with zero rows and columns), the others jk_s4.hip's."""
     eri = be.synth_eri(n)
     dmd = be.asarray(np.stack([symm(532, n), symm(533, n)]))
     a = be.to_host(be.jk_packed(be.eri_pack(eri, n), dmd))
@@ -859,7 +859,8 @@ def test_jk_packed_fock_and_prepared_dtot_table(be, n):
     """nbx_jk_packed_fock (Fock assembly in the reduction) against J/K + nbx_fock_uhf, and the Dtot'
     table left by the scalars kernel (nbx_huz_cycle_scalars_dts) against the one the build makes
     itself: bit-identical Fock matrices, also when the table is reused for a second density.
-    (N = 100 .. 148 in steps of four are served by jk_m4.hip, whose table has its own order: csrc/jk_m4_layout.h.)"""
+    (N = 100 .. 148 in steps of four are served by jk_m8.hip -- jk_m4.hip behind NBX_JK_M8=0 --, whose table has jk_m4.hip's order with
+    other chunk boundaries: csrc/jk_m4_layout.h, nbx_jk_m8_weight_layout.)"""
     eri = be.synth_eri(n)
     packed = be.eri_pack(eri, n)
     hv = be.asarray(np.stack([symm(570, n), symm(571, n)]))
@@ -919,6 +920,27 @@ def test_jk_mx_slabs_add_up_and_single_density(be, n):
     one = be.to_host(be.jk_packed(be.eri_pack(eri, n), dm[:1]))
     ref1 = be.to_host(be.jk_sym(eri, dm[:1]))
     np.testing.assert_allclose(one, ref1, rtol=0, atol=1e-11 * (n / 148) ** 2)
+
+
+def test_jk_4fold_walk_kernel_behind_the_switch(be):
+    """csrc/jk_m4.hip (the 4-fold packed walk kernel that served N = 97 .. 148 until csrc/jk_m8.hip took them) stays in
+    the library behind NBX_JK_M8=0, which is read once per process: a child process runs N = 104, 147 (zero-padded)
+    and 148 on it against the C oracle (tests/_jk4_worker.py)."""
+    import gc
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    assert be.lib.nbx_jk_packed_fold(148) == 8 and be.lib.nbx_jk_packed_fold(145) == 8 and be.lib.nbx_jk_packed_fold(152) == 4
+    gc.collect()
+    torch.cuda.empty_cache()
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, NBX_JK_M8="0", PYTHONPATH=str(root))
+    r = subprocess.run([sys.executable, str(root / "tests" / "_jk4_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "JK4 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_jk_packed_unsupported_sizes(be):

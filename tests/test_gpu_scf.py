@@ -281,9 +281,11 @@ def test_mu_cycle_call_equals_step_by_step(be, monkeypatch, n, nocc, n_env, mu):
     np.testing.assert_array_equal(m2.mo_coeff, m3.mo_coeff)
     assert m2.scf_summary == m3.scf_summary
     assert not m1.kernel_info.get("restarts")
-    # (the stopping rule sits at the rounding level of a mu = 1e6 Fock matrix: which cycle crosses it moves with the
-    #  summation order of the J/K kernel -- two apart at N = 148 since the 8-fold kernel, one apart before)
-    assert abs(m1.cycles - m2.cycles) <= 2
+    # (conv_tol = 1e-10 on |dE| with mu = 1e6 in F sits below the rounding of the Fock matrix at N = 148: the energy of the
+    #  last cycles wanders by ~1e-10, and WHICH cycle happens to pass depends on the summation order of the J/K kernel --
+    #  7 / 7 cycles with the 4-fold kernel, 14 / 8 with the 8-fold one, each run-to-run identical (tools/dbg/mu_det.py);
+    #  the energies below agree to 1e-8 either way)
+    assert abs(m1.cycles - m2.cycles) <= (8 if n >= 97 else 1)  # (n >= 97: the sizes of the 8-fold kernel; 7 / 9 at N = 102)
     # (mu = 1e6 puts eigenvalues of 1e6 into F: absolute accuracy of the others is ~1e6 x 2e-16 x N)
     assert abs(e1 - e2) < 1e-8
     np.testing.assert_allclose(m1.mo_energy[:, : n - n_env], m2.mo_energy[:, : n - n_env], rtol=0, atol=1e-7)
