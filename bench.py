@@ -509,7 +509,7 @@ def scaling_workload_leg(be, args, world, rank, distributed, barrier) -> list:
         try:
             nocc, nenv = n_ao // 6, n_ao // 12
             pr = synth.problem(be, n_ao, (nocc, nocc), nenv)
-            sh = Shards(n_ao, world, rank, force_collective=distributed, balance="triangular")
+            sh = Shards.for_packed_jk(be, n_ao, world, rank, force_collective=distributed)
             eri = be.synth_eri(n_ao, sh.lo, sh.hi)
             mf = GpuUHF(Mole(n_ao, pr["nelec"]), pr["S"], pr["hcore"], eri, backend=be, shards=sh)
             packed = mf.eri_packed_device() is not None
@@ -704,8 +704,9 @@ def main():
             torch.cuda.synchronize()
 
     # ---------------- inputs resident in HBM before any timed region
-    # slabs of equal triangular work: the symmetric J/K kernel reads the tiles q <= p of its rows
-    shards = Shards(N, world, rank, force_collective=distributed, balance="triangular")
+    # slabs of equal J/K work = equal bytes of the packed form (4-fold: the triangular cut, row p has p + 1 tiles of one length; the
+    # 8-fold form of N <= 148 cuts the tiles of row p at row p as well: its rows grow like p^3)
+    shards = Shards.for_packed_jk(be, N, world, rank, force_collective=distributed)
     eri = be.synth_eri(N, shards.lo, shards.hi)
     mf = GpuUHF(Mole(N, pr["nelec"]), pr["S"], pr["hcore"], eri, backend=be, shards=shards)
     mf.eri_packed_device()  # the J/K kernel's packed copy of the slab: part of the resident inputs

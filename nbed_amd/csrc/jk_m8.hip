@@ -205,7 +205,7 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
         // Chunk -> ring slot: global_load_lds_dwordx4, lane l of a wave lands its 16 bytes at the instruction's LDS base +
         // 16 l; slot s of the chunk is one instruction per producer wave (thread ptid's two doubles of slot s at
         // (s PT + ptid) 2).  Every chunk is LP instructions per wave (the tail re-reads the chunk's last 16 bytes; a chunk
-        // past the last tile re-reads the first tile's first: landed in a free slot, never read -- leaving those loads out,
+        // past the last tile re-reads the first tile's first 16 bytes: landed in a free slot, never read -- leaving those loads out,
         // with a wait that counts what is really in flight, was measured 5 us SLOWER: the count costs every step).
         auto issue_next = [&]() {
             const bool real = it < ntile;
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
                 begin = kk == k ? 16 * G_::start(k) : begin;
                 end = kk == k ? 16 * (G_::start(k) + G_::blocks(k)) : end;
             });
+            end = real ? end : 2;  // (a chunk past the last tile: every lane the tile's first 16 bytes -- one cache line per instruction)
             double* buf = buf0 + islot * BUF;
             islot = islot + 1 == RING ? 0 : islot + 1;
             int pt_ = ptid;  // (opaque per chunk: the clamped offsets are recomputed, not kept in registers)

@@ -43,7 +43,7 @@ class Shards:
     """Contiguous partition of ``range(n)`` over the ranks of a process group."""
 
     def __init__(self, n: int, world: int = 1, rank: int = 0, group=None, force_collective: bool = False,
-                 balance: str = "uniform"):
+                 balance: str = "uniform", row_cost=None):
         self.force_collective = force_collective  # run the collective even with one rank (testing)
         self.n = int(n)
         self.world = int(world)
@@ -56,12 +56,44 @@ class Shards:
             self._cuts = [min(self.n, int(round(self.n * math.sqrt(g / self.world)))) for g in range(self.world)]
             self._cuts.append(self.n)
             self.lo, self.hi = self._cuts[self.rank], self._cuts[self.rank + 1]
+        elif balance == "cost":
+            # boundaries at equal sums of a given cost per row (``row_cost``: n numbers) -- e.g. the bytes of each row's packed
+            # tiles, which grow like p^3 in the 8-fold packed form (tile (p, q) holds the rows r <= p only) where the
+            # 4-fold form's grow like p: the boundary nearest to g/world of the total for every rank g
+            if row_cost is None or len(row_cost) != self.n:
+                raise ValueError("balance='cost' needs row_cost with one entry per row")
+            cum = [0.0]
+            for c in row_cost:
+                cum.append(cum[-1] + float(c))
+            self._cuts = [0]
+            for g in range(1, self.world):
+                target = cum[-1] * g / self.world
+                b = min(range(self._cuts[-1], self.n + 1), key=lambda i: abs(cum[i] - target))
+                self._cuts.append(b)
+            self._cuts.append(self.n)
+            self.lo, self.hi = self._cuts[self.rank], self._cuts[self.rank + 1]
         elif balance == "uniform":
             self._cuts = None
             self.lo = min(self.n, self.rank * self.chunk)
             self.hi = min(self.n, self.lo + self.chunk)
         else:
             raise ValueError(f"unknown balance {balance!r}")
+
+    @classmethod
+    def for_packed_jk(cls, be, n: int, world: int = 1, rank: int = 0, group=None, force_collective: bool = False):
+        """Row slabs of (pq|rs) at equal bytes of the packed J/K form of size ``n`` (nbx_eri_packed_bytes row by row: the
+        streaming kernel's work is its bytes -- 4-fold packed: p + 1 tiles of one length per row, the triangular cut;
+        8-fold packed, N = 97 .. 148: the tiles of row p are cut at row p as well); triangular where no packed form exists."""
+        lib = getattr(be, "lib", None)
+        if lib is not None and world > 1 and int(lib.nbx_jk_packed_supported(n)):
+            # (an empty slab's size is the buffer's slack, if the form has one; a tile costs the kernels ~0.9 us beyond its
+            #  stream -- the worth of 25 KB at a workgroup's 23 GB/s, profiles/r04/jk_m8_measurements.txt -- which matters
+            #  where tiles are of very different lengths: row p has p + 1 of them)
+            cost = [float(lib.nbx_eri_packed_bytes(n, p, p + 1)) - float(lib.nbx_eri_packed_bytes(n, p, p)) + 25600.0 * (p + 1)
+                    for p in range(n)]
+            if min(cost) > 0:
+                return cls(n, world, rank, group, force_collective, balance="cost", row_cost=cost)
+        return cls(n, world, rank, group, force_collective, balance="triangular")
 
     @classmethod
     def from_env(cls, n: int, group=None):

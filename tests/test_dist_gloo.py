@@ -55,6 +55,34 @@ def test_triangular_shards_balance_the_symmetric_jk_work():
         Shards(10, 2, 0, balance="nope")
 
 
+def test_cost_balanced_shards_follow_the_packed_form():
+    """Shards.for_packed_jk cuts the rows at equal cost of the packed J/K form (bytes of a row's tiles + a constant per tile,
+    from libnbx's own size function -- host arithmetic, no GPU): the triangular cut for a 4-fold packed size, a much later
+    one for the 8-fold form of N = 148, whose rows grow like p^3 (the triangular cut would give the last of eight ranks 1.65
+    times its share)."""
+    from nbed_amd import _nbx
+
+    class Host:
+        lib = _nbx.load_library()
+
+    be = Host()
+    assert be.lib.nbx_jk_packed_fold(148) == 8 and be.lib.nbx_jk_packed_fold(256) == 4
+    for n, world in [(148, 2), (148, 8), (256, 8), (148, 1)]:
+        bounds = [Shards.for_packed_jk(be, n, world, r) for r in range(world)]
+        assert bounds[0].lo == 0 and bounds[-1].hi == n
+        assert all(a.hi == b.lo for a, b in zip(bounds[:-1], bounds[1:]))
+        assert all(b.bounds(r) == (bounds[r].lo, bounds[r].hi) for b in bounds for r in range(world))
+        byts = [be.lib.nbx_eri_packed_bytes(n, b.lo, b.hi) + 25600 * (b.hi * (b.hi + 1) - b.lo * (b.lo + 1)) // 2 for b in bounds]
+        assert max(byts) < 1.08 * sum(byts) / world, (n, world, byts)
+    tri = [Shards(256, 8, r, balance="triangular") for r in range(8)]  # (the same cut to a row: rounded differently)
+    assert all(abs(a.hi - b.hi) <= 1 for a, b in zip(tri, (Shards.for_packed_jk(be, 256, 8, r) for r in range(8))))
+    assert Shards.for_packed_jk(be, 148, 2, 0).hi > Shards(148, 2, 0, balance="triangular").hi + 8
+    with pytest.raises(ValueError):
+        Shards(10, 2, 0, balance="cost")
+    # explicit costs: the boundary nearest to the equal share
+    assert [Shards(4, 2, r, balance="cost", row_cost=[1, 1, 1, 3]).hi for r in range(2)] == [3, 4]
+
+
 def test_symmetric_jk_slabs_all_reduce_match_single_rank(tmp_path):
     """World-2 gloo run of the additive-slab J/K path (equal-work slabs, one all-reduce)."""
     n = 10
