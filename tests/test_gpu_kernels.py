@@ -897,9 +897,10 @@ def test_jk_packed_fock_of_the_sizes_that_make_their_own_table(be, n):
         np.testing.assert_array_equal(be.to_host(vhf0), be.to_host(v_ref))
 
 
-@pytest.mark.parametrize("n", [148, 160, 250, 304])
+@pytest.mark.parametrize("n", [104, 132, 148, 160, 250, 304])
 def test_jk_mx_slabs_add_up_and_single_density(be, n):
-    """csrc/jk_m8.hip (N = 148: the 8-fold packed form, workgroup ranges cut at equal cost inside every slab) and
+    """csrc/jk_m8.hip (N = 104 -- three chunks per tile --, 132, 148: the 8-fold packed form, workgroup ranges cut at equal
+    cost inside every slab) and
     csrc/jk_mx.hip through the slab interface that the multi-GPU split uses (three row slabs cut at equal triangular
     work, packed separately, partial J/K added: the whole-tensor result to rounding) and with ONE density (the NDM = 1
     instances), at a size with whole-row chunks, a zero-padded one and one with band-segment chunks; against the
