@@ -15,9 +15,10 @@
 // Tiles are of different lengths now, so (a) the chunk sequence of a range is produced by run-time iterators (which chunk
 // of which tile goes into the ring next) while every chunk is the same number of LDS-DMA instructions -- the s_waitcnt
 // immediates stay static --, (b) the code of a step is still specialised per chunk: the steps of a tile are unrolled
-// over k with a uniform exit at k = nk(p), (c) the ranges of the persistent workgroups are cut at equal COST
-// (m8_first_tile), not at equal tile counts.
-// Roles, ring, LDS-DMA, X operands, fixed-order partial rows: jk_m4.hip / jk_mx.hip.
+// over k with a uniform exit at k = nk(p), (c) the ranges of the persistent workgroups are cut at equal COST -- a tile costs
+// its blocks plus a constant -- on the host (m8_ranges) and handed to the kernels as an argument, not at equal tile counts.
+// Roles, ring, LDS-DMA, X operands, fixed-order partial rows: jk_m4.hip / jk_mx.hip.  Measurements, ablations and what was
+// tried and dropped: profiles/r04/jk_m8_measurements.txt, DESIGN.md section 9 (4).
 #include <cstdlib>
 #include <type_traits>
 
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
 
 // ---------------------------------------------------------------------------------------------- the reductions
 // (1) kpf[x][r][c] = Kp[r][c], every column: the row-p partials of the workgroups whose range has tiles of row r (c <= r)
-//     + the row-q partials of the tiles (P, r), P > r, P >= c.   N NDM ceil(N / 64) blocks, 256 threads = 4 interleaved
+//     + the row-q partials of the tiles (P, r), P > r, P >= c.   N NDM ceil(N / 64) blocks, 512 threads = 8 interleaved
 //     partial sums over P x 64 columns; fixed summation order.
 // (2) (the blocks behind those, same launch) j2sum[e] = sum over the workgroups of jpart[w][e], e in the staging order
 template <class G>
