@@ -398,7 +398,7 @@ __global__ __launch_bounds__(M4_THREADS, 1) void jk_m4_kernel(const double* __re
                 // but the wait for chunk g + 1 stands between this wave and the barrier once that chunk is there
                 jpass(g);
                 if (k == 3) {  // this wave's share of tile t's J
-                    jacc = nbx_wave_sum(jacc);
+                    jacc = nbx_wave_sum_dpp(jacc);  // (lane moves, not six ds_bpermute round trips: jk_m8.hip)
                     if (lane == 0) jred[(t & 1) * 4 + (wave - 4)] = jacc;
                     jacc = 0.0;
                 }

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(MX_THREADS, 1) void jk_mx_kernel(const double* __re
                                                     //  the tile's end and keeps every chunk's read-back alive until then)
                 }
                 if (k == NCH - 1) {  // this wave's share of tile t's J
-                    jacc = nbx_wave_sum(jacc);
+                    jacc = nbx_wave_sum_dpp(jacc);  // (lane moves, not six ds_bpermute round trips: jk_m8.hip)
                     if (lane == 0) jred[(t & 1) * 4 + (wave - 4)] = jacc;
                     jacc = 0.0;
                 }

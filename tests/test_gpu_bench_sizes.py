@@ -77,9 +77,15 @@ def test_jk_packed_every_instance_vs_c_oracle(be, n):
     column segments; 156, 188, 252, 300 run zero-padded as the next instance) -- on three row slabs (first, middle,
     last rows) of J and K against the C oracle (oracle/c/jk_ref.c) on slabs of the generated tensor.  (N = 148 itself:
     all rows, above.)"""
+    import gc
+
     import torch
 
-    torch.cuda.empty_cache()  # (the dense tensor of N = 384 is 174 GB)
+    # (the dense tensor of N = 384 is 174 GB: nothing of the size before may stay reserved -- a workspace of the backend
+    #  that the allocator carved out of the freed 146 GB segment of N = 368 pins that whole segment)
+    be.release_workspaces()
+    gc.collect()
+    torch.cuda.empty_cache()
     eri = be.synth_eri(n)
     dm = np.stack([symm(534, n), symm(535, n)])
     packed = be.eri_pack(eri, n)
