@@ -547,8 +547,29 @@ __global__ void js_scatter_rows_kernel(const double* __restrict__ slab, double* 
 }
 }  // namespace
 
+static int jk_dense_sym_impl(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri, const double* d_dm,
+                             int64_t ndm, double* d_jk, void* d_work, size_t work_bytes, const double* d_hv, double* d_fock,
+                             double* d_vhf);
+
 extern "C" int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri,
                                 const double* d_dm, int64_t ndm, double* d_jk, void* d_work, size_t work_bytes) {
+    return jk_dense_sym_impl(ctx, nao, p0, p1, d_eri, d_dm, ndm, d_jk, d_work, work_bytes, nullptr, nullptr, nullptr);
+}
+
+// The whole tensor with two densities and the Fock assembly F = hv + J - K[x], vhf = J - K[x] in the reduction kernel's
+// epilogue (the SCF cycle on the dense tensor: N < 97 and the sizes the packed kernels have no instance for) -- what
+// nbx_jk_dense_sym + nbx_fock_uhf give, bit for bit, in one launch less.  NBX_E_UNSUPPORTED (nothing launched): no symmetric
+// kernel for this size (odd N): the caller takes the two calls.
+int nbx_jk_dense_sym_fock(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_dm, const double* d_hv, double* d_jk,
+                          double* d_fock, double* d_vhf, void* d_work, size_t work_bytes) {
+    NBX_CHECK_ARG(d_hv && d_fock);
+    if (!nbx_jk_sym_supported(nao)) return NBX_E_UNSUPPORTED;
+    return jk_dense_sym_impl(ctx, nao, 0, nao, d_eri, d_dm, 2, d_jk, d_work, work_bytes, d_hv, d_fock, d_vhf);
+}
+
+static int jk_dense_sym_impl(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p1, const double* d_eri, const double* d_dm,
+                             int64_t ndm, double* d_jk, void* d_work, size_t work_bytes, const double* d_hv, double* d_fock,
+                             double* d_vhf) {
     NBX_CHECK_ARG(ctx && d_dm && d_jk);
     NBX_CHECK_ARG(nao > 0 && p0 >= 0 && p1 >= p0 && p1 <= nao);
     NBX_CHECK_ARG(d_eri != nullptr || p0 == p1);  // an empty slab has no storage
@@ -612,8 +633,8 @@ extern "C" int nbx_jk_dense_sym(nbx_ctx* ctx, int64_t nao, int64_t p0, int64_t p
     NBX_LAUNCH_CHECK();
     hipLaunchKernelGGL(jk_sym_reduce_kernel<4>, dim3((unsigned)N, (unsigned)ndm, (unsigned)nbx_cdiv(N, 64)), dim3(256), 0,
                        ctx->stream, k1, k2,
-                       d_jk + n2, (int)N, (int)p0, (int)np, (int)ndm, t_begin, pl.L, pl.S, 0, nullptr, nullptr, nullptr, nullptr, 0,
-                       1);
+                       d_jk + n2, (int)N, (int)p0, (int)np, (int)ndm, t_begin, pl.L, pl.S, 0, d_fock ? d_jk : nullptr, d_hv, d_fock,
+                       d_vhf, 0, 1);
     NBX_LAUNCH_CHECK();
     return NBX_OK;
 }

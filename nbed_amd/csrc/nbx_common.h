@@ -46,6 +46,10 @@ int* nbx_eigh_lds_skip_ptr(int64_t n, int64_t batch, void* d_work);
 int nbx_apply_rotation_log_t(nbx_ctx* ctx, int n, int np_even, int steps, const void* d_rot, const int* d_flags,
                              const int* d_nsteps, const int* d_rank, double* d_vt);
 
+// jk_sym.hip
+int nbx_jk_dense_sym_fock(nbx_ctx* ctx, int64_t nao, const double* d_eri, const double* d_dm, const double* d_hv, double* d_jk,
+                          double* d_fock, double* d_vhf, void* d_work, size_t work_bytes);
+
 // gemm.hip
 int nbx_gemm_q1_synth(nbx_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* d_a, int64_t lda, uint64_t seed,
                       double scale, int64_t r, int64_t s0, double* d_y, int64_t ldy, int64_t stride_y, int64_t batch);

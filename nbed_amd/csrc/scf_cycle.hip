@@ -94,11 +94,18 @@ extern "C" int nbx_huz_cycle(nbx_ctx* ctx, const nbx_huz_state* st, const double
                                 st->jk_work_bytes, (dts_ready && st->d_dts) ? st->d_dts : nullptr);
         if (rc != NBX_OK) return rc;
     } else {
-        // the symmetric kernel on the dense tensor (N < 100; sizes the packed kernel has no instance for), or a
-        // one-rank "slab" run: J/K, then the Fock assembly as its own launch
-        rc = nbx_huz_cycle_jk(ctx, st, d_dm_in);
-        if (rc != NBX_OK) return rc;
-        rc = nbx_fock_uhf(ctx, N, st->d_hv, 3, nullptr, st->d_jk, st->d_fock, st->d_vhf);
+        // the symmetric kernel on the dense tensor (N < 97; sizes the packed kernel has no instance for) with the Fock assembly
+        // in its reduction where it has the whole tensor; else (odd N, a one-rank "slab" run): J/K, then the assembly as its
+        // own launch
+        rc = NBX_E_UNSUPPORTED;
+        if (st->jk_kind == NBX_HUZ_JK_SYM && huz_whole_tensor(st) && st->d_eri)
+            rc = nbx_jk_dense_sym_fock(ctx, N, st->d_eri, d_dm_in, st->d_hv, st->d_jk, st->d_fock, st->d_vhf, st->d_jk_work,
+                                       st->jk_work_bytes);
+        if (rc == NBX_E_UNSUPPORTED) {
+            rc = nbx_huz_cycle_jk(ctx, st, d_dm_in);
+            if (rc != NBX_OK) return rc;
+            rc = nbx_fock_uhf(ctx, N, st->d_hv, 3, nullptr, st->d_jk, st->d_fock, st->d_vhf);
+        }
         if (rc != NBX_OK) return rc;
     }
     return huz_cycle_rest(ctx, st, d_dm_in, d_c_in, d_dm_out, d_c_out, d_v_out, d_w_out, d_hz_out, mode, refine_iters,
@@ -297,9 +304,15 @@ extern "C" int nbx_mu_cycle_fock(nbx_ctx* ctx, const nbx_huz_state* st, const do
                                 st->jk_work_bytes, nullptr);
         if (rc != NBX_OK) return rc;
     } else {
-        rc = nbx_huz_cycle_jk(ctx, st, d_dm);
-        if (rc != NBX_OK) return rc;
-        rc = nbx_fock_uhf(ctx, N, st->d_hv, 3, nullptr, st->d_jk, d_fock_out, d_vhf_out);
+        rc = NBX_E_UNSUPPORTED;
+        if (st->jk_kind == NBX_HUZ_JK_SYM && huz_whole_tensor(st) && st->d_eri)
+            rc = nbx_jk_dense_sym_fock(ctx, N, st->d_eri, d_dm, st->d_hv, st->d_jk, d_fock_out, d_vhf_out, st->d_jk_work,
+                                       st->jk_work_bytes);
+        if (rc == NBX_E_UNSUPPORTED) {
+            rc = nbx_huz_cycle_jk(ctx, st, d_dm);
+            if (rc != NBX_OK) return rc;
+            rc = nbx_fock_uhf(ctx, N, st->d_hv, 3, nullptr, st->d_jk, d_fock_out, d_vhf_out);
+        }
         if (rc != NBX_OK) return rc;
     }
     return mu_cycle_tail(ctx, st, d_dm, d_dm_old, d_c, d_fock_out, d_vhf_out, mode, d_status_tracked, h_out);
