@@ -146,6 +146,26 @@ def test_asm_sgpr_hazard_checker_sees_the_pattern():
     assert len(bad) == 2 and all("s[12:13]" in b[1] for b in bad)
 
 
+def test_packed_sizes_are_host_arithmetic_and_additive_over_slabs():
+    """nbx_jk_packed_fold / nbx_eri_packed_bytes need no GPU: the 8-fold form of N = 97 .. 148 (every integral once + the
+    padding of whole chunks: 0.624 GB at N = 148 against 0.992 GB of the 4-fold blocks), the 4-fold form above, and slabs
+    that add up (what nbed_amd.dist.Shards.for_packed_jk cuts the rows of a multi-GPU run by)."""
+    lib = _nbx.load_library()
+    assert [lib.nbx_jk_packed_fold(n) for n in (24, 96, 97, 100, 147, 148, 149, 152, 256, 400, 402)] == [4, 4, 8, 8, 8, 8, 4, 4, 4, 4, 0]
+    slack = lib.nbx_eri_packed_bytes(148, 7, 7)
+    whole = lib.nbx_eri_packed_bytes(148, 0, 148) - slack
+    assert whole == 624329728  # (tests/native/m8_geometry_check.hip prints the same number for NB = 37, LP = 6)
+    unique = 8 * (148 * 149 // 2) * (148 * 149 // 2 + 1) // 2
+    assert unique < whole < 1.3 * unique
+    for cut in (1, 60, 116, 147):
+        assert lib.nbx_eri_packed_bytes(148, 0, cut) + lib.nbx_eri_packed_bytes(148, cut, 148) - 2 * slack == whole
+    rows = [lib.nbx_eri_packed_bytes(148, p, p + 1) - slack for p in range(148)]
+    assert sum(rows) == whole and all(b >= a for a, b in zip(rows[:-1], rows[1:]))
+    assert rows[147] > 500 * rows[0]  # (the 8-fold form's rows grow like p^3; the 4-fold form's like p)
+    rows4 = [lib.nbx_eri_packed_bytes(256, p, p + 1) - lib.nbx_eri_packed_bytes(256, 3, 3) for p in range(256)]
+    assert rows4[255] == 256 * rows4[0]
+
+
 def test_jk_m8_geometry(tmp_path):
     """The compile-time geometry of csrc/jk_m8.hip (the 8-fold packed tiles: chunks of whole block rows, tile lengths and
     addresses, ring / LDS / vmcnt budgets, the staging order of the Dtot' table and of the J partials and its identity with
