@@ -154,12 +154,15 @@ __global__ __launch_bounds__(M8_THREADS, 1) void jk_m8_kernel(const double* __re
         }
     };
     // the consumers' partial rows of a finished tile: summed over the four consumer waves, in wave order; `last`: the
-    // last column that is stored.  Loading thread u < 16 NG has two neighbouring rows of one spin (lanes 2 j + parity and
+    // last column that is stored.  Loading thread 64 + u, u < 16 NG, has two neighbouring rows of one spin (lanes 2 j + parity and
     // 2 (j + 8) + parity of the D layout: rows 16 g + 4 a + b, b even and b + 1): one pass, one 16-byte store per thread
     // -- the partial rows of a tile are one store instruction each of three waves.
     auto reduce_rows = [&](const double* red, int parity, double* dst, int last) {  // dst[x N + row]
-        if (ptid < 16 * NG) {
-            const int g = ptid >> 4, w = ptid & 15;
+        // (the threads of loading waves 1 .. 3: wave 0 keeps the tiles' J -- 3.5 us of the kernel)
+        static_assert(16 * NG <= 3 * 64, "the partial rows' pairs fit three waves");
+        const int u = ptid - 64;
+        if (u >= 0 && u < 16 * NG) {
+            const int g = u >> 4, w = u & 15;
             const int x = w & 1, a4 = (w >> 1) & 3, b2 = (w >> 3) & 1;
             const int e0 = g * 32 + x + 2 * a4 + 16 * b2, e1 = e0 + 8;
             const int row = 16 * g + 4 * a4 + 2 * b2;
